@@ -1,0 +1,180 @@
+"""CPU fp32 restatement of KGnet's network + losses (TEST INFRASTRUCTURE, not product).
+
+Table-driven functional restatement (torch.nn.functional on CPU tensors -- the
+reference itself delegates all arithmetic to these torch ops) of
+  * ResNet.forward_dec          KGnet.py:275-318
+  * get_patches / forward_seg   KGnet.py:246-267, 321-350
+  * DetectionLossAll            loss.py:12-49
+  * SEG_loss                    seg_loss.py:14-96
+operating on a plain state_dict (oracle/weightgen.py).  Pinned against
+tests/golden/net_*.npz generated from the reference (tools/gen_goldens.py).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+EDGES = [(0, 1), (0, 2), (0, 3), (0, 4), (1, 2), (1, 3), (1, 4), (2, 3), (2, 4), (3, 4)]
+LAYERS = [("layer1", 64, 3, 1), ("layer2", 128, 4, 2), ("layer3", 256, 6, 2)]
+
+
+class Net:
+    """Functional KGnet over a dict of tensors (leaf tensors may require grad)."""
+
+    def __init__(self, sd, training=False):
+        self.sd = sd
+        self.training = training
+
+    # -- primitives ---------------------------------------------------------
+    def conv(self, x, name, stride=1, pad=0, relu=False):
+        y = F.conv2d(x, self.sd[name + ".weight"], self.sd.get(name + ".bias"), stride, pad)
+        return F.relu(y) if relu else y
+
+    def bn(self, x, name, relu=False):
+        y = F.batch_norm(x, self.sd[name + ".running_mean"], self.sd[name + ".running_var"],
+                         self.sd[name + ".weight"], self.sd[name + ".bias"], self.training, 0.1, 1e-5)
+        if self.training:
+            self.sd[name + ".num_batches_tracked"] += 1
+        return F.relu(y) if relu else y
+
+    def bottleneck(self, x, p, stride, has_ds):
+        o = self.bn(self.conv(x, p + ".conv1"), p + ".bn1", True)
+        o = self.bn(self.conv(o, p + ".conv2", stride, 1), p + ".bn2", True)
+        o = self.bn(self.conv(o, p + ".conv3"), p + ".bn3")
+        idt = self.bn(self.conv(x, p + ".downsample.0", stride), p + ".downsample.1") if has_ds else x
+        return F.relu(o + idt)
+
+    @staticmethod
+    def up(x, ref):
+        return F.interpolate(x, ref.shape[2:], mode="bilinear", align_corners=False)
+
+    # -- KGnet.py:275-318 ---------------------------------------------------
+    def forward_dec(self, x):
+        c0 = self.conv(self.conv(x, "c0_conv.0", 1, 1, True), "c0_conv.2", 1, 1, True)
+        c1 = self.bn(self.conv(x, "conv1", 2, 3), "bn1", True)
+        f = F.max_pool2d(c1, 3, 2, 1)
+        feats = [c0, c1]
+        for name, planes, blocks, stride in LAYERS:
+            for b in range(blocks):
+                f = self.bottleneck(f, f"{name}.{b}", stride if b == 0 else 1, b == 0)
+            feats.append(f)
+        c0, c1, c2, c3, c4 = feats
+        cat = c4
+        cats = {}
+        for lvl, skip in ((3, c3), (2, c2), (1, c1), (0, c0)):
+            u = self.conv(self.up(cat, skip), f"c{lvl + 1}_up_conv.0", 1, 1, True)
+            cat = self.conv(torch.cat((u, skip), 1), f"c{lvl}_cat_refine.0", 1, 0, True)
+            cats[lvl] = cat
+        dec = []
+        for lvl in range(4):
+            h = cats[lvl]
+            out = []
+            for head in ("kp", "short_offset", "mid_offset"):
+                p = f"{head}_head_c{lvl}"
+                y = self.conv(self.conv(h, p + ".0", 1, 3, True), p + ".2", 1, 3)
+                out.append(torch.sigmoid(y) if head == "kp" else y)
+            dec.append(out)
+        return dec[0], dec[1], dec[2], dec[3], feats
+
+    # -- KGnet.py:246-256 ---------------------------------------------------
+    @staticmethod
+    def crop_coords(box4, h0, w0, h, w):
+        """float32 arithmetic exactly as numpy 2.x evaluates KGnet.py:332-335 + 248-252:
+        normalise by c0's (h0,w0) in f32, scale by the level's (h,w) in f32, rint
+        (half-to-even), clamp.  Returns (y1,x1,y2,x2) int or None when rejected."""
+        y1, x1, y2, x2 = np.asarray(box4, np.float32)
+        ny1 = y1 / np.float32(h0); nx1 = x1 / np.float32(w0)
+        ny2 = y2 / np.float32(h0); nx2 = x2 / np.float32(w0)
+        iy1 = max(0, int(np.int32(np.round(ny1 * np.float32(h)))))
+        ix1 = max(0, int(np.int32(np.round(nx1 * np.float32(w)))))
+        iy2 = min(int(np.int32(np.round(ny2 * np.float32(h)))), h - 1)
+        ix2 = min(int(np.int32(np.round(nx2 * np.float32(w)))), w - 1)
+        if iy2 < iy1 or ix2 < ix1 or iy2 - iy1 < 2 or ix2 - ix1 < 2:
+            return None
+        return iy1, ix1, iy2, ix2
+
+    # -- KGnet.py:258-267, 321-350 -------------------------------------------
+    def forward_seg(self, feats, bboxes):
+        patches = [[] for _ in bboxes]
+        dets = [[] for _ in bboxes]
+        h0, w0 = feats[0].shape[2:]
+        for i, bb in enumerate(bboxes):
+            if len(bb) == 0:
+                continue
+            for row in bb:
+                box, score = row[:4], row[4]
+                crops = []
+                for f in feats:
+                    cc = self.crop_coords(box, h0, w0, f.shape[2], f.shape[3])
+                    if cc is None:
+                        break
+                    crops.append(f[i:i + 1, :, cc[0]:cc[2], cc[1]:cc[3]])
+                if not crops:
+                    continue
+                pre = crops[-1]
+                for lvl in range(len(crops) - 2, -1, -1):
+                    u = self.conv(self.up(pre, crops[lvl]), f"skip_combine.{lvl}.up.0", 1, 1, True)
+                    pre = self.conv(torch.cat((crops[lvl], u), 1), f"skip_combine.{lvl}.cat_conv.0", 1, 0, True)
+                y = self.conv(self.conv(pre, "seg_head.0", 1, 1, True), "seg_head.2", 1, 1)
+                patches[i].append(torch.sigmoid(y)[0, 0])
+                dets[i].append(torch.tensor(np.append(np.asarray(box, np.float32), np.float32(score))))
+        return [patches, dets]
+
+    def forward(self, x, bboxes):
+        d0, d1, d2, d3, feats = self.forward_dec(x)
+        return d0, d1, d2, d3, self.forward_seg(feats, bboxes)
+
+
+# -- loss.py:12-49 -----------------------------------------------------------
+def detection_loss(pred, gt, kp_radius=5):
+    pr_kp, pr_short, pr_mid = pred
+    gt_kp, gt_short, gt_mid = gt[:, :5], gt[:, 5:15], gt[:, 15:]
+    l_kp = F.binary_cross_entropy(pr_kp, gt_kp)
+    m2 = gt_kp.repeat_interleave(2, 1)
+    l_short = (torch.abs(pr_short - gt_short) / kp_radius * m2).sum() / (m2.sum() + 1e-10)
+    frm = [e[0] for e in EDGES] + [e[1] for e in EDGES]
+    m4 = gt_kp[:, frm].repeat_interleave(2, 1)
+    l_mid = (torch.abs(pr_mid - gt_mid) / kp_radius * m4).sum() / (m4.sum() + 1e-10)
+    return l_kp + l_short + 0.25 * l_mid
+
+
+def nearest_resize(a, h1, w1):
+    """cv2.resize(..., INTER_NEAREST) rule src = min(floor(dst*src/dst_size), src-1)
+    (seg_loss.py:77; cv2 is absent from the build container, so this rule is the
+    build's stated assumption -- identity whenever the sizes already agree)."""
+    h0, w0 = a.shape
+    yi = np.minimum(np.floor(np.arange(h1) * (h0 / h1)).astype(np.int64), h0 - 1)
+    xi = np.minimum(np.floor(np.arange(w1) * (w0 / w1)).astype(np.int64), w0 - 1)
+    return a[yi][:, xi]
+
+
+def jaccard(a, b):
+    """seg_loss.py:14-29 on float32 box coordinates (torch.Tensor elements)."""
+    a = [np.float32(v) for v in a]; b = [np.float32(v) for v in b]
+    area_a = (a[2] - a[0]) * (a[3] - a[1]); area_b = (b[2] - b[0]) * (b[3] - b[1])
+    ih = max(min(a[2], b[2]) - max(a[0], b[0]), np.float32(0.))
+    iw = max(min(a[3], b[3]) - max(a[1], b[1]), np.float32(0.))
+    inter = ih * iw
+    union = area_a + area_b - inter
+    return 0. if union <= 2 else float(inter / union)
+
+
+def seg_loss(predictions, gt_masks, gt_boxes, height, width):
+    """seg_loss.py:31-96; returns a tensor or None."""
+    patches, dets = predictions
+    total, ran = 0, False
+    for i in range(len(patches)):
+        lb, n = 0, 0
+        for j, pr in enumerate(patches[i]):
+            pbox = dets[i][j][:4]
+            for g in range(gt_boxes[i].shape[0]):
+                if jaccard(pbox.numpy(), gt_boxes[i][g][:4]) >= 0.5:
+                    y1, x1, y2, x2 = pbox.numpy()
+                    y1 = max(0, int(np.int32(np.round(y1)))); x1 = max(0, int(np.int32(np.round(x1))))
+                    y2 = min(int(np.int32(np.round(y2))), height - 1); x2 = min(int(np.int32(np.round(x2))), width - 1)
+                    gm = nearest_resize(gt_masks[i][g][y1:y2, x1:x2], pr.shape[0], pr.shape[1])
+                    lb = lb + F.binary_cross_entropy(pr, torch.from_numpy(np.ascontiguousarray(gm, np.float32)))
+                    n += 1
+                    ran = True
+        if n:
+            total = total + lb / n
+    return total / len(patches) if ran else None

@@ -1,0 +1,81 @@
+"""Deterministic KGnet weight generator (TEST/BENCH INFRASTRUCTURE).
+
+w = f(key, shape, seed): the same 346-entry state_dict can be materialised in
+the reference (tools/gen_goldens.py), in the oracle and in the HIP product
+without ever committing the 296 MB of weights.  Key names/shapes follow the
+reference's state_dict (KGnet.py:125-227).
+"""
+import zlib
+import numpy as np
+
+
+def _bottleneck_layer(prefix, inplanes, planes, blocks, specs):
+    for b in range(blocks):
+        p = f"{prefix}.{b}"
+        cin = inplanes if b == 0 else planes * 4
+        specs.append((f"{p}.conv1.weight", (planes, cin, 1, 1)))
+        specs += _bn(f"{p}.bn1", planes)
+        specs.append((f"{p}.conv2.weight", (planes, planes, 3, 3)))
+        specs += _bn(f"{p}.bn2", planes)
+        specs.append((f"{p}.conv3.weight", (planes * 4, planes, 1, 1)))
+        specs += _bn(f"{p}.bn3", planes * 4)
+        if b == 0:
+            specs.append((f"{p}.downsample.0.weight", (planes * 4, cin, 1, 1)))
+            specs += _bn(f"{p}.downsample.1", planes * 4)
+
+
+def _bn(p, c):
+    return [(f"{p}.weight", (c,)), (f"{p}.bias", (c,)), (f"{p}.running_mean", (c,)),
+            (f"{p}.running_var", (c,)), (f"{p}.num_batches_tracked", ())]
+
+
+def _conv(p, cout, cin, k):
+    return [(f"{p}.weight", (cout, cin, k, k)), (f"{p}.bias", (cout,))]
+
+
+def param_specs():
+    """Ordered (key, shape) list == reference state_dict() order (346 entries)."""
+    s = [("conv1.weight", (64, 3, 7, 7))] + _bn("bn1", 64)
+    _bottleneck_layer("layer1", 64, 64, 3, s)
+    _bottleneck_layer("layer2", 256, 128, 4, s)
+    _bottleneck_layer("layer3", 512, 256, 6, s)
+    s += _conv("c0_conv.0", 64, 3, 3) + _conv("c0_conv.2", 64, 64, 3)
+    for i, (cin, cout, ccat) in enumerate([(64, 64, 128), (256, 64, 128), (512, 256, 512), (1024, 512, 1024)]):
+        s += _conv(f"skip_combine.{i}.up.0", cout, cin, 3) + _conv(f"skip_combine.{i}.cat_conv.0", cout, ccat, 1)
+    s += _conv("seg_head.0", 64, 64, 3) + _conv("seg_head.2", 1, 64, 3)
+    s += _conv("c4_up_conv.0", 512, 1024, 3) + _conv("c3_up_conv.0", 256, 512, 3)
+    s += _conv("c2_up_conv.0", 64, 256, 3) + _conv("c1_up_conv.0", 64, 64, 3)
+    s += _conv("c3_cat_refine.0", 512, 1024, 1) + _conv("c2_cat_refine.0", 256, 512, 1)
+    s += _conv("c1_cat_refine.0", 64, 128, 1) + _conv("c0_cat_refine.0", 64, 128, 1)
+    for lvl, c in [(3, 512), (2, 256), (1, 64), (0, 64)]:
+        for name, cout in [("kp", 5), ("short_offset", 10), ("mid_offset", 40)]:
+            s += _conv(f"{name}_head_c{lvl}.0", c, c, 7) + _conv(f"{name}_head_c{lvl}.2", cout, c, 7)
+    return s
+
+
+def gen_state_dict(seed=0, as_torch=True, head_bias=None):
+    """Seeded state_dict.  conv weights ~ kaiming-normal(fan_out) (KGnet.py:212-214),
+    biases/BN affine/running stats non-trivial so that every term is exercised.
+    head_bias: optional float added to the kp heads' last-layer biases."""
+    out = {}
+    for key, shape in param_specs():
+        rng = np.random.default_rng([seed, zlib.crc32(key.encode())])
+        if key.endswith("num_batches_tracked"):
+            a = np.zeros((), np.int64)
+        elif len(shape) == 4:
+            fan_out = shape[0] * shape[2] * shape[3]
+            a = rng.standard_normal(shape, dtype=np.float32) * np.float32(np.sqrt(2.0 / fan_out))
+        elif key.endswith("running_mean"):
+            a = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+        elif key.endswith("running_var"):
+            a = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif ".bn" in key or key.startswith("bn1") or "downsample.1" in key:
+            a = (rng.uniform(0.8, 1.2, shape) if key.endswith("weight")
+                 else rng.standard_normal(shape) * 0.05).astype(np.float32)
+        else:  # conv bias
+            a = rng.uniform(-0.05, 0.05, shape).astype(np.float32)
+        out[key] = a
+    if as_torch:
+        import torch
+        out = {k: torch.from_numpy(np.array(v)) for k, v in out.items()}
+    return out

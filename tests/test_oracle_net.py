@@ -1,0 +1,117 @@
+"""CPU: the torch-functional oracle (oracle/net.py) reproduces the reference network,
+seg branch and losses on the fixtures generated from the reference."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import net as onet
+from oracle import synth
+
+
+def sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def sub(t, step=3):
+    a = t.detach().numpy()
+    return a[..., ::step, ::step] if a.shape[-1] > 32 else a
+
+
+def _x(g, name):
+    N, H, W, s = [int(v) for v in g[f"{name}.cfg"]]
+    x = torch.rand(N, 3, H, W, generator=torch.Generator().manual_seed(s)) - 0.5
+    assert np.array_equal(sha(x.numpy()), g[f"{name}.x_sha"])
+    return x
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_forward_dec_eval(golden, state_dict0, name):
+    g = golden("net.npz")
+    x = _x(g, name)
+    net = onet.Net({k: v.clone() for k, v in state_dict0.items()}, training=False)
+    with torch.no_grad():
+        d0, d1, d2, d3, feats = net.forward_dec(x)
+        for l, d in enumerate((d0, d1, d2, d3)):
+            for nm, t in zip(("kp", "short", "mid"), d):
+                np.testing.assert_allclose(sub(t), g[f"{name}.eval.c{l}.{nm}"], rtol=1e-5, atol=1e-5)
+        for l, f in enumerate(feats):
+            np.testing.assert_allclose(sub(f, 5)[:, ::7], g[f"{name}.eval.feat{l}"], rtol=1e-5, atol=1e-5)
+        if name == "b":
+            boxes = [g["b.boxes0"], g["b.boxes1"]]
+            patches, dets = net.forward_seg(feats, boxes)
+            for i in range(2):
+                assert len(patches[i]) == int(g[f"b.seg.count{i}"])
+                for j, p in enumerate(patches[i]):
+                    assert p.shape == g[f"b.seg.{i}.{j}"].shape
+                    np.testing.assert_allclose(p.numpy(), g[f"b.seg.{i}.{j}"], rtol=1e-5, atol=1e-6)
+                    assert np.array_equal(dets[i][j].numpy(), g[f"b.segdet.{i}.{j}"])
+
+
+def test_detection_loss_and_grads(golden):
+    g = golden("loss.npz")
+    t = [torch.tensor(g[k], requires_grad=True) for k in ("kp", "short", "mid")]
+    l = onet.detection_loss(t, torch.from_numpy(g["gt"]))
+    assert abs(float(l) - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    l.backward()
+    for tt, k in zip(t, ("g_kp", "g_short", "g_mid")):
+        np.testing.assert_allclose(tt.grad.numpy(), g[k], rtol=1e-5, atol=1e-9)
+    l0 = onet.detection_loss([x.detach() for x in t], torch.zeros_like(torch.from_numpy(g["gt"])))
+    assert abs(float(l0) - float(g["loss_empty"])) <= 1e-6
+
+
+def test_seg_loss(golden):
+    g = golden("loss.npz")
+    patches = [[torch.from_numpy(g[f"seg.patch.{i}.{j}"]) for j in range(n)] for i, n in ((0, 2), (1, 1))]
+    dets = [[torch.from_numpy(g[f"seg.det.{i}.{j}"]) for j in range(n)] for i, n in ((0, 2), (1, 1))]
+    gm = [g["seg.gmask.0"], g["seg.gmask.1"]]
+    gb = [g["seg.gbox.0"], g["seg.gbox.1"]]
+    l = onet.seg_loss([patches, dets], gm, gb, 40, 48)
+    assert abs(float(l) - float(g["seg.loss"])) <= 1e-6
+    assert onet.seg_loss([[[patches[1][0]]], [[dets[1][0]]]], [gm[1]], [gb[1]], 40, 48) is None
+
+
+def train_inputs(g):
+    N, H, W, s = [int(v) for v in g["train.cfg"]]
+    x = torch.rand(N, 3, H, W, generator=torch.Generator().manual_seed(s)) - 0.5
+    gt_boxes, gt_masks = [], []
+    for i in range(N):
+        bx = synth.random_boxes(H, W, 4, 300 + i, 14, 30)
+        gt_boxes.append(np.concatenate([bx, np.ones((len(bx), 1))], 1).astype(np.float32))
+        m = np.zeros((len(bx), H, W), np.float32)
+        for k, b in enumerate(bx.astype(int)):
+            yy, xx = np.mgrid[0:H, 0:W]
+            cy, cx = (b[0] + b[2]) / 2, (b[1] + b[3]) / 2
+            m[k] = (((yy - cy) / ((b[2] - b[0]) / 2 + .5)) ** 2 + ((xx - cx) / ((b[3] - b[1]) / 2 + .5)) ** 2 <= 1).astype(np.float32)
+        gt_masks.append(m)
+    gt_lv = [torch.from_numpy(np.stack([synth.gt_maps(np.floor(gt_boxes[i][:, :4] / sc), H // sc, W // sc) for i in range(N)]))
+             for sc in (1, 2, 4, 8)]
+    return x, gt_boxes, gt_masks, gt_lv
+
+
+def test_train_step(golden, state_dict0):
+    g = golden("net.npz")
+    x, gt_boxes, gt_masks, gt_lv = train_inputs(g)
+    assert np.array_equal(sha(x.numpy()), g["train.x_sha"])
+    sd = {k: v.clone() for k, v in state_dict0.items()}
+    names = [str(n) for n in g["train.grad_names"]]
+    for n in names:
+        sd[n].requires_grad_(True)
+    net = onet.Net(sd, training=True)
+    d0, d1, d2, d3, pred = net.forward(x, gt_boxes)
+    l1 = [onet.detection_loss(p, t) for p, t in zip((d0, d1, d2, d3), gt_lv)]
+    l2 = onet.seg_loss(pred, gt_masks, gt_boxes, x.shape[2], x.shape[3])
+    np.testing.assert_allclose([float(v) for v in l1], g["train.loss_dec"], rtol=2e-5)
+    assert abs(float(l2) - float(g["train.loss_seg"])) <= 2e-5 * abs(float(g["train.loss_seg"]))
+    assert [len(p) for p in pred[0]] == list(g["train.npatch"])
+    (sum(l1) + l2).backward()
+    norms = np.array([float(sd[n].grad.double().norm()) for n in names])
+    np.testing.assert_allclose(norms, g["train.grad_norm"], rtol=2e-3, atol=1e-7)
+    for k in ("kp_head_c0.2.bias", "mid_offset_head_c3.2.bias", "seg_head.2.bias", "bn1.weight", "c0_conv.0.weight"):
+        ref = g[f"train.grad.{k}"]
+        np.testing.assert_allclose(sd[k].grad.numpy(), ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max())
+    for k in ("bn1.running_mean", "bn1.running_var", "layer3.5.bn3.running_mean", "layer3.5.bn3.running_var",
+              "layer2.0.downsample.1.running_var"):
+        np.testing.assert_allclose(sd[k].detach().numpy(), g[f"train.stat.{k}"], rtol=1e-4, atol=1e-6)
+    assert int(sd["bn1.num_batches_tracked"]) == int(g["train.stat.bn1.num_batches_tracked"])
