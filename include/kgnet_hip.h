@@ -1,0 +1,106 @@
+/*
+ * kgnet_hip.h -- C ABI of libkgnet_hip.so: the MI355X (gfx950) hot path of KGnet.
+ *
+ * The reference (yijingru/KG_Instance_Segmentation) has no FFI; its boundary is the Python module
+ * surface its drivers import (train.py:3-11, test.py:3-12).  The drop-in Python modules in
+ * kg_instance_segmentation_amd/ bind the entry points below with ctypes; every entry point cites the
+ * reference code it replaces.  Conventions:
+ *   - extern "C", plain pointers and sizes, no torch types.  All pointers are DEVICE pointers unless
+ *     stated otherwise; the library never allocates or retains device memory.
+ *   - every call enqueues on the caller's `stream` (a hipStream_t) and does not synchronise.
+ *   - return value: 0 = ok, otherwise kg_last_error() (thread-local) describes the failure.
+ *   - activations ("rows"): bf16, pixel-major [row][ld] (NHWC), channel counts multiples of 8.
+ *   - weights: fp32 OIHW master copies are packed to bf16 [Cout_pad][K] by kg_pack_weight.
+ */
+#ifndef KGNET_HIP_H
+#define KGNET_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* kg_last_error(void);
+int kg_version(void);
+int kg_device_arch(char* out, int cap);   /* host buffer */
+int kg_tr_probe(void* out_u16x256, void* stream);                       /* test probe: ds_read_b64_tr_b16 lane map */
+int kg_f64_probe(const double* a, const double* b, double* out5n, int n, void* stream); /* test probe: fp64 rounding */
+
+/* ---- convolution: torch.nn.Conv2d forward / input-gradient (KGnet.py:22-29, 131-209 -> F.conv2d) ----
+ * y[m][co] = act( sum_{tap,ci} x[src(m,tap)][ci] * w[co][tap][ci] + bias[co] + res[m][co] ) (* mask>0)
+ * mode 0: dense forward (H,W = input dims, OH,OW = output dims); mode 1: dense transposed = gradient w.r.t.
+ * the input of a forward conv (H,W = dY dims, OH,OW = dX dims, weights packed transposed);
+ * mode 2/3: the same on a ragged pixel list with per-row descriptors {(y<<16)|x, (h<<16)|w}.
+ * y (bf16 rows) and/or y_f32 (fp32 NCHW [N][f32_C][OH*OW]) receive the result.  tile 0 = auto. */
+int kg_conv2d_igemm(const void* x, const void* w, const float* bias, void* y, float* y_f32, const void* res,
+                    const void* mask, const int* rowdesc, int M, int H, int W, int OH, int OW, int cin_pad, int ldx,
+                    int Cout, int ldy, int ldres, int ldmask, int K, int KH, int KW, int stride, int pad, int dil,
+                    int mode, int relu, int f32_C, int tile, void* stream);
+/* fp32 OIHW parameter -> packed bf16 matrix rows (forward) or its transpose (data gradient). */
+int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad, int row0, int c0,
+                   int transposed, void* stream);
+/* weight gradient (autograd of nn.Conv2d at train.py:153): partial sums [nsplit][Cout][taps][Cin] fp32 */
+int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const int* rowdesc, int M, int H, int W, int OH, int OW,
+                    int ldx, int lddy, int Cin, int Cout, int cin_lim, int cout_lim, int KH, int KW, int stride, int pad,
+                    int dil, int mode, int nsplit, long split_stride, void* stream);
+int kg_wgrad_reduce(const float* part, float* grad_oihw, int Cout, int Cin, int KH, int KW, int nsplit, long split_stride,
+                    int accumulate, void* stream);
+int kg_bias_grad(const void* dy, float* db, float* scratch, int scratch_floats, int M, int C, int ld, int accumulate,
+                 void* stream);
+int kg_set_wgrad_tr(int use_transpose_read);   /* test switch: LDS transpose-read vs scalar fragment loads */
+
+/* ---- backbone glue: image pack, BatchNorm2d (KGnet.py:82-97,132), MaxPool2d (KGnet.py:134), bilinear
+ *      F.interpolate(align_corners=False) (KGnet.py:110,288-297), elementwise joins ---- */
+int kg_img_pack(const float* img_nchw, void* out_rows8, int N, int C, int H, int W, void* stream);
+int kg_bn_stats_train(const void* x, int ldx, int M, int C, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float momentum, float eps, float* mean_out, float* invstd_out, float* scale,
+                      float* shift, float* scratch, int scratch_floats, void* stream);
+int kg_bn_scale_shift_eval(int C, const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, float eps, float* scale, float* shift, void* stream);
+int kg_bn_apply(const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldres, void* y,
+                int ldy, int M, int C, int relu, void* stream);
+int kg_bn_bwd(const void* x, int ldx, const void* dy, int lddy, const float* gamma, const float* mean,
+              const float* invstd, float* dgamma, float* dbeta, int accumulate, void* dx, int lddx, int M, int C,
+              float* scratch, int scratch_floats, void* stream);
+int kg_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, void* stream);
+int kg_maxpool3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C,
+                      void* stream);
+int kg_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int IH, int IW, int OH, int OW, int C,
+                    const int* boxdesc, const int* row2box, long total_out_rows, void* stream);
+int kg_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int IH, int IW, int OH, int OW, int C,
+                    const int* boxdesc, const int* row2box, long total_in_rows, void* stream);
+int kg_add_rows(const void* a, int lda, const void* b, int ldb, const void* mask, int ldm, void* y, int ldy, long M,
+                int C, void* stream);
+int kg_sigmoid_inplace(float* x, long n, void* stream);                              /* torch.sigmoid, KGnet.py:300,345 */
+int kg_grad_pack(const float* g_nchw, const float* prob, void* out_rows, int N, int C, int H, int W, int ld, int cpad,
+                 void* stream);
+
+/* ---- losses: DetectionLossAll (loss.py:12-49) and the per-pair mask BCE of SEG_loss (seg_loss.py:86-94) ---- */
+int kg_detection_loss_fwd(const float* kp, const float* sh, const float* md, const float* gt, int N, int H, int W,
+                          float kp_radius, const float* den_override, float* scratch, int scratch_floats, float* out8,
+                          void* stream);
+int kg_detection_loss_bwd(const float* kp, const float* sh, const float* md, const float* gt, int N, int H, int W,
+                          float kp_radius, const float* fin8, const float* grad_out, float* g_kp, float* g_sh,
+                          float* g_md, void* stream);
+int kg_seg_loss(const float* prob, const void* tgt_u8, const int* patches, const void* pairs, int npatches, float* part,
+                float* out1, const float* grad_out, float* gprob, void* stream);
+
+/* ---- post-processing in float64, bit-identical to postprocessing.py:16-261 and nms.py:4-53 ---- */
+long kg_postproc_workspace_bytes(int H, int W, int peak_cap, int skel_cap);
+int kg_postproc_scale(const float* kp, const float* soff, const float* mid, int H, int W, double thresh, void* ws,
+                      long ws_bytes, int peak_cap, int skel_cap, double* skel, int* nskel, double* heat_out,
+                      double* blur_out, int* peaks_out, double* peak_conf_out, int* npeaks_out, void* stream);
+int kg_skeleton_boxes(const double* skel, const int* nskel, int skel_cap, double scale, int do_refine, double* boxes,
+                      int* nbox, int box_cap, void* stream);
+int kg_nms(const double* boxes, const int* nbox, int box_cap, double thresh, void* ws, long ws_bytes, double* out,
+           int* nkeep, void* stream);
+
+/* ---- per-box segmentation branch (KGnet.py:246-267, 321-350): ragged row bookkeeping ---- */
+int kg_seg_build_rows(const int* boxtab8, int nb, int* rowdesc, int* row2box, int* srcrow, void* stream);
+int kg_rows_gather(const void* src, int ldsrc, const int* srcrow, void* dst, int lddst, long nrows, int C, void* stream);
+int kg_rows_scatter_add(const void* g, int ld, const int* srcrow, float* acc, int C, long nrows, int accld, void* stream);
+int kg_f32_to_bf16_rows(const float* acc, void* out, int C, long rows, int ldout, const void* addto, int ldadd,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

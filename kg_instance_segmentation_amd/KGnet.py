@@ -1,0 +1,169 @@
+"""Drop-in replacement of the reference's `KGnet` module (KGnet.py) backed by hand-written HIP kernels.
+
+Same surface as the reference: `resnet50(pretrained)` returns an `nn.Module` whose
+`state_dict()` has the reference's 346 keys/shapes (fp32 OIHW master weights), and which supports
+  forward(x, bboxes)            KGnet.py:269-272
+  forward_dec(x)                KGnet.py:275-318
+  forward_seg(feat_seg, bboxes) KGnet.py:321-350
+with autograd (`loss.backward()` fills `.grad` of all parameters).  There is no PyTorch/CPU fallback
+for the arithmetic: a missing libkgnet_hip.so or a non-GPU tensor raises.
+
+Numerics: convolutions run on bf16 MFMA with fp32 accumulation over bf16 activations; head maps are
+exported as fp32 NCHW, feature maps c0..c4 as bf16 NCHW-shaped channels-last views (they are only
+ever fed back into forward_seg).
+"""
+import math
+import os
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import arch, _lib
+from .engine import Engine
+from .seg import SegBranch
+
+__all__ = ["ResNet", "resnet50", "resnet101", "resnet152"]
+
+
+class _Node(nn.Module):
+    """Pure container so that parameter keys match the reference's dotted names."""
+
+
+class _DecFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        eng = model._engine
+        record = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        maps, feats, dims = eng.forward_dec(x, record)
+        N = x.shape[0]
+        outs = list(maps)
+        for fv, (h, w) in zip(feats, dims):
+            outs.append(fv.t.view(N, h, w, fv.C).permute(0, 3, 1, 2))
+        ctx.model, ctx.recorded = model, record
+        ctx.keys = model._param_keys
+        ctx.mark_non_differentiable()
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if not ctx.recorded:
+            raise RuntimeError("KGnet forward was run without gradient recording")
+        eng = ctx.model._engine
+        fg = []
+        for g in grads[12:]:
+            if g is None:
+                fg.append(None)
+            else:
+                n, c, h, w = g.shape
+                fg.append(g.permute(0, 2, 3, 1).reshape(n * h * w, c).to(torch.bfloat16).contiguous())
+        pg = eng.backward_dec(list(grads[:12]), fg)
+        out = [None, None]
+        for k in ctx.keys:
+            out.append(pg.get(k))
+        return tuple(out)
+
+
+class ResNet(nn.Module):
+    """KGnet (ResNet-50[:layer3] + top-down decoder + 12 heads + per-box seg branch)."""
+
+    def __init__(self, block=None, layers=(3, 4, 6, 3), num_classes=1000, zero_init_residual=False):
+        super().__init__()
+        if tuple(layers[:3]) != (3, 4, 6):
+            raise NotImplementedError("only the Bottleneck [3,4,6,*] trunk used by the reference drivers is built "
+                                      "(KGnet.py:135-137 uses layers[0..2] only)")
+        self._param_keys = []
+        for key, shape, kind in arch.state_spec():
+            parts = key.split(".")
+            node = self
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _Node())
+                node = node._modules[p]
+            if kind == "conv_w":
+                t = torch.empty(shape)
+                nn.init.kaiming_normal_(t, mode="fan_out", nonlinearity="relu")  # KGnet.py:212-214
+                node.register_parameter(parts[-1], nn.Parameter(t))
+            elif kind == "conv_b":
+                fan_in = None
+                w = node._parameters["weight"]
+                fan_in = w.shape[1] * w.shape[2] * w.shape[3]
+                bound = 1.0 / math.sqrt(fan_in)
+                node.register_parameter(parts[-1], nn.Parameter(torch.empty(shape).uniform_(-bound, bound)))
+            elif kind == "bn_w":
+                node.register_parameter(parts[-1], nn.Parameter(torch.ones(shape)))
+            elif kind == "bn_b":
+                node.register_parameter(parts[-1], nn.Parameter(torch.zeros(shape)))
+            elif kind == "bn_rm":
+                node.register_buffer(parts[-1], torch.zeros(shape))
+            elif kind == "bn_rv":
+                node.register_buffer(parts[-1], torch.ones(shape))
+            else:
+                node.register_buffer(parts[-1], torch.tensor(0, dtype=torch.long))
+            if kind in ("conv_w", "conv_b", "bn_w", "bn_b"):
+                self._param_keys.append(key)
+        if zero_init_residual:
+            for name, _, _, blocks, _ in arch.LAYERS:
+                for b in range(blocks):
+                    nn.init.constant_(self.get_tensor(f"{name}.{b}.bn3.weight"), 0)
+        self._engine = Engine(self)
+        self._seg = SegBranch(self)
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    def get_tensor(self, key):
+        parts = key.split(".")
+        node = self
+        for p in parts[:-1]:
+            node = node._modules[p]
+        t = node._parameters.get(parts[-1])
+        return t if t is not None else node._buffers[parts[-1]]
+
+    def _check_input(self, x):
+        if not x.is_cuda:
+            raise _lib.KGLibraryError("KGnet (MI355X build) runs on the GPU only: input tensor is on %s" % x.device)
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("expected an [N,3,H,W] image batch")
+        if x.shape[2] % 8 or x.shape[3] % 8:
+            raise ValueError("input height/width must be multiples of 8 (4 pyramid levels, SURVEY 5)")
+        _lib.load()
+
+    # ---- reference API ----------------------------------------------------------------------------
+    def forward_dec(self, x):
+        self._check_input(x)
+        params = [self.get_tensor(k) for k in self._param_keys]
+        outs = _DecFunction.apply(self, x, *params)
+        d = [list(outs[3 * i:3 * i + 3]) for i in range(4)]
+        return d[0], d[1], d[2], d[3], list(outs[12:17])
+
+    def forward_seg(self, feat_seg, bboxes):
+        return self._seg.forward(feat_seg, bboxes)
+
+    def forward(self, x, bboxes):
+        dec0, dec1, dec2, dec3, feat_seg = self.forward_dec(x)
+        seg = self.forward_seg(feat_seg, bboxes)
+        return dec0, dec1, dec2, dec3, seg
+
+
+def _load_pretrained(model):
+    """The reference downloads torchvision's ImageNet ResNet-50 (KGnet.py:384-385, strict=False).
+    Offline, a local checkpoint can be supplied through KG_RESNET50_PTH; otherwise warn and keep the init."""
+    path = os.environ.get("KG_RESNET50_PTH")
+    if path and os.path.exists(path):
+        model.load_state_dict(torch.load(path, map_location="cpu"), strict=False)
+    else:
+        warnings.warn("pretrained=True: no network access and KG_RESNET50_PTH is not set; keeping the random init")
+
+
+def resnet50(pretrained=False, **kwargs):
+    model = ResNet(None, [3, 4, 6, 3], **kwargs)
+    if pretrained:
+        _load_pretrained(model)
+    return model
+
+
+def resnet101(pretrained=False, **kwargs):
+    raise NotImplementedError("the reference drivers hard-code resnet50 (train.py:35, test.py:53, eval.py:30)")
+
+
+resnet152 = resnet101

@@ -1,0 +1,96 @@
+"""ctypes binding of libkgnet_hip.so (the C ABI declared in include/kgnet_hip.h).
+
+The product path has NO fallback: if the HIP library is missing, or a call fails, this module
+raises.  Nothing here imports oracle/ or any CPU implementation of the hot path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkgnet_hip.so")
+
+c_int, c_long, c_float, c_double, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
+P = c_void_p
+
+# name -> argtypes (restype is int status unless listed in _RESTYPE)
+_SIGS = {
+    "kg_version": [],
+    "kg_device_arch": [ctypes.c_char_p, c_int],
+    "kg_tr_probe": [P, P],
+    "kg_conv2d_igemm": [P, P, P, P, P, P, P, P] + [c_int] * 21 + [P],
+    "kg_pack_weight": [P, P] + [c_int] * 9 + [P],
+    "kg_set_wgrad_tr": [c_int],
+    "kg_conv2d_wgrad": [P, P, P, P] + [c_int] * 18 + [c_long, P],
+    "kg_wgrad_reduce": [P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, P],
+    "kg_bias_grad": [P, P, P, c_int, c_int, c_int, c_int, c_int, P],
+    "kg_img_pack": [P, P, c_int, c_int, c_int, c_int, P],
+    "kg_bn_stats_train": [P, c_int, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P, c_int, P],
+    "kg_bn_scale_shift_eval": [c_int, P, P, P, P, c_float, P, P, P],
+    "kg_bn_apply": [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P],
+    "kg_bn_bwd": [P, c_int, P, c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_int, P, c_int, P],
+    "kg_maxpool3s2_fwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P],
+    "kg_maxpool3s2_bwd": [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P],
+    "kg_bilinear_fwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_long, P],
+    "kg_bilinear_bwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_long, P],
+    "kg_add_rows": [P, c_int, P, c_int, P, c_int, P, c_int, c_long, c_int, P],
+    "kg_detection_loss_fwd": [P, P, P, P, c_int, c_int, c_int, c_float, P, P, c_int, P, P],
+    "kg_detection_loss_bwd": [P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, P, P, P],
+    "kg_seg_loss": [P, P, P, P, c_int, P, P, P, P, P],
+    "kg_sigmoid_inplace": [P, c_long, P],
+    "kg_grad_pack": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "kg_postproc_workspace_bytes": [c_int, c_int, c_int, c_int],
+    "kg_postproc_scale": [P, P, P, c_int, c_int, c_double, P, c_long, c_int, c_int, P, P, P, P, P, P, P, P],
+    "kg_skeleton_boxes": [P, P, c_int, c_double, c_int, P, P, c_int, P],
+    "kg_nms": [P, P, c_int, c_double, P, c_long, P, P, P],
+    "kg_f64_probe": [P, P, P, c_int, P],
+    "kg_seg_build_rows": [P, c_int, P, P, P, P],
+    "kg_rows_gather": [P, c_int, P, P, c_int, c_long, c_int, P],
+    "kg_rows_scatter_add": [P, c_int, P, P, c_int, c_long, c_int, P],
+    "kg_f32_to_bf16_rows": [P, P, c_int, c_long, c_int, P, c_int, P],
+}
+_RESTYPE = {"kg_postproc_workspace_bytes": c_long}
+SYMBOLS = tuple(_SIGS) + ("kg_last_error",)
+
+_lib = None
+
+
+class KGLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the HIP library; raises KGLibraryError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KGLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m kg_instance_segmentation_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the KGnet hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.kg_last_error.restype = ctypes.c_char_p
+    lib.kg_last_error.argtypes = []
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError => ABI drift, surface it
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Calls a status-returning entry point and raises on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise KGLibraryError(f"{name} failed ({rc}): {lib.kg_last_error().decode()}")
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else c_void_p(t.data_ptr())

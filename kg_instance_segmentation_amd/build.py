@@ -1,0 +1,69 @@
+"""Builds kg_instance_segmentation_amd/libkgnet_hip.so for gfx950 with hipcc (in-tree, no JIT cache).
+
+    python -m kg_instance_segmentation_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  postproc.hip is compiled with -ffp-contract=off (its float64
+arithmetic must round exactly like the reference's NumPy operations).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libkgnet_hip.so")
+SOURCES = {
+    "api.hip": [],
+    "conv_igemm.hip": [],
+    "conv_wgrad.hip": [],
+    "norm_pool.hip": [],
+    "loss.hip": [],
+    "postproc.hip": ["-ffp-contract=off"],
+    "seg.hip": [],
+}
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(out, deps):
+    return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hdr = os.path.join(CSRC, "kg_common.h")
+    jobs = []
+    for src, extra in SOURCES.items():
+        s = os.path.join(CSRC, src)
+        if not os.path.exists(s):
+            continue
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if force or _stale(o, [s, hdr, __file__]):
+            jobs.append((s, o, [HIPCC] + FLAGS + extra + ["-c", s, "-o", o]))
+
+    def run(job):
+        s, o, cmd = job
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr}")
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for warn in ex.map(run, jobs):
+            if warn and verbose:
+                print(warn)
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

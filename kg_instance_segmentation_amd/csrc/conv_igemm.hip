@@ -1,0 +1,324 @@
+// conv_igemm.hip -- bf16 MFMA implicit-GEMM convolution for gfx950 (forward and data-gradient).
+//
+// Replaces the torch conv2d calls on KGnet's hot path (reference KGnet.py:22-29, 131-209 via
+// torch.nn.Conv2d -> cuDNN/MIOpen).  One kernel family:
+//   D[cout][pixel] = sum_k  Wp[cout][k] * Xg[pixel][k],   k = (tap, cin)
+// with the weights as the MFMA "A" operand and the gathered NHWC pixels as "B", so that each lane
+// ends up owning 4*CF consecutive output channels of one pixel (wide NHWC stores).
+//   * activations: bf16, pixel-major rows [row][ld] (NHWC), 16-byte channel chunks
+//   * weights: pre-packed bf16 [Cout_pad][K], K = ntaps*cin_pad (see pack kernels below)
+//   * accumulation: fp32 in MFMA accumulators (v_mfma_f32_16x16x32_bf16)
+//   * LDS: [sub-step][row][32 k] tiles, XOR-swizzled 16-byte slots -> conflict-free ds_read_b128
+//   * epilogue: bias, residual add, ReLU, ReLU-mask (for dgrad), bf16 NHWC and/or fp32 NCHW store
+#include "kg_common.h"
+
+struct ConvArgs {
+    const bf16_t* x; const bf16_t* w; const float* bias;
+    bf16_t* y; float* y_f32; const bf16_t* res; const bf16_t* mask; const int2* rowdesc;
+    int M, H, W, OH, OW;
+    int ldx, ldy, ldres, ldmask;
+    int Cout, K, cpt, cpt_magic, ntaps, KW, stride_log2, pad, dil;
+    int mode;  // 0 dense forward, 1 dense transposed (dgrad), 2 ragged (+), 3 ragged transposed (-)
+    int relu, f32_C;
+};
+
+__device__ __forceinline__ int fperm(int q) { return (4 - q) & 3; }
+
+template <int WC, int WP, int CF, int KS>
+__global__ __launch_bounds__(WC* WP * 64) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int TC = WC * CF * 16, TP = WP * 64, NT = WC * WP * 64;
+    constexpr int XPT = TP * 4 / NT;
+    constexpr int WPT = (TC * 4 + NT - 1) / NT;
+    constexpr int LOG_CF = CF == 4 ? 2 : (CF == 2 ? 1 : 0);
+    constexpr int W_BYTES = KS * TC * 64, X_BYTES = KS * TP * 64, BUF_BYTES = W_BYTES + X_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* taptab = (int*)(smem + 2 * BUF_BYTES);  // [64] packed (dy<<16)|(dx&0xffff), already *dil - pad
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave / WP, wp = wave % WP;
+    const int m0 = blockIdx.x * TP, c0 = blockIdx.y * TC;
+
+    if (tid < 64) {
+        int t = tid, dy = t / a.KW, dx = t - dy * a.KW;
+        int oy = dy * a.dil - a.pad, ox = dx * a.dil - a.pad;
+        taptab[t] = (oy << 16) | (ox & 0xffff);
+    }
+
+    // ---- per-thread staging assignment --------------------------------------------------
+    const int slot = tid & 3;
+    const int xrow0 = tid >> 2;                                // + (NT/4)*i
+    const int xchunk = slot ^ fperm((xrow0 >> 2) & 3);         // logical k-chunk this thread fetches
+    const int wrow0 = tid >> 2;
+    const int wchunk = slot ^ fperm((wrow0 >> (2 + LOG_CF)) & 3);
+    int py[XPT], px[XPT], pbase[XPT];  // output coords / row base; pbase<0 => row out of range
+    int ph[XPT], pw[XPT];
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        int m = m0 + xrow0 + (NT / 4) * i;
+        if (m >= a.M) { pbase[i] = -1; py[i] = px[i] = 0; ph[i] = pw[i] = 0; continue; }
+        if (a.mode >= 2) {
+            int2 d = a.rowdesc[m];
+            py[i] = d.x >> 16; px[i] = d.x & 0xffff; ph[i] = d.y >> 16; pw[i] = d.y & 0xffff; pbase[i] = m;
+        } else {
+            int ohw = a.OH * a.OW;
+            int n = m / ohw, rem = m - n * ohw;
+            int oy = rem / a.OW, ox = rem - oy * a.OW;
+            py[i] = oy; px[i] = ox; pbase[i] = n * a.H * a.W; ph[i] = a.H; pw[i] = a.W;
+        }
+    }
+    __syncthreads();
+
+    uint4 xr[KS][XPT], wr[KS][WPT];
+    const int nk = a.K / (32 * KS);
+    const int smask = (1 << a.stride_log2) - 1;
+
+    auto load_tiles = [&](int kk) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int q = (kk * KS + s) * 4 + xchunk;
+            int tap = (q * a.cpt_magic) >> 16;
+            const int cc = q - tap * a.cpt;
+            const bool tapok = tap < a.ntaps;
+            tap = tap < 63 ? tap : 63;
+            const int tt = taptab[tap];
+            const int dy = tt >> 16, dx = (int)(short)(tt & 0xffff);
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (tapok && pbase[i] >= 0) {
+                    int iy, ix; bool ok; long row;
+                    if (a.mode == 0) {
+                        iy = (py[i] << a.stride_log2) + dy; ix = (px[i] << a.stride_log2) + dx;
+                        ok = (unsigned)iy < (unsigned)ph[i] && (unsigned)ix < (unsigned)pw[i];
+                        row = (long)pbase[i] + (long)iy * pw[i] + ix;
+                    } else if (a.mode == 1) {
+                        int ty = py[i] - dy, tx = px[i] - dx;
+                        ok = ty >= 0 && tx >= 0 && ((ty | tx) & smask) == 0;
+                        iy = ty >> a.stride_log2; ix = tx >> a.stride_log2;
+                        ok = ok && iy < ph[i] && ix < pw[i];
+                        row = (long)pbase[i] + (long)iy * pw[i] + ix;
+                    } else {
+                        int sy = a.mode == 2 ? dy : -dy, sx = a.mode == 2 ? dx : -dx;
+                        iy = py[i] + sy; ix = px[i] + sx;
+                        ok = (unsigned)iy < (unsigned)ph[i] && (unsigned)ix < (unsigned)pw[i];
+                        row = (long)pbase[i] + (long)sy * pw[i] + sx;
+                    }
+                    if (ok) v = *reinterpret_cast<const uint4*>(a.x + row * a.ldx + cc * 8);
+                }
+                xr[s][i] = v;
+            }
+            const int qw = (kk * KS + s) * 4 + wchunk;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                int r = wrow0 + (NT / 4) * i;
+                if (TC * 4 >= NT || r < TC)
+                    wr[s][i] = *reinterpret_cast<const uint4*>(a.w + (long)(c0 + r) * a.K + qw * 8);
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        unsigned char* sw = smem + buf * BUF_BYTES;
+        unsigned char* sx = sw + W_BYTES;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int i = 0; i < XPT; ++i)
+                *reinterpret_cast<uint4*>(sx + s * TP * 64 + (xrow0 + (NT / 4) * i) * 64 + slot * 16) = xr[s][i];
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                int r = wrow0 + (NT / 4) * i;
+                if (TC * 4 >= NT || r < TC)
+                    *reinterpret_cast<uint4*>(sw + s * TC * 64 + r * 64 + slot * 16) = wr[s][i];
+            }
+        }
+    };
+
+    f32x4 acc[CF][4];
+#pragma unroll
+    for (int i = 0; i < CF; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addressing (constant over k)
+    const int lm = lane & 15, g = lane >> 4;
+    int a_off[CF], b_off[4];
+#pragma unroll
+    for (int i = 0; i < CF; ++i) {
+        int r = wc * CF * 16 + (lm >> 2) * (4 * CF) + i * 4 + (lm & 3);
+        a_off[i] = r * 64 + ((g ^ fperm((r >> (2 + LOG_CF)) & 3)) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int r = wp * 64 + j * 16 + lm;
+        b_off[j] = r * 64 + ((g ^ fperm((r >> 2) & 3)) * 16);
+    }
+
+    load_tiles(0);
+    for (int kk = 0; kk < nk; ++kk) {
+        const int buf = kk & 1;
+        store_tiles(buf);
+        __syncthreads();
+        if (kk + 1 < nk) load_tiles(kk + 1);
+        const unsigned char* sw = smem + buf * BUF_BYTES;
+        const unsigned char* sx = sw + W_BYTES;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 af[CF], bfr[4];
+#pragma unroll
+            for (int i = 0; i < CF; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sw + s * TC * 64 + a_off[i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sx + s * TP * 64 + b_off[j]);
+#pragma unroll
+            for (int i = 0; i < CF; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------
+    constexpr int NV = 4 * CF;
+    const int cb = c0 + wc * CF * 16 + g * NV;  // first output channel of this lane
+    if (cb >= a.Cout) return;
+    const bool full = cb + NV <= a.Cout;
+    float bv[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+    const int ohw = a.OH * a.OW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wp * 64 + j * 16 + lm;
+        if (m >= a.M) continue;
+        float v[NV];
+#pragma unroll
+        for (int i = 0; i < CF; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bv[i * 4 + r];
+        if (a.res) {
+            const bf16_t* rp = a.res + (long)m * a.ldres + cb;
+#pragma unroll
+            for (int e = 0; e < NV; ++e)
+                if (full || cb + e < a.Cout) v[e] += bf2f(rp[e]);
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if (a.mask) {
+            const bf16_t* mp = a.mask + (long)m * a.ldmask + cb;
+#pragma unroll
+            for (int e = 0; e < NV; ++e)
+                if (full || cb + e < a.Cout) v[e] = bf2f(mp[e]) > 0.f ? v[e] : 0.f;
+        }
+        if (a.y) {
+            bf16_t* yp = a.y + (long)m * a.ldy + cb;
+            if (full && ((reinterpret_cast<uintptr_t>(yp) & 7) == 0)) {
+#pragma unroll
+                for (int i = 0; i < CF; ++i) {
+                    uint2 pk = make_uint2(pack2bf(v[i * 4], v[i * 4 + 1]), pack2bf(v[i * 4 + 2], v[i * 4 + 3]));
+                    *reinterpret_cast<uint2*>(yp + i * 4) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < NV; ++e)
+                    if (cb + e < a.Cout) yp[e] = f2bf(v[e]);
+            }
+        }
+        if (a.y_f32) {
+            const int n = m / ohw, pix = m - n * ohw;
+#pragma unroll
+            for (int e = 0; e < NV; ++e)
+                if (cb + e < a.Cout) a.y_f32[((long)n * a.f32_C + cb + e) * ohw + pix] = v[e];
+        }
+    }
+}
+
+template <int WC, int WP, int CF, int KS>
+static int launch_cfg(const ConvArgs& a, hipStream_t st) {
+    constexpr int TC = WC * CF * 16, TP = WP * 64, NT = WC * WP * 64;
+    constexpr int smem = 2 * (KS * TC * 64 + KS * TP * 64) + 256;
+    static bool attr_done = false;
+    if (!attr_done) {
+        KG_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<WC, WP, CF, KS>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    dim3 grid(kg_cdiv(a.M, TP), kg_cdiv(a.Cout, TC));
+    hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, CF, KS>), grid, dim3(NT), smem, st, a);
+    KG_CHECK_LAUNCH("conv_igemm");
+    return KG_OK;
+}
+
+static int magic_for(int cpt, int qmax, int* magic) {
+    int mg = (65536 + cpt - 1) / cpt;
+    for (int q = 0; q <= qmax; ++q)
+        if (((q * mg) >> 16) != q / cpt) return 0;
+    *magic = mg;
+    return 1;
+}
+
+extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, void* y, float* y_f32,
+                               const void* res, const void* mask, const int* rowdesc, int M, int H, int W,
+                               int OH, int OW, int cin_pad, int ldx, int Cout, int ldy, int ldres, int ldmask,
+                               int K, int KH, int KW, int stride, int pad, int dil, int mode, int relu,
+                               int f32_C, int tile, void* stream) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    KG_CHECK_ARG(x && w && (y || y_f32), "kg_conv2d_igemm: null pointer");
+    KG_CHECK_ARG(cin_pad > 0 && cin_pad % 8 == 0 && ldx % 8 == 0, "kg_conv2d_igemm: cin_pad/ldx must be multiples of 8 (got %d, %d)", cin_pad, ldx);
+    KG_CHECK_ARG(K % 64 == 0 && K >= KH * KW * cin_pad, "kg_conv2d_igemm: K=%d must be a multiple of 64 and >= taps*cin_pad=%d", K, KH * KW * cin_pad);
+    KG_CHECK_ARG(KH * KW <= 49 && KH * KW >= 1, "kg_conv2d_igemm: at most 49 taps");
+    KG_CHECK_ARG(stride == 1 || stride == 2, "kg_conv2d_igemm: stride must be 1 or 2");
+    KG_CHECK_ARG(mode >= 0 && mode <= 3, "kg_conv2d_igemm: bad mode");
+    KG_CHECK_ARG(mode < 2 || (rowdesc && stride == 1), "kg_conv2d_igemm: ragged mode needs rowdesc and stride 1");
+    KG_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0, "kg_conv2d_igemm: x/w must be 16-byte aligned");
+    KG_CHECK_ARG(M > 0 && Cout > 0, "kg_conv2d_igemm: empty problem");
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.y_f32 = y_f32;
+    a.res = (const bf16_t*)res; a.mask = (const bf16_t*)mask; a.rowdesc = (const int2*)rowdesc;
+    a.M = M; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.ldx = ldx; a.ldy = ldy; a.ldres = ldres; a.ldmask = ldmask;
+    a.Cout = Cout; a.K = K; a.cpt = cin_pad / 8; a.ntaps = KH * KW; a.KW = KW;
+    a.stride_log2 = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil; a.mode = mode; a.relu = relu; a.f32_C = f32_C;
+    KG_CHECK_ARG(magic_for(a.cpt, K / 8, &a.cpt_magic), "kg_conv2d_igemm: no exact magic divisor for cpt=%d", a.cpt);
+    hipStream_t st = (hipStream_t)stream;
+    // tile: 0 auto; 1 = 16 couts x 256 px; 2 = 32 x 256; 3 = 64 x 256; 4 = 128 x 128; 5 = 64 x 128
+    if (tile == 0) tile = Cout <= 16 ? 1 : (Cout <= 32 ? 2 : (Cout <= 64 ? 3 : 4));
+    switch (tile) {
+        case 1: return launch_cfg<1, 4, 1, 2>(a, st);
+        case 2: return launch_cfg<1, 4, 2, 2>(a, st);
+        case 3: return launch_cfg<1, 4, 4, 2>(a, st);
+        case 4: return launch_cfg<2, 2, 4, 2>(a, st);
+        case 5: return launch_cfg<1, 2, 4, 2>(a, st);
+        default: kg_set_error("kg_conv2d_igemm: bad tile %d", tile); return KG_ERR_ARG;
+    }
+}
+
+// ---- weight packing ---------------------------------------------------------------------------
+// fp32 OIHW [Cout][Cin][KH][KW] -> bf16 rows of a packed matrix.
+//  transposed == 0 (forward):  dst[(row0+co)*K + tap*cin_pad + c0 + ci]         = w[co][ci][tap]
+//  transposed == 1 (dgrad):    dst[(row0+ci)*K + tap*cin_pad + c0 + co]         = w[co][ci][tap]
+// Padding entries must have been zeroed by the caller (hipMemsetAsync once at plan time).
+__global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int Cout, int Cin,
+                                   int taps, int K, int cin_pad, int row0, int c0, int transposed) {
+    long total = (long)Cout * Cin * taps;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int tap = (int)(i % taps);
+        long r = i / taps;
+        int ci = (int)(r % Cin), co = (int)(r / Cin);
+        float v = w[i];
+        long d = transposed ? ((long)(row0 + ci) * K + (long)tap * cin_pad + c0 + co)
+                            : ((long)(row0 + co) * K + (long)tap * cin_pad + c0 + ci);
+        dst[d] = f2bf(v);
+    }
+}
+
+extern "C" int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad,
+                              int row0, int c0, int transposed, void* stream) {
+    KG_CHECK_ARG(w && dst, "kg_pack_weight: null pointer");
+    long total = (long)Cout * Cin * KH * KW;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, Cout,
+                       Cin, KH * KW, K, cin_pad, row0, c0, transposed);
+    KG_CHECK_LAUNCH("pack_weight");
+    return KG_OK;
+}

@@ -1,0 +1,263 @@
+// conv_wgrad.hip -- bf16 MFMA weight-gradient convolution for gfx950.
+//
+// Replaces autograd's conv weight-gradient on KGnet's hot path (reference train.py:153
+// loss.backward() through the nn.Conv2d layers of KGnet.py).
+//   dW[co][tap][ci] = sum_pixels dY[pixel][co] * X[src(pixel, tap)][ci]
+// The reduction dimension is the pixel index, which is the strided dimension of both NHWC
+// operands; the [pixel][channel] tiles are staged in LDS as they lie in memory and the MFMA
+// fragments are fetched with the gfx950 transpose read (ds_read_b64_tr_b16).
+// One block = (64 co) x (64 ci) x one tap x one pixel split; partial sums go to a
+// [split][co][tap][ci] fp32 buffer reduced (deterministically) by kg_wgrad_reduce.
+#include "kg_common.h"
+
+struct WgradArgs {
+    const bf16_t* x; const bf16_t* dy; float* dwp; const int2* rowdesc;
+    int M, H, W, OH, OW, ldx, lddy;
+    int Cin, Cout;          // real channel counts (output bounds)
+    int cin_lim, cout_lim;  // readable channels (multiples of 8) in x / dy rows
+    int ntaps, KW, stride_log2, pad, dil, mode;
+    int chunks_per_split;   // 64-pixel chunks per z-split
+    long split_stride;      // elements between partial buffers
+};
+
+__device__ __forceinline__ int tr_f(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); }
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+template <bool USE_TR>
+__device__ __forceinline__ bf16x8 load_tr_frag(const unsigned char* tile, int p0, int cf0, int lane) {
+    // fragment for an MFMA operand: "row" = channel cf0*16 + (lane&15), k = pixel p0 + (lane>>4)*8 + j
+    const int i = lane & 15, G = lane >> 4;
+    bf16x8 out;
+    if (USE_TR) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int r = p0 + G * 8 + h * 4 + (i >> 2);
+            int off = r * 128 + ((cf0 ^ tr_f(r)) * 32) + (i & 3) * 8;
+            bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + off));
+            out[h * 4 + 0] = v[0]; out[h * 4 + 1] = v[1]; out[h * 4 + 2] = v[2]; out[h * 4 + 3] = v[3];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int r = p0 + G * 8 + j;
+            int off = r * 128 + ((cf0 ^ tr_f(r)) * 32) + i * 2;
+            out[j] = *reinterpret_cast<const __bf16*>(tile + off);
+        }
+    }
+    return out;
+}
+
+template <bool USE_TR>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * 8192];  // [buf][dy | x][64 px][128 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wco = wave >> 1, wci = wave & 1;
+    const int n_ci_tiles = (a.cin_lim + 63) / 64;
+    const int ci0 = (blockIdx.x % n_ci_tiles) * 64, co0 = (blockIdx.x / n_ci_tiles) * 64;
+    const int tap = blockIdx.y, split = blockIdx.z;
+    const int tdy = tap / a.KW, tdx = tap - tdy * a.KW;
+    const int d_y = tdy * a.dil - a.pad, d_x = tdx * a.dil - a.pad;
+
+    const int c8 = tid & 7;       // 16-byte channel chunk within the 64-channel tile
+    const int prow = tid >> 3;    // + 32*i
+    const bool x_c_ok = ci0 + c8 * 8 < a.cin_lim;
+    const bool y_c_ok = co0 + c8 * 8 < a.cout_lim;
+    const int ohw = a.OH * a.OW;
+
+    uint4 xr[2], yr[2];
+    auto load_chunk = [&](int chunk) {
+        const int mbase = chunk * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mbase + prow + 32 * i;
+            uint4 xv = make_uint4(0, 0, 0, 0), yv = make_uint4(0, 0, 0, 0);
+            if (m < a.M) {
+                if (y_c_ok) yv = *reinterpret_cast<const uint4*>(a.dy + (long)m * a.lddy + co0 + c8 * 8);
+                if (x_c_ok) {
+                    long row; bool ok;
+                    if (a.mode >= 2) {
+                        int2 d = a.rowdesc[m];
+                        int y = (d.x >> 16) + d_y, x = (d.x & 0xffff) + d_x, h = d.y >> 16, w = d.y & 0xffff;
+                        ok = (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
+                        row = (long)m + (long)d_y * w + d_x;
+                    } else {
+                        int n = m / ohw, rem = m - n * ohw;
+                        int oy = rem / a.OW, ox = rem - oy * a.OW;
+                        int iy = (oy << a.stride_log2) + d_y, ix = (ox << a.stride_log2) + d_x;
+                        ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                        row = ((long)n * a.H + iy) * a.W + ix;
+                    }
+                    if (ok) xv = *reinterpret_cast<const uint4*>(a.x + row * a.ldx + ci0 + c8 * 8);
+                }
+            }
+            xr[i] = xv; yr[i] = yv;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        unsigned char* sy = smem + buf * 16384;
+        unsigned char* sx = sy + 8192;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r = prow + 32 * i;
+            int off = r * 128 + (((c8 >> 1) ^ tr_f(r)) * 32) + (c8 & 1) * 16;
+            *reinterpret_cast<uint4*>(sy + off) = yr[i];
+            *reinterpret_cast<uint4*>(sx + off) = xr[i];
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int total_chunks = (a.M + 63) / 64;
+    const int cbeg = split * a.chunks_per_split;
+    int cend = cbeg + a.chunks_per_split;
+    if (cend > total_chunks) cend = total_chunks;
+
+    if (cbeg < cend) load_chunk(cbeg);
+    for (int ch = cbeg; ch < cend; ++ch) {
+        const int buf = (ch - cbeg) & 1;
+        store_chunk(buf);
+        __syncthreads();
+        if (ch + 1 < cend) load_chunk(ch + 1);
+        const unsigned char* sy = smem + buf * 16384;
+        const unsigned char* sx = sy + 8192;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = load_tr_frag<USE_TR>(sy, s * 32, wco * 2 + i, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = load_tr_frag<USE_TR>(sx, s * 32, wci * 2 + j, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    float* out = a.dwp + (long)split * a.split_stride;
+    const int lm = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ci = ci0 + (wci * 2 + j) * 16 + lm;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + (wco * 2 + i) * 16 + g * 4 + r;
+                if (co < a.Cout && ci < a.Cin) out[((long)co * a.ntaps + tap) * a.Cin + ci] = acc[i][j][r];
+            }
+        }
+}
+
+static int g_wgrad_use_tr = 1;
+extern "C" int kg_set_wgrad_tr(int use_tr) { g_wgrad_use_tr = use_tr; return KG_OK; }
+
+extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const int* rowdesc, int M, int H, int W,
+                               int OH, int OW, int ldx, int lddy, int Cin, int Cout, int cin_lim, int cout_lim,
+                               int KH, int KW, int stride, int pad, int dil, int mode, int nsplit,
+                               long split_stride, void* stream) {
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    KG_CHECK_ARG(x && dy && dwp, "kg_conv2d_wgrad: null pointer");
+    KG_CHECK_ARG(ldx % 8 == 0 && lddy % 8 == 0 && cin_lim % 8 == 0 && cout_lim % 8 == 0, "kg_conv2d_wgrad: ld/lim must be multiples of 8");
+    KG_CHECK_ARG(stride == 1 || stride == 2, "kg_conv2d_wgrad: stride must be 1 or 2");
+    KG_CHECK_ARG(mode == 0 || (mode == 2 && rowdesc && stride == 1), "kg_conv2d_wgrad: bad mode");
+    KG_CHECK_ARG(nsplit >= 1 && M > 0, "kg_conv2d_wgrad: bad split/M");
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dwp = dwp; a.rowdesc = (const int2*)rowdesc;
+    a.M = M; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.ldx = ldx; a.lddy = lddy; a.Cin = Cin; a.Cout = Cout;
+    a.cin_lim = cin_lim; a.cout_lim = cout_lim; a.ntaps = KH * KW; a.KW = KW; a.stride_log2 = stride == 2 ? 1 : 0;
+    a.pad = pad; a.dil = dil; a.mode = mode;
+    int total_chunks = (M + 63) / 64;
+    a.chunks_per_split = (total_chunks + nsplit - 1) / nsplit;
+    a.split_stride = split_stride;
+    dim3 grid(((cin_lim + 63) / 64) * ((cout_lim + 63) / 64), KH * KW, nsplit);
+    if (g_wgrad_use_tr)
+        hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    KG_CHECK_LAUNCH("conv_wgrad");
+    return KG_OK;
+}
+
+// Sum the split partials [S][Cout][taps][Cin] and write the OIHW fp32 gradient [Cout][Cin][taps]
+// (accumulate != 0: grad += sum).  Fixed summation order => bitwise reproducible gradients.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int Cout, int Cin,
+                                    int taps, int S, long split_stride, int accumulate) {
+    long total = (long)Cout * Cin * taps;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int tap = (int)(i % taps);
+        long r = i / taps;
+        int ci = (int)(r % Cin), co = (int)(r / Cin);
+        long src = ((long)co * taps + tap) * Cin + ci;
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += part[k * split_stride + src];
+        grad[i] = accumulate ? grad[i] + s : s;
+    }
+}
+
+extern "C" int kg_wgrad_reduce(const float* part, float* grad, int Cout, int Cin, int KH, int KW, int nsplit,
+                               long split_stride, int accumulate, void* stream) {
+    KG_CHECK_ARG(part && grad, "kg_wgrad_reduce: null pointer");
+    long total = (long)Cout * Cin * KH * KW;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, part, grad, Cout, Cin,
+                       KH * KW, nsplit, split_stride, accumulate);
+    KG_CHECK_LAUNCH("wgrad_reduce");
+    return KG_OK;
+}
+
+// Bias gradient: db[c] = sum over rows of dy[row][c] (bf16 rows, fp32 sum), fixed-order two-stage.
+__global__ void bias_grad_kernel(const bf16_t* __restrict__ dy, float* __restrict__ part, int M, int C, int ld,
+                                 int rows_per_block) {
+    extern __shared__ float red[];
+    const int nrl = blockDim.x / C;  // row lanes
+    const int c = threadIdx.x % C, rl = threadIdx.x / C;
+    float s = 0.f;
+    int r0 = blockIdx.x * rows_per_block, r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    for (int r = r0 + rl; r < r1; r += nrl) s += bf2f(dy[(long)r * ld + c]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0) {
+        float t = 0.f;
+        for (int k = 0; k < nrl; ++k) t += red[k * C + c];
+        part[(long)blockIdx.x * C + c] = t;
+    }
+}
+__global__ void bias_grad_final_kernel(const float* __restrict__ part, float* __restrict__ db, int nb, int C,
+                                       int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += part[(long)b * C + c];
+    db[c] = accumulate ? db[c] + s : s;
+}
+
+extern "C" int kg_bias_grad(const void* dy, float* db, float* scratch, int scratch_floats, int M, int C, int ld,
+                            int accumulate, void* stream) {
+    KG_CHECK_ARG(dy && db && scratch, "kg_bias_grad: null pointer");
+    KG_CHECK_ARG(C >= 1 && C <= 1024, "kg_bias_grad: C out of range");
+    int nrl = 1024 / C;
+    if (nrl < 1) nrl = 1;
+    int threads = nrl * C;
+    int nb = scratch_floats / C;
+    if (nb > 1024) nb = 1024;
+    int need = (M + 63) / 64;
+    if (nb > need) nb = need;
+    KG_CHECK_ARG(nb >= 1, "kg_bias_grad: scratch too small");
+    int rpb = (M + nb - 1) / nb;
+    nb = (M + rpb - 1) / rpb;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(nb), dim3(threads), threads * sizeof(float), (hipStream_t)stream,
+                       (const bf16_t*)dy, scratch, M, C, ld, rpb);
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, db,
+                       nb, C, accumulate);
+    KG_CHECK_LAUNCH("bias_grad");
+    return KG_OK;
+}

@@ -1,0 +1,499 @@
+// norm_pool.hip -- HBM-bound layer kernels of KGnet's backbone/decoder for gfx950:
+//   image pack (fp32 NCHW -> bf16 NHWC8), BatchNorm2d (train/eval, forward/backward),
+//   MaxPool 3x3 s2 p1, bilinear resize (align_corners=False), elementwise helpers.
+// Reference ops replaced: KGnet.py:131-134 (bn1/relu/maxpool), :64-99 (Bottleneck BN/ReLU/add),
+// :288-297 (F.interpolate bilinear).  All activations are bf16 pixel-major rows [row][ld]; every
+// thread moves 16-byte channel chunks (8 bf16) so a wave covers whole 128-byte lines.
+#include "kg_common.h"
+
+// ---------------------------------------------------------------------------------------------
+__global__ void img_pack_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int N, int C, int HW) {
+    long total = (long)N * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long n = i / HW, p = i - n * HW;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = c < C ? img[(n * C + c) * HW + p] : 0.f;
+        uint4 o = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        *reinterpret_cast<uint4*>(out + i * 8) = o;
+    }
+}
+extern "C" int kg_img_pack(const float* img, void* out, int N, int C, int H, int W, void* stream) {
+    KG_CHECK_ARG(img && out && C <= 8, "kg_img_pack: bad args");
+    long total = (long)N * H * W;
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(img_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, N, C, H * W);
+    KG_CHECK_LAUNCH("img_pack");
+    return KG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column reductions over bf16 rows.  Block (256 threads) = [32 row lanes][8 chunk lanes]; each
+// block handles a 64-channel slab and a contiguous row range; partials [nb][C][NQ] fp32 are
+// combined in double by the finalize kernels (fixed order => reproducible).
+// MODE 0: (sum x, sum x^2)      MODE 1: (sum dy, sum dy*xhat) with xhat=(x-mean)*invstd
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict__ x, int ldx,
+                                                        const bf16_t* __restrict__ dy, int lddy,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, float* __restrict__ part,
+                                                        int M, int C, int rows_per_block) {
+    __shared__ float red[32][8][16];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = blockIdx.y * 64 + cl * 8;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+    if (c0 < C) {
+        float mu[8], is[8];
+        if (MODE == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; }
+        }
+        int r0 = blockIdx.x * rows_per_block, r1 = r0 + rows_per_block;
+        if (r1 > M) r1 = M;
+        for (int r = r0 + rl; r < r1; r += 32) {
+            uint4 xv = *reinterpret_cast<const uint4*>(x + (long)r * ldx + c0);
+            const bf16_t* xs = reinterpret_cast<const bf16_t*>(&xv);
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float f = bf2f(xs[e]); s0[e] += f; s1[e] += f * f; }
+            } else {
+                uint4 dv = *reinterpret_cast<const uint4*>(dy + (long)r * lddy + c0);
+                const bf16_t* ds = reinterpret_cast<const bf16_t*>(&dv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float d = bf2f(ds[e]), xh = (bf2f(xs[e]) - mu[e]) * is[e];
+                    s0[e] += d; s1[e] += d * xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[rl][cl][e] = s0[e]; red[rl][cl][8 + e] = s1[e]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int c = threadIdx.x & 63, q = threadIdx.x >> 6;  // q: which sum
+        float t = 0.f;
+        for (int k = 0; k < 32; ++k) t += red[k][c >> 3][q * 8 + (c & 7)];
+        const int cg = blockIdx.y * 64 + c;
+        if (cg < C) part[((long)blockIdx.x * C + cg) * 2 + q] = t;
+    }
+}
+
+// train-mode finalize: mean / biased var -> invstd, scale/shift, running stats (momentum 0.1,
+// unbiased var), matching torch.nn.functional.batch_norm(training=True) (KGnet.py:82-93).
+__global__ void bn_finalize_train_kernel(const float* __restrict__ part, int nb, int C, long M,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                         float momentum, float eps, float* __restrict__ mean_out,
+                                         float* __restrict__ invstd_out, float* __restrict__ scale,
+                                         float* __restrict__ shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0., ss = 0.;
+    for (int b = 0; b < nb; ++b) { s += part[((long)b * C + c) * 2]; ss += part[((long)b * C + c) * 2 + 1]; }
+    double mu = s / (double)M;
+    double var = ss / (double)M - mu * mu;
+    if (var < 0.) var = 0.;
+    float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean_out[c] = (float)mu; invstd_out[c] = is;
+    float sc = gamma[c] * is;
+    scale[c] = sc; shift[c] = beta[c] - (float)mu * sc;
+    if (running_mean) {
+        double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+__global__ void bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        const float* __restrict__ running_mean,
+                                        const float* __restrict__ running_var, float eps,
+                                        float* __restrict__ scale, float* __restrict__ shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float is = 1.f / sqrtf(running_var[c] + eps);
+    float sc = gamma[c] * is;
+    scale[c] = sc; shift[c] = beta[c] - running_mean[c] * sc;
+}
+// backward finalize: dgamma, dbeta and the per-channel coefficients of
+//   dx = a*dy + b*xhat + c0   with a = gamma*invstd, b = -a*dgamma/M, c0 = -a*dbeta/M
+__global__ void bn_finalize_bwd_kernel(const float* __restrict__ part, int nb, int C, long M,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                       float* __restrict__ coef) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0., sx = 0.;
+    for (int b = 0; b < nb; ++b) { s += part[((long)b * C + c) * 2]; sx += part[((long)b * C + c) * 2 + 1]; }
+    float db = (float)s, dg = (float)sx;
+    dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+    dbeta[c] = accumulate ? dbeta[c] + db : db;
+    float a = gamma[c] * invstd[c];
+    coef[c] = a; coef[C + c] = (float)(-(double)a * sx / (double)M); coef[2 * C + c] = (float)(-(double)a * s / (double)M);
+}
+
+static int reduce_geometry(int M, int C, int scratch_floats, int* nb, int* rpb) {
+    int n = scratch_floats / (2 * C);
+    if (n > 512) n = 512;
+    int need = (M + 255) / 256;
+    if (n > need) n = need;
+    if (n < 1) return 0;
+    *rpb = (M + n - 1) / n;
+    *nb = (M + *rpb - 1) / *rpb;
+    return 1;
+}
+
+extern "C" int kg_bn_stats_train(const void* x, int ldx, int M, int C, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps,
+                                 float* mean_out, float* invstd_out, float* scale, float* shift, float* scratch,
+                                 int scratch_floats, void* stream) {
+    KG_CHECK_ARG(x && gamma && beta && mean_out && invstd_out && scale && shift && scratch, "kg_bn_stats_train: null pointer");
+    KG_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0, "kg_bn_stats_train: C/ld must be multiples of 8");
+    int nb, rpb;
+    KG_CHECK_ARG(reduce_geometry(M, C, scratch_floats, &nb, &rpb), "kg_bn_stats_train: scratch too small");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colreduce_kernel<0>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                       (const bf16_t*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, scratch, M, C, rpb);
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 127) / 128), dim3(128), 0, st, scratch, nb, C, (long)M, gamma,
+                       beta, running_mean, running_var, momentum, eps, mean_out, invstd_out, scale, shift);
+    KG_CHECK_LAUNCH("bn_stats_train");
+    return KG_OK;
+}
+extern "C" int kg_bn_scale_shift_eval(int C, const float* gamma, const float* beta, const float* running_mean,
+                                      const float* running_var, float eps, float* scale, float* shift, void* stream) {
+    KG_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift, "kg_bn_scale_shift_eval: null pointer");
+    hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, C, gamma, beta,
+                       running_mean, running_var, eps, scale, shift);
+    KG_CHECK_LAUNCH("bn_scale_shift_eval");
+    return KG_OK;
+}
+
+// y = [relu]( x*scale + shift [+ res] )
+__global__ void bn_apply_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const bf16_t* __restrict__ res, int ldres,
+                                bf16_t* __restrict__ y, int ldy, long M, int C8, int relu) {
+    long total = M * C8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / C8; int c = (int)(i - r * C8) * 8;
+        uint4 xv = *reinterpret_cast<const uint4*>(x + r * ldx + c);
+        const bf16_t* xs = reinterpret_cast<const bf16_t*>(&xv);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(xs[e]) * scale[c + e] + shift[c + e];
+        if (res) {
+            uint4 rv = *reinterpret_cast<const uint4*>(res + r * ldres + c);
+            const bf16_t* rs = reinterpret_cast<const bf16_t*>(&rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bf2f(rs[e]);
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        uint4 o = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        *reinterpret_cast<uint4*>(y + r * ldy + c) = o;
+    }
+}
+extern "C" int kg_bn_apply(const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldres,
+                           void* y, int ldy, int M, int C, int relu, void* stream) {
+    KG_CHECK_ARG(x && scale && shift && y, "kg_bn_apply: null pointer");
+    KG_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (!res || ldres % 8 == 0), "kg_bn_apply: C/ld must be multiples of 8");
+    long total = (long)M * (C / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, scale,
+                       shift, (const bf16_t*)res, ldres, (bf16_t*)y, ldy, (long)M, C / 8, relu);
+    KG_CHECK_LAUNCH("bn_apply");
+    return KG_OK;
+}
+
+// dx = coef_a*dy + coef_b*xhat + coef_c   (train-mode BN backward, second pass)
+__global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dy, int lddy,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ coef, bf16_t* __restrict__ dx, int lddx, long M, int C) {
+    const int C8 = C / 8;
+    long total = M * C8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / C8; int c = (int)(i - r * C8) * 8;
+        uint4 xv = *reinterpret_cast<const uint4*>(x + r * ldx + c);
+        uint4 dv = *reinterpret_cast<const uint4*>(dy + r * lddy + c);
+        const bf16_t* xs = reinterpret_cast<const bf16_t*>(&xv);
+        const bf16_t* ds = reinterpret_cast<const bf16_t*>(&dv);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float xh = (bf2f(xs[e]) - mean[c + e]) * invstd[c + e];
+            v[e] = coef[c + e] * bf2f(ds[e]) + coef[C + c + e] * xh + coef[2 * C + c + e];
+        }
+        uint4 o = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        *reinterpret_cast<uint4*>(dx + r * lddx + c) = o;
+    }
+}
+extern "C" int kg_bn_bwd(const void* x, int ldx, const void* dy, int lddy, const float* gamma, const float* mean,
+                         const float* invstd, float* dgamma, float* dbeta, int accumulate, void* dx, int lddx, int M,
+                         int C, float* scratch, int scratch_floats, void* stream) {
+    KG_CHECK_ARG(x && dy && gamma && mean && invstd && dgamma && dbeta && dx && scratch, "kg_bn_bwd: null pointer");
+    KG_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "kg_bn_bwd: C/ld must be multiples of 8");
+    int nb, rpb;
+    KG_CHECK_ARG(reduce_geometry(M, C, scratch_floats - 3 * C, &nb, &rpb), "kg_bn_bwd: scratch too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = scratch; float* part = scratch + 3 * C;
+    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, (const bf16_t*)x, ldx,
+                       (const bf16_t*)dy, lddy, mean, invstd, part, M, C, rpb);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 127) / 128), dim3(128), 0, st, part, nb, C, (long)M, gamma,
+                       invstd, dgamma, dbeta, accumulate, coef);
+    long total = (long)M * (C / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy,
+                       mean, invstd, coef, (bf16_t*)dx, lddx, (long)M, C);
+    KG_CHECK_LAUNCH("bn_bwd");
+    return KG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d(3, stride 2, pad 1) (KGnet.py:134).  First maximum in (kh,kw) scan order wins ties,
+// as torch's max_pool2d does.
+__device__ __forceinline__ void pool_window_max(const bf16_t* __restrict__ x, int ldx, long nbase, int H, int W,
+                                                int oy, int ox, int c, float* best, int* arg) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = -1; }
+    for (int kh = 0; kh < 3; ++kh) {
+        int iy = oy * 2 - 1 + kh;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            int ix = ox * 2 - 1 + kw;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(x + (nbase + (long)iy * W + ix) * ldx + c);
+            const bf16_t* s = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = bf2f(s[e]);
+                if (f > best[e] || arg[e] < 0) { best[e] = f; arg[e] = kh * 3 + kw; }
+            }
+        }
+    }
+}
+__global__ void maxpool_fwd_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int N, int H,
+                                   int W, int OH, int OW, int C8) {
+    long total = (long)N * OH * OW * C8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C8) * 8; long p = i / C8;
+        int ox = (int)(p % OW); long q = p / OW; int oy = (int)(q % OH); long n = q / OH;
+        float best[8]; int arg[8];
+        pool_window_max(x, ldx, n * H * W, H, W, oy, ox, c, best, arg);
+        uint4 o = make_uint4(pack2bf(best[0], best[1]), pack2bf(best[2], best[3]), pack2bf(best[4], best[5]), pack2bf(best[6], best[7]));
+        *reinterpret_cast<uint4*>(y + p * ldy + c) = o;
+    }
+}
+// gather-form backward: each input pixel sums dy of the (<=4) windows whose argmax it is.
+__global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dy, int lddy,
+                                   bf16_t* __restrict__ dx, int lddx, int N, int H, int W, int OH, int OW, int C8) {
+    long total = (long)N * H * W * C8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C8) * 8; long p = i / C8;
+        int ix = (int)(p % W); long q = p / W; int iy = (int)(q % H); long n = q / H;
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = 0.f;
+        // windows (oy,ox) with oy*2-1+kh == iy  =>  oy in {(iy+1)/2 (kh=...)}
+        for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {
+            if (oy >= OH) continue;
+            int kh = iy - (oy * 2 - 1);
+            if (kh < 0 || kh > 2) continue;
+            for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox >= OW) continue;
+                int kw = ix - (ox * 2 - 1);
+                if (kw < 0 || kw > 2) continue;
+                float best[8]; int arg[8];
+                pool_window_max(x, ldx, n * H * W, H, W, oy, ox, c, best, arg);
+                uint4 dv = *reinterpret_cast<const uint4*>(dy + ((n * OH + oy) * OW + ox) * lddy + c);
+                const bf16_t* ds = reinterpret_cast<const bf16_t*>(&dv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (arg[e] == kh * 3 + kw) g[e] += bf2f(ds[e]);
+            }
+        }
+        uint4 o = make_uint4(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]), pack2bf(g[4], g[5]), pack2bf(g[6], g[7]));
+        *reinterpret_cast<uint4*>(dx + p * lddx + c) = o;
+    }
+}
+extern "C" int kg_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, void* stream) {
+    KG_CHECK_ARG(x && y && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "kg_maxpool3s2_fwd: bad args");
+    int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    long total = (long)N * OH * OW * (C / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y,
+                       ldy, N, H, W, OH, OW, C / 8);
+    KG_CHECK_LAUNCH("maxpool_fwd");
+    return KG_OK;
+}
+extern "C" int kg_maxpool3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H,
+                                 int W, int C, void* stream) {
+    KG_CHECK_ARG(x && dy && dx && C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "kg_maxpool3s2_bwd: bad args");
+    int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    long total = (long)N * H * W * (C / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, N, H, W, OH, OW, C / 8);
+    KG_CHECK_LAUNCH("maxpool_bwd");
+    return KG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bilinear resize, align_corners=False (F.interpolate, KGnet.py:110, 288-297):
+//   src = max(scale*(dst+0.5)-0.5, 0), scale = in/out (fp32), i0=(int)src, i1=min(i0+1,in-1).
+__device__ __forceinline__ void bil_src(int dst, float scale, int in, int* i0, int* i1, float* l1) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    int a = (int)s;
+    if (a > in - 1) a = in - 1;
+    *i0 = a; *i1 = a + (a < in - 1 ? 1 : 0); *l1 = s - (float)a;
+}
+// Dense mode: images [N][IH][IW] -> [N][OH][OW].
+// Ragged mode (desc != null): one box per "image"; desc[b] = {in_row0, ih, iw, out_row0, oh, ow} and
+// rows are box-local raster order (used by the per-box seg branch, KGnet.py:258-267).
+struct BilBox { int in_row0, ih, iw, out_row0, oh, ow; };
+__global__ void bilinear_fwd_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int IH,
+                                    int IW, int OH, int OW, int C8, long total_rows, const BilBox* __restrict__ desc,
+                                    const int* __restrict__ row2box) {
+    long total = total_rows * C8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C8) * 8; long p = i / C8;
+        long in0; int ih, iw, oh, ow, oy, ox;
+        if (desc) {
+            BilBox b = desc[row2box[p]];
+            int loc = (int)(p - b.out_row0);
+            ih = b.ih; iw = b.iw; oh = b.oh; ow = b.ow; oy = loc / ow; ox = loc - oy * ow; in0 = b.in_row0;
+        } else {
+            ih = IH; iw = IW; oh = OH; ow = OW;
+            ox = (int)(p % OW); long q = p / OW; oy = (int)(q % OH); in0 = (q / OH) * IH * IW;
+        }
+        int y0, y1, x0, x1; float ly, lx;
+        bil_src(oy, (float)ih / (float)oh, ih, &y0, &y1, &ly);
+        bil_src(ox, (float)iw / (float)ow, iw, &x0, &x1, &lx);
+        float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+        uint4 a = *reinterpret_cast<const uint4*>(x + (in0 + (long)y0 * iw + x0) * ldx + c);
+        uint4 b = *reinterpret_cast<const uint4*>(x + (in0 + (long)y0 * iw + x1) * ldx + c);
+        uint4 d = *reinterpret_cast<const uint4*>(x + (in0 + (long)y1 * iw + x0) * ldx + c);
+        uint4 e4 = *reinterpret_cast<const uint4*>(x + (in0 + (long)y1 * iw + x1) * ldx + c);
+        const bf16_t *pa = (const bf16_t*)&a, *pb = (const bf16_t*)&b, *pd = (const bf16_t*)&d, *pe = (const bf16_t*)&e4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = w00 * bf2f(pa[e]) + w01 * bf2f(pb[e]) + w10 * bf2f(pd[e]) + w11 * bf2f(pe[e]);
+        uint4 o = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        *reinterpret_cast<uint4*>(y + p * ldy + c) = o;
+    }
+}
+// gather-form backward: each input pixel scans the output pixels that can reference it.
+__device__ __forceinline__ void bil_cand(int i, float scale, int out, int* lo, int* hi) {
+    // outputs o with src(o) in (i-1, i+1):  o in ((i-0.5)/scale-0.5, (i+1.5)/scale-0.5); widen by one.
+    float a = ((float)i - 0.5f) / scale - 0.5f, b = ((float)i + 1.5f) / scale - 0.5f;
+    int l = (int)floorf(a) - 1, h = (int)ceilf(b) + 1;
+    *lo = l < 0 ? 0 : l; *hi = h > out - 1 ? out - 1 : h;
+}
+__global__ void bilinear_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dx, int lddx, int IH,
+                                    int IW, int OH, int OW, int C8, long total_rows, const BilBox* __restrict__ desc,
+                                    const int* __restrict__ row2box) {
+    long total = total_rows * C8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C8) * 8; long p = i / C8;
+        long out0; int ih, iw, oh, ow, iy, ix;
+        if (desc) {
+            BilBox b = desc[row2box[p]];
+            int loc = (int)(p - b.in_row0);
+            ih = b.ih; iw = b.iw; oh = b.oh; ow = b.ow; iy = loc / iw; ix = loc - iy * iw; out0 = b.out_row0;
+        } else {
+            ih = IH; iw = IW; oh = OH; ow = OW;
+            ix = (int)(p % IW); long q = p / IW; iy = (int)(q % IH); out0 = (q / IH) * OH * OW;
+        }
+        const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
+        int ylo, yhi, xlo, xhi;
+        bil_cand(iy, sy, oh, &ylo, &yhi); bil_cand(ix, sx, ow, &xlo, &xhi);
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = 0.f;
+        for (int oy = ylo; oy <= yhi; ++oy) {
+            int y0, y1; float ly;
+            bil_src(oy, sy, ih, &y0, &y1, &ly);
+            float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+            if (y0 != iy && y1 != iy) continue;
+            for (int ox = xlo; ox <= xhi; ++ox) {
+                int x0, x1; float lx;
+                bil_src(ox, sx, iw, &x0, &x1, &lx);
+                if (x0 != ix && x1 != ix) continue;
+                float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                float w = wy * wx;
+                uint4 dv = *reinterpret_cast<const uint4*>(dy + (out0 + (long)oy * ow + ox) * lddy + c);
+                const bf16_t* ds = reinterpret_cast<const bf16_t*>(&dv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] += w * bf2f(ds[e]);
+            }
+        }
+        uint4 o = make_uint4(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]), pack2bf(g[4], g[5]), pack2bf(g[6], g[7]));
+        *reinterpret_cast<uint4*>(dx + p * lddx + c) = o;
+    }
+}
+extern "C" int kg_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int IH, int IW, int OH, int OW, int C,
+                               const int* boxdesc, const int* row2box, long total_out_rows, void* stream) {
+    KG_CHECK_ARG(x && y && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "kg_bilinear_fwd: bad args");
+    long rows = boxdesc ? total_out_rows : (long)N * OH * OW;
+    if (rows == 0) return KG_OK;
+    long total = rows * (C / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (bf16_t*)y, ldy, IH, IW, OH, OW, C / 8, rows, (const BilBox*)boxdesc, row2box);
+    KG_CHECK_LAUNCH("bilinear_fwd");
+    return KG_OK;
+}
+extern "C" int kg_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int IH, int IW, int OH, int OW, int C,
+                               const int* boxdesc, const int* row2box, long total_in_rows, void* stream) {
+    KG_CHECK_ARG(dy && dx && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "kg_bilinear_bwd: bad args");
+    long rows = boxdesc ? total_in_rows : (long)N * IH * IW;
+    if (rows == 0) return KG_OK;
+    long total = rows * (C / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy,
+                       (bf16_t*)dx, lddx, IH, IW, OH, OW, C / 8, rows, (const BilBox*)boxdesc, row2box);
+    KG_CHECK_LAUNCH("bilinear_bwd");
+    return KG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[row][c] = a[row][c] + b[row][c] (+ optional ReLU mask by m > 0); used for gradient joins.
+__global__ void add_rows_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb,
+                                const bf16_t* __restrict__ m, int ldm, bf16_t* __restrict__ y, int ldy, long M, int C8) {
+    long total = M * C8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / C8; int c = (int)(i - r * C8) * 8;
+        uint4 av = *reinterpret_cast<const uint4*>(a + r * lda + c);
+        const bf16_t* as = (const bf16_t*)&av;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(as[e]);
+        if (b) {
+            uint4 bv = *reinterpret_cast<const uint4*>(b + r * ldb + c);
+            const bf16_t* bs = (const bf16_t*)&bv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bf2f(bs[e]);
+        }
+        if (m) {
+            uint4 mv = *reinterpret_cast<const uint4*>(m + r * ldm + c);
+            const bf16_t* ms = (const bf16_t*)&mv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bf2f(ms[e]) > 0.f ? v[e] : 0.f;
+        }
+        uint4 o = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        *reinterpret_cast<uint4*>(y + r * ldy + c) = o;
+    }
+}
+extern "C" int kg_add_rows(const void* a, int lda, const void* b, int ldb, const void* mask, int ldm, void* y, int ldy,
+                           long M, int C, void* stream) {
+    KG_CHECK_ARG(a && y && C % 8 == 0 && lda % 8 == 0 && ldy % 8 == 0 && (!b || ldb % 8 == 0) && (!mask || ldm % 8 == 0), "kg_add_rows: bad args");
+    if (M == 0) return KG_OK;
+    long total = M * (C / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(add_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda,
+                       (const bf16_t*)b, ldb, (const bf16_t*)mask, ldm, (bf16_t*)y, ldy, M, C / 8);
+    KG_CHECK_LAUNCH("add_rows");
+    return KG_OK;
+}

@@ -1,0 +1,563 @@
+// postproc.hip -- KGnet post-processing on gfx950 in float64, bit-identical to the reference's
+// NumPy/SciPy path (postprocessing.py:16-261, nms.py:4-53).  Compiled with -ffp-contract=off: every
+// multiply/add below rounds exactly as the reference's separate NumPy operations do; the single
+// fused operation of the reference (np.linalg.norm -> ddot) is written as an explicit fma().
+//
+// Stages (all on the caller's stream, no host sync inside):
+//   P1 Hough vote   : count -> scan -> fill -> per-cell ordered sum (reproduces the sequential
+//                     COO scatter order: corner block, then raster index)
+//   P2 Gaussian     : separable 17-tap, scipy's symmetric pairing order, 'reflect' border
+//   P3 peaks        : cross-footprint local max == value, > thresh, ordered compaction
+//   P4 grouping     : greedy confidence-ordered star matching, one workgroup (4 waves = 4 edges)
+//   P6/P7 boxes     : refine + 8-case box assembly, ordered compaction, 4 scales appended
+//   P9 NMS          : greedy IoU suppression, one workgroup
+#include "kg_common.h"
+
+#define KG_NUM_KPS 5
+
+__device__ __forceinline__ int f2i_np(double v) {  // numpy f64 -> int32 cast on x86 (cvttsd2si)
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return INT32_MIN;
+    return (int)v;
+}
+
+// One vote contribution of source pixel i (corner b) of channel c.  Returns false when dropped.
+__device__ __forceinline__ bool hough_contrib(const float* __restrict__ kp, const float* __restrict__ soff, int H,
+                                              int W, int c, int b, int i, int* cell, double* val) {
+    const long HW = (long)H * W;
+    const int y = i / W, x = i - y * W;
+    const double xs = (double)x + (double)soff[(long)(2 * c) * HW + i];
+    const double ys = (double)y + (double)soff[(long)(2 * c + 1) * HW + i];
+    const double ps = (double)kp[(long)c * HW + i];
+    const int fx = f2i_np(floor(xs)), fy = f2i_np(floor(ys));
+    const int cx = f2i_np(ceil(xs)), cy = f2i_np(ceil(ys));
+    const double dx = xs - (double)fx, dy = ys - (double)fy;
+    int I, J; double v;
+    switch (b) {
+        case 0: I = fy; J = fx; v = ps * (1. - dx) * (1. - dy); break;
+        case 1: I = fy; J = cx; v = ps * dx * (1. - dy); break;
+        case 2: I = cy; J = fx; v = ps * dy * (1. - dx); break;
+        default: I = cy; J = cx; v = ps * dy * dx; break;
+    }
+    if (I < 0 || I >= H || J < 0 || J >= W) return false;
+    *cell = I * W + J; *val = v;
+    return true;
+}
+
+__global__ void hough_count_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W,
+                                   int* __restrict__ count) {
+    const int c = blockIdx.y, HW = H * W;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 4 * HW; e += gridDim.x * blockDim.x) {
+        int b = e / HW, i = e - b * HW, cell; double v;
+        if (hough_contrib(kp, soff, H, W, c, b, i, &cell, &v)) atomicAdd(&count[c * HW + cell], 1);
+    }
+}
+// exclusive scan of count[c][0..HW) -> offs; one block (1024 threads) per channel.
+__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ count, int* __restrict__ offs, int n) {
+    __shared__ int tot[1024];
+    const int* in = count + (long)blockIdx.x * n;
+    int* out = offs + (long)blockIdx.x * n;
+    const int per = (n + 1023) / 1024, b0 = threadIdx.x * per;
+    int s = 0;
+    for (int i = b0; i < b0 + per && i < n; ++i) s += in[i];
+    tot[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        int v = threadIdx.x >= d ? tot[threadIdx.x - d] : 0;
+        __syncthreads();
+        tot[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = threadIdx.x ? tot[threadIdx.x - 1] : 0;
+    for (int i = b0; i < b0 + per && i < n; ++i) { int v = in[i]; out[i] = run; run += v; }
+}
+__global__ void hough_fill_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W,
+                                  const int* __restrict__ offs, int* __restrict__ cursor,
+                                  unsigned* __restrict__ keys, double* __restrict__ vals) {
+    const int c = blockIdx.y, HW = H * W;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 4 * HW; e += gridDim.x * blockDim.x) {
+        int b = e / HW, i = e - b * HW, cell; double v;
+        if (hough_contrib(kp, soff, H, W, c, b, i, &cell, &v)) {
+            int slot = offs[c * HW + cell] + atomicAdd(&cursor[c * HW + cell], 1);
+            keys[(long)c * 4 * HW + slot] = (unsigned)e;
+            vals[(long)c * 4 * HW + slot] = v;
+        }
+    }
+}
+// Ordered per-cell sum.  Cells with <= 24 votes: one thread, selection by increasing key.  Heavier
+// cells are queued and handled by one wave each (rank sort, then lane 0 adds in order).
+#define HOUGH_LIGHT 24
+__global__ void hough_sum_light_kernel(int HW, const int* __restrict__ count, const int* __restrict__ offs,
+                                       const unsigned* __restrict__ keys, const double* __restrict__ vals,
+                                       double norm, double* __restrict__ heat, int* __restrict__ heavy_n,
+                                       int* __restrict__ heavy_list) {
+    const int c = blockIdx.y;
+    for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < HW; cell += gridDim.x * blockDim.x) {
+        const int n = count[c * HW + cell];
+        if (n > HOUGH_LIGHT) { heavy_list[atomicAdd(heavy_n, 1)] = c * HW + cell; continue; }
+        const unsigned* k = keys + (long)c * 4 * HW + offs[c * HW + cell];
+        const double* v = vals + (long)c * 4 * HW + offs[c * HW + cell];
+        double s = 0.;
+        long last = -1;
+        for (int t = 0; t < n; ++t) {
+            unsigned best = 0xffffffffu; int bi = 0;
+            for (int j = 0; j < n; ++j) {
+                unsigned kj = k[j];
+                if ((long)kj > last && kj < best) { best = kj; bi = j; }
+            }
+            s += v[bi];
+            last = best;
+        }
+        heat[(long)c * HW + cell] = s / norm;
+    }
+}
+__global__ __launch_bounds__(64) void hough_sum_heavy_kernel(int HW, const int* __restrict__ count,
+                                                             const int* __restrict__ offs,
+                                                             const unsigned* __restrict__ keys,
+                                                             const double* __restrict__ vals,
+                                                             double* __restrict__ sorted, double norm,
+                                                             double* __restrict__ heat, const int* __restrict__ heavy_n,
+                                                             const int* __restrict__ heavy_list) {
+    const int nh = *heavy_n;
+    for (int h = blockIdx.x; h < nh; h += gridDim.x) {
+        const int cc = heavy_list[h];
+        const int c = cc / HW;
+        const int n = count[cc];
+        const long base = (long)c * 4 * HW + offs[cc];
+        const unsigned* k = keys + base;
+        for (int e = threadIdx.x; e < n; e += 64) {
+            const unsigned ke = k[e];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += k[j] < ke;
+            sorted[base + rank] = vals[base + e];
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.;
+            for (int t = 0; t < n; ++t) s += sorted[base + t];
+            heat[cc] = s / norm;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- P2 ---------------------------------------------------------------------------------------
+__constant__ double KG_GW[17] = {
+    0x1.18aad19e4159bp-14, 0x1.c98b8c5d0dda5p-12, 0x1.227362b5fc92dp-9, 0x1.1f30504e20207p-7, 0x1.ba4d4125ffd2ap-6,
+    0x1.0941b71ceef37p-4,  0x1.ef9093fc46e5ap-4,  0x1.68856f9ab1982p-3, 0x1.98862a07ae7b4p-3, 0x1.68856f9ab1982p-3,
+    0x1.ef9093fc46e5ap-4,  0x1.0941b71ceef37p-4,  0x1.ba4d4125ffd2ap-6, 0x1.1f30504e20207p-7, 0x1.227362b5fc92dp-9,
+    0x1.c98b8c5d0dda5p-12, 0x1.18aad19e4159bp-14};
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i - 1;
+        if (i >= n) i = 2 * n - 1 - i;
+    }
+    return i;
+}
+template <int AXIS>  // 0: along y (rows), 1: along x
+__global__ void gauss_kernel(const double* __restrict__ in, double* __restrict__ out, int C, int H, int W) {
+    const long total = (long)C * H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W); const long q = i / W; const int y = (int)(q % H); const long c = q / H;
+        const double* src = in + c * H * W;
+        double acc = src[(long)y * W + x] * KG_GW[8];
+#pragma unroll
+        for (int j = -8; j < 0; ++j) {
+            double a, b;
+            if (AXIS == 0) { a = src[(long)reflect_idx(y + j, H) * W + x]; b = src[(long)reflect_idx(y - j, H) * W + x]; }
+            else { a = src[(long)y * W + reflect_idx(x + j, W)]; b = src[(long)y * W + reflect_idx(x - j, W)]; }
+            acc = acc + (a + b) * KG_GW[8 + j];
+        }
+        out[i] = acc;
+    }
+}
+
+// ---- P3 ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_peak(const double* __restrict__ h, int H, int W, int y, int x, double thresh) {
+    const double v = h[(long)y * W + x];
+    double m = v;
+    if (y > 0 && h[(long)(y - 1) * W + x] > m) m = h[(long)(y - 1) * W + x];
+    if (y < H - 1 && h[(long)(y + 1) * W + x] > m) m = h[(long)(y + 1) * W + x];
+    if (x > 0 && h[(long)y * W + x - 1] > m) m = h[(long)y * W + x - 1];
+    if (x < W - 1 && h[(long)y * W + x + 1] > m) m = h[(long)y * W + x + 1];
+    return m == v && v > thresh;
+}
+// pass 0: per-block counts; pass 1: write at base offsets (blockbase from scan_kernel over block counts)
+template <int PASS>
+__global__ __launch_bounds__(256) void peaks_kernel(const double* __restrict__ heat, int H, int W, double thresh,
+                                                    int* __restrict__ blockcount, const int* __restrict__ blockbase,
+                                                    int cap, int* __restrict__ ids, int* __restrict__ xs,
+                                                    int* __restrict__ ys, double* __restrict__ conf) {
+    const long HW = (long)H * W, total = 5 * HW;
+    const long i0 = (long)blockIdx.x * 1024 + threadIdx.x * 4;  // 4 consecutive elements per thread
+    bool f[4]; int cnt = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        long i = i0 + e;
+        f[e] = false;
+        if (i < total) {
+            int c = (int)(i / HW); long r = i - c * HW;
+            f[e] = is_peak(heat + c * HW, H, W, (int)(r / W), (int)(r % W), thresh);
+        }
+        cnt += f[e];
+    }
+    __shared__ int sc[256];
+    sc[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        int v = threadIdx.x >= d ? sc[threadIdx.x - d] : 0;
+        __syncthreads();
+        sc[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (PASS == 0) {
+        if (threadIdx.x == 255) blockcount[blockIdx.x] = sc[255];
+    } else {
+        int pos = blockbase[blockIdx.x] + sc[threadIdx.x] - cnt;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (f[e]) {
+                long i = i0 + e; int c = (int)(i / HW); long r = i - c * HW;
+                if (pos < cap) { ids[pos] = c; xs[pos] = (int)(r % W); ys[pos] = (int)(r / W); conf[pos] = heat[i]; }
+                ++pos;
+            }
+    }
+}
+__global__ void peaks_total_kernel(const int* __restrict__ blockcount, const int* __restrict__ blockbase, int nblocks,
+                                   int* __restrict__ total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *total = blockbase[nblocks - 1] + blockcount[nblocks - 1];
+}
+
+// ---- P4 ---------------------------------------------------------------------------------------
+__constant__ int KG_MID_IDX[5][5] = {{-1, 0, 1, 2, 3}, {10, -1, 4, 5, 6}, {11, 14, -1, 7, 8}, {12, 15, 17, -1, 9}, {13, 16, 18, 19, -1}};
+__device__ __forceinline__ double norm2(double dx, double dy) { return sqrt(fma(dy, dy, dx * dx)); }
+
+// stable rank sort by confidence descending (postprocessing.py:87)
+__global__ void kp_rank_kernel(const int* __restrict__ npk, int cap, const int* __restrict__ ids,
+                               const int* __restrict__ xs, const int* __restrict__ ys, const double* __restrict__ conf,
+                               int* __restrict__ sid, int* __restrict__ sx, int* __restrict__ sy,
+                               double* __restrict__ sconf) {
+    int n = *npk; if (n > cap) n = cap;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double ci = conf[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { double cj = conf[j]; rank += (cj > ci) || (cj == ci && j < i); }
+        sid[rank] = ids[i]; sx[rank] = xs[i]; sy[rank] = ys[i]; sconf[rank] = ci;
+    }
+}
+__global__ __launch_bounds__(256) void group_kernel(const int* __restrict__ npk, int cap, const int* __restrict__ sid,
+                                                    const int* __restrict__ sx, const int* __restrict__ sy,
+                                                    const double* __restrict__ sconf, const float* __restrict__ mid,
+                                                    int H, int W, unsigned char* __restrict__ alive, int skcap,
+                                                    int* __restrict__ skxy, double* __restrict__ skel,
+                                                    int* __restrict__ nskel) {
+    // skxy[s][5][2]: integer slot coordinates of skeleton s (missing slot = (0,0)) for the <=10 test
+    int n = *npk; if (n > cap) n = cap;
+    const long HW = (long)H * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < n; i += 256) alive[i] = 1;
+    __shared__ int s_ns, s_match[4];
+    if (threadIdx.x == 0) s_ns = 0;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        if (!alive[i]) continue;  // uniform: alive[] only changes between barriers
+        const int id = sid[i], kx = sx[i], ky = sy[i];
+        const int ns = s_ns;
+        int hit = 0;
+        const int nsc = ns < skcap ? ns : skcap;
+        for (int s = threadIdx.x; s < nsc; s += 256) {
+            int dx = kx - skxy[(s * 5 + id) * 2], dy = ky - skxy[(s * 5 + id) * 2 + 1];
+            // integer-valued coordinates: sqrt(dx^2+dy^2) <= 10  <=>  dx^2+dy^2 <= 100 exactly
+            hit |= ((long)dx * dx + (long)dy * dy) <= 100;
+        }
+        hit = __syncthreads_or(hit);
+        if (hit) { if (threadIdx.x == 0) alive[i] = 0; __syncthreads(); continue; }
+        // wave w searches the w-th target type (ascending t, skipping the seed's own type)
+        const int t = wave + (wave >= id ? 1 : 0);
+        const int m = KG_MID_IDX[id][t];
+        const long pix = (long)ky * W + kx;
+        const double px = (double)kx + (double)mid[(long)(2 * m) * HW + pix];
+        const double py = (double)ky + (double)mid[(long)(2 * m + 1) * HW + pix];
+        double bd = 1e300; int bj = 0x7fffffff;
+        for (int j = i + 1 + lane; j < n; j += 64) {
+            if (!alive[j] || sid[j] != t) continue;
+            double d = norm2(px - (double)sx[j], py - (double)sy[j]);
+            if (d <= 6. && (d < bd || (d == bd && j < bj))) { bd = d; bj = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            double od = __shfl_xor(bd, o, 64); int oj = __shfl_xor(bj, o, 64);
+            if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+        }
+        if (lane == 0) s_match[wave] = bj;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            alive[i] = 0;
+            double sk[15]; int xy[10];
+            for (int q = 0; q < 15; ++q) sk[q] = 0.;
+            for (int q = 0; q < 10; ++q) xy[q] = 0;
+            sk[id * 3] = (double)kx; sk[id * 3 + 1] = (double)ky; sk[id * 3 + 2] = sconf[i];
+            xy[id * 2] = kx; xy[id * 2 + 1] = ky;
+            for (int w = 0; w < 4; ++w) {
+                int j = s_match[w];
+                if (j == 0x7fffffff) continue;
+                int tt = w + (w >= id ? 1 : 0);
+                alive[j] = 0;
+                sk[tt * 3] = (double)sx[j]; sk[tt * 3 + 1] = (double)sy[j]; sk[tt * 3 + 2] = sconf[j];
+                xy[tt * 2] = sx[j]; xy[tt * 2 + 1] = sy[j];
+            }
+            if (ns < skcap) {
+                for (int q = 0; q < 15; ++q) skel[(long)ns * 15 + q] = sk[q];
+                for (int q = 0; q < 10; ++q) skxy[ns * 10 + q] = xy[q];
+            }
+            s_ns = ns + 1;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *nskel = s_ns;
+}
+
+// ---- P6 + P7 ------------------------------------------------------------------------------------
+__device__ __forceinline__ double dmin(double a, double b) { return b < a ? b : a; }
+__device__ __forceinline__ double dmax(double a, double b) { return b > a ? b : a; }
+// returns 0 (no box), 1 (box)
+__device__ int skeleton_box(const double* __restrict__ sk_in, double scale, int do_refine, double* box) {
+    double s[15];
+    for (int q = 0; q < 15; ++q) s[q] = sk_in[q];
+    int m[5], cnt = 0;
+    for (int j = 0; j < 5; ++j) { m[j] = s[j * 3] > 0.; cnt += m[j]; }
+    if (do_refine && !((cnt >= 3) || (m[0] && m[3]) || (m[1] && m[2]))) return 0;
+    for (int j = 0; j < 5; ++j) { s[j * 3] *= scale; s[j * 3 + 1] *= scale; }
+    const double *tl = s, *tr = s + 3, *bl = s + 6, *br = s + 9, *cc = s + 12;
+    const int nc = m[0] + m[1] + m[2] + m[3];
+    double sum = 0.;
+    for (int j = 0; j < 5; ++j) if (m[j]) sum += s[j * 3 + 2];
+    double y1, x1, y2, x2;
+    if (nc == 4) { y1 = dmin(tl[1], tr[1]); y2 = dmax(bl[1], br[1]); x1 = dmin(tl[0], bl[0]); x2 = dmax(tr[0], br[0]); }
+    else if (nc == 3) {
+        y1 = (m[0] && m[1]) ? dmin(tl[1], tr[1]) : dmax(tl[1], tr[1]); y2 = dmax(bl[1], br[1]);
+        x1 = (m[0] && m[2]) ? dmin(tl[0], bl[0]) : dmax(tl[0], bl[0]); x2 = dmax(tr[0], br[0]);
+    } else if (nc == 2) {
+        if (m[0] && m[3]) { y1 = tl[1]; y2 = br[1]; x1 = tl[0]; x2 = br[0]; }
+        else if (m[1] && m[2]) { y1 = tr[1]; y2 = bl[1]; x1 = bl[0]; x2 = tr[0]; }
+        else if (m[0] && m[1] && m[4]) { y1 = dmin(tl[1], tr[1]); y2 = y1 + (cc[1] - y1) * 2; x1 = tl[0]; x2 = tr[0]; }
+        else if (m[0] && m[2] && m[4]) { y1 = tl[1]; y2 = bl[1]; x1 = dmin(tl[0], bl[0]); x2 = x1 + (cc[0] - x1) * 2; }
+        else if (m[1] && m[3] && m[4]) { y1 = tr[1]; y2 = br[1]; x2 = dmax(tr[0], br[0]); x1 = x2 - (x2 - cc[0]) * 2; }
+        else if (m[2] && m[3] && m[4]) { y2 = dmax(bl[1], br[1]); y1 = y2 - (y2 - cc[1]) * 2; x1 = bl[0]; x2 = br[0]; }
+        else return 0;
+    } else return 0;
+    box[0] = y1; box[1] = x1; box[2] = y2; box[3] = x2; box[4] = sum / (double)cnt;
+    return 1;
+}
+// one block; appends the boxes of this scale after the *nbox already present (order preserved)
+__global__ __launch_bounds__(1024) void boxes_kernel(const int* __restrict__ nskel, int skcap,
+                                                     const double* __restrict__ skel, double scale, int do_refine,
+                                                     int boxcap, double* __restrict__ boxes, int* __restrict__ nbox) {
+    __shared__ int sc[1024];
+    __shared__ int s_base;
+    int n = *nskel; if (n > skcap) n = skcap;
+    if (threadIdx.x == 0) s_base = *nbox;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + threadIdx.x;
+        double b[5]; int ok = 0;
+        if (i < n) ok = skeleton_box(skel + (long)i * 15, scale, do_refine, b);
+        sc[threadIdx.x] = ok;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            int v = threadIdx.x >= d ? sc[threadIdx.x - d] : 0;
+            __syncthreads();
+            sc[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const int pos = s_base + sc[threadIdx.x] - ok;
+        if (ok && pos < boxcap)
+            for (int q = 0; q < 5; ++q) boxes[(long)pos * 5 + q] = b[q];
+        __syncthreads();
+        if (threadIdx.x == 1023) s_base += sc[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *nbox = s_base;
+}
+
+// ---- P9 ---------------------------------------------------------------------------------------
+// one block.  order[] = indices sorted by confidence ascending (ties: index ascending).
+__global__ __launch_bounds__(1024) void nms_kernel(const int* __restrict__ nbox, int boxcap,
+                                                   const double* __restrict__ boxes, double thresh,
+                                                   int* __restrict__ order, unsigned char* __restrict__ dead,
+                                                   int* __restrict__ keep, int* __restrict__ nkeep) {
+    int n = *nbox; if (n > boxcap) n = boxcap;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const double ci = boxes[(long)i * 5 + 4];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { double cj = boxes[(long)j * 5 + 4]; rank += (cj < ci) || (cj == ci && j < i); }
+        order[rank] = i; dead[i] = 0;
+    }
+    __syncthreads();
+    int nk = 0;
+    for (int p = n - 1; p >= 0; --p) {
+        const int cur = order[p];
+        if (dead[cur]) continue;  // uniform
+        if (threadIdx.x == 0) keep[nk] = cur;
+        ++nk;
+        const double cy1 = boxes[(long)cur * 5], cx1 = boxes[(long)cur * 5 + 1], cy2 = boxes[(long)cur * 5 + 2],
+                     cx2 = boxes[(long)cur * 5 + 3];
+        const double carea = (cx2 - cx1) * (cy2 - cy1);
+        for (int q = threadIdx.x; q < p; q += 1024) {
+            const int k = order[q];
+            if (dead[k]) continue;
+            const double* b = boxes + (long)k * 5;
+            double yy1 = b[0] > cy1 ? b[0] : cy1, xx1 = b[1] > cx1 ? b[1] : cx1;
+            double yy2 = b[2] < cy2 ? b[2] : cy2, xx2 = b[3] < cx2 ? b[3] : cx2;
+            double w = xx2 - xx1, h = yy2 - yy1;
+            w = w > 0. ? w : 0.; h = h > 0. ? h : 0.;
+            double inter = w * h;
+            double area = (b[3] - b[1]) * (b[2] - b[0]);
+            double uni = (area - inter) + carea;
+            double iou = inter / uni;
+            if (!(iou <= thresh)) dead[k] = 1;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *nkeep = nk;
+}
+__global__ void gather_rows5_kernel(const double* __restrict__ boxes, const int* __restrict__ keep,
+                                    const int* __restrict__ nkeep, double* __restrict__ out) {
+    int n = *nkeep;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * 5; i += gridDim.x * blockDim.x)
+        out[i] = boxes[(long)keep[i / 5] * 5 + (i % 5)];
+}
+
+// ---- C ABI ------------------------------------------------------------------------------------
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" long kg_postproc_workspace_bytes(int H, int W, int peak_cap, int skel_cap) {
+    size_t HW = (size_t)H * W, b = 0;
+    b += al256(5 * HW * 4) * 3;            // count, offs, cursor
+    b += al256(5 * 4 * HW * 4);            // keys
+    b += al256(5 * 4 * HW * 8) * 2;        // vals, sorted
+    b += al256(5 * HW * 8) * 3;            // heat, tmp, blur
+    b += al256(5 * HW * 4) + 256;          // heavy list + counter
+    size_t nblk = (5 * HW + 1023) / 1024;
+    b += al256(nblk * 4) * 2 + 256;        // peak block counts / bases / total
+    b += (al256((size_t)peak_cap * 4) * 3 + al256((size_t)peak_cap * 8)) * 2;  // peaks + sorted peaks
+    b += al256(peak_cap);                  // alive
+    b += al256((size_t)skel_cap * 10 * 4);  // skxy
+    return (long)b + 4096;
+}
+
+struct PPWs {
+    int *count, *offs, *cursor; unsigned* keys; double *vals, *sorted, *heat, *tmp, *blur;
+    int *heavy_list, *heavy_n, *blkcount, *blkbase, *npk;
+    int *ids, *xs, *ys; double* conf; int *sid, *sx, *sy; double* sconf;
+    unsigned char* alive; int* skxy; int nblk;
+};
+static void carve(void* ws, int H, int W, int peak_cap, int skel_cap, PPWs* p) {
+    size_t HW = (size_t)H * W;
+    unsigned char* q = (unsigned char*)ws;
+    auto take = [&](size_t bytes) { void* r = q; q += al256(bytes); return r; };
+    p->count = (int*)take(5 * HW * 4); p->offs = (int*)take(5 * HW * 4); p->cursor = (int*)take(5 * HW * 4);
+    p->keys = (unsigned*)take(5 * 4 * HW * 4);
+    p->vals = (double*)take(5 * 4 * HW * 8); p->sorted = (double*)take(5 * 4 * HW * 8);
+    p->heat = (double*)take(5 * HW * 8); p->tmp = (double*)take(5 * HW * 8); p->blur = (double*)take(5 * HW * 8);
+    p->heavy_list = (int*)take(5 * HW * 4); p->heavy_n = (int*)take(256);
+    p->nblk = (int)((5 * HW + 1023) / 1024);
+    p->blkcount = (int*)take((size_t)p->nblk * 4); p->blkbase = (int*)take((size_t)p->nblk * 4); p->npk = (int*)take(256);
+    p->ids = (int*)take((size_t)peak_cap * 4); p->xs = (int*)take((size_t)peak_cap * 4); p->ys = (int*)take((size_t)peak_cap * 4);
+    p->conf = (double*)take((size_t)peak_cap * 8);
+    p->sid = (int*)take((size_t)peak_cap * 4); p->sx = (int*)take((size_t)peak_cap * 4); p->sy = (int*)take((size_t)peak_cap * 4);
+    p->sconf = (double*)take((size_t)peak_cap * 8);
+    p->alive = (unsigned char*)take(peak_cap); p->skxy = (int*)take((size_t)skel_cap * 10 * 4);
+}
+
+// P1..P4 for one scale (batch element 0 of the maps).  kp [5][H][W], soff [10][H][W], mid [40][H][W] fp32
+// device pointers.  Outputs (device): skel [skel_cap][5][3] f64, nskel, and optionally copies of the
+// intermediate stages (heat_out/blur_out [5][H][W] f64, peaks) for parity tests.
+extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float* mid, int H, int W, double thresh,
+                                 void* ws, long ws_bytes, int peak_cap, int skel_cap, double* skel, int* nskel,
+                                 double* heat_out, double* blur_out, int* peaks_out, double* peak_conf_out,
+                                 int* npeaks_out, void* stream) {
+    KG_CHECK_ARG(kp && soff && mid && ws && skel && nskel, "kg_postproc_scale: null pointer");
+    KG_CHECK_ARG(H >= 1 && W >= 1 && (long)H * W <= (1L << 28) / 4, "kg_postproc_scale: bad size");
+    KG_CHECK_ARG(W < 65536 && H < 65536, "kg_postproc_scale: map too large");
+    KG_CHECK_ARG(ws_bytes >= kg_postproc_workspace_bytes(H, W, peak_cap, skel_cap), "kg_postproc_scale: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    PPWs p; carve(ws, H, W, peak_cap, skel_cap, &p);
+    const int HW = H * W;
+    const double norm = 3.141592653589793 * 25.0;  // np.pi * KP_RADIUS**2 (postprocessing.py:51)
+    KG_HIP(hipMemsetAsync(p.count, 0, (size_t)5 * HW * 4, st));
+    KG_HIP(hipMemsetAsync(p.cursor, 0, (size_t)5 * HW * 4, st));
+    KG_HIP(hipMemsetAsync(p.heavy_n, 0, 4, st));
+    int gx = (4 * HW + 255) / 256; if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(hough_count_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.count);
+    hipLaunchKernelGGL(scan_kernel, dim3(5), dim3(1024), 0, st, p.count, p.offs, HW);
+    hipLaunchKernelGGL(hough_fill_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.offs, p.cursor, p.keys, p.vals);
+    int gc = (HW + 255) / 256; if (gc > 4096) gc = 4096;
+    hipLaunchKernelGGL(hough_sum_light_kernel, dim3(gc, 5), dim3(256), 0, st, HW, p.count, p.offs, p.keys, p.vals, norm, p.heat,
+                       p.heavy_n, p.heavy_list);
+    hipLaunchKernelGGL(hough_sum_heavy_kernel, dim3(2048), dim3(64), 0, st, HW, p.count, p.offs, p.keys, p.vals, p.sorted, norm,
+                       p.heat, p.heavy_n, p.heavy_list);
+    int gg = (5 * HW + 255) / 256; if (gg > 8192) gg = 8192;
+    hipLaunchKernelGGL(gauss_kernel<0>, dim3(gg), dim3(256), 0, st, p.heat, p.tmp, 5, H, W);
+    hipLaunchKernelGGL(gauss_kernel<1>, dim3(gg), dim3(256), 0, st, p.tmp, p.blur, 5, H, W);
+    hipLaunchKernelGGL(peaks_kernel<0>, dim3(p.nblk), dim3(256), 0, st, p.blur, H, W, thresh, p.blkcount, (const int*)nullptr, 0,
+                       (int*)nullptr, (int*)nullptr, (int*)nullptr, (double*)nullptr);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, p.blkcount, p.blkbase, p.nblk);
+    hipLaunchKernelGGL(peaks_total_kernel, dim3(1), dim3(64), 0, st, p.blkcount, p.blkbase, p.nblk, p.npk);
+    hipLaunchKernelGGL(peaks_kernel<1>, dim3(p.nblk), dim3(256), 0, st, p.blur, H, W, thresh, (int*)nullptr, p.blkbase, peak_cap,
+                       p.ids, p.xs, p.ys, p.conf);
+    hipLaunchKernelGGL(kp_rank_kernel, dim3(256), dim3(256), 0, st, p.npk, peak_cap, p.ids, p.xs, p.ys, p.conf, p.sid, p.sx, p.sy,
+                       p.sconf);
+    hipLaunchKernelGGL(group_kernel, dim3(1), dim3(256), 0, st, p.npk, peak_cap, p.sid, p.sx, p.sy, p.sconf, mid, H, W, p.alive,
+                       skel_cap, p.skxy, skel, nskel);
+    if (heat_out) KG_HIP(hipMemcpyAsync(heat_out, p.heat, (size_t)5 * HW * 8, hipMemcpyDeviceToDevice, st));
+    if (blur_out) KG_HIP(hipMemcpyAsync(blur_out, p.blur, (size_t)5 * HW * 8, hipMemcpyDeviceToDevice, st));
+    if (npeaks_out) KG_HIP(hipMemcpyAsync(npeaks_out, p.npk, 4, hipMemcpyDeviceToDevice, st));
+    if (peaks_out) {
+        KG_HIP(hipMemcpyAsync(peaks_out, p.ids, (size_t)peak_cap * 4, hipMemcpyDeviceToDevice, st));
+        KG_HIP(hipMemcpyAsync(peaks_out + peak_cap, p.xs, (size_t)peak_cap * 4, hipMemcpyDeviceToDevice, st));
+        KG_HIP(hipMemcpyAsync(peaks_out + 2 * (size_t)peak_cap, p.ys, (size_t)peak_cap * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (peak_conf_out) KG_HIP(hipMemcpyAsync(peak_conf_out, p.conf, (size_t)peak_cap * 8, hipMemcpyDeviceToDevice, st));
+    KG_CHECK_LAUNCH("postproc_scale");
+    return KG_OK;
+}
+
+// P6+P7: append boxes of one scale's skeletons to boxes[] (nbox is read-modify-written on device).
+extern "C" int kg_skeleton_boxes(const double* skel, const int* nskel, int skel_cap, double scale, int do_refine,
+                                 double* boxes, int* nbox, int box_cap, void* stream) {
+    KG_CHECK_ARG(skel && nskel && boxes && nbox, "kg_skeleton_boxes: null pointer");
+    hipLaunchKernelGGL(boxes_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nskel, skel_cap, skel, scale, do_refine, box_cap,
+                       boxes, nbox);
+    KG_CHECK_LAUNCH("skeleton_boxes");
+    return KG_OK;
+}
+// P9: ws needs box_cap*(4+1+4) bytes (+ alignment).  out [box_cap][5] kept boxes in pick order.
+extern "C" int kg_nms(const double* boxes, const int* nbox, int box_cap, double thresh, void* ws, long ws_bytes,
+                      double* out, int* nkeep, void* stream) {
+    KG_CHECK_ARG(boxes && nbox && ws && out && nkeep, "kg_nms: null pointer");
+    KG_CHECK_ARG(ws_bytes >= (long)(al256((size_t)box_cap * 4) * 2 + al256(box_cap)), "kg_nms: workspace too small");
+    unsigned char* q = (unsigned char*)ws;
+    int* order = (int*)q; q += al256((size_t)box_cap * 4);
+    int* keep = (int*)q; q += al256((size_t)box_cap * 4);
+    unsigned char* dead = q;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), 0, st, nbox, box_cap, boxes, thresh, order, dead, keep, nkeep);
+    hipLaunchKernelGGL(gather_rows5_kernel, dim3(64), dim3(256), 0, st, boxes, keep, nkeep, out);
+    KG_CHECK_LAUNCH("nms");
+    return KG_OK;
+}
+
+// fp64 primitive probe for the parity tests: out = {a/b, sqrt(|a|), fma(a,a,b*b), floor(a), ceil(a)}
+__global__ void f64_probe_kernel(const double* a, const double* b, double* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = a[i] / b[i]; out[n + i] = sqrt(fabs(a[i])); out[2 * n + i] = sqrt(fma(a[i], a[i], b[i] * b[i]));
+    out[3 * n + i] = floor(a[i]); out[4 * n + i] = ceil(a[i]);
+}
+extern "C" int kg_f64_probe(const double* a, const double* b, double* out, int n, void* stream) {
+    hipLaunchKernelGGL(f64_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    KG_CHECK_LAUNCH("f64_probe");
+    return KG_OK;
+}

@@ -1,0 +1,351 @@
+"""Executor of KGnet's dense network (forward_dec, KGnet.py:275-318) on the HIP kernels.
+
+A small explicit tape replaces per-op torch.autograd: every op launches its HIP kernels in forward
+and records one closure that launches the matching backward kernels.  Activations are bf16
+pixel-major rows; channel concatenations (torch.cat at KGnet.py:289-298) never happen -- producers
+write straight into column slices of the concat buffer.  ReLU backward is folded into the
+data-gradient kernels' epilogue (mask operand) whenever every contribution passes through one.
+"""
+import torch
+
+from . import arch, ops
+from .ops import BF16, PackedWeight
+
+
+class Var:
+    """Activation (bf16 rows view) + its gradient slot."""
+    __slots__ = ("t", "C", "relu", "grad", "masked", "req", "parent", "c0")
+
+    def __init__(self, t, C, relu=False, req=True, parent=None, c0=0):
+        self.t, self.C, self.relu, self.req = t, C, relu, req
+        self.grad, self.masked = None, True
+        self.parent, self.c0 = parent, c0
+
+    @property
+    def rows(self):
+        return self.t.shape[0]
+
+    def alloc_grad(self):
+        """Buffer the data-gradient kernel should write (a slice of the parent's grad for slice vars)."""
+        if self.parent is not None:
+            p = self.parent
+            if p.grad is None:
+                p.grad = torch.empty(p.t.shape[0], p.C, dtype=BF16, device=p.t.device)
+                p.masked = True
+            return p.grad[:, self.c0:self.c0 + self.C]
+        return torch.empty(self.t.shape[0], self.C, dtype=BF16, device=self.t.device)
+
+    def add_grad(self, g, masked):
+        if self.parent is not None:      # written in place into the parent's buffer
+            self.parent.masked = self.parent.masked and masked
+            return
+        if self.grad is None:
+            self.grad, self.masked = g, masked
+        else:
+            ops.add_rows(self.grad, g, self.grad, self.C)
+            self.masked = self.masked and masked
+
+    def take_grad(self):
+        g = self.grad
+        if g is not None and self.relu and not self.masked:
+            ops.add_rows(g, None, g, self.C, mask=self.t)
+            self.masked = True
+        return g
+
+
+class ConvSpec:
+    """One convolution (or a group fused along Cout that shares its input)."""
+
+    def __init__(self, names, cin, couts, k, stride, pad, bias):
+        self.names, self.cin, self.couts, self.k, self.stride, self.pad, self.has_bias = names, cin, couts, k, stride, pad, bias
+        self.cout = sum(couts)
+        self.cin_pad = ops.round_up(cin, 8)
+        self.pw = None       # forward packed weights
+        self.pwT = None      # dgrad packed weights
+        self.bias_cat = None
+        self.versions = None
+
+
+class Engine:
+    def __init__(self, module):
+        self.m = module
+        self.specs = {}
+        self.tape = None
+        self.param_grads = None
+
+    # ---- parameters ---------------------------------------------------------------------------
+    def P(self, key):
+        return self.m.get_tensor(key)
+
+    def spec(self, key, cin, cout, k, stride=1, pad=0, bias=True, fused=None):
+        s = self.specs.get(key)
+        if s is None:
+            names = fused if fused else [key]
+            couts = [cout] * len(names) if fused else [cout]
+            s = ConvSpec(names, cin, couts, k, stride, pad, bias)
+            self.specs[key] = s
+        return s
+
+    def prepare(self, s, need_T):
+        """(Re)pack weights when the fp32 master parameters changed (tracked by tensor versions)."""
+        ws = [self.P(n + ".weight") for n in s.names]
+        ver = tuple(w._version for w in ws) + tuple(w.data_ptr() for w in ws)
+        dev = ws[0].device
+        taps = s.k * s.k
+        if s.pw is None or s.versions != ver or s.pw.buf.device != dev:
+            if s.pw is None or s.pw.buf.device != dev:
+                s.pw = PackedWeight(s.cout, taps, s.cin_pad, dev)
+                s.pwT = None
+            r = 0
+            for w, co in zip(ws, s.couts):
+                s.pw.pack(w.detach(), row0=r)
+                r += co
+            if s.has_bias:
+                bs = [self.P(n + ".bias").detach() for n in s.names]
+                s.bias_cat = bs[0] if len(bs) == 1 else torch.cat(bs)
+            s.versions = ver
+            if s.pwT is not None:
+                s.pwT.stale = True
+        if need_T and (s.pwT is None or getattr(s.pwT, "stale", True)):
+            if s.pwT is None:
+                s.pwT = PackedWeight(s.cin, taps, ops.round_up(s.cout, 8), dev)
+            r = 0
+            for w, co in zip(ws, s.couts):
+                s.pwT.pack(w.detach(), c0=r, transposed=True)
+                r += co
+            s.pwT.stale = False
+
+    # ---- ops ------------------------------------------------------------------------------------
+    def conv(self, xv, s, N, H, W, relu, out=None, y_f32=None, tile=0):
+        """xv: Var over [N*H*W, >=cin_pad]; returns Var over [N*OH*OW, cout] (or fp32 NCHW when y_f32)."""
+        train = self.tape is not None
+        self.prepare(s, need_T=train and xv.req)
+        OH = (H + 2 * s.pad - s.k) // s.stride + 1
+        OW = (W + 2 * s.pad - s.k) // s.stride + 1
+        M = N * OH * OW
+        dev = xv.t.device
+        if y_f32 is None and out is None:
+            out = torch.empty(M, s.cout, dtype=BF16, device=dev)
+        geom = (M, H, W, OH, OW, s.k, s.k, s.stride, s.pad)
+        ops.conv_igemm(xv.t, s.pw, s.cout, geom, y=out, y_f32=y_f32, bias=s.bias_cat if s.has_bias else None, relu=relu, tile=tile)
+        yv = Var(out, s.cout, relu=relu)
+        if train:
+            def bwd():
+                g = yv.take_grad()
+                if g is None:
+                    return
+                grads, off = [], 0
+                for n, co in zip(s.names, s.couts):
+                    w = self.P(n + ".weight")
+                    gw = torch.empty_like(w)
+                    self.param_grads[n + ".weight"] = gw
+                    grads.append((gw, off, co))
+                    off += co
+                ops.conv_wgrad(xv.t, g, s.cin, s.cout, geom, grads)
+                if s.has_bias:
+                    db = torch.empty(s.cout, dtype=torch.float32, device=dev)
+                    ops.bias_grad(g, s.cout, db)
+                    off = 0
+                    for n, co in zip(s.names, s.couts):
+                        self.param_grads[n + ".bias"] = db[off:off + co]
+                        off += co
+                if xv.req:
+                    existing = xv.grad if xv.parent is None else None
+                    dx = existing if existing is not None else xv.alloc_grad()
+                    gin = (N * H * W, OH, OW, H, W, s.k, s.k, s.stride, s.pad)
+                    ops.conv_igemm(g, s.pwT, s.cin, gin, y=dx, res=existing, mask=xv.t if xv.relu else None, mode=1)
+                    if existing is None:
+                        xv.add_grad(dx, masked=xv.relu)
+                    else:
+                        xv.masked = xv.masked or xv.relu
+            self.tape.append(bwd)
+        return yv, OH, OW
+
+    def bn(self, xv, p, relu, res=None, out=None):
+        C = xv.C
+        dev = xv.t.device
+        gamma, beta = self.P(p + ".weight"), self.P(p + ".bias")
+        rm, rv = self.P(p + ".running_mean"), self.P(p + ".running_var")
+        if out is None:
+            out = torch.empty(xv.rows, C, dtype=BF16, device=dev)
+        if self.m.training:
+            mean, invstd, scale, shift = ops.bn_stats_train(xv.t, C, gamma.detach(), beta.detach(), rm, rv)
+            self.P(p + ".num_batches_tracked").add_(1)
+        else:
+            scale, shift = ops.bn_scale_shift_eval(C, gamma.detach(), beta.detach(), rm, rv)
+            mean = invstd = None
+        ops.bn_apply(xv.t, C, scale, shift, out, res=res.t if res is not None else None, relu=relu)
+        yv = Var(out, C, relu=relu)
+        if self.tape is not None:
+            if mean is None:
+                raise NotImplementedError("backward through eval-mode BatchNorm is not supported; call model.train()")
+
+            def bwd():
+                g = yv.take_grad()
+                if g is None:
+                    return
+                dg = torch.empty(C, dtype=torch.float32, device=dev)
+                db = torch.empty(C, dtype=torch.float32, device=dev)
+                dx = torch.empty(xv.rows, C, dtype=BF16, device=dev)
+                ops.bn_bwd(xv.t, g, C, gamma.detach(), mean, invstd, dg, db, dx)
+                self.param_grads[p + ".weight"] = dg
+                self.param_grads[p + ".bias"] = db
+                xv.add_grad(dx, masked=True)
+                if res is not None:
+                    res.add_grad(g, masked=False)
+            self.tape.append(bwd)
+        return yv
+
+    def maxpool(self, xv, N, H, W):
+        C = xv.C
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty(N * OH * OW, C, dtype=BF16, device=xv.t.device)
+        ops.maxpool_fwd(xv.t, out, N, H, W, C)
+        yv = Var(out, C, relu=False)
+        if self.tape is not None:
+            def bwd():
+                g = yv.take_grad()
+                if g is None:
+                    return
+                dx = torch.empty(xv.rows, C, dtype=BF16, device=xv.t.device)
+                ops.maxpool_bwd(xv.t, g, dx, N, H, W, C)
+                xv.add_grad(dx, masked=False)
+            self.tape.append(bwd)
+        return yv, OH, OW
+
+    def upsample(self, xv, N, IH, IW, OH, OW):
+        C = xv.C
+        out = torch.empty(N * OH * OW, C, dtype=BF16, device=xv.t.device)
+        ops.bilinear_fwd(xv.t, out, N, IH, IW, OH, OW, C)
+        yv = Var(out, C, relu=False)
+        if self.tape is not None:
+            def bwd():
+                g = yv.take_grad()
+                if g is None:
+                    return
+                dx = torch.empty(xv.rows, C, dtype=BF16, device=xv.t.device)
+                ops.bilinear_bwd(g, dx, N, IH, IW, OH, OW, C)
+                xv.add_grad(dx, masked=False)
+            self.tape.append(bwd)
+        return yv
+
+    def concat(self, buf, parts):
+        """buf [rows, sum C]; parts = Vars whose .t are the column slices of buf (already written)."""
+        cv = Var(buf, buf.shape[1], relu=all(p.relu for p in parts))
+        if self.tape is not None:
+            def bwd():
+                g = cv.take_grad()
+                if g is None:
+                    return
+                c = 0
+                for p in parts:
+                    p.add_grad(g[:, c:c + p.C], masked=cv.relu)
+                    c += p.C
+            self.tape.append(bwd)
+        return cv
+
+    # ---- the network ------------------------------------------------------------------------------
+    def bottleneck(self, xv, p, N, H, W, inplanes, planes, stride, has_ds, out=None):
+        a, _, _ = self.conv(xv, self.spec(p + ".conv1", inplanes, planes, 1, bias=False), N, H, W, False)
+        a = self.bn(a, p + ".bn1", True)
+        b, OH, OW = self.conv(a, self.spec(p + ".conv2", planes, planes, 3, stride, 1, bias=False), N, H, W, False)
+        b = self.bn(b, p + ".bn2", True)
+        c, _, _ = self.conv(b, self.spec(p + ".conv3", planes, planes * 4, 1, bias=False), N, OH, OW, False)
+        if has_ds:
+            d, _, _ = self.conv(xv, self.spec(p + ".downsample.0", inplanes, planes * 4, 1, stride, 0, bias=False), N, H, W, False)
+            idt = self.bn(d, p + ".downsample.1", False)
+        else:
+            idt = xv
+        y = self.bn(c, p + ".bn3", True, res=idt, out=out)
+        return y, OH, OW
+
+    def forward_dec(self, img, record):
+        """img fp32 [N,3,H,W].  Returns (maps: 12 fp32 NCHW tensors, feats: 5 Vars, dims)."""
+        N, _, H, W = img.shape
+        dev = img.device
+        self.tape = [] if record else None
+        self.param_grads = {}
+        x8 = Var(ops.img_pack(img), 8, relu=False, req=False)
+        dims = [(H, W)]
+        # c0 branch (KGnet.py:276): both convs at full resolution; c0 lands in cat0[:, 64:128]
+        cat0 = torch.empty(N * H * W, 128, dtype=BF16, device=dev)
+        c0a, _, _ = self.conv(x8, self.spec("c0_conv.0", 3, 64, 3, 1, 1), N, H, W, True)
+        c0, _, _ = self.conv(c0a, self.spec("c0_conv.2", 64, 64, 3, 1, 1), N, H, W, True, out=cat0[:, 64:128])
+        # stem (KGnet.py:278-282)
+        s1, H1, W1 = self.conv(x8, self.spec("conv1", 3, 64, 7, 2, 3, bias=False), N, H, W, False)
+        cat1 = torch.empty(N * H1 * W1, 128, dtype=BF16, device=dev)
+        c1 = self.bn(s1, "bn1", True, out=cat1[:, 64:128])
+        f, Hc, Wc = self.maxpool(c1, N, H1, W1)
+        dims.append((H1, W1))
+        feats = [c0, c1]
+        cats = [cat0, cat1]
+        for li, (name, inplanes, planes, blocks, stride) in enumerate(arch.LAYERS):
+            for b in range(blocks):
+                st = stride if b == 0 else 1
+                Ho, Wo = (Hc - 1) // st + 1, (Wc - 1) // st + 1
+                out = None
+                if b == blocks - 1 and li < 2:  # c2 / c3 land in their concat buffers
+                    catb = torch.empty(N * Ho * Wo, planes * 8, dtype=BF16, device=dev)
+                    cats.append(catb)
+                    out = catb[:, planes * 4:planes * 8]
+                f, Hc, Wc = self.bottleneck(f, f"{name}.{b}", N, Hc, Wc, inplanes if b == 0 else planes * 4, planes, st, b == 0, out=out)
+            feats.append(f)
+            dims.append((Hc, Wc))
+        # top-down decoder (KGnet.py:288-298)
+        cur = feats[4]
+        catv = {}
+        up_ch = {3: (1024, 512), 2: (512, 256), 1: (256, 64), 0: (64, 64)}
+        for lvl in (3, 2, 1, 0):
+            (IH, IW), (OH, OW) = dims[lvl + 1], dims[lvl]
+            cin, cu = up_ch[lvl]
+            u_in = self.upsample(cur, N, IH, IW, OH, OW)
+            buf = cats[lvl]
+            u, _, _ = self.conv(u_in, self.spec(f"c{lvl + 1}_up_conv.0", cin, cu, 3, 1, 1), N, OH, OW, True, out=buf[:, 0:cu])
+            cv = self.concat(buf, [u, feats[lvl]])
+            cur, _, _ = self.conv(cv, self.spec(f"c{lvl}_cat_refine.0", buf.shape[1], cu, 1), N, OH, OW, True)
+            catv[lvl] = cur
+        # heads (KGnet.py:300-316): three first 7x7 convs fused along Cout, three second convs
+        maps = []
+        self.head_vars = []
+        for lvl in range(4):
+            C = arch.HEAD_CH[lvl]
+            Hh, Wh = dims[lvl]
+            fused = [f"{h}_head_c{lvl}.0" for h, _ in arch.HEADS]
+            hid, _, _ = self.conv(catv[lvl], self.spec(f"heads_c{lvl}.0", C, C, 7, 1, 3, fused=fused), N, Hh, Wh, True)
+            for k, (h, co) in enumerate(arch.HEADS):
+                hv = Var(hid.t[:, k * C:(k + 1) * C], C, relu=True, parent=hid, c0=k * C)
+                o = torch.empty(N, co, Hh, Wh, dtype=torch.float32, device=dev)
+                ov, _, _ = self.conv(hv, self.spec(f"{h}_head_c{lvl}.2", C, co, 7, 1, 3), N, Hh, Wh, False, y_f32=o)
+                ov.C = co
+                if h == "kp":
+                    ops.sigmoid_(o)
+                maps.append(o)
+                self.head_vars.append(ov)
+        self.feats, self.dims, self.N, self.maps = feats, dims, N, maps
+        return maps, feats, dims
+
+    def backward_dec(self, map_grads, feat_grads):
+        """map_grads: 12 fp32 NCHW (or None); feat_grads: 5 bf16 rows tensors (or None)."""
+        N = self.N
+        for i, (ov, g) in enumerate(zip(self.head_vars, map_grads)):
+            lvl, k = divmod(i, 3)
+            Hh, Wh = self.dims[lvl]
+            co = arch.HEADS[k][1]
+            cpad = ops.round_up(co, 8)
+            dev = self.maps[i].device
+            if g is None:   # no gradient reaches this map: its slice of the fused hidden gradient must still be defined
+                packed = torch.zeros(N * Hh * Wh, cpad, dtype=BF16, device=dev)
+            else:
+                packed = torch.empty(N * Hh * Wh, cpad, dtype=BF16, device=dev)
+                prob = self.maps[i] if k == 0 else None
+                ops.grad_pack(g.contiguous().float(), prob, packed, N, co, Hh, Wh, cpad)
+            ov.grad, ov.masked = packed, True
+        for fv, g in zip(self.feats, feat_grads):
+            if g is not None:
+                fv.add_grad(g, masked=False)
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = None
+        grads = self.param_grads
+        self.param_grads = {}
+        return grads

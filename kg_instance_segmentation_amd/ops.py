@@ -1,0 +1,177 @@
+"""Tensor-level wrappers over the C ABI (kg_* entry points of libkgnet_hip.so).
+
+Activations are 2-D bf16 "rows" tensors [rows, C] with unit channel stride; the row stride (ld) may
+exceed C when the tensor is a channel slice of a wider (concat) buffer.  PyTorch only owns memory
+and streams here; every arithmetic kernel is hand-written HIP behind the C ABI.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import c_int, c_long, c_float, c_double, ptr, stream_ptr
+
+BF16 = torch.bfloat16
+_scratch = {}
+
+
+def scratch_f32(nfloats, dev, tag="default"):
+    """Grow-only fp32 scratch buffer per (device, tag)."""
+    key = (str(dev), tag)
+    t = _scratch.get(key)
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=dev)
+        _scratch[key] = t
+    return t
+
+
+def _rows(t):
+    assert t.dim() == 2 and t.dtype == BF16 and (t.shape[1] == 1 or t.stride(1) == 1), (t.shape, t.stride(), t.dtype)
+    return t
+
+
+def ld(t):
+    return t.stride(0)
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class PackedWeight:
+    """bf16 [rows_pad][K] matrix for kg_conv2d_igemm: K = taps * cin_pad (padded to 64)."""
+
+    def __init__(self, rows, taps, cin_pad, dev):
+        self.rows, self.taps, self.cin_pad = rows, taps, cin_pad
+        self.K = round_up(taps * cin_pad, 64)
+        self.buf = torch.zeros(round_up(rows, 128), self.K, dtype=BF16, device=dev)
+
+    def pack(self, w, row0=0, c0=0, transposed=False):
+        """w: fp32 OIHW parameter.  forward: rows=Cout, channels=Cin; transposed (dgrad): rows=Cin, channels=Cout."""
+        Cout, Cin, KH, KW = w.shape
+        assert w.dtype == torch.float32 and w.is_contiguous()
+        _lib.call("kg_pack_weight", ptr(w), ptr(self.buf), Cout, Cin, KH, KW, self.K, self.cin_pad, row0, c0,
+                  1 if transposed else 0, stream_ptr())
+
+
+def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, mode=0,
+               rowdesc=None, tile=0):
+    """geom = (M, H, W, OH, OW, KH, KW, stride, pad): H, W = gathered tensor's dims, OH, OW = output dims."""
+    M, H, W, OH, OW, KH, KW, stride, pad = geom
+    _rows(x)
+    f32_C = 0
+    if y_f32 is not None:
+        assert y_f32.dtype == torch.float32 and y_f32.is_contiguous()
+        f32_C = y_f32.shape[1] if y_f32.dim() == 4 else 1
+    _lib.call("kg_conv2d_igemm", ptr(x), ptr(pw.buf), ptr(bias), ptr(y), ptr(y_f32), ptr(res), ptr(mask), ptr(rowdesc),
+              M, H, W, OH, OW, pw.cin_pad, ld(x), cout, ld(y) if y is not None else 0,
+              ld(res) if res is not None else 0, ld(mask) if mask is not None else 0, pw.K, KH, KW, stride, pad, 1,
+              mode, 1 if relu else 0, f32_C, tile, stream_ptr())
+
+
+def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):
+    base = math.ceil(cin_lim / 64) * math.ceil(cout_lim / 64) * taps
+    chunks = math.ceil(M / 64)
+    s = max(1, min(math.ceil(2048 / base), max(1, chunks // 4)))
+    while s > 1 and s * nelem * 4 > (768 << 20):
+        s -= 1
+    return s
+
+
+def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=False):
+    """grads: list of (fp32 OIHW grad tensor, cout_offset, cout_count) sharing x (fused heads) or one entry."""
+    M, H, W, OH, OW, KH, KW, stride, pad = geom
+    _rows(x); _rows(dy)
+    cin_lim = min(round_up(cin, 8), x.shape[1])
+    cout_lim = min(round_up(cout, 8), dy.shape[1])
+    nelem = cout * KH * KW * cin
+    S = wgrad_splits(M, cin_lim, cout_lim, KH * KW, nelem)
+    part = scratch_f32(S * nelem, x.device, "wgrad")
+    _lib.call("kg_conv2d_wgrad", ptr(x), ptr(dy), ptr(part), ptr(rowdesc), M, H, W, OH, OW, ld(x), ld(dy), cin, cout,
+              cin_lim, cout_lim, KH, KW, stride, pad, 1, mode, S, c_long(nelem), stream_ptr())
+    for g, off, cnt in grads:
+        _lib.call("kg_wgrad_reduce", ctypes_offset(part, off * KH * KW * cin), ptr(g), cnt, cin, KH, KW, S, c_long(nelem),
+                  1 if accumulate else 0, stream_ptr())
+
+
+def ctypes_offset(t, elem_off):
+    return _lib.c_void_p(t.data_ptr() + elem_off * t.element_size())
+
+
+def bias_grad(dy, C, db, accumulate=False):
+    _rows(dy)
+    sc = scratch_f32(1024 * max(C, 1), dy.device, "bias")
+    _lib.call("kg_bias_grad", ptr(dy), ptr(db), ptr(sc), sc.numel(), dy.shape[0], C, ld(dy), 1 if accumulate else 0, stream_ptr())
+
+
+def img_pack(img):
+    N, C, H, W = img.shape
+    img = img.contiguous().float()
+    out = torch.empty(N * H * W, 8, dtype=BF16, device=img.device)
+    _lib.call("kg_img_pack", ptr(img), ptr(out), N, C, H, W, stream_ptr())
+    return out
+
+
+def bn_stats_train(x, C, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5):
+    """Returns (mean, invstd, scale, shift) fp32 [C]; updates running stats in place (may be None)."""
+    _rows(x)
+    dev = x.device
+    st = torch.empty(4, C, dtype=torch.float32, device=dev)
+    sc = scratch_f32(2 * C * 512, dev, "bn")
+    _lib.call("kg_bn_stats_train", ptr(x), ld(x), x.shape[0], C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+              c_float(momentum), c_float(eps), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), ptr(sc), sc.numel(), stream_ptr())
+    return st[0], st[1], st[2], st[3]
+
+
+def bn_scale_shift_eval(C, gamma, beta, rmean, rvar, eps=1e-5):
+    st = torch.empty(2, C, dtype=torch.float32, device=gamma.device)
+    _lib.call("kg_bn_scale_shift_eval", C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), c_float(eps), ptr(st[0]), ptr(st[1]), stream_ptr())
+    return st[0], st[1]
+
+
+def bn_apply(x, C, scale, shift, y, res=None, relu=False):
+    _rows(x); _rows(y)
+    _lib.call("kg_bn_apply", ptr(x), ld(x), ptr(scale), ptr(shift), ptr(res), ld(res) if res is not None else 0, ptr(y), ld(y),
+              x.shape[0], C, 1 if relu else 0, stream_ptr())
+
+
+def bn_bwd(x, dy, C, gamma, mean, invstd, dgamma, dbeta, dx, accumulate=False):
+    _rows(x); _rows(dy); _rows(dx)
+    sc = scratch_f32(2 * C * 512 + 3 * C, x.device, "bn")
+    _lib.call("kg_bn_bwd", ptr(x), ld(x), ptr(dy), ld(dy), ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
+              1 if accumulate else 0, ptr(dx), ld(dx), x.shape[0], C, ptr(sc), sc.numel(), stream_ptr())
+
+
+def maxpool_fwd(x, y, N, H, W, C):
+    _lib.call("kg_maxpool3s2_fwd", ptr(_rows(x)), ld(x), ptr(_rows(y)), ld(y), N, H, W, C, stream_ptr())
+
+
+def maxpool_bwd(x, dy, dx, N, H, W, C):
+    _lib.call("kg_maxpool3s2_bwd", ptr(_rows(x)), ld(x), ptr(_rows(dy)), ld(dy), ptr(_rows(dx)), ld(dx), N, H, W, C, stream_ptr())
+
+
+def bilinear_fwd(x, y, N, IH, IW, OH, OW, C, boxdesc=None, row2box=None):
+    rows = y.shape[0] if boxdesc is not None else 0
+    _lib.call("kg_bilinear_fwd", ptr(_rows(x)), ld(x), ptr(_rows(y)), ld(y), N, IH, IW, OH, OW, C, ptr(boxdesc), ptr(row2box),
+              c_long(rows), stream_ptr())
+
+
+def bilinear_bwd(dy, dx, N, IH, IW, OH, OW, C, boxdesc=None, row2box=None):
+    rows = dx.shape[0] if boxdesc is not None else 0
+    _lib.call("kg_bilinear_bwd", ptr(_rows(dy)), ld(dy), ptr(_rows(dx)), ld(dx), N, IH, IW, OH, OW, C, ptr(boxdesc), ptr(row2box),
+              c_long(rows), stream_ptr())
+
+
+def add_rows(a, b, y, C, mask=None):
+    """y = (a + b) [masked by mask > 0]; b may be None."""
+    _lib.call("kg_add_rows", ptr(_rows(a)), ld(a), ptr(b), ld(b) if b is not None else 0, ptr(mask),
+              ld(mask) if mask is not None else 0, ptr(_rows(y)), ld(y), c_long(a.shape[0]), C, stream_ptr())
+
+
+def sigmoid_(x):
+    _lib.call("kg_sigmoid_inplace", ptr(x), c_long(x.numel()), stream_ptr())
+    return x
+
+
+def grad_pack(g, prob, out, N, C, H, W, cpad):
+    _lib.call("kg_grad_pack", ptr(g), ptr(prob), ptr(_rows(out)), N, C, H, W, ld(out), cpad, stream_ptr())

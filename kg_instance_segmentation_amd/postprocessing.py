@@ -1,0 +1,129 @@
+"""Drop-in `postprocessing` module (reference postprocessing.py) on the float64 HIP pipeline.
+
+Hough vote -> Gaussian -> peaks -> greedy keypoint-graph grouping run on the GPU with the
+reference's exact float64 arithmetic and summation order; only the (tiny) skeleton list is copied to
+the host, where the reference's list-of-ndarray return types are rebuilt."""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ptr, stream_ptr, c_double, c_long
+
+PEAK_THRESH = 0.004   # postprocessing.py:145
+
+
+class _Workspace:
+    cache = {}
+
+    @classmethod
+    def get(cls, H, W, dev, peak_cap, skel_cap):
+        key = (H, W, str(dev), peak_cap, skel_cap)
+        ws = cls.cache.get(key)
+        if ws is None:
+            nbytes = _lib.load().kg_postproc_workspace_bytes(H, W, peak_cap, skel_cap)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            cls.cache[key] = ws
+        return ws
+
+
+def caps(H, W):
+    peak_cap = min(5 * H * W, 1 << 16)
+    return peak_cap, peak_cap
+
+
+def skeletons_device(kp, short, mid, debug=False):
+    """kp [.,5,H,W], short [.,10,H,W], mid [.,40,H,W] device fp32 (batch element 0 is used,
+    postprocessing.py:138-140).  Returns (skel [cap,5,3] f64 device, nskel int32[1] device[, debug dict])."""
+    if not kp.is_cuda:
+        raise _lib.KGLibraryError("postprocessing (MI355X build) needs GPU tensors")
+    kp0 = kp.detach()[0].contiguous().float(); sh0 = short.detach()[0].contiguous().float(); md0 = mid.detach()[0].contiguous().float()
+    _, H, W = kp0.shape
+    dev = kp0.device
+    peak_cap, skel_cap = caps(H, W)
+    ws = _Workspace.get(H, W, dev, peak_cap, skel_cap)
+    skel = torch.empty(skel_cap, 5, 3, dtype=torch.float64, device=dev)
+    nsk = torch.zeros(1, dtype=torch.int32, device=dev)
+    dbg = None
+    args = [None] * 5
+    if debug:
+        dbg = {"heat": torch.empty(5, H, W, dtype=torch.float64, device=dev), "blur": torch.empty(5, H, W, dtype=torch.float64, device=dev),
+               "peaks": torch.empty(3, peak_cap, dtype=torch.int32, device=dev), "conf": torch.empty(peak_cap, dtype=torch.float64, device=dev),
+               "npeaks": torch.zeros(1, dtype=torch.int32, device=dev)}
+        args = [ptr(dbg["heat"]), ptr(dbg["blur"]), ptr(dbg["peaks"]), ptr(dbg["conf"]), ptr(dbg["npeaks"])]
+    _lib.call("kg_postproc_scale", ptr(kp0), ptr(sh0), ptr(md0), H, W, c_double(PEAK_THRESH), ptr(ws), c_long(ws.numel()), peak_cap,
+              skel_cap, ptr(skel), ptr(nsk), *args, stream_ptr())
+    return (skel, nsk, dbg) if debug else (skel, nsk)
+
+
+def get_skeletons_and_masks(kp_maps, short_offsets, mid_offsets):
+    """== postprocessing.get_skeletons_and_masks (postprocessing.py:129-147): list of 5x3 float64 arrays."""
+    skel, nsk = skeletons_device(kp_maps, short_offsets, mid_offsets)
+    n = int(nsk.item())
+    if n > skel.shape[0]:
+        raise _lib.KGLibraryError(f"skeleton capacity exceeded ({n} > {skel.shape[0]})")
+    host = skel[:n].cpu().numpy()
+    return [host[i].copy() for i in range(n)]
+
+
+def refine_skeleton(skeletons):
+    """postprocessing.py:150-159 (host: a few hundred 5x3 arrays)."""
+    out = []
+    for s in skeletons:
+        mask = s[:, 0] > 0.
+        if mask.sum() >= 3 or mask[[0, 3]].sum() == 2 or mask[[1, 2]].sum() == 2:
+            out.append(s)
+    return out
+
+
+def _boxes_device(skel_list, scale, boxes, nbox, cap, dev):
+    n = len(skel_list)
+    if n == 0:
+        return
+    sk = torch.from_numpy(np.ascontiguousarray(np.asarray(skel_list, np.float64).reshape(n, 15))).to(dev)
+    ns = torch.tensor([n], dtype=torch.int32, device=dev)
+    _lib.call("kg_skeleton_boxes", ptr(sk), ptr(ns), n, c_double(scale), 0, ptr(boxes), ptr(nbox), cap, stream_ptr())
+
+
+def skeleton_to_box(skeletons, scale):
+    """postprocessing.py:164-242 -> list of [y1,x1,y2,x2,conf]; scales the skeletons in place like the reference."""
+    if len(skeletons) == 0:
+        return []
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cap = len(skeletons)
+    boxes = torch.empty(cap, 5, dtype=torch.float64, device=dev)
+    nbox = torch.zeros(1, dtype=torch.int32, device=dev)
+    _boxes_device(skeletons, scale, boxes, nbox, cap, dev)
+    k = int(nbox.item())
+    for s in skeletons:
+        s[:, :2] *= scale
+    return [list(r) for r in boxes[:k].cpu().numpy()]
+
+
+def gather_skeleton(skeleton0, skeleton1, skeleton2, skeleton3):
+    """postprocessing.py:255-261: boxes of the four scales concatenated (N x 5 float64, or shape (0,))."""
+    b = skeleton_to_box(skeleton0, 1) + skeleton_to_box(skeleton1, 2) + skeleton_to_box(skeleton2, 4) + skeleton_to_box(skeleton3, 8)
+    return np.asarray(b)
+
+
+def gather_skeleton_single(skeleton0, skeleton1, skeleton2, skeleton3):
+    return (np.asarray(skeleton_to_box(skeleton0, 1)), np.asarray(skeleton_to_box(skeleton1, 2)),
+            np.asarray(skeleton_to_box(skeleton2, 4)), np.asarray(skeleton_to_box(skeleton3, 8)))
+
+
+def detect(dec, nms_thresh=0.5):
+    """Fused test.py:105-116: four scales -> refine -> boxes -> NMS with a single device->host copy.
+    dec = ([kp,short,mid] x 4).  Returns N x 5 float64 ndarray or None."""
+    from . import nms as _nms
+    dev = dec[0][0].device
+    sks = [skeletons_device(*d) for d in dec]
+    cap = sum(s[0].shape[0] for s in sks)
+    cap = min(cap, 1 << 15)
+    boxes = torch.empty(cap, 5, dtype=torch.float64, device=dev)
+    nbox = torch.zeros(1, dtype=torch.int32, device=dev)
+    for (skel, nsk), scale in zip(sks, (1, 2, 4, 8)):
+        _lib.call("kg_skeleton_boxes", ptr(skel), ptr(nsk), skel.shape[0], c_double(scale), 1, ptr(boxes), ptr(nbox), cap, stream_ptr())
+    out, nk = _nms.nms_device(boxes, nbox, cap, float(nms_thresh))
+    k = int(nk.item())
+    if k == 0:
+        return None
+    return out[:k].cpu().numpy()

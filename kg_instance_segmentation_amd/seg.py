@@ -1,0 +1,307 @@
+"""Per-box segmentation branch (reference KGnet.py:246-267, 321-350) as batched ragged HIP work.
+
+The reference crops c0..c4 per box and runs ~15 tiny PyTorch kernels per box in a Python loop.
+Here every pyramid level holds ONE ragged pixel list for all boxes of the batch (box-major, raster
+inside a box); the top-down combine and the seg head are a handful of ragged implicit-GEMM launches.
+Host glue (this file) only computes the integer crop rectangles with the reference's float32
+rounding rules and uploads the box tables.
+"""
+import numpy as np
+import torch
+
+from . import arch, ops, _lib
+from ._lib import ptr, stream_ptr, c_long
+from .ops import BF16, PackedWeight
+
+
+def crop_rects(boxes, h0, w0, sizes):
+    """Vectorised restatement of KGnet.py:332-335 + 248-254 in float32 (numpy 2.x semantics of the
+    reference: np.float32 / float -> float32; np.round = rint half-to-even).
+    boxes [n,4] float32 (y1,x1,y2,x2) in c0 pixels.  Returns rect [L][n,4] int32 (y1,x1,y2,x2
+    end-exclusive slices) and depth [n] = number of leading accepted levels."""
+    b = np.asarray(boxes, np.float32).reshape(-1, 4)
+    n = len(b)
+    ny1 = b[:, 0] / np.float32(h0); nx1 = b[:, 1] / np.float32(w0)
+    ny2 = b[:, 2] / np.float32(h0); nx2 = b[:, 3] / np.float32(w0)
+    rects, depth, alive = [], np.zeros(n, np.int32), np.ones(n, bool)
+    for (h, w) in sizes:
+        y1 = np.maximum(0, np.round(ny1 * np.float32(h)).astype(np.int32))
+        x1 = np.maximum(0, np.round(nx1 * np.float32(w)).astype(np.int32))
+        y2 = np.minimum(np.round(ny2 * np.float32(h)).astype(np.int32), h - 1)
+        x2 = np.minimum(np.round(nx2 * np.float32(w)).astype(np.int32), w - 1)
+        ok = ~((y2 < y1) | (x2 < x1) | (y2 - y1 < 2) | (x2 - x1 < 2))
+        alive &= ok
+        depth += alive
+        rects.append(np.stack([y1, x1, y2, x2], 1))
+    return rects, depth
+
+
+class _Plan:
+    """Box tables of one forward_seg call (host numpy + device copies)."""
+
+
+class _SegFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, branch, plan, f0, f1, f2, f3, f4, *params):
+        record = torch.is_grad_enabled()
+        flat, saved = branch.run_forward(plan, [f0, f1, f2, f3, f4], record)
+        ctx.branch, ctx.plan, ctx.saved = branch, plan, saved
+        ctx.feat_shapes = [tuple(f.shape) for f in (f0, f1, f2, f3, f4)]
+        return flat
+
+    @staticmethod
+    def backward(ctx, gflat):
+        if ctx.saved is None:
+            raise RuntimeError("forward_seg was run without gradient recording")
+        gfeats, pgrads = ctx.branch.run_backward(ctx.plan, ctx.saved, gflat.contiguous().float(), ctx.feat_shapes)
+        out = [None, None] + gfeats
+        for k in ctx.branch.param_keys:
+            out.append(pgrads.get(k))
+        return tuple(out)
+
+
+class SegBranch:
+    def __init__(self, module):
+        self.m = module
+        self.param_keys = []
+        for i in range(4):
+            for sub in ("up", "cat_conv"):
+                self.param_keys += [f"skip_combine.{i}.{sub}.0.weight", f"skip_combine.{i}.{sub}.0.bias"]
+        self.param_keys += ["seg_head.0.weight", "seg_head.0.bias", "seg_head.2.weight", "seg_head.2.bias"]
+        self.packed = {}
+
+    def P(self, k):
+        return self.m.get_tensor(k)
+
+    def packw(self, key, need_T):
+        """key -> (PackedWeight fwd, PackedWeight dgrad, bias) repacked when the parameter version changes."""
+        w = self.P(key + ".weight")
+        ver = (w._version, w.data_ptr())
+        e = self.packed.get(key)
+        cout, cin, k, _ = w.shape
+        if e is None or e["ver"] != ver or e["pw"].buf.device != w.device:
+            pw = e["pw"] if e is not None and e["pw"].buf.device == w.device else PackedWeight(cout, k * k, ops.round_up(cin, 8), w.device)
+            pw.pack(w.detach())
+            e = {"ver": ver, "pw": pw, "pwT": e["pwT"] if e is not None and e["pw"].buf.device == w.device else None, "T_ok": False}
+            self.packed[key] = e
+        if need_T and not e["T_ok"]:
+            if e["pwT"] is None:
+                e["pwT"] = PackedWeight(cin, k * k, ops.round_up(cout, 8), w.device)
+            e["pwT"].pack(w.detach(), transposed=True)
+            e["T_ok"] = True
+        return e["pw"], e["pwT"], self.P(key + ".bias").detach()
+
+    # ---- planning (host) ----------------------------------------------------------------------------
+    def make_plan(self, feats, bboxes):
+        dev = feats[0].device
+        sizes = [tuple(f.shape[2:]) for f in feats]
+        h0, w0 = sizes[0]
+        img_idx, box_idx, allb = [], [], []
+        for i, bb in enumerate(bboxes):
+            if bb is None or len(bb) == 0:
+                continue
+            bb = np.asarray(bb.detach().cpu().numpy() if hasattr(bb, "detach") else bb, np.float32).reshape(-1, 5)
+            allb.append(bb)
+            img_idx += [i] * len(bb)
+            box_idx += list(range(len(bb)))
+        p = _Plan()
+        p.nimg = len(bboxes)
+        p.sizes = sizes
+        if not allb:
+            p.nb = [0] * 5
+            return p
+        allb = np.concatenate(allb, 0)
+        img_idx = np.asarray(img_idx, np.int32); box_idx = np.asarray(box_idx, np.int32)
+        rects, depth = crop_rects(allb[:, :4], h0, w0, sizes)
+        keep = depth > 0
+        order = np.argsort(-depth[keep], kind="stable")
+        sel = np.nonzero(keep)[0][order]
+        p.boxes = allb[sel]; p.img = img_idx[sel]; p.box_in_img = box_idx[sel]; p.depth = depth[sel]
+        p.nb = [int((p.depth > l).sum()) for l in range(5)]
+        p.row0, p.hw, tabs = [], [], []
+        for l in range(5):
+            nb = p.nb[l]
+            r = rects[l][sel][:nb]
+            h = (r[:, 2] - r[:, 0]).astype(np.int32); w = (r[:, 3] - r[:, 1]).astype(np.int32)
+            row0 = np.zeros(nb + 1, np.int64)
+            np.cumsum(h.astype(np.int64) * w, out=row0[1:])
+            p.row0.append(row0); p.hw.append((h, w))
+            H, W = sizes[l]
+            tab = np.stack([p.img[:nb], r[:, 0], r[:, 1], h, w, row0[:-1].astype(np.int32),
+                            np.full(nb, H, np.int32), np.full(nb, W, np.int32)], 1).astype(np.int32)
+            tabs.append(tab)
+        bil = []
+        for l in range(4):   # level l+1 -> level l for the nb[l+1] combine boxes
+            nc = p.nb[l + 1]
+            (hi, wi), (ho, wo) = p.hw[l + 1], p.hw[l]
+            bil.append(np.stack([p.row0[l + 1][:nc].astype(np.int32), hi[:nc], wi[:nc], p.row0[l][:nc].astype(np.int32),
+                                 ho[:nc], wo[:nc]], 1).astype(np.int32))
+        blob = np.concatenate([t.ravel() for t in tabs] + [b.ravel() for b in bil]).astype(np.int32)
+        dblob = torch.from_numpy(blob).to(dev, non_blocking=True)
+        off = 0
+        p.tab_d, p.bil_d = [], []
+        for t in tabs:
+            p.tab_d.append(dblob[off:off + t.size]); off += t.size
+        for b in bil:
+            p.bil_d.append(dblob[off:off + b.size]); off += b.size
+        p.rows = [int(p.row0[l][-1]) for l in range(5)]
+        p.rowdesc, p.row2box, p.srcrow = [], [], []
+        for l in range(5):
+            R = max(p.rows[l], 1)
+            rd = torch.empty(R, 2, dtype=torch.int32, device=dev)
+            r2b = torch.empty(R, dtype=torch.int32, device=dev)
+            sr = torch.empty(R, dtype=torch.int32, device=dev)
+            if p.nb[l]:
+                _lib.call("kg_seg_build_rows", ptr(p.tab_d[l]), p.nb[l], ptr(rd), ptr(r2b), ptr(sr), stream_ptr())
+            p.rowdesc.append(rd); p.row2box.append(r2b); p.srcrow.append(sr)
+        return p
+
+    # ---- device work --------------------------------------------------------------------------------
+    @staticmethod
+    def feat_rows(f):
+        n, c, h, w = f.shape
+        r = f.permute(0, 2, 3, 1)
+        if r.dtype != BF16:
+            r = r.to(BF16)
+        return r.reshape(n * h * w, c) if r.is_contiguous() or r.stride(3) == 1 else r.contiguous().reshape(n * h * w, c)
+
+    def gather(self, frows, srcrow, dst, nrows, C, row_off=0):
+        if nrows:
+            _lib.call("kg_rows_gather", ptr(frows), ops.ld(frows), _lib.c_void_p(srcrow.data_ptr() + 4 * row_off),
+                      ptr(dst), ops.ld(dst), c_long(nrows), C, stream_ptr())
+
+    def rconv(self, x, pw, cout, rowdesc, M, k, y=None, y_f32=None, bias=None, relu=False, mask=None, mode=2):
+        geom = (M, 0, 0, M, 1, k, k, 1, (k - 1) // 2)
+        ops.conv_igemm(x, pw, cout, geom, y=y, y_f32=y_f32, bias=bias, relu=relu, mask=mask, mode=mode, rowdesc=rowdesc)
+
+    def run_forward(self, plan, feats, record):
+        dev = feats[0].device
+        if plan.nb[0] == 0:
+            return torch.zeros(0, dtype=torch.float32, device=dev), None
+        fr = [self.feat_rows(f) for f in feats]
+        CH = arch.FEAT_CH
+        pre = [None] * 5
+        cats, uins = [None] * 4, [None] * 4
+        top = max(l for l in range(5) if plan.nb[l] > 0)
+        pre[top] = torch.empty(plan.rows[top], CH[top], dtype=BF16, device=dev)
+        self.gather(fr[top], plan.srcrow[top], pre[top], plan.rows[top], CH[top])
+        for l in range(top - 1, -1, -1):
+            cin, cout, ccat = arch.SKIP[l]
+            nc = plan.nb[l + 1]
+            rowsC = int(plan.row0[l][nc])
+            rows = plan.rows[l]
+            pre[l] = torch.empty(rows, CH[l], dtype=BF16, device=dev)
+            if nc:
+                uin = torch.empty(rowsC, CH[l + 1], dtype=BF16, device=dev)
+                ops.bilinear_fwd(pre[l + 1], uin, 0, 0, 0, 0, 0, CH[l + 1], boxdesc=plan.bil_d[l], row2box=plan.row2box[l])
+                cat = torch.empty(rowsC, ccat, dtype=BF16, device=dev)
+                pw, _, b = self.packw(f"skip_combine.{l}.up.0", record)
+                self.rconv(uin, pw, cout, plan.rowdesc[l], rowsC, 3, y=cat[:, CH[l]:CH[l] + cout], bias=b, relu=True)
+                self.gather(fr[l], plan.srcrow[l], cat[:, 0:CH[l]], rowsC, CH[l])
+                pw, _, b = self.packw(f"skip_combine.{l}.cat_conv.0", record)
+                self.rconv(cat, pw, cout, plan.rowdesc[l], rowsC, 1, y=pre[l][:rowsC], bias=b, relu=True)
+                cats[l], uins[l] = cat, uin
+            self.gather(fr[l], plan.srcrow[l], pre[l][rowsC:], rows - rowsC, CH[l], row_off=rowsC)
+        rows0 = plan.rows[0]
+        hid = torch.empty(rows0, 64, dtype=BF16, device=dev)
+        pw, _, b = self.packw("seg_head.0", record)
+        self.rconv(pre[0], pw, 64, plan.rowdesc[0], rows0, 3, y=hid, bias=b, relu=True)
+        flat = torch.empty(rows0, dtype=torch.float32, device=dev)
+        pw, _, b = self.packw("seg_head.2", record)
+        self.rconv(hid, pw, 1, plan.rowdesc[0], rows0, 3, y_f32=flat, bias=b)
+        ops.sigmoid_(flat)
+        saved = (pre, cats, uins, hid, flat, top) if record else None
+        return flat, saved
+
+    def conv_bwd(self, key, x, g, rowdesc, M, k, pgrads, dx=None, mask=None):
+        """wgrad + bias grad (+ dgrad into dx) of one ragged conv; g must already be pre-activation."""
+        w = self.P(key + ".weight")
+        cout, cin = w.shape[0], w.shape[1]
+        geom = (M, 0, 0, M, 1, k, k, 1, (k - 1) // 2)
+        gw = torch.empty_like(w)
+        ops.conv_wgrad(x, g, cin, cout, geom, [(gw, 0, cout)], mode=2, rowdesc=rowdesc)
+        db = torch.empty(cout, dtype=torch.float32, device=w.device)
+        ops.bias_grad(g, cout, db)
+        pgrads[key + ".weight"], pgrads[key + ".bias"] = gw, db
+        if dx is not None:
+            _, pwT, _ = self.packw(key, True)
+            self.rconv(g, pwT, cin, rowdesc, M, k, y=dx, mask=mask, mode=3)
+
+    def run_backward(self, plan, saved, gflat, feat_shapes):
+        pre, cats, uins, hid, flat, top = saved
+        dev = gflat.device
+        CH = arch.FEAT_CH
+        pgrads = {}
+        rows0 = plan.rows[0]
+        gz = torch.empty(rows0, 8, dtype=BF16, device=dev)
+        ops.grad_pack(gflat, flat, gz, 1, 1, rows0, 1, 8)
+        dhid = torch.empty(rows0, 64, dtype=BF16, device=dev)
+        self.conv_bwd("seg_head.2", hid, gz, plan.rowdesc[0], rows0, 3, pgrads, dx=dhid, mask=hid)
+        dpre = torch.empty(rows0, 64, dtype=BF16, device=dev)
+        self.conv_bwd("seg_head.0", pre[0], dhid, plan.rowdesc[0], rows0, 3, pgrads, dx=dpre, mask=pre[0])
+        acc = []
+        for l in range(5):
+            n, c, h, w = feat_shapes[l]
+            acc.append(torch.zeros(n * h * w, c, dtype=torch.float32, device=dev) if plan.nb[l] else None)
+
+        def scatter(g, l, nrows, row_off=0):
+            if nrows:
+                _lib.call("kg_rows_scatter_add", ptr(g), ops.ld(g), _lib.c_void_p(plan.srcrow[l].data_ptr() + 4 * row_off),
+                          ptr(acc[l]), CH[l], c_long(nrows), CH[l], stream_ptr())
+
+        for l in range(0, top):
+            cin, cout, ccat = arch.SKIP[l]
+            nc = plan.nb[l + 1]
+            rowsC = int(plan.row0[l][nc])
+            rows = plan.rows[l]
+            scatter(dpre[rowsC:], l, rows - rowsC, row_off=rowsC)
+            nxt = None
+            if nc:
+                cat, uin = cats[l], uins[l]
+                dcat = torch.empty(rowsC, ccat, dtype=BF16, device=dev)
+                self.conv_bwd(f"skip_combine.{l}.cat_conv.0", cat, dpre[:rowsC], plan.rowdesc[l], rowsC, 1, pgrads, dx=dcat, mask=cat)
+                scatter(dcat[:, 0:CH[l]], l, rowsC)
+                duin = torch.empty(rowsC, CH[l + 1], dtype=BF16, device=dev)
+                self.conv_bwd(f"skip_combine.{l}.up.0", uin, dcat[:, CH[l]:CH[l] + cout], plan.rowdesc[l], rowsC, 3, pgrads, dx=duin)
+                nxt = torch.empty(plan.rows[l + 1], CH[l + 1], dtype=BF16, device=dev)
+                ops.bilinear_bwd(duin, nxt, 0, 0, 0, 0, 0, CH[l + 1], boxdesc=plan.bil_d[l], row2box=plan.row2box[l + 1])
+                ops.add_rows(nxt, None, nxt, CH[l + 1], mask=pre[l + 1])
+            dpre = nxt
+        if dpre is not None:
+            scatter(dpre, top, plan.rows[top])
+        gfeats = []
+        for l in range(5):
+            n, c, h, w = feat_shapes[l]
+            if acc[l] is None:
+                gfeats.append(None)
+                continue
+            g = torch.empty(n * h * w, c, dtype=BF16, device=dev)
+            _lib.call("kg_f32_to_bf16_rows", ptr(acc[l]), ptr(g), c, c_long(n * h * w), c, None, 0, stream_ptr())
+            gfeats.append(g.view(n, h, w, c).permute(0, 3, 1, 2))
+        # parameters of levels that no box reached get zero gradients (autograd accumulates nothing for None)
+        return gfeats, pgrads
+
+    # ---- reference API --------------------------------------------------------------------------------
+    def forward(self, feat_seg, bboxes):
+        """== ResNet.forward_seg (KGnet.py:321-350): returns [mask_patches, mask_dets]."""
+        plan = self.make_plan(feat_seg, bboxes)
+        mask_patches = [[] for _ in range(len(bboxes))]
+        mask_dets = [[] for _ in range(len(bboxes))]
+        if plan.nb[0] == 0:
+            return [mask_patches, mask_dets]
+        params = [self.P(k) for k in self.param_keys]
+        flat = _SegFunction.apply(self, plan, *feat_seg, *params)
+        h0, w0 = plan.hw[0]
+        r0 = plan.row0[0]
+        # emit in the reference's order: image by image, boxes in input order
+        order = np.lexsort((plan.box_in_img, plan.img))
+        info = []
+        for b in order:
+            i = int(plan.img[b])
+            patch = flat[int(r0[b]):int(r0[b + 1])].view(int(h0[b]), int(w0[b]))
+            mask_patches[i].append(patch)
+            mask_dets[i].append(torch.from_numpy(plan.boxes[b].copy()))
+            info.append((i, int(r0[b]), int(h0[b]), int(w0[b])))
+        out = [mask_patches, mask_dets]
+        self.last = {"flat": flat, "info": info, "patches": mask_patches}
+        return out

@@ -66,3 +66,23 @@ def head_maps(H, W, n_cells, seed, sigma_kp=0.05, sigma_off=0.5, smin=14, smax=4
     short = (gt[5:15] + rng.normal(0, sigma_off, (10, H, W))).astype(np.float32)
     mid = (gt[15:55] + rng.normal(0, sigma_off, (40, H, W))).astype(np.float32)
     return kp[None], short[None], mid[None], boxes
+
+
+def train_batch(N, H, W, seed, n_boxes=4, smin=14, smax=30):
+    """Seeded training batch in the collater's layout (collater.py:4-25): image [N,3,H,W] f32,
+    GT maps for the 4 scales [N,55,H/s,W/s], instance masks (ellipses) and GT boxes [n,5]."""
+    import torch
+    x = torch.rand(N, 3, H, W, generator=torch.Generator().manual_seed(seed)) - 0.5
+    gt_boxes, gt_masks = [], []
+    for i in range(N):
+        bx = random_boxes(H, W, n_boxes, 300 + i, smin, smax)
+        gt_boxes.append(np.concatenate([bx, np.ones((len(bx), 1))], 1).astype(np.float32))
+        m = np.zeros((len(bx), H, W), np.float32)
+        for k, b in enumerate(bx.astype(int)):
+            yy, xx = np.mgrid[0:H, 0:W]
+            cy, cx = (b[0] + b[2]) / 2, (b[1] + b[3]) / 2
+            m[k] = (((yy - cy) / ((b[2] - b[0]) / 2 + .5)) ** 2 + ((xx - cx) / ((b[3] - b[1]) / 2 + .5)) ** 2 <= 1).astype(np.float32)
+        gt_masks.append(m)
+    gt_lv = [torch.from_numpy(np.stack([gt_maps(np.floor(gt_boxes[i][:, :4] / sc), H // sc, W // sc) for i in range(N)]))
+             for sc in (1, 2, 4, 8)]
+    return x, gt_boxes, gt_masks, gt_lv

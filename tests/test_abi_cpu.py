@@ -1,0 +1,108 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/kgnet_hip.h declares; the
+host-side glue (crop rectangles, loss matching, module keys) behaves like the reference's.  No
+compute entry point is called here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from kg_instance_segmentation_amd import build
+    return ctypes.CDLL(build.build())
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "kgnet_hip.h")).read()
+    names = set(re.findall(r"\b(kg_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 30
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_binding_table_matches_header(lib):
+    from kg_instance_segmentation_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "kgnet_hip.h")).read()
+    names = set(re.findall(r"\b(kg_[a-z0-9_]+)\s*\(", hdr))
+    assert set(_lib.SYMBOLS) == names
+    # argument counts of the ctypes table agree with the header prototypes
+    for m in re.finditer(r"\b(?:int|long|const char\*)\s+(kg_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", hdr, re.S):
+        name, args = m.group(1), m.group(2).strip()
+        n = 0 if args in ("", "void") else len(args.split(","))
+        if name in _lib._SIGS:
+            assert len(_lib._SIGS[name]) == n, (name, len(_lib._SIGS[name]), n)
+
+
+def test_version_and_error_channel(lib):
+    lib.kg_last_error.restype = ctypes.c_char_p
+    assert lib.kg_version() >= 100
+    # argument validation happens on the host before any launch
+    rc = lib.kg_conv2d_igemm(None, None, None, None, None, None, None, None, *([0] * 21), None)
+    assert rc != 0 and b"kg_conv2d_igemm" in lib.kg_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from kg_instance_segmentation_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libkgnet_hip.so")
+    with pytest.raises(_lib.KGLibraryError):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "kg_instance_segmentation_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "/root/reference" not in src, f
+
+
+def test_module_keys_and_cpu_refusal(state_dict0):
+    from kg_instance_segmentation_amd import KGnet, _lib
+    m = KGnet.resnet50(pretrained=False)
+    assert list(m.state_dict().keys()) == list(state_dict0.keys())
+    m.load_state_dict(state_dict0)
+    assert len(list(m.parameters())) == 217
+    with pytest.raises(_lib.KGLibraryError):   # no silent CPU fallback
+        m.forward_dec(torch.zeros(1, 3, 64, 64))
+
+
+def test_crop_rects_match_oracle():
+    from kg_instance_segmentation_amd.seg import crop_rects
+    from oracle.net import Net
+    rng = np.random.default_rng(3)
+    sizes = [(96, 128), (48, 64), (24, 32), (12, 16), (6, 8)]
+    boxes = np.concatenate([rng.uniform(0, 100, (200, 4)), [[10.5, 12.5, 40.5, 50.5], [0, 0, 95, 127], [30.5, 60.5, 37.5, 71.5],
+                                                            [50, 20, 52, 90], [2.5, 3.5, 14.5, 17.5]]]).astype(np.float32)
+    boxes[:, 2:] = np.maximum(boxes[:, 2:], boxes[:, :2] + rng.uniform(0, 60, (len(boxes), 2)).astype(np.float32))
+    rects, depth = crop_rects(boxes, 96, 128, sizes)
+    for b in range(len(boxes)):
+        d = 0
+        for l, (h, w) in enumerate(sizes):
+            cc = Net.crop_coords(boxes[b], 96, 128, h, w)
+            if cc is None:
+                break
+            assert tuple(rects[l][b]) == cc
+            d += 1
+        assert d == depth[b]
+
+
+def test_seg_loss_host_matching_matches_oracle(golden):
+    from kg_instance_segmentation_amd.seg_loss import jaccard_numpy, nearest_resize
+    from oracle import net as onet
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        a = rng.uniform(0, 50, 4).astype(np.float32); b = rng.uniform(0, 50, 4).astype(np.float32)
+        a[2:] += a[:2]; b[2:] += b[:2]
+        assert jaccard_numpy(a, b) == onet.jaccard(a, b)
+    m = (rng.random((13, 17)) > 0.5).astype(np.float32)
+    assert np.array_equal(nearest_resize(m, 7, 9), onet.nearest_resize(m, 7, 9))
+    assert nearest_resize(m, 13, 17) is m

@@ -1,0 +1,334 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (ops.py -> libkgnet_hip.so).
+
+Checker: the same torch fp32/fp64 CPU primitives the oracle (oracle/net.py) is written in.  Inputs are
+made bf16-representable so that the only differences are accumulation order (fp32) and the final bf16
+rounding of stored activations; tolerances below are stated per test."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from kg_instance_segmentation_amd import _lib, ops  # noqa: E402
+from kg_instance_segmentation_amd.ops import BF16, PackedWeight  # noqa: E402
+
+DEV = "cuda"
+
+
+def bfr(t):
+    """round to bf16-representable fp32"""
+    return t.to(BF16).float()
+
+
+def rows_of(x):  # NCHW fp32 -> bf16 rows [N*H*W, C]
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * h * w, c).to(BF16).contiguous()
+
+
+def nchw_of(rows, n, h, w):
+    return rows.float().view(n, h, w, -1).permute(0, 3, 1, 2)
+
+
+def report(name, got, ref, atol, rtol):
+    got = got.detach().double().cpu(); ref = ref.detach().double().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = int((err > tol).sum())
+    idx = int(err.argmax())
+    print(f"[{name}] max_abs_err={float(err.max()):.3e} at flat {idx} (got {float(got.flatten()[idx]):.6g} ref {float(ref.flatten()[idx]):.6g}) "
+          f"ref_absmax={float(ref.abs().max()):.3e} bad={bad}/{err.numel()}")
+    if bad:
+        bi = torch.nonzero((err > tol).flatten())[:8].flatten().tolist()
+        print("   first bad:", [(i, float(got.flatten()[i]), float(ref.flatten()[i])) for i in bi])
+    assert bad == 0, name
+
+
+def test_library_and_arch():
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(128)
+    assert lib.kg_device_arch(buf, 128) == 0
+    print("arch:", buf.value.decode())
+    assert buf.value.decode().startswith("gfx950")
+
+
+def test_tr_read_semantics():
+    """ds_read_b64_tr_b16: within a 16-lane group lane i supplies 4 contiguous b16 (row i>>2, cols 4*(i&3)..)
+    and receives column i of the 4x16 block (rows 0..3).  conv_wgrad.hip relies on exactly this."""
+    out = torch.zeros(256, dtype=torch.int16, device=DEV)
+    _lib.call("kg_tr_probe", _lib.ptr(out), _lib.stream_ptr())
+    got = out.cpu().numpy().astype(np.int64).reshape(64, 4)
+    exp = np.zeros((64, 4), np.int64)
+    for l in range(64):
+        G, i = l // 16, l % 16
+        for j in range(4):
+            exp[l, j] = (G * 16 + j * 4 + (i >> 2)) * 4 + (i & 3)
+    if not np.array_equal(got, exp):
+        print("tr probe mapping (lane: got | expected):")
+        for l in range(64):
+            print(l, got[l].tolist(), exp[l].tolist())
+    assert np.array_equal(got, exp)
+
+
+def test_f64_primitives_bit_exact():
+    """fp64 div / sqrt / fma / floor / ceil on the GPU must round exactly like the host's IEEE arithmetic."""
+    rng = np.random.default_rng(0)
+    n = 1 << 16
+    a = rng.normal(size=n) * 10 ** rng.uniform(-3, 3, n)
+    b = rng.normal(size=n) * 10 ** rng.uniform(-3, 3, n)
+    a[:8] = [0.5, 1.5, 2.5, -0.5, 36.0, 100.0, 1e-300, 3.0]
+    ad, bd = torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)
+    out = torch.empty(5 * n, dtype=torch.float64, device=DEV)
+    _lib.call("kg_f64_probe", _lib.ptr(ad), _lib.ptr(bd), _lib.ptr(out), n, _lib.stream_ptr())
+    o = out.cpu().numpy().reshape(5, n)
+    libm = ctypes.CDLL("libm.so.6"); libm.fma.restype = ctypes.c_double; libm.fma.argtypes = [ctypes.c_double] * 3
+    fm = np.array([math.sqrt(libm.fma(x, x, y * y)) for x, y in zip(a, b)])
+    for name, got, ref in (("div", o[0], a / b), ("sqrt", o[1], np.sqrt(np.abs(a))), ("norm_fma", o[2], fm),
+                           ("floor", o[3], np.floor(a)), ("ceil", o[4], np.ceil(a))):
+        nbad = int((got != ref).sum())
+        print(f"[f64 {name}] mismatches {nbad}/{n}")
+        assert nbad == 0, name
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, N, H, W, relu, bias, tile
+    (64, 64, 3, 1, 1, 2, 20, 28, True, True, 0),
+    (64, 64, 7, 1, 3, 1, 24, 40, True, True, 0),
+    (64, 192, 7, 1, 3, 1, 16, 24, True, True, 0),
+    (128, 64, 1, 1, 0, 2, 16, 16, True, True, 0),
+    (64, 64, 3, 2, 1, 2, 18, 22, False, False, 0),
+    (256, 512, 1, 2, 0, 1, 16, 24, False, False, 0),
+    (3, 64, 7, 2, 3, 2, 32, 40, False, False, 0),
+    (3, 64, 3, 1, 1, 1, 24, 24, True, True, 0),
+    (256, 256, 3, 1, 1, 1, 12, 20, True, True, 4),
+    (64, 64, 3, 1, 1, 1, 16, 16, False, True, 5),
+    (1024, 512, 3, 1, 1, 1, 8, 8, True, True, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward(case):
+    cin, cout, k, stride, pad, N, H, W, relu, bias, tile = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = bfr(torch.randn(N, cin, H, W, generator=g))
+    w = bfr(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k))
+    b = torch.randn(cout, generator=g) if bias else None
+    ref = F.conv2d(x.double(), w.double(), b.double() if bias else None, stride, pad)
+    if relu:
+        ref = F.relu(ref)
+    cin_pad = ops.round_up(cin, 8)
+    xr = torch.zeros(N * H * W, cin_pad, dtype=BF16)
+    xr[:, :cin] = rows_of(x)
+    xr = xr.to(DEV)
+    pw = PackedWeight(cout, k * k, cin_pad, DEV)
+    pw.pack(w.to(DEV))
+    OH, OW = ref.shape[2:]
+    M = N * OH * OW
+    y = torch.empty(M, cout, dtype=BF16, device=DEV)
+    geom = (M, H, W, OH, OW, k, k, stride, pad)
+    ops.conv_igemm(xr, pw, cout, geom, y=y, bias=b.to(DEV) if bias else None, relu=relu, tile=tile)
+    torch.cuda.synchronize()
+    report(f"conv_fwd{case}", nchw_of(y.cpu(), N, OH, OW), ref, atol=2e-2, rtol=1e-2)
+    # fp32 NCHW export path is not rounded to bf16: tight tolerance
+    yf = torch.empty(N, cout, OH, OW, dtype=torch.float32, device=DEV)
+    ops.conv_igemm(xr, pw, cout, geom, y_f32=yf, bias=b.to(DEV) if bias else None, relu=relu, tile=tile)
+    report(f"conv_fwd_f32{case}", yf.cpu(), ref, atol=2e-4, rtol=2e-4)
+
+
+@pytest.mark.parametrize("cout", [5, 10, 40])
+def test_conv_small_cout_f32(cout):
+    cin, k, N, H, W = 64, 7, 2, 16, 24
+    g = torch.Generator().manual_seed(cout)
+    x = bfr(torch.randn(N, 192, H, W, generator=g))   # consume a 64-channel slice of a 192-wide buffer
+    w = bfr(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k))
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x[:, 64:128].double(), w.double(), b.double(), 1, 3)
+    xr = rows_of(x).to(DEV)
+    pw = PackedWeight(cout, k * k, cin, DEV)
+    pw.pack(w.to(DEV))
+    yf = torch.empty(N, cout, H, W, dtype=torch.float32, device=DEV)
+    ops.conv_igemm(xr[:, 64:128], pw, cout, (N * H * W, H, W, H, W, k, k, 1, 3), y_f32=yf, bias=b.to(DEV))
+    report(f"conv_small_cout{cout}", yf.cpu(), ref, atol=2e-4, rtol=2e-4)
+
+
+def test_conv_residual_mask_and_slice_output():
+    cin, cout, N, H, W = 64, 64, 1, 16, 16
+    g = torch.Generator().manual_seed(3)
+    x = bfr(torch.randn(N, cin, H, W, generator=g)); w = bfr(torch.randn(cout, cin, 3, 3, generator=g) / 24)
+    res = bfr(torch.randn(N, cout, H, W, generator=g)); msk = bfr(torch.randn(N, cout, H, W, generator=g))
+    ref = (F.conv2d(x.double(), w.double(), None, 1, 1) + res.double()) * (msk > 0)
+    pw = PackedWeight(cout, 9, cin, DEV); pw.pack(w.to(DEV))
+    buf = torch.zeros(N * H * W, 128, dtype=BF16, device=DEV)
+    ops.conv_igemm(rows_of(x).to(DEV), pw, cout, (N * H * W, H, W, H, W, 3, 3, 1, 1), y=buf[:, 64:128],
+                   res=rows_of(res).to(DEV), mask=rows_of(msk).to(DEV))
+    report("conv_res_mask", nchw_of(buf[:, 64:128].cpu(), N, H, W), ref, atol=2e-2, rtol=1e-2)
+    assert float(buf[:, :64].abs().max()) == 0.0
+
+
+DGRAD_CASES = [(64, 64, 3, 1, 1, 2, 20, 28), (64, 192, 7, 1, 3, 1, 16, 24), (64, 64, 3, 2, 1, 2, 18, 22),
+               (256, 512, 1, 2, 0, 1, 16, 24), (128, 64, 1, 1, 0, 1, 16, 16), (64, 40, 7, 1, 3, 1, 16, 16), (64, 5, 7, 1, 3, 1, 16, 16)]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_conv_dgrad(case):
+    cin, cout, k, stride, pad, N, H, W = case
+    g = torch.Generator().manual_seed(7)
+    x = bfr(torch.randn(N, cin, H, W, generator=g)).double().requires_grad_(True)
+    w = bfr(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k))
+    y = F.conv2d(x, w.double(), None, stride, pad)
+    OH, OW = y.shape[2:]
+    dy = bfr(torch.randn(N, cout, OH, OW, generator=g))
+    y.backward(dy.double())
+    cpad = ops.round_up(cout, 8)
+    dyr = torch.zeros(N * OH * OW, cpad, dtype=BF16); dyr[:, :cout] = rows_of(dy)
+    pwT = PackedWeight(cin, k * k, cpad, DEV)
+    pwT.pack(w.to(DEV), transposed=True)
+    dx = torch.empty(N * H * W, cin, dtype=BF16, device=DEV)
+    ops.conv_igemm(dyr.to(DEV), pwT, cin, (N * H * W, OH, OW, H, W, k, k, stride, pad), y=dx, mode=1)
+    report(f"conv_dgrad{case}", nchw_of(dx.cpu(), N, H, W), x.grad, atol=2e-2, rtol=1e-2)
+
+
+WGRAD_CASES = [(64, 64, 3, 1, 1, 2, 20, 28), (64, 192, 7, 1, 3, 1, 16, 24), (64, 64, 3, 2, 1, 2, 18, 22), (256, 512, 1, 2, 0, 1, 16, 24),
+               (3, 64, 7, 2, 3, 2, 32, 40), (64, 5, 7, 1, 3, 1, 16, 16), (1024, 512, 1, 1, 0, 1, 8, 8)]
+
+
+@pytest.mark.parametrize("use_tr", [1, 0])
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad(case, use_tr):
+    cin, cout, k, stride, pad, N, H, W = case
+    g = torch.Generator().manual_seed(11)
+    x = bfr(torch.randn(N, cin, H, W, generator=g))
+    w = torch.randn(cout, cin, k, k, generator=g).double().requires_grad_(True)
+    y = F.conv2d(x.double(), w, None, stride, pad)
+    OH, OW = y.shape[2:]
+    dy = bfr(torch.randn(N, cout, OH, OW, generator=g))
+    y.backward(dy.double())
+    cin_pad, cpad = ops.round_up(cin, 8), ops.round_up(cout, 8)
+    xr = torch.zeros(N * H * W, cin_pad, dtype=BF16); xr[:, :cin] = rows_of(x)
+    dyr = torch.zeros(N * OH * OW, cpad, dtype=BF16); dyr[:, :cout] = rows_of(dy)
+    gw = torch.full((cout, cin, k, k), float("nan"), dtype=torch.float32, device=DEV)
+    _lib.call("kg_set_wgrad_tr", use_tr)
+    try:
+        ops.conv_wgrad(xr.to(DEV), dyr.to(DEV), cin, cout, (N * OH * OW, H, W, OH, OW, k, k, stride, pad), [(gw, 0, cout)])
+        torch.cuda.synchronize()
+    finally:
+        _lib.call("kg_set_wgrad_tr", 1)
+    scale = float(w.grad.abs().max())
+    report(f"conv_wgrad{case} tr={use_tr}", gw.cpu(), w.grad, atol=2e-4 * scale, rtol=1e-4)
+    db = torch.empty(cout, dtype=torch.float32, device=DEV)
+    ops.bias_grad(dyr.to(DEV), cout, db)
+    report(f"bias_grad{case}", db.cpu(), dy.double().sum((0, 2, 3)), atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("C,res,relu", [(64, False, True), (256, True, True), (1024, False, False)])
+def test_batchnorm_train_forward_backward(C, res, relu):
+    N, H, W = 2, 12, 20
+    g = torch.Generator().manual_seed(C)
+    x = bfr(torch.randn(N, C, H, W, generator=g) * 2 + 0.5)
+    gamma = torch.rand(C, generator=g) + 0.5; beta = torch.randn(C, generator=g) * 0.1
+    rm = torch.randn(C, generator=g) * 0.1; rv = torch.rand(C, generator=g) + 0.5
+    r = bfr(torch.randn(N, C, H, W, generator=g)) if res else None
+    xd = x.double().requires_grad_(True); gd = gamma.double().requires_grad_(True); bd = beta.double().requires_grad_(True)
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    y = F.batch_norm(xd, rm_ref, rv_ref, gd, bd, True, 0.1, 1e-5)
+    if res:
+        y = y + r.double()
+    if relu:
+        y = F.relu(y)
+    dy = bfr(torch.randn(N, C, H, W, generator=g))
+    dy_eff = dy.double() * (y > 0) if relu else dy.double()
+    y.backward(dy.double())
+    xr = rows_of(x).to(DEV)
+    rm_d, rv_d = rm.to(DEV), rv.to(DEV)
+    mean, invstd, scale, shift = ops.bn_stats_train(xr, C, gamma.to(DEV), beta.to(DEV), rm_d, rv_d)
+    out = torch.empty_like(xr)
+    ops.bn_apply(xr, C, scale, shift, out, res=rows_of(r).to(DEV) if res else None, relu=relu)
+    report(f"bn_fwd C={C}", nchw_of(out.cpu(), N, H, W), y, atol=3e-2, rtol=1e-2)
+    report(f"bn_running_mean C={C}", rm_d.cpu(), rm_ref, atol=1e-5, rtol=1e-5)
+    report(f"bn_running_var C={C}", rv_d.cpu(), rv_ref, atol=1e-5, rtol=1e-4)
+    dg = torch.empty(C, device=DEV); db = torch.empty(C, device=DEV)
+    dx = torch.empty_like(xr)
+    ops.bn_bwd(xr, rows_of(bfr(dy_eff.float())).to(DEV), C, gamma.to(DEV), mean, invstd, dg, db, dx)
+    report(f"bn_dgamma C={C}", dg.cpu(), gd.grad, atol=5e-2, rtol=5e-3)
+    report(f"bn_dbeta C={C}", db.cpu(), bd.grad, atol=5e-2, rtol=5e-3)
+    report(f"bn_dx C={C}", nchw_of(dx.cpu(), N, H, W), xd.grad, atol=2e-2, rtol=1e-2)
+    sc_e, sh_e = ops.bn_scale_shift_eval(C, gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV))
+    ops.bn_apply(xr, C, sc_e, sh_e, out, relu=False)
+    report(f"bn_eval C={C}", nchw_of(out.cpu(), N, H, W), F.batch_norm(x.double(), rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.1, 1e-5),
+           atol=3e-2, rtol=1e-2)
+
+
+def test_maxpool_forward_backward():
+    N, C, H, W = 2, 64, 18, 22
+    g = torch.Generator().manual_seed(5)
+    x = F.relu(bfr(torch.randn(N, C, H, W, generator=g)))
+    xd = x.double().requires_grad_(True)
+    y = F.max_pool2d(xd, 3, 2, 1)
+    dy = bfr(torch.randn(*y.shape, generator=g))
+    y.backward(dy.double())
+    xr = rows_of(x).to(DEV)
+    OH, OW = y.shape[2:]
+    out = torch.empty(N * OH * OW, C, dtype=BF16, device=DEV)
+    ops.maxpool_fwd(xr, out, N, H, W, C)
+    report("maxpool_fwd", nchw_of(out.cpu(), N, OH, OW), y, atol=0, rtol=0)
+    dx = torch.empty_like(xr)
+    ops.maxpool_bwd(xr, rows_of(dy).to(DEV), dx, N, H, W, C)
+    # ties at exactly 0 (ReLU plateaus) may route differently; the network masks those positions (x==0) afterwards
+    m = (x > 0).double()
+    report("maxpool_bwd", nchw_of(dx.cpu(), N, H, W) * m, xd.grad * m, atol=2e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 8, 12, 16, 24), (1, 256, 5, 7, 10, 14)])
+def test_bilinear_forward_backward(shape):
+    N, C, IH, IW, OH, OW = shape
+    g = torch.Generator().manual_seed(9)
+    x = bfr(torch.randn(N, C, IH, IW, generator=g))
+    xd = x.double().requires_grad_(True)
+    y = F.interpolate(xd, (OH, OW), mode="bilinear", align_corners=False)
+    dy = bfr(torch.randn(N, C, OH, OW, generator=g))
+    y.backward(dy.double())
+    out = torch.empty(N * OH * OW, C, dtype=BF16, device=DEV)
+    ops.bilinear_fwd(rows_of(x).to(DEV), out, N, IH, IW, OH, OW, C)
+    report("bilinear_fwd", nchw_of(out.cpu(), N, OH, OW), y, atol=2e-2, rtol=1e-2)
+    dx = torch.empty(N * IH * IW, C, dtype=BF16, device=DEV)
+    ops.bilinear_bwd(rows_of(dy).to(DEV), dx, N, IH, IW, OH, OW, C)
+    report("bilinear_bwd", nchw_of(dx.cpu(), N, IH, IW), xd.grad, atol=3e-2, rtol=1e-2)
+
+
+def test_detection_loss_matches_golden(golden):
+    from kg_instance_segmentation_amd.loss import DetectionLossAll
+    g = golden("loss.npz")
+    t = [torch.tensor(g[k], device=DEV, requires_grad=True) for k in ("kp", "short", "mid")]
+    l = DetectionLossAll(kp_radius=5)(t, torch.from_numpy(g["gt"]).to(DEV))
+    print("loss", float(l), float(g["loss"]))
+    assert abs(float(l) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    l.backward()
+    for tt, k in zip(t, ("g_kp", "g_short", "g_mid")):
+        report(k, tt.grad.cpu(), torch.from_numpy(g[k]), atol=1e-9, rtol=2e-5)
+    l0 = DetectionLossAll(kp_radius=5)([x.detach() for x in t], torch.zeros_like(torch.from_numpy(g["gt"])).to(DEV))
+    assert abs(float(l0) - float(g["loss_empty"])) <= 2e-6
+
+
+def test_seg_loss_matches_golden(golden):
+    from kg_instance_segmentation_amd.seg_loss import SEG_loss
+    g = golden("loss.npz")
+    patches = [[torch.tensor(g[f"seg.patch.{i}.{j}"], device=DEV, requires_grad=True) for j in range(n)] for i, n in ((0, 2), (1, 1))]
+    dets = [[torch.from_numpy(g[f"seg.det.{i}.{j}"]) for j in range(n)] for i, n in ((0, 2), (1, 1))]
+    gm = [g["seg.gmask.0"], g["seg.gmask.1"]]; gb = [g["seg.gbox.0"], g["seg.gbox.1"]]
+    l = SEG_loss(40, 48)([patches, dets], gm, gb)
+    print("seg loss", float(l), float(g["seg.loss"]))
+    assert abs(float(l) - float(g["seg.loss"])) <= 2e-6
+    l.backward()
+    # gradient check against the oracle restatement (torch CPU)
+    from oracle import net as onet
+    pc = [[torch.tensor(g[f"seg.patch.{i}.{j}"], requires_grad=True) for j in range(n)] for i, n in ((0, 2), (1, 1))]
+    onet.seg_loss([pc, dets], gm, gb, 40, 48).backward()
+    for i in range(2):
+        for a, b in zip(patches[i], pc[i]):
+            ref = b.grad if b.grad is not None else torch.zeros_like(b)
+            got = a.grad.cpu() if a.grad is not None else torch.zeros_like(b)
+            report(f"seg_grad{i}", got, ref, atol=1e-8, rtol=2e-5)
+    assert SEG_loss(40, 48)([[[patches[1][0]]], [[dets[1][0]]]], [gm[1]], [gb[1]]) is None

@@ -1,0 +1,146 @@
+"""GPU parity tests of the float64 post-processing pipeline: bit-exact against the golden fixtures
+generated from the reference and against the CPU oracle (oracle/kg_oracle.c) on larger seeded inputs."""
+import hashlib
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from kg_instance_segmentation_amd import nms as knms  # noqa: E402
+from kg_instance_segmentation_amd import postprocessing as kpp  # noqa: E402
+from oracle import postproc as op  # noqa: E402
+from oracle import synth  # noqa: E402
+
+DEV = "cuda"
+
+
+def sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def _inputs(g, name):
+    if name == "adv":
+        return g["adv.kp"], g["adv.short"], g["adv.mid"]
+    H, W, n, seed = [int(v) for v in g[f"{name}.cfg"]]
+    kp, short, mid, _ = synth.head_maps(H, W, n, seed)
+    return kp, short, mid
+
+
+def run_stages(kp, short, mid):
+    t = [torch.from_numpy(a).to(DEV) for a in (kp, short, mid)]
+    skel, nsk, dbg = kpp.skeletons_device(*t, debug=True)
+    torch.cuda.synchronize()
+    npk = int(dbg["npeaks"].item())
+    pk = dbg["peaks"][:, :npk].cpu().numpy().T  # [n,3] id,x,y
+    return dict(heat=dbg["heat"].cpu().numpy(), blur=dbg["blur"].cpu().numpy(), peaks=pk, peak_conf=dbg["conf"][:npk].cpu().numpy(),
+                skel=skel[:int(nsk.item())].cpu().numpy())
+
+
+def diff_report(name, got, ref):
+    if got.shape != ref.shape:
+        print(f"[{name}] shape {got.shape} vs {ref.shape}")
+        return False
+    nbad = int((got != ref).sum())
+    if nbad:
+        idx = np.argwhere(got != ref)[:6]
+        print(f"[{name}] {nbad} mismatches; first:", [(tuple(i), got[tuple(i)], ref[tuple(i)]) for i in idx])
+    else:
+        print(f"[{name}] bit-exact ({got.size} values)")
+    return nbad == 0
+
+
+@pytest.mark.parametrize("name", ["s64", "s96x128", "s256", "adv"])
+def test_stages_vs_golden(golden, name):
+    g = golden("postproc.npz")
+    kp, short, mid = _inputs(g, name)
+    r = run_stages(kp, short, mid)
+    ok = True
+    if f"{name}.heat" in g:
+        ok &= diff_report(name + ".heat", r["heat"], g[f"{name}.heat"])
+        ok &= diff_report(name + ".blur", r["blur"], g[f"{name}.blur"])
+    else:
+        ok &= bool(np.array_equal(sha(r["heat"]), g[f"{name}.heat_sha"]))
+        ok &= bool(np.array_equal(sha(r["blur"]), g[f"{name}.blur_sha"]))
+        if not ok:  # localise with the oracle
+            diff_report(name + ".heat(oracle)", r["heat"], op.hough(kp, short))
+            diff_report(name + ".blur(oracle)", r["blur"], op.gauss(op.hough(kp, short)))
+    ok &= diff_report(name + ".peaks", r["peaks"], g[f"{name}.peaks"])
+    ok &= diff_report(name + ".peak_conf", r["peak_conf"], g[f"{name}.peak_conf"])
+    ok &= diff_report(name + ".skel", r["skel"], g[f"{name}.skel"])
+    assert ok
+    # public API
+    sk = kpp.get_skeletons_and_masks(*[torch.from_numpy(a).to(DEV) for a in (kp, short, mid)])
+    assert len(sk) == len(g[f"{name}.skel"]) and all(np.array_equal(a, b) for a, b in zip(sk, g[f"{name}.skel"]))
+    ref = kpp.refine_skeleton(sk)
+    assert np.array_equal(np.array(ref).reshape(-1, 5, 3), g[f"{name}.refined"])
+
+
+def test_boxes_gather_nms_vs_golden(golden):
+    g = golden("postproc.npz")
+    sks = [[s.copy() for s in g[k]] for k in ("s256.refined", "s96x128.refined", "s64.refined", "adv.refined")]
+    for s, sc in zip(sks, (1, 2, 4, 8)):
+        b = np.asarray(kpp.skeleton_to_box([a.copy() for a in s], sc)).reshape(-1, 5)
+        assert diff_report(f"boxes.scale{sc}", b, g[f"boxes.scale{sc}"])
+    gat = kpp.gather_skeleton(*sks)
+    assert diff_report("gather", gat, g["gather"])
+    for th in (0.5, 0.3):
+        assert diff_report(f"nms.{th}", knms.non_maximum_suppression_numpy(gat, th), g[f"nms.{th}"])
+    assert knms.non_maximum_suppression_numpy(np.zeros((0, 5)), 0.5) is None
+    hand = g["hand.skel"]
+    assert diff_report("hand.boxes_all", np.asarray(kpp.skeleton_to_box([s.copy() for s in hand], 2)).reshape(-1, 5), g["hand.boxes_all"])
+    assert diff_report("hand.nms", knms.non_maximum_suppression_numpy(g["hand.boxes_all"], 0.5), g["hand.nms"])
+    assert np.array_equal(np.array(kpp.refine_skeleton([s for s in hand])).reshape(-1, 5, 3), g["hand.refined"])
+
+
+@pytest.mark.parametrize("H,W,n,seed", [(512, 512, 300, 3), (128, 192, 40, 4), (1024, 1024, 300, 5)])
+def test_full_size_vs_oracle(H, W, n, seed):
+    """BASELINE config sizes: dense cells (about 300 instances); every stage bit-identical to the CPU oracle."""
+    kp, short, mid, _ = synth.head_maps(H, W, n, seed)
+    t0 = time.time(); r = run_stages(kp, short, mid); t_gpu = time.time() - t0
+    t0 = time.time()
+    heat = op.hough(kp, short); blur = op.gauss(heat); ids, xs, ys, conf = op.peaks(blur); skel = op.group(ids, xs, ys, conf, mid)
+    t_cpu = time.time() - t0
+    print(f"{H}x{W}: peaks {len(ids)} skeletons {len(skel)} gpu {t_gpu*1e3:.1f} ms (incl. copies) oracle {t_cpu*1e3:.1f} ms")
+    ok = diff_report("heat", r["heat"], heat)
+    ok &= diff_report("blur", r["blur"], blur)
+    ok &= diff_report("peaks", r["peaks"], np.stack([ids, xs, ys], 1).reshape(-1, 3))
+    ok &= diff_report("conf", r["peak_conf"], conf)
+    ok &= diff_report("skel", r["skel"], skel)
+    assert ok
+
+
+def test_random_maps_many_peaks():
+    """Random (untrained-net-like) maps: thousands of peaks, large offsets, heavy Hough cells."""
+    rng = np.random.default_rng(12)
+    H, W = 192, 256
+    kp = (rng.random((1, 5, H, W)) ** 2).astype(np.float32)
+    short = (rng.normal(size=(1, 10, H, W)) * 3).astype(np.float32)
+    short[0, :, 50:60, 50:60] = 0.25      # many votes into few cells
+    mid = (rng.normal(size=(1, 40, H, W)) * 8).astype(np.float32)
+    r = run_stages(kp, short, mid)
+    heat = op.hough(kp, short); blur = op.gauss(heat); ids, xs, ys, conf = op.peaks(blur); skel = op.group(ids, xs, ys, conf, mid)
+    print("peaks", len(ids), "skeletons", len(skel))
+    ok = diff_report("heat", r["heat"], heat) & diff_report("blur", r["blur"], blur)
+    ok &= diff_report("peaks", r["peaks"], np.stack([ids, xs, ys], 1).reshape(-1, 3)) & diff_report("skel", r["skel"], skel)
+    assert ok
+
+
+def test_detect_fused_matches_oracle():
+    decs = []
+    for sc, (H, W, n, seed) in zip((1, 2, 4, 8), [(256, 256, 60, 21), (128, 128, 30, 22), (64, 64, 10, 23), (32, 32, 3, 24)]):
+        kp, short, mid, _ = synth.head_maps(H, W, n, seed, smin=12 // min(sc, 2), smax=40 // sc + 8)
+        decs.append((kp, short, mid))
+    ref = op.detect(decs, 0.5)
+    got = kpp.detect([[torch.from_numpy(a).to(DEV) for a in d] for d in decs], 0.5)
+    assert ref is not None and got is not None
+    assert diff_report("detect", got, ref)
+
+
+def test_empty_maps():
+    z = [torch.zeros(1, c, 16, 16, device=DEV) for c in (5, 10, 40)]
+    assert kpp.get_skeletons_and_masks(*z) == []
+    assert kpp.gather_skeleton([], [], [], []).shape == (0,)
+    assert kpp.detect([z, z, z, z]) is None

@@ -74,20 +74,7 @@ def test_seg_loss(golden):
 
 def train_inputs(g):
     N, H, W, s = [int(v) for v in g["train.cfg"]]
-    x = torch.rand(N, 3, H, W, generator=torch.Generator().manual_seed(s)) - 0.5
-    gt_boxes, gt_masks = [], []
-    for i in range(N):
-        bx = synth.random_boxes(H, W, 4, 300 + i, 14, 30)
-        gt_boxes.append(np.concatenate([bx, np.ones((len(bx), 1))], 1).astype(np.float32))
-        m = np.zeros((len(bx), H, W), np.float32)
-        for k, b in enumerate(bx.astype(int)):
-            yy, xx = np.mgrid[0:H, 0:W]
-            cy, cx = (b[0] + b[2]) / 2, (b[1] + b[3]) / 2
-            m[k] = (((yy - cy) / ((b[2] - b[0]) / 2 + .5)) ** 2 + ((xx - cx) / ((b[3] - b[1]) / 2 + .5)) ** 2 <= 1).astype(np.float32)
-        gt_masks.append(m)
-    gt_lv = [torch.from_numpy(np.stack([synth.gt_maps(np.floor(gt_boxes[i][:, :4] / sc), H // sc, W // sc) for i in range(N)]))
-             for sc in (1, 2, 4, 8)]
-    return x, gt_boxes, gt_masks, gt_lv
+    return synth.train_batch(N, H, W, s)
 
 
 def test_train_step(golden, state_dict0):
