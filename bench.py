@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""bench.py -- KGnet train-step throughput on MI355X (metric of BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--size S] [--boxes NB]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = the body of the reference's training loop (train.py:137-156) on one synthetic batch:
+zero_grad, forward (forward_dec + forward_seg on the GT boxes), 4x DetectionLossAll + SEG_loss, backward,
+Adam step, loss.item().  Per GPU: batch 8 of 3x512x512 images with 300 GT boxes each (BASELINE configs[1]/[3],
+weak scaling).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line with the
+whole-job imgs/s, the roofline of the dominant kernel (HIP events around its launches during the timed steps) and a
+CPU baseline (the oracle's torch restatement of the same step, timed on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def make_batch(N, S, nboxes, seed, dev):
+    """Synthetic batch in the collater's layout (collater.py:4-25).  GT maps come from the build's synthesizer
+    (oracle/synth.py is data generation here, not a checker)."""
+    from oracle import synth
+    x = torch.rand(N, 3, S, S, generator=torch.Generator().manual_seed(seed)) - 0.5
+    gt_boxes, gt_masks, lv = [], [], [[] for _ in range(4)]
+    for i in range(N):
+        bx = synth.random_boxes(S, S, nboxes, seed * 1000 + i)
+        gt_boxes.append(np.concatenate([bx, np.ones((len(bx), 1))], 1).astype(np.float32))
+        m = np.zeros((len(bx), S, S), np.float32)
+        for k, b in enumerate(bx.astype(int)):
+            m[k, b[0]:b[2] + 1, b[1]:b[3] + 1] = 1.0
+        gt_masks.append(m)
+        for l, sc in enumerate((1, 2, 4, 8)):
+            lv[l].append(synth.gt_maps(np.floor(bx / sc), S // sc, S // sc))
+    gt = [torch.from_numpy(np.stack(v)).to(dev) for v in lv]
+    return x.to(dev), gt, gt_masks, gt_boxes
+
+
+class KernelTimer:
+    """HIP-event brackets around every kg_conv2d_igemm / kg_conv2d_wgrad launch on the launch stream."""
+
+    def __init__(self):
+        self.rec = []
+        self.on = False
+
+    def install(self):
+        from kg_instance_segmentation_amd import ops
+        timer = self
+        orig_conv, orig_wgrad = ops.conv_igemm, ops.conv_wgrad
+
+        def conv(x, pw, cout, geom, *a, **k):
+            if not timer.on:
+                return orig_conv(x, pw, cout, geom, *a, **k)
+            M, _, _, _, _, KH, KW, _, _ = geom
+            tile = k.get("tile", 0) or (1 if cout <= 16 else 2 if cout <= 32 else 3 if cout <= 64 else 4)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); r = orig_conv(x, pw, cout, geom, *a, **k); e.record()
+            timer.rec.append((f"conv_igemm_tile{tile}", 2.0 * M * cout * KH * KW * pw.cin_pad, s, e))
+            return r
+
+        def wgrad(x, dy, cin, cout, geom, grads, *a, **k):
+            if not timer.on:
+                return orig_wgrad(x, dy, cin, cout, geom, grads, *a, **k)
+            M, _, _, _, _, KH, KW, _, _ = geom
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); r = orig_wgrad(x, dy, cin, cout, geom, grads, *a, **k); e.record()
+            timer.rec.append(("conv_wgrad", 2.0 * M * cout * KH * KW * cin, s, e))
+            return r
+        orig_halo = ops.conv_halo
+
+        def halo(x, pw, cout, N, H, W, KS, *a, **k):
+            if not timer.on:
+                return orig_halo(x, pw, cout, N, H, W, KS, *a, **k)
+            wc = 3 if (cout % 192 == 0 or cout > 128) else (2 if cout > 64 else 1)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); r = orig_halo(x, pw, cout, N, H, W, KS, *a, **k); e.record()
+            timer.rec.append((f"conv_halo<{KS},{wc}>", 2.0 * N * H * W * cout * KS * KS * pw.cin_pad, s, e))
+            return r
+        # engine/seg call through `ops.<fn>` (and conv_auto resolves these names at call time)
+        ops.conv_igemm, ops.conv_wgrad, ops.conv_halo = conv, wgrad, halo
+
+    def summary(self):
+        agg = {}
+        for name, fl, s, e in self.rec:
+            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a[0] += s.elapsed_time(e) * 1e-3; a[1] += fl; a[2] += 1
+        return {k: {"seconds": v[0], "flops": v[1], "launches": v[2]} for k, v in agg.items()}
+
+
+def cpu_baseline(S, nboxes, seed=0):
+    """The oracle's torch-CPU restatement of ONE train step at batch 1 (bounded sample), all host cores."""
+    from oracle import net as onet, synth, weightgen
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))   # bs=1 convs stop scaling (and regress) beyond a few dozen threads
+    sd = weightgen.gen_state_dict(seed)
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    for n in names:
+        sd[n].requires_grad_(True)
+    x = torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(seed)) - 0.5
+    bx = synth.random_boxes(S, S, nboxes, seed)
+    gt_boxes = [np.concatenate([bx, np.ones((len(bx), 1))], 1).astype(np.float32)]
+    gt_masks = [np.zeros((len(bx), S, S), np.float32)]
+    for k, b in enumerate(bx.astype(int)):
+        gt_masks[0][k, b[0]:b[2] + 1, b[1]:b[3] + 1] = 1.0
+    gt = [torch.from_numpy(synth.gt_maps(np.floor(bx / sc), S // sc, S // sc))[None] for sc in (1, 2, 4, 8)]
+    opt = torch.optim.Adam([sd[n] for n in names], lr=1e-4)
+    t0 = time.time()
+    net = onet.Net(sd, training=True)
+    opt.zero_grad()
+    d0, d1, d2, d3, pred = net.forward(x, gt_boxes)
+    loss = sum(onet.detection_loss(p, t) for p, t in zip((d0, d1, d2, d3), gt))
+    l2 = onet.seg_loss(pred, gt_masks, gt_boxes, S, S)
+    if l2 is not None:
+        loss = loss + l2
+    loss.backward()
+    opt.step()
+    float(loss)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "imgs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 train step, batch 1, 3x{S}x{S}, {nboxes} GT boxes, torch-CPU oracle (oracle/net.py), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--boxes", type=int, default=300)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    from kg_instance_segmentation_amd import KGnet, parallel
+    from kg_instance_segmentation_amd.loss import DetectionLossAll
+    from kg_instance_segmentation_amd.seg_loss import SEG_loss
+    import torch.distributed as dist
+
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    torch.manual_seed(1234)
+    model = KGnet.resnet50(pretrained=False).to(dev).train()
+    parallel.broadcast_parameters(model)
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4)   # train.py:71
+    ldec, lseg = DetectionLossAll(kp_radius=5), SEG_loss(height=args.size, width=args.size)
+    x, gt, gt_masks, gt_boxes = make_batch(args.batch, args.size, args.boxes, 100 + rank, dev)
+    den = parallel.detection_denominators(gt) if world > 1 else None
+    reducer = parallel.GradReducer(model.parameters()) if world > 1 else None
+    timer = KernelTimer()
+    if not args.no_kernel_timer:
+        timer.install()
+
+    def step():
+        opt.zero_grad()
+        p0, p1, p2, p3, pred = model(x, gt_boxes)
+        if den is None:
+            l1 = ldec(p0, gt[0]) + ldec(p1, gt[1]) + ldec(p2, gt[2]) + ldec(p3, gt[3])
+        else:
+            l1 = sum(ldec(p, g, denominators=den[i]) for i, (p, g) in enumerate(zip((p0, p1, p2, p3), gt)))
+        l2 = lseg(pred, gt_masks, gt_boxes)
+        loss = l1 if l2 is None else l1 + l2 / world
+        loss.backward()
+        if reducer is not None:
+            reducer.reduce()
+        opt.step()
+        return loss.item()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.on = not args.no_kernel_timer
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    imgs = args.batch * world * args.steps
+    out = {"metric": "imgs/s (train fwd+bwd) at 512x512", "value": imgs / dt, "unit": "imgs/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"KGnet train step (forward_dec+forward_seg, 4x DetectionLossAll + SEG_loss, backward, Adam), "
+                                  f"batch {args.batch}/GPU, 3x{args.size}x{args.size}, {args.boxes} GT boxes/img, full HIP path",
+                      "global_batch": args.batch * world, "parallelism": f"dp{world}", "last_loss": last}}
+    if not args.no_kernel_timer:
+        summ = timer.summary()
+        if summ:
+            name = max(summ, key=lambda k: summ[k]["seconds"])
+            s = summ[name]
+            ach = s["flops"] / s["seconds"] / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "avg_launch_ms": 1e3 * s["seconds"] / s["launches"], "launches": s["launches"],
+                               "share_of_step": s["seconds"] / dt}
+            out["kernels"] = {k: {"ms_per_step": 1e3 * v["seconds"] / args.steps, "tflops": v["flops"] / max(v["seconds"], 1e-12) / 1e12,
+                                  "launches_per_step": v["launches"] / args.steps} for k, v in summ.items()}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.size, 20)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,11 @@ int kg_conv2d_igemm(const void* x, const void* w, const float* bias, void* y, fl
                     const void* mask, const int* rowdesc, int M, int H, int W, int OH, int OW, int cin_pad, int ldx,
                     int Cout, int ldy, int ldres, int ldmask, int K, int KH, int KW, int stride, int pad, int dil,
                     int mode, int relu, int f32_C, int tile, void* stream);
+/* the same convolution for stride 1, "same" padding, KS in {3,7}, cin_pad % 64 == 0: input halo resident in LDS
+ * (the 7x7 head convolutions of KGnet.py:161-209 are 86 % of the network's FLOPs).  flip = 1: input gradient. */
+int kg_conv2d_halo(const void* x, const void* w, const float* bias, void* y, float* y_f32, const void* res,
+                   const void* mask, int N, int H, int W, int cin_pad, int ldx, int Cout, int ldy, int ldres, int ldmask,
+                   int K, int KS, int flip, int relu, int f32_C, int wc, void* stream);
 /* fp32 OIHW parameter -> packed bf16 matrix rows (forward) or its transpose (data gradient). */
 int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad, int row0, int c0,
                    int transposed, void* stream);

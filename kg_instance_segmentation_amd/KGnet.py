@@ -33,9 +33,8 @@ class _Node(nn.Module):
 
 class _DecFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, x, *params):
-        eng = model._engine
-        record = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    def forward(ctx, model, record, x, *params):
+        eng = model._engine   # (grad mode is off inside Function.forward: `record` is decided by the caller)
         maps, feats, dims = eng.forward_dec(x, record)
         N = x.shape[0]
         outs = list(maps)
@@ -43,7 +42,6 @@ class _DecFunction(torch.autograd.Function):
             outs.append(fv.t.view(N, h, w, fv.C).permute(0, 3, 1, 2))
         ctx.model, ctx.recorded = model, record
         ctx.keys = model._param_keys
-        ctx.mark_non_differentiable()
         return tuple(outs)
 
     @staticmethod
@@ -59,7 +57,7 @@ class _DecFunction(torch.autograd.Function):
                 n, c, h, w = g.shape
                 fg.append(g.permute(0, 2, 3, 1).reshape(n * h * w, c).to(torch.bfloat16).contiguous())
         pg = eng.backward_dec(list(grads[:12]), fg)
-        out = [None, None]
+        out = [None, None, None]
         for k in ctx.keys:
             out.append(pg.get(k))
         return tuple(out)
@@ -132,7 +130,8 @@ class ResNet(nn.Module):
     def forward_dec(self, x):
         self._check_input(x)
         params = [self.get_tensor(k) for k in self._param_keys]
-        outs = _DecFunction.apply(self, x, *params)
+        record = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        outs = _DecFunction.apply(self, record, x, *params)
         d = [list(outs[3 * i:3 * i + 3]) for i in range(4)]
         return d[0], d[1], d[2], d[3], list(outs[12:17])
 

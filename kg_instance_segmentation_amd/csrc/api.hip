@@ -32,7 +32,7 @@ __global__ void tr_probe_kernel(unsigned short* out) {
     for (int j = 0; j < 4; ++j) lds[l * 4 + j] = (unsigned short)(l * 4 + j);  // element id, lane-linear 8-byte pieces
     __syncthreads();
     bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(&lds[l * 4]));
-    for (int j = 0; j < 4; ++j) out[l * 4 + j] = __builtin_bit_cast(unsigned short, v[j]);
+    *reinterpret_cast<uint2*>(&out[l * 4]) = __builtin_bit_cast(uint2, v);
 }
 extern "C" int kg_tr_probe(void* out, void* stream) {
     hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned short*)out);

@@ -1,0 +1,238 @@
+// conv_halo.hip -- stride-1 "same" 3x3 / 7x7 bf16 MFMA convolution with the input halo resident in LDS.
+//
+// KGnet's FLOPs are 86 % 7x7 stride-1 head convolutions (KGnet.py:161-209) and most of the rest 3x3 stride-1
+// (KGnet.py:139-158); in an im2col-style implicit GEMM every tap re-stages the pixel tile.  Here one workgroup
+// owns a 16x16 output tile and TC = 64*WC output channels:
+//   * the (16+KS-1)^2 x 64-channel input halo is staged into LDS ONCE per 64-channel chunk and re-read by all
+//     KS*KS taps (49x reuse for 7x7) with shifted ds_read_b128 fragment addresses;
+//   * only the [TC][64] weight slice of the current tap streams through a 2-deep LDS ring (register prefetch
+//     two taps ahead), one barrier per tap; 4*WC waves (up to 3 per SIMD) hide each other's LDS/global latency;
+//   * both tiles use XOR-swizzled 16-byte slots so the 16-lane ds_read_b128 groups hit 16 distinct slots.
+// The same kernel computes the input gradient of such a conv (flip = 1, transposed-packed weights).
+// Wave tile = 64 couts x 64 pixels (4 rows of the 16x16 tile), 16 v_mfma_f32_16x16x32_bf16 per 32-wide k-step.
+#include "kg_common.h"
+
+struct HaloArgs {
+    const bf16_t* x; const bf16_t* w; const float* bias;
+    bf16_t* y; float* y_f32; const bf16_t* res; const bf16_t* mask;
+    int N, H, W, tiles_x, tiles_y;
+    int cin_pad, ldx, Cout, ldy, ldres, ldmask, K, flip, relu, f32_C;
+};
+
+template <int KS, int WC>
+__global__ __launch_bounds__(WC * 256) void conv_halo_kernel(const HaloArgs a) {
+    constexpr int PAD = KS / 2, HWD = 16 + KS - 1, HPIX = HWD * HWD, TC = WC * 64, NT = WC * 256, T = KS * KS;
+    constexpr int HALO_BYTES = HPIX * 128, WBUF_BYTES = TC * 128;
+    constexpr int WPT = TC * 8 / NT;  // weight chunks per thread per tap (= 2)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* halo = smem;
+    unsigned char* wbuf = smem + HALO_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave >> 2, wp = wave & 3;
+    const int lm = lane & 15, g = lane >> 4;
+    int bt = blockIdx.x;
+    const int tx = bt % a.tiles_x; bt /= a.tiles_x;
+    const int ty = bt % a.tiles_y; const int n = bt / a.tiles_y;
+    const int oy0 = ty * 16, ox0 = tx * 16;
+    const int c0 = blockIdx.y * TC;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // weight fragment rows (cout permutation: lane ends with 16 consecutive couts) and their swizzle keys
+    int a_row_off[4], a_key[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = wc * 64 + (lm >> 2) * 16 + i * 4 + (lm & 3);
+        a_row_off[i] = r * 128;
+        a_key[i] = 2 * ((r >> 4) & 3) + ((r >> 1) & 1);
+    }
+    // pixel fragment base halo index (tap offset added per tap)
+    int p_base[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p_base[j] = (wp * 4 + j) * HWD + lm;
+
+    // weight staging assignment
+    int w_row[WPT], w_lds[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        int e = tid + i * NT, r = e >> 3, c = e & 7;
+        w_row[i] = r;
+        w_lds[i] = r * 128 + ((c ^ (2 * ((r >> 4) & 3) + ((r >> 1) & 1))) * 16);
+    }
+    const int wc8 = (tid & 7) * 8;  // NT % 8 == 0: the channel chunk of a thread is the same for every i
+    uint4 wreg[WPT];
+
+    const int nchunks = a.cin_pad / 64;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        __syncthreads();
+        // ---- stage the halo of this 64-channel chunk ------------------------------------------------
+        for (int e = tid; e < HPIX * 8; e += NT) {
+            const int p = e >> 3, c = e & 7;
+            const int hy = p / HWD, hx = p - hy * HWD;
+            const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                v = *reinterpret_cast<const uint4*>(a.x + ((long)(n * a.H + iy) * a.W + ix) * a.ldx + cc * 64 + c * 8);
+            *reinterpret_cast<uint4*>(halo + p * 128 + ((c ^ ((p >> 1) & 7)) * 16)) = v;
+        }
+        auto wload = [&](int tap) {
+#pragma unroll
+            for (int i = 0; i < WPT; ++i)
+                wreg[i] = *reinterpret_cast<const uint4*>(a.w + (long)(c0 + w_row[i]) * a.K + (long)tap * a.cin_pad + cc * 64 + wc8);
+        };
+        auto wstore = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) *reinterpret_cast<uint4*>(wbuf + buf * WBUF_BYTES + w_lds[i]) = wreg[i];
+        };
+        wload(0); wstore(0);
+        if (T > 1) wload(1);
+        __syncthreads();
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            const int ky = t / KS, kx = t - ky * KS;
+            const int tapoff = a.flip ? ((KS - 1 - ky) * HWD + (KS - 1 - kx)) : (ky * HWD + kx);
+            const unsigned char* wb = wbuf + (t & 1) * WBUF_BYTES;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 af[4], bfr[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8*>(wb + a_row_off[i] + (((4 * s + g) ^ a_key[i]) * 16));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int p = p_base[j] + tapoff;
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(halo + p * 128 + (((4 * s + g) ^ ((p >> 1) & 7)) * 16));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            if (t + 1 < T) {
+                wstore((t + 1) & 1);
+                if (t + 2 < T) wload(t + 2);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane owns pixel (oy0 + wp*4 + j, ox0 + lm) and couts cb .. cb+15 ----------------------
+    const int cb = c0 + wc * 64 + g * 16;
+    if (cb >= a.Cout) return;
+    const bool full = cb + 16 <= a.Cout;
+    float bv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+    const int ox = ox0 + lm;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int oy = oy0 + wp * 4 + j;
+        if (oy >= a.H || ox >= a.W) continue;
+        const long m = (long)(n * a.H + oy) * a.W + ox;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bv[i * 4 + r];
+        if (a.res) {
+            const bf16_t* rp = a.res + m * a.ldres + cb;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (full || cb + e < a.Cout) v[e] += bf2f(rp[e]);
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if (a.mask) {
+            const bf16_t* mp = a.mask + m * a.ldmask + cb;
+            if (full && ((reinterpret_cast<uintptr_t>(mp) & 15) == 0)) {
+                uint4 m0 = *reinterpret_cast<const uint4*>(mp), m1 = *reinterpret_cast<const uint4*>(mp + 8);
+                const bf16_t* ms0 = reinterpret_cast<const bf16_t*>(&m0);
+                const bf16_t* ms1 = reinterpret_cast<const bf16_t*>(&m1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[e] = bf2f(ms0[e]) > 0.f ? v[e] : 0.f; v[8 + e] = bf2f(ms1[e]) > 0.f ? v[8 + e] : 0.f; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (full || cb + e < a.Cout) v[e] = bf2f(mp[e]) > 0.f ? v[e] : 0.f;
+            }
+        }
+        if (a.y) {
+            bf16_t* yp = a.y + m * a.ldy + cb;
+            if (full && ((reinterpret_cast<uintptr_t>(yp) & 15) == 0)) {
+                uint4 o0 = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+                uint4 o1 = make_uint4(pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15]));
+                *reinterpret_cast<uint4*>(yp) = o0;
+                *reinterpret_cast<uint4*>(yp + 8) = o1;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (cb + e < a.Cout) yp[e] = f2bf(v[e]);
+            }
+        }
+        if (a.y_f32) {
+            const long hw = (long)a.H * a.W, pix = (long)oy * a.W + ox;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (cb + e < a.Cout) a.y_f32[((long)n * a.f32_C + cb + e) * hw + pix] = v[e];
+        }
+    }
+}
+
+template <int KS, int WC>
+static int launch_halo(const HaloArgs& a, hipStream_t st) {
+    constexpr int HWD = 16 + KS - 1, TC = WC * 64;
+    constexpr int smem = HWD * HWD * 128 + 2 * TC * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        KG_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<KS, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    dim3 grid(a.N * a.tiles_x * a.tiles_y, kg_cdiv(a.Cout, TC));
+    hipLaunchKernelGGL((conv_halo_kernel<KS, WC>), grid, dim3(WC * 256), smem, st, a);
+    KG_CHECK_LAUNCH("conv_halo");
+    return KG_OK;
+}
+
+// Stride-1 "same" convolution, KS in {3,7}; cin_pad % 64 == 0; weight rows padded to a multiple of 64*wc.
+// wc: 0 = auto (3 when Cout % 192 == 0 or Cout > 128, 2 when Cout > 64, else 1).
+extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, void* y, float* y_f32, const void* res,
+                              const void* mask, int N, int H, int W, int cin_pad, int ldx, int Cout, int ldy, int ldres,
+                              int ldmask, int K, int KS, int flip, int relu, int f32_C, int wc, void* stream) {
+    HaloArgs a;
+    memset(&a, 0, sizeof(a));
+    KG_CHECK_ARG(x && w && (y || y_f32), "kg_conv2d_halo: null pointer");
+    KG_CHECK_ARG(KS == 3 || KS == 7, "kg_conv2d_halo: kernel size must be 3 or 7");
+    KG_CHECK_ARG(cin_pad % 64 == 0 && ldx % 8 == 0, "kg_conv2d_halo: cin_pad must be a multiple of 64 (got %d)", cin_pad);
+    KG_CHECK_ARG(K >= KS * KS * cin_pad, "kg_conv2d_halo: K too small");
+    KG_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0, "kg_conv2d_halo: empty problem");
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.y_f32 = y_f32;
+    a.res = (const bf16_t*)res; a.mask = (const bf16_t*)mask;
+    a.N = N; a.H = H; a.W = W; a.tiles_x = kg_cdiv(W, 16); a.tiles_y = kg_cdiv(H, 16);
+    a.cin_pad = cin_pad; a.ldx = ldx; a.Cout = Cout; a.ldy = ldy; a.ldres = ldres; a.ldmask = ldmask; a.K = K;
+    a.flip = flip; a.relu = relu; a.f32_C = f32_C;
+    if (wc == 0) wc = (Cout % 192 == 0 || Cout > 128) ? 3 : (Cout > 64 ? 2 : 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (KS == 7) {
+        switch (wc) {
+            case 1: return launch_halo<7, 1>(a, st);
+            case 2: return launch_halo<7, 2>(a, st);
+            case 3: return launch_halo<7, 3>(a, st);
+        }
+    } else {
+        switch (wc) {
+            case 1: return launch_halo<3, 1>(a, st);
+            case 2: return launch_halo<3, 2>(a, st);
+            case 3: return launch_halo<3, 3>(a, st);
+        }
+    }
+    kg_set_error("kg_conv2d_halo: bad wc %d", wc);
+    return KG_ERR_ARG;
+}

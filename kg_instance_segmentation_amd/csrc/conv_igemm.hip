@@ -47,9 +47,9 @@ __global__ __launch_bounds__(WC* WP * 64) void conv_igemm_kernel(const ConvArgs 
     // ---- per-thread staging assignment --------------------------------------------------
     const int slot = tid & 3;
     const int xrow0 = tid >> 2;                                // + (NT/4)*i
-    const int xchunk = slot ^ fperm((xrow0 >> 2) & 3);         // logical k-chunk this thread fetches
+    const int xchunk = slot ^ fperm((xrow0 >> 2) & 3);         // logical k-chunk this thread fetches (rows step by NT/4: same key)
     const int wrow0 = tid >> 2;
-    const int wchunk = slot ^ fperm((wrow0 >> (2 + LOG_CF)) & 3);
+    static_assert((NT / 4) % 16 == 0, "pixel-row swizzle key must not depend on the staging pass");
     int py[XPT], px[XPT], pbase[XPT];  // output coords / row base; pbase<0 => row out of range
     int ph[XPT], pw[XPT];
 #pragma unroll
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(WC* WP * 64) void conv_igemm_kernel(const ConvArgs 
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int q = (kk * KS + s) * 4 + xchunk;
-            int tap = (q * a.cpt_magic) >> 16;
+            int tap = (int)(((unsigned)q * (unsigned)a.cpt_magic) >> 24);
             const int cc = q - tap * a.cpt;
             const bool tapok = tap < a.ntaps;
             tap = tap < 63 ? tap : 63;
@@ -107,10 +107,10 @@ __global__ __launch_bounds__(WC* WP * 64) void conv_igemm_kernel(const ConvArgs 
                 }
                 xr[s][i] = v;
             }
-            const int qw = (kk * KS + s) * 4 + wchunk;
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
                 int r = wrow0 + (NT / 4) * i;
+                const int qw = (kk * KS + s) * 4 + (slot ^ fperm((r >> (2 + LOG_CF)) & 3));
                 if (TC * 4 >= NT || r < TC)
                     wr[s][i] = *reinterpret_cast<const uint4*>(a.w + (long)(c0 + r) * a.K + qw * 8);
             }
@@ -250,9 +250,9 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
 }
 
 static int magic_for(int cpt, int qmax, int* magic) {
-    int mg = (65536 + cpt - 1) / cpt;
+    int mg = ((1 << 24) + cpt - 1) / cpt;   // tap = (q * mg) >> 24; q*mg < taps * 2^24 < 2^31
     for (int q = 0; q <= qmax; ++q)
-        if (((q * mg) >> 16) != q / cpt) return 0;
+        if ((int)(((unsigned)q * (unsigned)mg) >> 24) != q / cpt) return 0;
     *magic = mg;
     return 1;
 }

@@ -243,21 +243,24 @@ __global__ void bias_grad_final_kernel(const float* __restrict__ part, float* __
 extern "C" int kg_bias_grad(const void* dy, float* db, float* scratch, int scratch_floats, int M, int C, int ld,
                             int accumulate, void* stream) {
     KG_CHECK_ARG(dy && db && scratch, "kg_bias_grad: null pointer");
-    KG_CHECK_ARG(C >= 1 && C <= 1024, "kg_bias_grad: C out of range");
-    int nrl = 1024 / C;
-    if (nrl < 1) nrl = 1;
-    int threads = nrl * C;
-    int nb = scratch_floats / C;
-    if (nb > 1024) nb = 1024;
-    int need = (M + 63) / 64;
-    if (nb > need) nb = need;
-    KG_CHECK_ARG(nb >= 1, "kg_bias_grad: scratch too small");
-    int rpb = (M + nb - 1) / nb;
-    nb = (M + rpb - 1) / rpb;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(nb), dim3(threads), threads * sizeof(float), (hipStream_t)stream,
-                       (const bf16_t*)dy, scratch, M, C, ld, rpb);
-    hipLaunchKernelGGL(bias_grad_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, db,
-                       nb, C, accumulate);
+    KG_CHECK_ARG(C >= 1 && M >= 1, "kg_bias_grad: empty problem");
+    for (int c0 = 0; c0 < C; c0 += 1024) {   // channel slabs of <= 1024 (one thread per channel and row lane)
+        const int Cs = C - c0 < 1024 ? C - c0 : 1024;
+        int nrl = 1024 / Cs;
+        if (nrl < 1) nrl = 1;
+        int threads = nrl * Cs;
+        int nb = scratch_floats / Cs;
+        if (nb > 1024) nb = 1024;
+        int need = (M + 63) / 64;
+        if (nb > need) nb = need;
+        KG_CHECK_ARG(nb >= 1, "kg_bias_grad: scratch too small");
+        int rpb = (M + nb - 1) / nb;
+        nb = (M + rpb - 1) / rpb;
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(nb), dim3(threads), threads * sizeof(float), (hipStream_t)stream,
+                           (const bf16_t*)dy + c0, scratch, M, Cs, ld, rpb);
+        hipLaunchKernelGGL(bias_grad_final_kernel, dim3((Cs + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch,
+                           db + c0, nb, Cs, accumulate);
+    }
     KG_CHECK_LAUNCH("bias_grad");
     return KG_OK;
 }

@@ -127,7 +127,7 @@ class Engine:
         if y_f32 is None and out is None:
             out = torch.empty(M, s.cout, dtype=BF16, device=dev)
         geom = (M, H, W, OH, OW, s.k, s.k, s.stride, s.pad)
-        ops.conv_igemm(xv.t, s.pw, s.cout, geom, y=out, y_f32=y_f32, bias=s.bias_cat if s.has_bias else None, relu=relu, tile=tile)
+        ops.conv_auto(xv.t, s.pw, s.cout, geom, N, y=out, y_f32=y_f32, bias=s.bias_cat if s.has_bias else None, relu=relu, tile=tile)
         yv = Var(out, s.cout, relu=relu)
         if train:
             def bwd():
@@ -153,7 +153,7 @@ class Engine:
                     existing = xv.grad if xv.parent is None else None
                     dx = existing if existing is not None else xv.alloc_grad()
                     gin = (N * H * W, OH, OW, H, W, s.k, s.k, s.stride, s.pad)
-                    ops.conv_igemm(g, s.pwT, s.cin, gin, y=dx, res=existing, mask=xv.t if xv.relu else None, mode=1)
+                    ops.conv_auto(g, s.pwT, s.cin, gin, N, y=dx, res=existing, mask=xv.t if xv.relu else None, transposed=True)
                     if existing is None:
                         xv.add_grad(dx, masked=xv.relu)
                     else:

@@ -44,7 +44,7 @@ class PackedWeight:
     def __init__(self, rows, taps, cin_pad, dev):
         self.rows, self.taps, self.cin_pad = rows, taps, cin_pad
         self.K = round_up(taps * cin_pad, 64)
-        self.buf = torch.zeros(round_up(rows, 128), self.K, dtype=BF16, device=dev)
+        self.buf = torch.zeros(round_up(rows, 384), self.K, dtype=BF16, device=dev)   # rows cover any 64/128/192 cout tile
 
     def pack(self, w, row0=0, c0=0, transposed=False):
         """w: fp32 OIHW parameter.  forward: rows=Cout, channels=Cin; transposed (dgrad): rows=Cin, channels=Cout."""
@@ -67,6 +67,31 @@ def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=
               M, H, W, OH, OW, pw.cin_pad, ld(x), cout, ld(y) if y is not None else 0,
               ld(res) if res is not None else 0, ld(mask) if mask is not None else 0, pw.K, KH, KW, stride, pad, 1,
               mode, 1 if relu else 0, f32_C, tile, stream_ptr())
+
+
+USE_HALO = True
+
+
+def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, flip=False, wc=0):
+    """Stride-1 "same" KSxKS conv (or its input gradient when flip) with the input halo resident in LDS."""
+    f32_C = 0
+    if y_f32 is not None:
+        f32_C = y_f32.shape[1] if y_f32.dim() == 4 else 1
+    _lib.call("kg_conv2d_halo", ptr(_rows(x)), ptr(pw.buf), ptr(bias), ptr(y), ptr(y_f32), ptr(res), ptr(mask), N, H, W,
+              pw.cin_pad, ld(x), cout, ld(y) if y is not None else 0, ld(res) if res is not None else 0,
+              ld(mask) if mask is not None else 0, pw.K, KS, 1 if flip else 0, 1 if relu else 0, f32_C, wc, stream_ptr())
+
+
+def conv_auto(x, pw, cout, geom, N, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, transposed=False, tile=0):
+    """Dense conv forward (transposed=False) or input gradient (True): picks the LDS-halo kernel for stride-1
+    "same" 3x3/7x7 convs over 64-channel-aligned inputs, else the gather implicit GEMM."""
+    M, H, W, OH, OW, KH, KW, stride, pad = geom
+    if (USE_HALO and stride == 1 and KH == KW and KH in (3, 7) and pad == KH // 2 and pw.cin_pad % 64 == 0
+            and x.shape[1] >= pw.cin_pad):
+        conv_halo(x, pw, cout, N, OH, OW, KH, y=y, y_f32=y_f32, bias=bias, res=res, mask=mask, relu=relu, flip=transposed)
+        return "halo"
+    conv_igemm(x, pw, cout, geom, y=y, y_f32=y_f32, bias=bias, res=res, mask=mask, relu=relu, mode=1 if transposed else 0, tile=tile)
+    return "igemm"
 
 
 def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):

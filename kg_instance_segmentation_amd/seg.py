@@ -40,10 +40,15 @@ class _Plan:
     """Box tables of one forward_seg call (host numpy + device copies)."""
 
 
+class SegPredictions(list):
+    """[mask_patches, mask_dets] exactly as the reference returns them (KGnet.py:350), plus the flat
+    probability buffer / per-patch metadata so that SEG_loss can skip per-patch host round trips."""
+    kg_meta = None
+
+
 class _SegFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, branch, plan, f0, f1, f2, f3, f4, *params):
-        record = torch.is_grad_enabled()
+    def forward(ctx, branch, plan, record, f0, f1, f2, f3, f4, *params):
         flat, saved = branch.run_forward(plan, [f0, f1, f2, f3, f4], record)
         ctx.branch, ctx.plan, ctx.saved = branch, plan, saved
         ctx.feat_shapes = [tuple(f.shape) for f in (f0, f1, f2, f3, f4)]
@@ -54,7 +59,7 @@ class _SegFunction(torch.autograd.Function):
         if ctx.saved is None:
             raise RuntimeError("forward_seg was run without gradient recording")
         gfeats, pgrads = ctx.branch.run_backward(ctx.plan, ctx.saved, gflat.contiguous().float(), ctx.feat_shapes)
-        out = [None, None] + gfeats
+        out = [None, None, None] + gfeats
         for k in ctx.branch.param_keys:
             out.append(pgrads.get(k))
         return tuple(out)
@@ -290,18 +295,18 @@ class SegBranch:
         if plan.nb[0] == 0:
             return [mask_patches, mask_dets]
         params = [self.P(k) for k in self.param_keys]
-        flat = _SegFunction.apply(self, plan, *feat_seg, *params)
+        record = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or any(f.requires_grad for f in feat_seg))
+        flat = _SegFunction.apply(self, plan, record, *feat_seg, *params)
         h0, w0 = plan.hw[0]
         r0 = plan.row0[0]
         # emit in the reference's order: image by image, boxes in input order
         order = np.lexsort((plan.box_in_img, plan.img))
-        info = []
         for b in order:
             i = int(plan.img[b])
             patch = flat[int(r0[b]):int(r0[b + 1])].view(int(h0[b]), int(w0[b]))
             mask_patches[i].append(patch)
             mask_dets[i].append(torch.from_numpy(plan.boxes[b].copy()))
-            info.append((i, int(r0[b]), int(h0[b]), int(w0[b])))
-        out = [mask_patches, mask_dets]
-        self.last = {"flat": flat, "info": info, "patches": mask_patches}
+        out = SegPredictions([mask_patches, mask_dets])
+        out.kg_meta = {"flat": flat, "order": order, "img": plan.img[order], "boxes": plan.boxes[order],
+                       "off": r0[:-1][order], "h": h0[order], "w": w0[order]}
         return out

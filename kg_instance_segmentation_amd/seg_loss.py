@@ -51,6 +51,18 @@ class _SegLossFn(torch.autograd.Function):
         return g, None, None, None, None
 
 
+def jaccard_matrix(a, b):
+    """Vectorised seg_loss.py:14-29 in float32 (same operation order as jaccard_numpy): a [P,4], b [G,4] -> [P,G]."""
+    a = np.asarray(a, np.float32).reshape(-1, 1, 4); b = np.asarray(b, np.float32).reshape(1, -1, 4)
+    area_a = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1]); area_b = (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+    ih = np.maximum(np.minimum(a[..., 2], b[..., 2]) - np.maximum(a[..., 0], b[..., 0]), np.float32(0.))
+    iw = np.maximum(np.minimum(a[..., 3], b[..., 3]) - np.maximum(a[..., 1], b[..., 1]), np.float32(0.))
+    inter = ih * iw
+    union = area_a + area_b - inter
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(union <= 2, np.float32(0.), inter / union)
+
+
 class SEG_loss(nn.Module):
     def __init__(self, height, width):
         super().__init__()
@@ -62,54 +74,59 @@ class SEG_loss(nn.Module):
     def forward(self, predictions, gt_masks, gt_boxes):
         mask_patches, mask_dets = predictions
         nimg = len(mask_patches)
-        plist, pairs, tgts = [], [], []   # per matched patch: (patch tensor, first pair, npairs)
-        toff = 0
+        meta = getattr(predictions, "kg_meta", None)
+        # per image: predicted boxes [P,4] f32, patch sizes, and where each patch lives
         per_img = []
-        for i in range(nimg):
-            entries = []
-            for j in range(len(mask_patches[i])):
-                pr = mask_patches[i][j]
-                pbox = np.asarray(mask_dets[i][j][:4].detach().cpu().numpy() if hasattr(mask_dets[i][j], "detach") else mask_dets[i][j][:4], np.float32)
-                h1, w1 = pr.shape
-                mine = []
-                for g in range(gt_boxes[i].shape[0]):
-                    if jaccard_numpy(pbox, gt_boxes[i][g][:4]) >= 0.5:
-                        y1 = max(0, int(np.int32(np.round(pbox[0])))); x1 = max(0, int(np.int32(np.round(pbox[1]))))
-                        y2 = min(int(np.int32(np.round(pbox[2]))), self.height - 1)
-                        x2 = min(int(np.int32(np.round(pbox[3]))), self.width - 1)
-                        gm = nearest_resize(np.asarray(gt_masks[i][g])[y1:y2, x1:x2], h1, w1)
-                        assert gm.shape == (h1, w1), "[loss.py] mask size does not match!"
-                        mine.append(np.ascontiguousarray(gm).astype(np.uint8).ravel())
-                if mine:
-                    entries.append((pr, mine))
-            per_img.append(entries)
-        if not any(per_img):
+        if meta is not None:
+            for i in range(nimg):
+                sel = np.nonzero(meta["img"] == i)[0]
+                per_img.append((meta["boxes"][sel, :4], meta["h"][sel], meta["w"][sel], meta["off"][sel], None))
+        else:
+            for i in range(nimg):
+                pl = mask_patches[i]
+                if len(pl) == 0:
+                    per_img.append((np.zeros((0, 4), np.float32), np.zeros(0, np.int64), np.zeros(0, np.int64), None, pl))
+                    continue
+                pb = np.stack([np.asarray(d[:4].detach().cpu().numpy() if hasattr(d, "detach") else d[:4], np.float32) for d in mask_dets[i]])
+                per_img.append((pb, np.array([p.shape[0] for p in pl]), np.array([p.shape[1] for p in pl]), None, pl))
+        recs, pairs, tgts, toff = [], [], [], 0   # recs: (img, patch index in image, npix, first pair, npairs)
+        for i, (pb, hs, ws, offs, pl) in enumerate(per_img):
+            gb = np.asarray(gt_boxes[i], np.float32).reshape(-1, 5) if len(gt_boxes[i]) else np.zeros((0, 5), np.float32)
+            if len(pb) == 0 or len(gb) == 0:
+                continue
+            match = jaccard_matrix(pb, gb[:, :4]) >= 0.5                       # seg_loss.py:55-56
+            nobj = int(match.sum())
+            if nobj == 0:
+                continue
+            y1 = np.maximum(0, np.round(pb[:, 0]).astype(np.int32)); x1 = np.maximum(0, np.round(pb[:, 1]).astype(np.int32))
+            y2 = np.minimum(np.round(pb[:, 2]).astype(np.int32), self.height - 1)
+            x2 = np.minimum(np.round(pb[:, 3]).astype(np.int32), self.width - 1)
+            gm_all = gt_masks[i]
+            for j in np.nonzero(match.any(1))[0]:
+                h1, w1 = int(hs[j]), int(ws[j])
+                gs = np.nonzero(match[j])[0]
+                recs.append((i, int(j), h1 * w1, len(pairs), len(gs)))
+                for g in gs:
+                    gm = nearest_resize(np.asarray(gm_all[g])[y1[j]:y2[j], x1[j]:x2[j]], h1, w1)   # seg_loss.py:64,77
+                    assert gm.shape == (h1, w1), "[loss.py] mask size does not match!"
+                    tgts.append(gm.astype(np.uint8).ravel())
+                    pairs.append((toff, 1.0 / (h1 * w1) / nobj / nimg))
+                    toff += h1 * w1
+        if not recs:
             return None                      # seg_loss.py:93-96
-        recs = []
-        for i, entries in enumerate(per_img):
-            nobj = sum(len(m) for _, m in entries)
-            for pr, mine in entries:
-                npix = pr.numel()
-                recs.append((pr, npix, len(pairs), len(mine)))
-                for t in mine:
-                    pairs.append((toff, 1.0 / npix / nobj / nimg))
-                    tgts.append(t); toff += npix
-        dev = recs[0][0].device
-        if not recs[0][0].is_cuda:
-            raise _lib.KGLibraryError("SEG_loss (MI355X build) needs GPU tensors")
-        # all patches of one forward_seg call are views of one flat probability buffer; find it
-        base = recs[0][0]._base if recs[0][0]._base is not None else None
-        same = base is not None and base.dim() == 1 and all(r[0]._base is base for r in recs)
-        if same:
-            flat = base
-            offs = [r[0].storage_offset() - base.storage_offset() for r in recs]
+        if meta is not None:
+            flat = meta["flat"]
+            offs = [int(per_img[i][3][j]) for i, j, _, _, _ in recs]
         else:                                # patches from elsewhere: concatenate (autograd-tracked)
-            flat = torch.cat([r[0].reshape(-1) for r in recs])
-            offs = list(np.cumsum([0] + [r[1] for r in recs[:-1]]))
-        ptab = np.array([[o, r[1], r[2], r[3]] for o, r in zip(offs, recs)], np.int32)
+            flat = torch.cat([per_img[i][4][j].reshape(-1) for i, j, _, _, _ in recs]).float()
+            offs = list(np.cumsum([0] + [r[2] for r in recs[:-1]]))
+        if not flat.is_cuda:
+            raise _lib.KGLibraryError("SEG_loss (MI355X build) needs GPU tensors")
+        dev = flat.device
+        ptab = np.array([[o, r[2], r[3], r[4]] for o, r in zip(offs, recs)], np.int32)
         pair_t = np.zeros(len(pairs), dtype=[("off", np.int32), ("w", np.float32)])
         pair_t["off"] = [p[0] for p in pairs]; pair_t["w"] = [p[1] for p in pairs]
         tgt = torch.from_numpy(np.concatenate(tgts)).to(dev)
         ptab_d = torch.from_numpy(ptab).to(dev)
         pairs_d = torch.from_numpy(pair_t.view(np.uint8)).to(dev)
-        return _SegLossFn.apply(flat.contiguous().float() if not same else flat, tgt, ptab_d, pairs_d, len(recs))
+        return _SegLossFn.apply(flat, tgt, ptab_d, pairs_d, len(recs))

@@ -25,6 +25,11 @@ class Net:
         self.training = training
 
     # -- primitives ---------------------------------------------------------
+    @staticmethod
+    def act(x):
+        """storage point of an activation (identity in fp32; rounded by the bf16 emulation subclass)"""
+        return x
+
     def conv(self, x, name, stride=1, pad=0, relu=False):
         y = F.conv2d(x, self.sd[name + ".weight"], self.sd.get(name + ".bias"), stride, pad)
         return F.relu(y) if relu else y
@@ -50,7 +55,7 @@ class Net:
     # -- KGnet.py:275-318 ---------------------------------------------------
     def forward_dec(self, x):
         c0 = self.conv(self.conv(x, "c0_conv.0", 1, 1, True), "c0_conv.2", 1, 1, True)
-        c1 = self.bn(self.conv(x, "conv1", 2, 3), "bn1", True)
+        c1 = self.act(self.bn(self.conv(x, "conv1", 2, 3), "bn1", True))
         f = F.max_pool2d(c1, 3, 2, 1)
         feats = [c0, c1]
         for name, planes, blocks, stride in LAYERS:

@@ -106,3 +106,13 @@ def test_seg_loss_host_matching_matches_oracle(golden):
     m = (rng.random((13, 17)) > 0.5).astype(np.float32)
     assert np.array_equal(nearest_resize(m, 7, 9), onet.nearest_resize(m, 7, 9))
     assert nearest_resize(m, 13, 17) is m
+
+
+def test_vectorised_matcher_equals_scalar():
+    from kg_instance_segmentation_amd.seg_loss import jaccard_matrix, jaccard_numpy
+    rng = np.random.default_rng(1)
+    a = rng.uniform(0, 50, (40, 4)).astype(np.float32); a[:, 2:] += a[:, :2]
+    b = rng.uniform(0, 50, (30, 4)).astype(np.float32); b[:, 2:] += b[:, :2]
+    b[:5] = a[:5]; b[5] = [0, 0, 1, 1]
+    m = jaccard_matrix(a, b)
+    assert all(np.float32(m[i, j]) == np.float32(jaccard_numpy(a[i], b[j])) for i in range(40) for j in range(30))

@@ -1,0 +1,210 @@
+"""GPU parity tests of sub-graphs of the engine (wiring of the tape: ReLU-mask folding, gradient
+accumulation over several consumers, concat slices, ragged seg branch) against the CPU oracle's
+autograd.  Sub-graphs are a few layers deep, so bf16 storage noise stays small and the tolerances
+are tight (cosine >= 0.985 on every gradient; the residual ~5-10 % relative L2 error is the ReLU-mask
+flip noise sqrt(2^-9) that any bf16-storage pipeline shows against fp32), unlike the whole random-init network whose deep
+gradients are chaotic under ANY bf16 rounding (see test_gpu_net.py / DESIGN.md "Numerics")."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from kg_instance_segmentation_amd import KGnet  # noqa: E402
+from kg_instance_segmentation_amd.engine import Var  # noqa: E402
+from kg_instance_segmentation_amd.ops import BF16  # noqa: E402
+from oracle import net as onet  # noqa: E402
+
+DEV = "cuda"
+
+
+def bfr(t):
+    return t.to(BF16).float()
+
+
+def rows_of(x):
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * h * w, c).to(BF16).contiguous()
+
+
+def nchw_of(rows, n, h, w):
+    return rows.float().cpu().view(n, h, w, -1).permute(0, 3, 1, 2)
+
+
+def cos(a, b):
+    a = a.detach().double().cpu().flatten(); b = b.detach().double().cpu().flatten()
+    return float(a @ b / (a.norm() * b.norm() + 1e-30))
+
+
+def check(name, got, ref, thr=0.985):
+    c = cos(got, ref)
+    rel = float((got.detach().double().cpu() - ref.detach().double().cpu()).norm() / (ref.detach().double().norm() + 1e-30))
+    print(f"[{name}] cos={c:.5f} rel_l2={rel:.4f}")
+    assert c >= thr, name
+
+
+@pytest.fixture(scope="module")
+def model(state_dict0):
+    m = KGnet.resnet50(pretrained=False)
+    m.load_state_dict(state_dict0)
+    return m.to(DEV).train()
+
+
+def oracle_params(state_dict0, prefix_list):
+    sd = {k: v.clone() for k, v in state_dict0.items()}
+    for k in sd:
+        if any(k.startswith(p) for p in prefix_list) and sd[k].is_floating_point() and "running" not in k:
+            sd[k].requires_grad_(True)
+    return sd
+
+
+@pytest.mark.parametrize("block,inpl,planes,stride,H,W", [("layer1.0", 64, 64, 1, 16, 24), ("layer1.1", 256, 64, 1, 16, 24),
+                                                       ("layer2.0", 256, 128, 2, 16, 24), ("layer3.0", 512, 256, 2, 12, 16)])
+def test_bottleneck_block(model, state_dict0, block, inpl, planes, stride, H, W):
+    N = 2
+    g = torch.Generator().manual_seed(1)
+    x = F.relu(bfr(torch.randn(N, inpl, H, W, generator=g)))
+    eng = model._engine
+    eng.tape, eng.param_grads = [], {}
+    xv = Var(rows_of(x).to(DEV), inpl, relu=True, req=True)
+    yv, OH, OW = eng.bottleneck(xv, block, N, H, W, inpl, planes, stride, block.endswith(".0"))
+    dy = bfr(torch.randn(N, planes * 4, OH, OW, generator=g))
+    yv.grad, yv.masked = rows_of(dy).to(DEV), False
+    for fn in reversed(eng.tape):
+        fn()
+    gx = xv.take_grad()
+    torch.cuda.synchronize()
+    sd = oracle_params(state_dict0, [block + "."])
+    net = onet.Net(sd, training=True)
+    xd = x.clone().requires_grad_(True)
+    xin = F.relu(xd)   # the block input is a ReLU output: its gradient carries that mask
+    y = net.bottleneck(xin, block, stride, block.endswith(".0"))
+    y.backward(dy)
+    check(block + ".out", nchw_of(yv.t, N, OH, OW), y)
+    check(block + ".dx", nchw_of(gx, N, H, W), xd.grad)
+    for k, gg in eng.param_grads.items():
+        check(k, gg, sd[k].grad)
+    eng.tape = None
+
+
+def test_stem_and_decoder_level(model, state_dict0):
+    """conv1+bn1+relu+maxpool, then one decoder level: upsample -> 3x3 conv into a concat slice -> 1x1 refine,
+    with the skip tensor also feeding a second consumer (gradient accumulation + mask folding)."""
+    N, H, W = 2, 32, 48
+    g = torch.Generator().manual_seed(2)
+    img = bfr(torch.rand(N, 3, H, W, generator=g) - 0.5)
+    eng = model._engine
+    eng.tape, eng.param_grads = [], {}
+    from kg_instance_segmentation_amd import ops
+    x8 = Var(ops.img_pack(img.to(DEV)), 8, relu=False, req=False)
+    s1, H1, W1 = eng.conv(x8, eng.spec("conv1", 3, 64, 7, 2, 3, bias=False), N, H, W, False)
+    cat1 = torch.empty(N * H1 * W1, 128, dtype=BF16, device=DEV)
+    c1 = eng.bn(s1, "bn1", True, out=cat1[:, 64:128])
+    p, Hp, Wp = eng.maxpool(c1, N, H1, W1)
+    # decoder level 1 style: upsample p (64 ch) to c1's size, c1_up_conv-like 3x3 (use c1_up_conv: 64->64), concat, c1_cat_refine
+    u_in = eng.upsample(p, N, Hp, Wp, H1, W1)
+    u, _, _ = eng.conv(u_in, eng.spec("c1_up_conv.0", 64, 64, 3, 1, 1), N, H1, W1, True, out=cat1[:, 0:64])
+    cv = eng.concat(cat1, [u, c1])
+    out, _, _ = eng.conv(cv, eng.spec("c1_cat_refine.0", 128, 64, 1), N, H1, W1, True)
+    dy = bfr(torch.randn(N, 64, H1, W1, generator=g))
+    out.grad, out.masked = rows_of(dy).to(DEV), False
+    for fn in reversed(eng.tape):
+        fn()
+    torch.cuda.synchronize()
+    sd = oracle_params(state_dict0, ["conv1.", "bn1.", "c1_up_conv.", "c1_cat_refine."])
+    net = onet.Net(sd, training=True)
+    c1o = net.bn(net.conv(img, "conv1", 2, 3), "bn1", True)
+    po = F.max_pool2d(c1o, 3, 2, 1)
+    uo = net.conv(net.up(po, c1o), "c1_up_conv.0", 1, 1, True)
+    oo = net.conv(torch.cat((uo, c1o), 1), "c1_cat_refine.0", 1, 0, True)
+    oo.backward(dy)
+    check("stem.c1", nchw_of(c1.t, N, H1, W1), c1o)
+    check("dec.out", nchw_of(out.t, N, H1, W1), oo)
+    for k, gg in eng.param_grads.items():
+        check(k, gg, sd[k].grad)
+    eng.tape = None
+
+
+def test_heads_level(model, state_dict0):
+    """fused first 7x7 convs + three second convs + sigmoid, gradients from fp32 NCHW map grads."""
+    N, H, W, C = 1, 16, 24, 64
+    g = torch.Generator().manual_seed(3)
+    x = F.relu(bfr(torch.randn(N, C, H, W, generator=g)))
+    eng = model._engine
+    eng.tape, eng.param_grads = [], {}
+    from kg_instance_segmentation_amd import arch, ops
+    xv = Var(rows_of(x).to(DEV), C, relu=True, req=True)
+    fused = [f"{h}_head_c1.0" for h, _ in arch.HEADS]
+    hid, _, _ = eng.conv(xv, eng.spec("heads_c1.0", C, C, 7, 1, 3, fused=fused), N, H, W, True)
+    outs, ovs = [], []
+    for k, (h, co) in enumerate(arch.HEADS):
+        hv = Var(hid.t[:, k * C:(k + 1) * C], C, relu=True, parent=hid, c0=k * C)
+        o = torch.empty(N, co, H, W, dtype=torch.float32, device=DEV)
+        ov, _, _ = eng.conv(hv, eng.spec(f"{h}_head_c1.2", C, co, 7, 1, 3), N, H, W, False, y_f32=o)
+        outs.append(o); ovs.append((ov, co))
+    ops.sigmoid_(outs[0])
+    gm = [torch.randn(N, co, H, W, generator=g) * 1e-3 for _, co in arch.HEADS]
+    for k, ((ov, co), gk) in enumerate(zip(ovs, gm)):
+        cpad = ops.round_up(co, 8)
+        packed = torch.empty(N * H * W, cpad, dtype=BF16, device=DEV)
+        ops.grad_pack(gk.to(DEV), outs[0] if k == 0 else None, packed, N, co, H, W, cpad)
+        ov.grad, ov.masked = packed, True
+    for fn in reversed(eng.tape):
+        fn()
+    gx = xv.take_grad()
+    torch.cuda.synchronize()
+    sd = oracle_params(state_dict0, [f"{h}_head_c1." for h, _ in arch.HEADS])
+    net = onet.Net(sd, training=True)
+    xd = x.clone().requires_grad_(True)
+    xin = F.relu(xd)
+    ref = []
+    for h, co in arch.HEADS:
+        y = net.conv(net.conv(xin, f"{h}_head_c1.0", 1, 3, True), f"{h}_head_c1.2", 1, 3)
+        ref.append(torch.sigmoid(y) if h == "kp" else y)
+    torch.autograd.backward(ref, gm)
+    for (h, _), o, r in zip(arch.HEADS, outs, ref):
+        check(f"head.{h}.out", o.cpu(), r)
+    check("head.dx", nchw_of(gx, N, H, W), xd.grad)
+    for k, gg in eng.param_grads.items():
+        check(k, gg, sd[k].grad)
+    eng.tape = None
+
+
+def test_seg_branch_forward_backward(model, state_dict0):
+    """forward_seg on given feature maps: patches, gradients w.r.t. the five feature maps and all seg parameters."""
+    N, H, W = 2, 96, 128
+    g = torch.Generator().manual_seed(4)
+    chans = [64, 64, 256, 512, 1024]
+    feats = [F.relu(bfr(torch.randn(N, c, H >> l, W >> l, generator=g))) for l, c in enumerate(chans)]
+    boxes = [np.array([[10.2, 12.7, 40.5, 50.5, 1.0], [0.0, 0.0, 95.0, 127.0, 0.9], [30.5, 60.5, 37.5, 71.5, 0.8],
+                       [50, 20, 52, 90, 0.7], [64.4, 100.6, 90.2, 126.9, 0.6], [2.5, 3.5, 14.5, 17.5, 0.5]], np.float32),
+             np.array([[20, 30, 60, 80, 1.0], [5, 100, 25, 120, 1.0], [70.5, 8.5, 93.5, 40.5, 1.0], [1, 1, 3, 3, 1.0]], np.float32)]
+    fd = []
+    for f in feats:
+        n, c, h, w = f.shape
+        t = rows_of(f).to(DEV).view(n, h, w, c).permute(0, 3, 1, 2).requires_grad_(True)
+        fd.append(t)
+    patches, dets = model.forward_seg(fd, boxes)
+    wts = [[torch.randn(p.shape, generator=g) for p in pp] for pp in patches]
+    loss = sum((p * w.to(DEV)).sum() for pp, ww in zip(patches, wts) for p, w in zip(pp, ww))
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    sd = oracle_params(state_dict0, ["skip_combine.", "seg_head."])
+    net = onet.Net(sd, training=True)
+    fo = [f.clone().requires_grad_(True) for f in feats]
+    op_, od = net.forward_seg([F.relu(f) for f in fo], boxes)
+    lo = sum((p * w).sum() for pp, ww in zip(op_, wts) for p, w in zip(pp, ww))
+    lo.backward()
+    for i in range(N):
+        assert len(patches[i]) == len(op_[i])
+        for j, (a, b) in enumerate(zip(patches[i], op_[i])):
+            assert tuple(a.shape) == tuple(b.shape)
+            check(f"seg.patch{i}.{j}{tuple(b.shape)}", a, b, thr=0.999)
+    for l in range(5):
+        check(f"seg.dfeat{l}", fd[l].grad.float(), fo[l].grad)
+    params = dict(model.named_parameters())
+    for k in sd:
+        if sd[k].requires_grad:
+            check(k, params[k].grad, sd[k].grad)

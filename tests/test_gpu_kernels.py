@@ -332,3 +332,47 @@ def test_seg_loss_matches_golden(golden):
             got = a.grad.cpu() if a.grad is not None else torch.zeros_like(b)
             report(f"seg_grad{i}", got, ref, atol=1e-8, rtol=2e-5)
     assert SEG_loss(40, 48)([[[patches[1][0]]], [[dets[1][0]]]], [gm[1]], [gb[1]]) is None
+
+
+HALO_CASES = [
+    # cin, cout, k, N, H, W, relu, bias
+    (64, 64, 3, 2, 20, 28, True, True),
+    (64, 64, 7, 1, 24, 40, True, True),
+    (64, 192, 7, 1, 32, 32, True, True),
+    (128, 128, 3, 1, 16, 16, False, True),
+    (256, 256, 7, 1, 16, 24, True, True),
+    (64, 100, 3, 1, 18, 21, False, False),
+    (1024, 512, 3, 1, 8, 8, True, True),
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv_halo_forward_and_dgrad(case):
+    """LDS-halo kernel (kg_conv2d_halo) forward and input-gradient vs F.conv2d / its autograd."""
+    cin, cout, k, N, H, W, relu, bias = case
+    pad = k // 2
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x = bfr(torch.randn(N, cin, H, W, generator=g)).double().requires_grad_(True)
+    w = bfr(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k))
+    b = torch.randn(cout, generator=g) if bias else None
+    pre = F.conv2d(x, w.double(), b.double() if bias else None, 1, pad)
+    ref = F.relu(pre) if relu else pre
+    dy = bfr(torch.randn(N, cout, H, W, generator=g))
+    pre.backward(dy.double())
+    xr = rows_of(x.detach().float()).to(DEV)
+    pw = PackedWeight(cout, k * k, cin, DEV); pw.pack(w.to(DEV))
+    geom = (N * H * W, H, W, H, W, k, k, 1, pad)
+    y = torch.empty(N * H * W, cout, dtype=BF16, device=DEV)
+    kind = ops.conv_auto(xr, pw, cout, geom, N, y=y, bias=b.to(DEV) if bias else None, relu=relu)
+    assert kind == "halo"
+    report(f"halo_fwd{case}", nchw_of(y.cpu(), N, H, W), ref, atol=2e-2, rtol=1e-2)
+    yf = torch.empty(N, cout, H, W, dtype=torch.float32, device=DEV)
+    ops.conv_auto(xr, pw, cout, geom, N, y_f32=yf, bias=b.to(DEV) if bias else None, relu=relu)
+    report(f"halo_fwd_f32{case}", yf.cpu(), ref, atol=3e-4, rtol=3e-4)
+    if cout % 64 == 0:
+        pwT = PackedWeight(cin, k * k, cout, DEV); pwT.pack(w.to(DEV), transposed=True)
+        dx = torch.empty(N * H * W, cin, dtype=BF16, device=DEV)
+        msk = bfr(torch.randn(N, cin, H, W, generator=g))
+        kind = ops.conv_auto(rows_of(dy).to(DEV), pwT, cin, geom, N, y=dx, mask=rows_of(msk).to(DEV), transposed=True)
+        assert kind == "halo"
+        report(f"halo_dgrad{case}", nchw_of(dx.cpu(), N, H, W), x.grad * (msk > 0), atol=2e-2, rtol=1e-2)
