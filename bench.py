@@ -74,7 +74,7 @@ class KernelTimer:
             M, _, _, _, _, KH, KW, _, _ = geom
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); r = orig_wgrad(x, dy, cin, cout, geom, grads, *a, **k); e.record()
-            timer.rec.append(("conv_wgrad", 2.0 * M * cout * KH * KW * cin, s, e))
+            timer.rec.append((f"conv_wgrad_{r}{KH}x{KW}", 2.0 * M * cout * KH * KW * cin, s, e))
             return r
         orig_halo = ops.conv_halo
 

@@ -46,6 +46,9 @@ int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW,
 int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const int* rowdesc, int M, int H, int W, int OH, int OW,
                     int ldx, int lddy, int Cin, int Cout, int cin_lim, int cout_lim, int KH, int KW, int stride, int pad,
                     int dil, int mode, int nsplit, long split_stride, void* stream);
+/* weight gradient of a dense stride-1 "same" 3x3 / 7x7 conv with dY tile + X halo resident in LDS (all taps per staging pass) */
+int kg_conv2d_wgrad_halo(const void* x, const void* dy, float* dwp, int N, int H, int W, int ldx, int lddy, int Cin, int Cout,
+                         int cin_lim, int cout_lim, int KS, int nsplit, long split_stride, void* stream);
 int kg_wgrad_reduce(const float* part, float* grad_oihw, int Cout, int Cin, int KH, int KW, int nsplit, long split_stride,
                     int accumulate, void* stream);
 int kg_bias_grad(const void* dy, float* db, float* scratch, int scratch_floats, int M, int C, int ld, int accumulate,

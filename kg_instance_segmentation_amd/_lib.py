@@ -22,6 +22,7 @@ _SIGS = {
     "kg_pack_weight": [P, P] + [c_int] * 9 + [P],
     "kg_set_wgrad_tr": [c_int],
     "kg_conv2d_wgrad": [P, P, P, P] + [c_int] * 18 + [c_long, P],
+    "kg_conv2d_wgrad_halo": [P, P, P] + [c_int] * 11 + [c_long, P],
     "kg_wgrad_reduce": [P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, P],
     "kg_bias_grad": [P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "kg_img_pack": [P, P, c_int, c_int, c_int, c_int, P],

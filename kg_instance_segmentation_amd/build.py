@@ -19,6 +19,7 @@ SOURCES = {
     "conv_igemm.hip": [],
     "conv_halo.hip": [],
     "conv_wgrad.hip": [],
+    "wgrad_halo.hip": [],
     "norm_pool.hip": [],
     "loss.hip": [],
     "postproc.hip": ["-ffp-contract=off"],

@@ -1,0 +1,200 @@
+// wgrad_halo.hip -- weight gradient of stride-1 "same" 3x3 / 7x7 convolutions with LDS-resident tiles.
+//
+//   dW[co][tap][ci] = sum over pixels  dY[px][co] * X[px + d(tap)][ci]
+//
+// One workgroup (8 waves) owns 64 output channels x CI = 16*CIF input channels x ALL KS*KS taps and walks over
+// 16x16 pixel tiles (its "split" of the image batch).  Per tile it stages the dY tile [256 px][64 co] and the X
+// halo [(16+KS-1)^2 px][CI] into LDS once; every tap re-reads the halo with a shifted window, so the 49 taps of
+// a 7x7 conv cost one staging pass instead of 49.  The reduction dimension (pixels) is the strided one in NHWC,
+// so both MFMA operands come from ds_read_b64_tr_b16 transpose reads.  Work split inside the workgroup: the
+// (tap, ci-fragment) units are dealt round-robin to the 8 waves; each wave keeps its <= 7 units x 4 co-fragments
+// of fp32 accumulators in registers across all tiles and writes them once at the end to the
+// [split][co][tap][ci] partial buffer that kg_wgrad_reduce sums (fixed order => reproducible).
+// Tiles are double-buffered through registers (loads of tile t+1 are in flight while tile t is multiplied).
+#include "kg_common.h"
+
+struct WgHaloArgs {
+    const bf16_t* x; const bf16_t* dy; float* dwp;
+    int N, H, W, tiles_x, tiles_y, ldx, lddy;
+    int Cin, Cout, cin_lim, cout_lim, nsplit;
+    long split_stride;
+};
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__device__ __forceinline__ int trf(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); }
+
+template <int KS, int CIF>
+__global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
+    constexpr int PAD = KS / 2, HWD = 16 + KS - 1, HPIX = HWD * HWD, T = KS * KS;
+    constexpr int XB = 32 * CIF;                       // bytes per halo pixel
+    constexpr int DY_BYTES = 256 * 128, X_BYTES = HPIX * XB, BUF = DY_BYTES + X_BYTES;
+    constexpr int UNITS = T * CIF, UPW = (UNITS + 7) / 8;
+    constexpr int DYPT = 256 * 8 / 512;                // dY 16-byte chunks per thread (4)
+    constexpr int XCH = HPIX * 2 * CIF, XPT = (XCH + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_ci_tiles = (a.cin_lim + 16 * CIF - 1) / (16 * CIF);
+    const int ci0 = (blockIdx.x % n_ci_tiles) * 16 * CIF, co0 = (blockIdx.x / n_ci_tiles) * 64;
+    const int split = blockIdx.y;
+    const int G = lane >> 4, i16 = lane & 15;
+
+    f32x4 acc[UPW][4];
+#pragma unroll
+    for (int q = 0; q < UPW; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[q][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 dyr[DYPT], xr[XPT];
+    const int tiles_total = a.N * a.tiles_x * a.tiles_y;
+
+    auto load_tile = [&](int t) {
+        int bt = t;
+        const int tx = bt % a.tiles_x; bt /= a.tiles_x;
+        const int ty = bt % a.tiles_y; const int n = bt / a.tiles_y;
+        const int oy0 = ty * 16, ox0 = tx * 16;
+#pragma unroll
+        for (int k = 0; k < DYPT; ++k) {
+            const int e = tid + k * 512, r = e >> 3, c8 = e & 7;
+            const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (oy < a.H && ox < a.W && co0 + c8 * 8 < a.cout_lim)
+                v = *reinterpret_cast<const uint4*>(a.dy + ((long)(n * a.H + oy) * a.W + ox) * a.lddy + co0 + c8 * 8);
+            dyr[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < XPT; ++k) {
+            const int e = tid + k * 512;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (e < XCH) {
+                const int p = e / (2 * CIF), c = e - p * (2 * CIF);
+                const int hy = p / HWD, hx = p - hy * HWD;
+                const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && ci0 + c * 8 < a.cin_lim)
+                    v = *reinterpret_cast<const uint4*>(a.x + ((long)(n * a.H + iy) * a.W + ix) * a.ldx + ci0 + c * 8);
+            }
+            xr[k] = v;
+        }
+    };
+    // halo byte address of 16-byte chunk c (8 channels) of halo pixel p
+    auto xaddr = [&](int p, int c) -> int {
+        if (CIF == 1) return ((p * 32) ^ (((p >> 3) & 1) << 7)) + c * 16;
+        return p * XB + (((c >> 1) ^ (trf(p) & (CIF - 1))) * 32) + (c & 1) * 16;
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* sy = smem + buf * BUF;
+        unsigned char* sx = sy + DY_BYTES;
+#pragma unroll
+        for (int k = 0; k < DYPT; ++k) {
+            const int e = tid + k * 512, r = e >> 3, c8 = e & 7;
+            *reinterpret_cast<uint4*>(sy + r * 128 + (((c8 >> 1) ^ trf(r)) * 32) + (c8 & 1) * 16) = dyr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < XPT; ++k) {
+            const int e = tid + k * 512;
+            if (e < XCH) {
+                const int p = e / (2 * CIF), c = e - p * (2 * CIF);
+                *reinterpret_cast<uint4*>(sx + xaddr(p, c)) = xr[k];
+            }
+        }
+    };
+
+    int t = split;
+    int cur = 0;
+    if (t < tiles_total) { load_tile(t); store_tile(0); }
+    for (; t < tiles_total; t += a.nsplit) {
+        __syncthreads();
+        const int tn = t + a.nsplit;
+        if (tn < tiles_total) load_tile(tn);
+        const unsigned char* sy = smem + cur * BUF;
+        const unsigned char* sx = sy + DY_BYTES;
+#pragma unroll 1
+        for (int s = 0; s < 8; ++s) {       // k-step: the 32 pixels of tile rows 2s, 2s+1
+            bf16x8 af[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {   // dY^T fragments: row = co, k = pixel
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int r = s * 32 + G * 8 + h * 4 + (i16 >> 2);
+                    const int off = r * 128 + ((c ^ trf(r)) * 32) + (i16 & 3) * 8;
+                    bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sy + off));
+                    af[c][h * 4 + 0] = v[0]; af[c][h * 4 + 1] = v[1]; af[c][h * 4 + 2] = v[2]; af[c][h * 4 + 3] = v[3];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < UPW; ++q) {
+                const int u = wave + 8 * q;
+                if (u < UNITS) {            // wave-uniform
+                    const int tap = u / CIF, f = u - tap * CIF;
+                    const int ky = tap / KS, kx = tap - ky * KS;
+                    bf16x8 bfr;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int k = G * 8 + h * 4 + (i16 >> 2);
+                        const int p = (2 * s + (k >> 4) + ky) * HWD + (k & 15) + kx;
+                        int off;
+                        if (CIF == 1) off = ((p * 32) ^ (((p >> 3) & 1) << 7)) + (i16 & 3) * 8;
+                        else off = p * XB + ((f ^ (trf(p) & (CIF - 1))) * 32) + (i16 & 3) * 8;
+                        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sx + off));
+                        bfr[h * 4 + 0] = v[0]; bfr[h * 4 + 1] = v[1]; bfr[h * 4 + 2] = v[2]; bfr[h * 4 + 3] = v[3];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfr, acc[q][c], 0, 0, 0);
+                }
+            }
+        }
+        if (tn < tiles_total) store_tile(cur ^ 1);
+        cur ^= 1;
+    }
+
+    float* out = a.dwp + (long)split * a.split_stride;
+#pragma unroll
+    for (int q = 0; q < UPW; ++q) {
+        const int u = wave + 8 * q;
+        if (u >= UNITS) continue;
+        const int tap = u / CIF, f = u - tap * CIF;
+        const int ci = ci0 + f * 16 + i16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + c * 16 + G * 4 + r;
+                if (co < a.Cout && ci < a.Cin) out[((long)co * T + tap) * a.Cin + ci] = acc[q][c][r];
+            }
+    }
+}
+
+template <int KS, int CIF>
+static int launch_wg(const WgHaloArgs& a, hipStream_t st) {
+    constexpr int HWD = 16 + KS - 1;
+    constexpr int smem = 2 * (256 * 128 + HWD * HWD * 32 * CIF);
+    static bool attr_done = false;
+    if (!attr_done) {
+        KG_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<KS, CIF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    const int n_ci = (a.cin_lim + 16 * CIF - 1) / (16 * CIF), n_co = (a.cout_lim + 63) / 64;
+    hipLaunchKernelGGL((wgrad_halo_kernel<KS, CIF>), dim3(n_ci * n_co, a.nsplit), dim3(512), smem, st, a);
+    KG_CHECK_LAUNCH("wgrad_halo");
+    return KG_OK;
+}
+
+// Weight gradient of a dense stride-1 "same" KSxKS conv, KS in {3,7}.  x [N*H*W][ldx], dy [N*H*W][lddy] bf16 rows;
+// dwp receives nsplit partial tensors [Cout][KS*KS][Cin] (fp32), split_stride elements apart.
+extern "C" int kg_conv2d_wgrad_halo(const void* x, const void* dy, float* dwp, int N, int H, int W, int ldx, int lddy,
+                                    int Cin, int Cout, int cin_lim, int cout_lim, int KS, int nsplit, long split_stride,
+                                    void* stream) {
+    WgHaloArgs a;
+    memset(&a, 0, sizeof(a));
+    KG_CHECK_ARG(x && dy && dwp, "kg_conv2d_wgrad_halo: null pointer");
+    KG_CHECK_ARG(KS == 3 || KS == 7, "kg_conv2d_wgrad_halo: kernel size must be 3 or 7");
+    KG_CHECK_ARG(ldx % 8 == 0 && lddy % 8 == 0 && cin_lim % 8 == 0 && cout_lim % 8 == 0, "kg_conv2d_wgrad_halo: ld/lim must be multiples of 8");
+    KG_CHECK_ARG(nsplit >= 1 && N > 0 && H > 0 && W > 0, "kg_conv2d_wgrad_halo: bad sizes");
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dwp = dwp; a.N = N; a.H = H; a.W = W;
+    a.tiles_x = kg_cdiv(W, 16); a.tiles_y = kg_cdiv(H, 16); a.ldx = ldx; a.lddy = lddy; a.Cin = Cin; a.Cout = Cout;
+    a.cin_lim = cin_lim; a.cout_lim = cout_lim; a.nsplit = nsplit; a.split_stride = split_stride;
+    hipStream_t st = (hipStream_t)stream;
+    if (KS == 7) return launch_wg<7, 1>(a, st);
+    return launch_wg<3, 4>(a, st);
+}

@@ -141,7 +141,7 @@ class Engine:
                     self.param_grads[n + ".weight"] = gw
                     grads.append((gw, off, co))
                     off += co
-                ops.conv_wgrad(xv.t, g, s.cin, s.cout, geom, grads)
+                ops.conv_wgrad(xv.t, g, s.cin, s.cout, geom, grads, N=N)
                 if s.has_bias:
                     db = torch.empty(s.cout, dtype=torch.float32, device=dev)
                     ops.bias_grad(g, s.cout, db)

@@ -103,20 +103,38 @@ def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):
     return s
 
 
-def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=False):
-    """grads: list of (fp32 OIHW grad tensor, cout_offset, cout_count) sharing x (fused heads) or one entry."""
+def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=False, N=None):
+    """grads: list of (fp32 OIHW grad tensor, cout_offset, cout_count) sharing x (fused heads) or one entry.
+    Dense stride-1 "same" 3x3/7x7 convs (N given) use the LDS-halo kernel, everything else the gather kernel."""
     M, H, W, OH, OW, KH, KW, stride, pad = geom
     _rows(x); _rows(dy)
     cin_lim = min(round_up(cin, 8), x.shape[1])
     cout_lim = min(round_up(cout, 8), dy.shape[1])
     nelem = cout * KH * KW * cin
-    S = wgrad_splits(M, cin_lim, cout_lim, KH * KW, nelem)
-    part = scratch_f32(S * nelem, x.device, "wgrad")
-    _lib.call("kg_conv2d_wgrad", ptr(x), ptr(dy), ptr(part), ptr(rowdesc), M, H, W, OH, OW, ld(x), ld(dy), cin, cout,
-              cin_lim, cout_lim, KH, KW, stride, pad, 1, mode, S, c_long(nelem), stream_ptr())
+    halo = USE_HALO and mode == 0 and N is not None and stride == 1 and KH == KW and KH in (3, 7) and pad == KH // 2
+    if halo:
+        cit = 16 if KH == 7 else 64
+        nblk = math.ceil(cin_lim / cit) * math.ceil(cout_lim / 64)
+        tiles = N * math.ceil(H / 16) * math.ceil(W / 16)
+        S = max(1, min(math.ceil(768 / nblk), tiles))
+        while S > 1 and S * nelem * 4 > (768 << 20):
+            S -= 1
+        part = scratch_f32(S * nelem, x.device, "wgrad")
+        wgrad_halo(x, dy, part, N, H, W, cin, cout, cin_lim, cout_lim, KH, S, nelem)
+    else:
+        S = wgrad_splits(M, cin_lim, cout_lim, KH * KW, nelem)
+        part = scratch_f32(S * nelem, x.device, "wgrad")
+        _lib.call("kg_conv2d_wgrad", ptr(x), ptr(dy), ptr(part), ptr(rowdesc), M, H, W, OH, OW, ld(x), ld(dy), cin, cout,
+                  cin_lim, cout_lim, KH, KW, stride, pad, 1, mode, S, c_long(nelem), stream_ptr())
     for g, off, cnt in grads:
         _lib.call("kg_wgrad_reduce", ctypes_offset(part, off * KH * KW * cin), ptr(g), cnt, cin, KH, KW, S, c_long(nelem),
                   1 if accumulate else 0, stream_ptr())
+    return "halo" if halo else "gather"
+
+
+def wgrad_halo(x, dy, part, N, H, W, cin, cout, cin_lim, cout_lim, KS, S, nelem):
+    _lib.call("kg_conv2d_wgrad_halo", ptr(x), ptr(dy), ptr(part), N, H, W, ld(x), ld(dy), cin, cout, cin_lim, cout_lim, KS, S,
+              c_long(nelem), stream_ptr())
 
 
 def ctypes_offset(t, elem_off):

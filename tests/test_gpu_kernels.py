@@ -376,3 +376,28 @@ def test_conv_halo_forward_and_dgrad(case):
         kind = ops.conv_auto(rows_of(dy).to(DEV), pwT, cin, geom, N, y=dx, mask=rows_of(msk).to(DEV), transposed=True)
         assert kind == "halo"
         report(f"halo_dgrad{case}", nchw_of(dx.cpu(), N, H, W), x.grad * (msk > 0), atol=2e-2, rtol=1e-2)
+
+
+WGRAD_HALO_CASES = [(64, 64, 3, 2, 20, 28), (64, 192, 7, 1, 32, 32), (64, 5, 7, 1, 16, 24), (3, 64, 3, 1, 24, 24),
+                    (256, 128, 3, 1, 16, 16), (128, 64, 7, 2, 18, 21), (1024, 512, 3, 1, 8, 8)]
+
+
+@pytest.mark.parametrize("case", WGRAD_HALO_CASES)
+def test_conv_wgrad_halo(case):
+    """kg_conv2d_wgrad_halo (all taps per staging pass) vs the autograd weight gradient of F.conv2d."""
+    cin, cout, k, N, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = bfr(torch.randn(N, cin, H, W, generator=g))
+    w = torch.randn(cout, cin, k, k, generator=g).double().requires_grad_(True)
+    y = F.conv2d(x.double(), w, None, 1, k // 2)
+    dy = bfr(torch.randn(N, cout, H, W, generator=g))
+    y.backward(dy.double())
+    cin_pad, cpad = ops.round_up(cin, 8), ops.round_up(cout, 8)
+    xr = torch.zeros(N * H * W, cin_pad, dtype=BF16); xr[:, :cin] = rows_of(x)
+    dyr = torch.zeros(N * H * W, cpad, dtype=BF16); dyr[:, :cout] = rows_of(dy)
+    gw = torch.full((cout, cin, k, k), float("nan"), dtype=torch.float32, device=DEV)
+    kind = ops.conv_wgrad(xr.to(DEV), dyr.to(DEV), cin, cout, (N * H * W, H, W, H, W, k, k, 1, k // 2), [(gw, 0, cout)], N=N)
+    assert kind == "halo"
+    torch.cuda.synchronize()
+    scale = float(w.grad.abs().max())
+    report(f"wgrad_halo{case}", gw.cpu(), w.grad, atol=2e-4 * scale, rtol=1e-4)
