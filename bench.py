@@ -65,7 +65,7 @@ class KernelTimer:
             tile = k.get("tile", 0) or (1 if cout <= 16 else 2 if cout <= 32 else 3 if cout <= 64 else 4)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); r = orig_conv(x, pw, cout, geom, *a, **k); e.record()
-            timer.rec.append((f"conv_igemm_tile{tile}", 2.0 * M * cout * KH * KW * pw.cin_pad, s, e))
+            timer.rec.append((f"conv_igemm_tile{tile}", 2.0 * M * cout * KH * KW * pw.cin_pad, s, e, f"M={M} cout={cout} k={KH} cinp={pw.cin_pad} mode={k.get('mode', 0)}"))
             return r
 
         def wgrad(x, dy, cin, cout, geom, grads, *a, **k):
@@ -74,7 +74,7 @@ class KernelTimer:
             M, _, _, _, _, KH, KW, _, _ = geom
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); r = orig_wgrad(x, dy, cin, cout, geom, grads, *a, **k); e.record()
-            timer.rec.append((f"conv_wgrad_{r}{KH}x{KW}", 2.0 * M * cout * KH * KW * cin, s, e))
+            timer.rec.append((f"conv_wgrad_{r}{KH}x{KW}", 2.0 * M * cout * KH * KW * cin, s, e, f"M={M} cout={cout} cin={cin} mode={k.get('mode', 0)}"))
             return r
         orig_halo = ops.conv_halo
 
@@ -84,14 +84,23 @@ class KernelTimer:
             wc = 3 if (cout % 192 == 0 or cout > 128) else (2 if cout > 64 else 1)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); r = orig_halo(x, pw, cout, N, H, W, KS, *a, **k); e.record()
-            timer.rec.append((f"conv_halo<{KS},{wc}>", 2.0 * N * H * W * cout * KS * KS * pw.cin_pad, s, e))
+            timer.rec.append((f"conv_halo<{KS},{wc}>", 2.0 * N * H * W * cout * KS * KS * pw.cin_pad, s, e, f"N={N} H={H} cout={cout} cinp={pw.cin_pad}"))
             return r
         # engine/seg call through `ops.<fn>` (and conv_auto resolves these names at call time)
         ops.conv_igemm, ops.conv_wgrad, ops.conv_halo = conv, wgrad, halo
 
+    def dump(self, path, steps):
+        rows = {}
+        for name, fl, s, e, desc in self.rec:
+            r = rows.setdefault((name, desc), [0.0, 0.0, 0])
+            r[0] += s.elapsed_time(e); r[1] += fl; r[2] += 1
+        with open(path, "w") as f:
+            for (name, desc), (ms, fl, n) in sorted(rows.items(), key=lambda kv: -kv[1][0]):
+                f.write(f"{ms / steps:8.3f} ms/step  {fl / max(ms, 1e-9) / 1e9:8.1f} TF  x{n / steps:5.1f}  {name}  {desc}\n")
+
     def summary(self):
         agg = {}
-        for name, fl, s, e in self.rec:
+        for name, fl, s, e, _ in self.rec:
             a = agg.setdefault(name, [0.0, 0.0, 0])
             a[0] += s.elapsed_time(e) * 1e-3; a[1] += fl; a[2] += 1
         return {k: {"seconds": v[0], "flops": v[1], "launches": v[2]} for k, v in agg.items()}
@@ -208,6 +217,8 @@ def main():
                                   f"batch {args.batch}/GPU, 3x{args.size}x{args.size}, {args.boxes} GT boxes/img, full HIP path",
                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "last_loss": last}}
     if not args.no_kernel_timer:
+        if os.environ.get("KG_BENCH_DUMP"):
+            timer.dump(os.environ["KG_BENCH_DUMP"], args.steps)
         summ = timer.summary()
         if summ:
             name = max(summ, key=lambda k: summ[k]["seconds"])

@@ -105,6 +105,7 @@ int kg_nms(const double* boxes, const int* nbox, int box_cap, double thresh, voi
 int kg_seg_build_rows(const int* boxtab8, int nb, int* rowdesc, int* row2box, int* srcrow, void* stream);
 int kg_rows_gather(const void* src, int ldsrc, const int* srcrow, void* dst, int lddst, long nrows, int C, void* stream);
 int kg_rows_scatter_add(const void* g, int ld, const int* srcrow, float* acc, int C, long nrows, int accld, void* stream);
+int kg_rows_scatter_add_bf16(const void* g, int ld, const int* srcrow, void* acc_bf16, int C, long nrows, int accld, void* stream);
 int kg_f32_to_bf16_rows(const float* acc, void* out, int C, long rows, int ldout, const void* addto, int ldadd,
                         void* stream);
 

@@ -48,6 +48,7 @@ _SIGS = {
     "kg_seg_build_rows": [P, c_int, P, P, P, P],
     "kg_rows_gather": [P, c_int, P, P, c_int, c_long, c_int, P],
     "kg_rows_scatter_add": [P, c_int, P, P, c_int, c_long, c_int, P],
+    "kg_rows_scatter_add_bf16": [P, c_int, P, P, c_int, c_long, c_int, P],
     "kg_f32_to_bf16_rows": [P, P, c_int, c_long, c_int, P, c_int, P],
 }
 _RESTYPE = {"kg_postproc_workspace_bytes": c_long}

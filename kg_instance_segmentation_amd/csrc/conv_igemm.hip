@@ -297,27 +297,44 @@ extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, 
 //  transposed == 0 (forward):  dst[(row0+co)*K + tap*cin_pad + c0 + ci]         = w[co][ci][tap]
 //  transposed == 1 (dgrad):    dst[(row0+ci)*K + tap*cin_pad + c0 + co]         = w[co][ci][tap]
 // Padding entries must have been zeroed by the caller (hipMemsetAsync once at plan time).
-__global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int Cout, int Cin,
-                                   int taps, int K, int cin_pad, int row0, int c0, int transposed) {
-    long total = (long)Cout * Cin * taps;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int tap = (int)(i % taps);
-        long r = i / taps;
-        int ci = (int)(r % Cin), co = (int)(r / Cin);
-        float v = w[i];
-        long d = transposed ? ((long)(row0 + ci) * K + (long)tap * cin_pad + c0 + co)
-                            : ((long)(row0 + co) * K + (long)tap * cin_pad + c0 + ci);
-        dst[d] = f2bf(v);
+// forward: one block per (co, 64-ci chunk): contiguous fp32 reads [ci][tap], LDS transpose, 128-byte bf16 writes
+// along ci for every tap.  transposed: one block per (64-co chunk, ci): reads `taps` contiguous floats per co,
+// writes 128-byte bf16 runs along co for every tap.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int Cout,
+                                                          int Cin, int taps, int K, int cin_pad, int row0, int c0,
+                                                          int transposed) {
+    __shared__ float tile[64 * 50];
+    if (!transposed) {
+        const int co = blockIdx.x, ci0 = blockIdx.y * 64;
+        const int nci = Cin - ci0 < 64 ? Cin - ci0 : 64;
+        const float* src = w + ((long)co * Cin + ci0) * taps;
+        for (int j = threadIdx.x; j < nci * taps; j += 256) { int ci = j / taps, tap = j - ci * taps; tile[ci * 50 + tap] = src[j]; }
+        __syncthreads();
+        for (int e = threadIdx.x; e < taps * 64; e += 256) {
+            const int tap = e >> 6, ci = e & 63;
+            if (ci < nci) dst[(long)(row0 + co) * K + (long)tap * cin_pad + c0 + ci0 + ci] = f2bf(tile[ci * 50 + tap]);
+        }
+    } else {
+        const int co0 = blockIdx.x * 64, ci = blockIdx.y;
+        const int nco = Cout - co0 < 64 ? Cout - co0 : 64;
+        for (int j = threadIdx.x; j < nco * taps; j += 256) {
+            int co = j / taps, tap = j - co * taps;
+            tile[co * 50 + tap] = w[((long)(co0 + co) * Cin + ci) * taps + tap];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < taps * 64; e += 256) {
+            const int tap = e >> 6, co = e & 63;
+            if (co < nco) dst[(long)(row0 + ci) * K + (long)tap * cin_pad + c0 + co0 + co] = f2bf(tile[co * 50 + tap]);
+        }
     }
 }
 
 extern "C" int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad,
                               int row0, int c0, int transposed, void* stream) {
     KG_CHECK_ARG(w && dst, "kg_pack_weight: null pointer");
-    long total = (long)Cout * Cin * KH * KW;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, Cout,
+    KG_CHECK_ARG(KH * KW <= 49, "kg_pack_weight: at most 49 taps");
+    dim3 grid = transposed ? dim3((Cout + 63) / 64, Cin) : dim3(Cout, (Cin + 63) / 64);
+    hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, Cout,
                        Cin, KH * KW, K, cin_pad, row0, c0, transposed);
     KG_CHECK_LAUNCH("pack_weight");
     return KG_OK;

@@ -186,28 +186,37 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
 }
 
 // Sum the split partials [S][Cout][taps][Cin] and write the OIHW fp32 gradient [Cout][Cin][taps]
-// (accumulate != 0: grad += sum).  Fixed summation order => bitwise reproducible gradients.
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int Cout, int Cin,
-                                    int taps, int S, long split_stride, int accumulate) {
-    long total = (long)Cout * Cin * taps;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int tap = (int)(i % taps);
-        long r = i / taps;
-        int ci = (int)(r % Cin), co = (int)(r / Cin);
-        long src = ((long)co * taps + tap) * Cin + ci;
+// (accumulate != 0: grad += sum).  Fixed summation order => bitwise reproducible gradients.  One block per
+// (co, 64-channel ci chunk): coalesced reads along ci, transpose through LDS, coalesced writes along (ci,tap).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad,
+                                                           int Cout, int Cin, int taps, int S, long split_stride,
+                                                           int accumulate) {
+    __shared__ float tile[49 * 65];
+    const int co = blockIdx.x, ci0 = blockIdx.y * 64;
+    const int nci = Cin - ci0 < 64 ? Cin - ci0 : 64;
+    for (int e = threadIdx.x; e < taps * 64; e += 256) {
+        const int tap = e >> 6, ci = e & 63;
         float s = 0.f;
-        for (int k = 0; k < S; ++k) s += part[k * split_stride + src];
-        grad[i] = accumulate ? grad[i] + s : s;
+        if (ci < nci) {
+            const long src = ((long)co * taps + tap) * Cin + ci0 + ci;
+            for (int k = 0; k < S; ++k) s += part[k * split_stride + src];
+        }
+        tile[tap * 65 + ci] = s;
+    }
+    __syncthreads();
+    float* dst = grad + ((long)co * Cin + ci0) * taps;
+    for (int j = threadIdx.x; j < nci * taps; j += 256) {
+        const int ci = j / taps, tap = j - ci * taps;
+        const float v = tile[tap * 65 + ci];
+        dst[j] = accumulate ? dst[j] + v : v;
     }
 }
 
 extern "C" int kg_wgrad_reduce(const float* part, float* grad, int Cout, int Cin, int KH, int KW, int nsplit,
                                long split_stride, int accumulate, void* stream) {
     KG_CHECK_ARG(part && grad, "kg_wgrad_reduce: null pointer");
-    long total = (long)Cout * Cin * KH * KW;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, part, grad, Cout, Cin,
+    KG_CHECK_ARG(KH * KW <= 49, "kg_wgrad_reduce: at most 49 taps");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout, (Cin + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, grad, Cout, Cin,
                        KH * KW, nsplit, split_stride, accumulate);
     KG_CHECK_LAUNCH("wgrad_reduce");
     return KG_OK;
@@ -233,11 +242,12 @@ __global__ void bias_grad_kernel(const bf16_t* __restrict__ dy, float* __restric
 }
 __global__ void bias_grad_final_kernel(const float* __restrict__ part, float* __restrict__ db, int nb, int C,
                                        int accumulate) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;   // one wave per channel, lanes stride over the block partials (fixed order)
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += part[(long)b * C + c];
-    db[c] = accumulate ? db[c] + s : s;
+    for (int b = threadIdx.x; b < nb; b += 64) s += part[(long)b * C + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
 }
 
 extern "C" int kg_bias_grad(const void* dy, float* db, float* scratch, int scratch_floats, int M, int C, int ld,
@@ -258,8 +268,8 @@ extern "C" int kg_bias_grad(const void* dy, float* db, float* scratch, int scrat
         nb = (M + rpb - 1) / rpb;
         hipLaunchKernelGGL(bias_grad_kernel, dim3(nb), dim3(threads), threads * sizeof(float), (hipStream_t)stream,
                            (const bf16_t*)dy + c0, scratch, M, Cs, ld, rpb);
-        hipLaunchKernelGGL(bias_grad_final_kernel, dim3((Cs + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch,
-                           db + c0, nb, Cs, accumulate);
+        hipLaunchKernelGGL(bias_grad_final_kernel, dim3(Cs), dim3(64), 0, (hipStream_t)stream, scratch, db + c0, nb, Cs,
+                           accumulate);
     }
     KG_CHECK_LAUNCH("bias_grad");
     return KG_OK;

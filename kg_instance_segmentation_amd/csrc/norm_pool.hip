@@ -81,6 +81,13 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
     }
 }
 
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return __shfl(v, 0, 64);
+}
+// The finalize kernels run ONE WAVE PER CHANNEL: lanes stride over the block partials (fixed order => reproducible).
+
 // train-mode finalize: mean / biased var -> invstd, scale/shift, running stats (momentum 0.1,
 // unbiased var), matching torch.nn.functional.batch_norm(training=True) (KGnet.py:82-93).
 __global__ void bn_finalize_train_kernel(const float* __restrict__ part, int nb, int C, long M,
@@ -89,10 +96,11 @@ __global__ void bn_finalize_train_kernel(const float* __restrict__ part, int nb,
                                          float momentum, float eps, float* __restrict__ mean_out,
                                          float* __restrict__ invstd_out, float* __restrict__ scale,
                                          float* __restrict__ shift) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double s = 0., ss = 0.;
-    for (int b = 0; b < nb; ++b) { s += part[((long)b * C + c) * 2]; ss += part[((long)b * C + c) * 2 + 1]; }
+    for (int b = threadIdx.x; b < nb; b += 64) { s += part[((long)b * C + c) * 2]; ss += part[((long)b * C + c) * 2 + 1]; }
+    s = wave_sum_d(s); ss = wave_sum_d(ss);
+    if (threadIdx.x != 0) return;
     double mu = s / (double)M;
     double var = ss / (double)M - mu * mu;
     if (var < 0.) var = 0.;
@@ -122,10 +130,11 @@ __global__ void bn_finalize_bwd_kernel(const float* __restrict__ part, int nb, i
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
                                        float* __restrict__ coef) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double s = 0., sx = 0.;
-    for (int b = 0; b < nb; ++b) { s += part[((long)b * C + c) * 2]; sx += part[((long)b * C + c) * 2 + 1]; }
+    for (int b = threadIdx.x; b < nb; b += 64) { s += part[((long)b * C + c) * 2]; sx += part[((long)b * C + c) * 2 + 1]; }
+    s = wave_sum_d(s); sx = wave_sum_d(sx);
+    if (threadIdx.x != 0) return;
     float db = (float)s, dg = (float)sx;
     dgamma[c] = accumulate ? dgamma[c] + dg : dg;
     dbeta[c] = accumulate ? dbeta[c] + db : db;
@@ -155,7 +164,7 @@ extern "C" int kg_bn_stats_train(const void* x, int ldx, int M, int C, const flo
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colreduce_kernel<0>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, (const bf16_t*)x, ldx,
                        (const bf16_t*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, scratch, M, C, rpb);
-    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 127) / 128), dim3(128), 0, st, scratch, nb, C, (long)M, gamma,
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(64), 0, st, scratch, nb, C, (long)M, gamma,
                        beta, running_mean, running_var, momentum, eps, mean_out, invstd_out, scale, shift);
     KG_CHECK_LAUNCH("bn_stats_train");
     return KG_OK;
@@ -240,7 +249,7 @@ extern "C" int kg_bn_bwd(const void* x, int ldx, const void* dy, int lddy, const
     float* coef = scratch; float* part = scratch + 3 * C;
     hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, (const bf16_t*)x, ldx,
                        (const bf16_t*)dy, lddy, mean, invstd, part, M, C, rpb);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + 127) / 128), dim3(128), 0, st, part, nb, C, (long)M, gamma,
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, st, part, nb, C, (long)M, gamma,
                        invstd, dgamma, dbeta, accumulate, coef);
     long total = (long)M * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;

@@ -247,11 +247,11 @@ class SegBranch:
         acc = []
         for l in range(5):
             n, c, h, w = feat_shapes[l]
-            acc.append(torch.zeros(n * h * w, c, dtype=torch.float32, device=dev) if plan.nb[l] else None)
+            acc.append(torch.zeros(n * h * w, c, dtype=BF16, device=dev) if plan.nb[l] else None)
 
         def scatter(g, l, nrows, row_off=0):
             if nrows:
-                _lib.call("kg_rows_scatter_add", ptr(g), ops.ld(g), _lib.c_void_p(plan.srcrow[l].data_ptr() + 4 * row_off),
+                _lib.call("kg_rows_scatter_add_bf16", ptr(g), ops.ld(g), _lib.c_void_p(plan.srcrow[l].data_ptr() + 4 * row_off),
                           ptr(acc[l]), CH[l], c_long(nrows), CH[l], stream_ptr())
 
         for l in range(0, top):
@@ -280,9 +280,7 @@ class SegBranch:
             if acc[l] is None:
                 gfeats.append(None)
                 continue
-            g = torch.empty(n * h * w, c, dtype=BF16, device=dev)
-            _lib.call("kg_f32_to_bf16_rows", ptr(acc[l]), ptr(g), c, c_long(n * h * w), c, None, 0, stream_ptr())
-            gfeats.append(g.view(n, h, w, c).permute(0, 3, 1, 2))
+            gfeats.append(acc[l].view(n, h, w, c).permute(0, 3, 1, 2))
         # parameters of levels that no box reached get zero gradients (autograd accumulates nothing for None)
         return gfeats, pgrads
 
