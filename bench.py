@@ -81,7 +81,7 @@ class KernelTimer:
         def halo(x, pw, cout, N, H, W, KS, *a, **k):
             if not timer.on:
                 return orig_halo(x, pw, cout, N, H, W, KS, *a, **k)
-            wc = 3 if (cout % 192 == 0 or cout > 128) else (2 if cout > 64 else 1)
+            wc = 1
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); r = orig_halo(x, pw, cout, N, H, W, KS, *a, **k); e.record()
             timer.rec.append((f"conv_halo<{KS},{wc}>", 2.0 * N * H * W * cout * KS * KS * pw.cin_pad, s, e, f"N={N} H={H} cout={cout} cinp={pw.cin_pad}"))

@@ -5,9 +5,11 @@
 // owns a 16x16 output tile and TC = 64*WC output channels:
 //   * the (16+KS-1)^2 x 64-channel input halo is staged into LDS ONCE per 64-channel chunk and re-read by all
 //     KS*KS taps (49x reuse for 7x7) with shifted ds_read_b128 fragment addresses;
-//   * only the [TC][64] weight slice of the current tap streams through a 2-deep LDS ring (register prefetch
-//     two taps ahead), one barrier per tap; 4*WC waves (up to 3 per SIMD) hide each other's LDS/global latency;
+//   * only the [TC][64] weight slice of the current tap streams through a 3-slot LDS ring (register prefetch
+//     three taps ahead), one barrier per tap; MFMA fragments of the next k-step are fetched while the current
+//     16 MFMAs run (register double buffering), so nobody waits on LDS right after a barrier;
 //   * both tiles use XOR-swizzled 16-byte slots so the 16-lane ds_read_b128 groups hit 16 distinct slots.
+// Cout <= 64 uses a 16x32 tile with 8 pixel-waves instead (same LDS budget, 2 waves/SIMD).
 // The same kernel computes the input gradient of such a conv (flip = 1, transposed-packed weights).
 // Wave tile = 64 couts x 64 pixels (4 rows of the 16x16 tile), 16 v_mfma_f32_16x16x32_bf16 per 32-wide k-step.
 #include "kg_common.h"
@@ -19,9 +21,10 @@ struct HaloArgs {
     int cin_pad, ldx, Cout, ldy, ldres, ldmask, K, flip, relu, f32_C;
 };
 
-template <int KS, int WC>
-__global__ __launch_bounds__(WC * 256) void conv_halo_kernel(const HaloArgs a) {
-    constexpr int PAD = KS / 2, HWD = 16 + KS - 1, HPIX = HWD * HWD, TC = WC * 64, NT = WC * 256, T = KS * KS;
+// WPX = pixel waves: 4 -> 16x16 output tile, 8 -> 16 rows x 32 columns (two 16x16 halves side by side)
+template <int KS, int WC, int WPX>
+__global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs a) {
+    constexpr int PAD = KS / 2, TW = 4 * WPX, HWD = TW + KS - 1, HPIX = (16 + KS - 1) * HWD, TC = WC * 64, NT = WC * WPX * 64, T = KS * KS;
     constexpr int HALO_BYTES = HPIX * 128, WBUF_BYTES = TC * 128;
     constexpr int WPT = TC * 8 / NT;  // weight chunks per thread per tap (= 2)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -29,12 +32,12 @@ __global__ __launch_bounds__(WC * 256) void conv_halo_kernel(const HaloArgs a) {
     unsigned char* wbuf = smem + HALO_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wc = wave >> 2, wp = wave & 3;
+    const int wc = wave / WPX, wp = wave % WPX;
     const int lm = lane & 15, g = lane >> 4;
     int bt = blockIdx.x;
     const int tx = bt % a.tiles_x; bt /= a.tiles_x;
     const int ty = bt % a.tiles_y; const int n = bt / a.tiles_y;
-    const int oy0 = ty * 16, ox0 = tx * 16;
+    const int oy0 = ty * 16, ox0 = tx * TW;
     const int c0 = blockIdx.y * TC;
 
     f32x4 acc[4][4];
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(WC * 256) void conv_halo_kernel(const HaloArgs a) {
     // pixel fragment base halo index (tap offset added per tap)
     int p_base[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p_base[j] = (wp * 4 + j) * HWD + lm;
+    for (int j = 0; j < 4; ++j) p_base[j] = ((wp & 3) * 4 + j) * HWD + (wp >> 2) * 16 + lm;
 
     // weight staging assignment
     int w_row[WPT], w_lds[WPT];
@@ -66,6 +69,32 @@ __global__ __launch_bounds__(WC * 256) void conv_halo_kernel(const HaloArgs a) {
     }
     const int wc8 = (tid & 7) * 8;  // NT % 8 == 0: the channel chunk of a thread is the same for every i
     uint4 wreg[WPT];
+
+    // Fragment loaders.  A: weight rows of ring slot `slot`; B: halo pixels shifted by the tap offset.
+    auto load_a = [&](bf16x8 (&af)[4], int slot, int s) {
+        const unsigned char* wb = wbuf + slot * WBUF_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            af[i] = *reinterpret_cast<const bf16x8*>(wb + a_row_off[i] + (((4 * s + g) ^ a_key[i]) * 16));
+    };
+    auto load_b = [&](bf16x8 (&bfr)[4], int t, int s) {
+        const int ky = t / KS, kx = t - ky * KS;
+        const int tapoff = a.flip ? ((KS - 1 - ky) * HWD + (KS - 1 - kx)) : (ky * HWD + kx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = p_base[j] + tapoff;
+            bfr[j] = *reinterpret_cast<const bf16x8*>(halo + p * 128 + (((4 * s + g) ^ ((p >> 1) & 7)) * 16));
+        }
+    };
+    auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[4]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
 
     const int nchunks = a.cin_pad / 64;
     for (int cc = 0; cc < nchunks; ++cc) {
@@ -85,38 +114,29 @@ __global__ __launch_bounds__(WC * 256) void conv_halo_kernel(const HaloArgs a) {
             for (int i = 0; i < WPT; ++i)
                 wreg[i] = *reinterpret_cast<const uint4*>(a.w + (long)(c0 + w_row[i]) * a.K + (long)tap * a.cin_pad + cc * 64 + wc8);
         };
-        auto wstore = [&](int buf) {
+        auto wstore = [&](int slot) {
 #pragma unroll
-            for (int i = 0; i < WPT; ++i) *reinterpret_cast<uint4*>(wbuf + buf * WBUF_BYTES + w_lds[i]) = wreg[i];
+            for (int i = 0; i < WPT; ++i) *reinterpret_cast<uint4*>(wbuf + slot * WBUF_BYTES + w_lds[i]) = wreg[i];
         };
+        // Weight ring of 3 slots: at the start of tap t slots t%3 and (t+1)%3 are visible, W(t+2) is in registers.
         wload(0); wstore(0);
-        if (T > 1) wload(1);
+        if (T > 1) { wload(1); wstore(1); }
+        if (T > 2) wload(2);
         __syncthreads();
+        // Software pipeline over (tap, k-step): the fragments of the NEXT k-step are fetched from LDS while the 16
+        // MFMAs of the current one run, so no wave waits on LDS right after the per-tap barrier.
+        bf16x8 a0[4], b0[4], a1[4], b1[4];
+        load_a(a0, 0, 0); load_b(b0, 0, 0);
 #pragma unroll 1
         for (int t = 0; t < T; ++t) {
-            const int ky = t / KS, kx = t - ky * KS;
-            const int tapoff = a.flip ? ((KS - 1 - ky) * HWD + (KS - 1 - kx)) : (ky * HWD + kx);
-            const unsigned char* wb = wbuf + (t & 1) * WBUF_BYTES;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 af[4], bfr[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    af[i] = *reinterpret_cast<const bf16x8*>(wb + a_row_off[i] + (((4 * s + g) ^ a_key[i]) * 16));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int p = p_base[j] + tapoff;
-                    bfr[j] = *reinterpret_cast<const bf16x8*>(halo + p * 128 + (((4 * s + g) ^ ((p >> 1) & 7)) * 16));
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
-            if (t + 1 < T) {
-                wstore((t + 1) & 1);
-                if (t + 2 < T) wload(t + 2);
+            const int slot = t % 3;
+            load_a(a1, slot, 1); load_b(b1, t, 1);
+            mma(a0, b0);
+            if (t + 1 < T) { load_a(a0, (t + 1) % 3, 0); load_b(b0, t + 1, 0); }
+            mma(a1, b1);
+            if (t + 2 < T) {
+                wstore((t + 2) % 3);
+                if (t + 3 < T) wload(t + 3);
             }
             __syncthreads();
         }
@@ -129,10 +149,10 @@ __global__ __launch_bounds__(WC * 256) void conv_halo_kernel(const HaloArgs a) {
     float bv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
-    const int ox = ox0 + lm;
+    const int ox = ox0 + (wp >> 2) * 16 + lm;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int oy = oy0 + wp * 4 + j;
+        const int oy = oy0 + (wp & 3) * 4 + j;
         if (oy >= a.H || ox >= a.W) continue;
         const long m = (long)(n * a.H + oy) * a.W + ox;
         float v[16];
@@ -186,23 +206,24 @@ __global__ __launch_bounds__(WC * 256) void conv_halo_kernel(const HaloArgs a) {
     }
 }
 
-template <int KS, int WC>
-static int launch_halo(const HaloArgs& a, hipStream_t st) {
-    constexpr int HWD = 16 + KS - 1, TC = WC * 64;
-    constexpr int smem = HWD * HWD * 128 + 2 * TC * 128;
+template <int KS, int WC, int WPX>
+static int launch_halo(HaloArgs a, hipStream_t st) {
+    constexpr int TW = 4 * WPX, HWD = TW + KS - 1, TC = WC * 64;
+    constexpr int smem = (16 + KS - 1) * HWD * 128 + 3 * TC * 128;
+    a.tiles_x = kg_cdiv(a.W, TW);
     static bool attr_done = false;
     if (!attr_done) {
-        KG_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<KS, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        KG_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<KS, WC, WPX>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
     dim3 grid(a.N * a.tiles_x * a.tiles_y, kg_cdiv(a.Cout, TC));
-    hipLaunchKernelGGL((conv_halo_kernel<KS, WC>), grid, dim3(WC * 256), smem, st, a);
+    hipLaunchKernelGGL((conv_halo_kernel<KS, WC, WPX>), grid, dim3(WC * WPX * 64), smem, st, a);
     KG_CHECK_LAUNCH("conv_halo");
     return KG_OK;
 }
 
 // Stride-1 "same" convolution, KS in {3,7}; cin_pad % 64 == 0; weight rows padded to a multiple of 64*wc.
-// wc: 0 = auto (3 when Cout % 192 == 0 or Cout > 128, 2 when Cout > 64, else 1).
+// wc: couts per workgroup / 64; 0 = default (1: 16x32-pixel tile, 8 waves); 2, 3: 16x16-pixel tile with 128 / 192 couts.
 extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, void* y, float* y_f32, const void* res,
                               const void* mask, int N, int H, int W, int cin_pad, int ldx, int Cout, int ldy, int ldres,
                               int ldmask, int K, int KS, int flip, int relu, int f32_C, int wc, void* stream) {
@@ -218,19 +239,19 @@ extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, v
     a.N = N; a.H = H; a.W = W; a.tiles_x = kg_cdiv(W, 16); a.tiles_y = kg_cdiv(H, 16);
     a.cin_pad = cin_pad; a.ldx = ldx; a.Cout = Cout; a.ldy = ldy; a.ldres = ldres; a.ldmask = ldmask; a.K = K;
     a.flip = flip; a.relu = relu; a.f32_C = f32_C;
-    if (wc == 0) wc = (Cout % 192 == 0 || Cout > 128) ? 3 : (Cout > 64 ? 2 : 1);
+    if (wc == 0) wc = 1;   // measured on MI355X: the 16x32-pixel x 64-cout tile (8 waves) beats the 16x16 x 128/192-cout tiles at every KGnet shape
     hipStream_t st = (hipStream_t)stream;
     if (KS == 7) {
         switch (wc) {
-            case 1: return launch_halo<7, 1>(a, st);
-            case 2: return launch_halo<7, 2>(a, st);
-            case 3: return launch_halo<7, 3>(a, st);
+            case 1: return launch_halo<7, 1, 8>(a, st);
+            case 2: return launch_halo<7, 2, 4>(a, st);
+            case 3: return launch_halo<7, 3, 4>(a, st);
         }
     } else {
         switch (wc) {
-            case 1: return launch_halo<3, 1>(a, st);
-            case 2: return launch_halo<3, 2>(a, st);
-            case 3: return launch_halo<3, 3>(a, st);
+            case 1: return launch_halo<3, 1, 8>(a, st);
+            case 2: return launch_halo<3, 2, 4>(a, st);
+            case 3: return launch_halo<3, 3, 4>(a, st);
         }
     }
     kg_set_error("kg_conv2d_halo: bad wc %d", wc);

@@ -188,26 +188,27 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
 // Sum the split partials [S][Cout][taps][Cin] and write the OIHW fp32 gradient [Cout][Cin][taps]
 // (accumulate != 0: grad += sum).  Fixed summation order => bitwise reproducible gradients.  One block per
 // (co, 64-channel ci chunk): coalesced reads along ci, transpose through LDS, coalesced writes along (ci,tap).
+template <int CH>   // ci chunk per block: 64 for big layers, 16 to get enough blocks on small ones
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad,
                                                            int Cout, int Cin, int taps, int S, long split_stride,
                                                            int accumulate) {
-    __shared__ float tile[49 * 65];
-    const int co = blockIdx.x, ci0 = blockIdx.y * 64;
-    const int nci = Cin - ci0 < 64 ? Cin - ci0 : 64;
-    for (int e = threadIdx.x; e < taps * 64; e += 256) {
-        const int tap = e >> 6, ci = e & 63;
+    __shared__ float tile[49 * (CH + 1)];
+    const int co = blockIdx.x, ci0 = blockIdx.y * CH;
+    const int nci = Cin - ci0 < CH ? Cin - ci0 : CH;
+    for (int e = threadIdx.x; e < taps * CH; e += 256) {
+        const int tap = e / CH, ci = e - tap * CH;
         float s = 0.f;
         if (ci < nci) {
             const long src = ((long)co * taps + tap) * Cin + ci0 + ci;
             for (int k = 0; k < S; ++k) s += part[k * split_stride + src];
         }
-        tile[tap * 65 + ci] = s;
+        tile[tap * (CH + 1) + ci] = s;
     }
     __syncthreads();
     float* dst = grad + ((long)co * Cin + ci0) * taps;
     for (int j = threadIdx.x; j < nci * taps; j += 256) {
         const int ci = j / taps, tap = j - ci * taps;
-        const float v = tile[tap * 65 + ci];
+        const float v = tile[tap * (CH + 1) + ci];
         dst[j] = accumulate ? dst[j] + v : v;
     }
 }
@@ -216,8 +217,12 @@ extern "C" int kg_wgrad_reduce(const float* part, float* grad, int Cout, int Cin
                                long split_stride, int accumulate, void* stream) {
     KG_CHECK_ARG(part && grad, "kg_wgrad_reduce: null pointer");
     KG_CHECK_ARG(KH * KW <= 49, "kg_wgrad_reduce: at most 49 taps");
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout, (Cin + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, grad, Cout, Cin,
-                       KH * KW, nsplit, split_stride, accumulate);
+    if ((long)Cout * ((Cin + 63) / 64) >= 2048)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(Cout, (Cin + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, grad, Cout,
+                           Cin, KH * KW, nsplit, split_stride, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(Cout, (Cin + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, grad, Cout,
+                           Cin, KH * KW, nsplit, split_stride, accumulate);
     KG_CHECK_LAUNCH("wgrad_reduce");
     return KG_OK;
 }

@@ -72,8 +72,12 @@ def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=
 USE_HALO = True
 
 
+HALO_WC = int(__import__("os").environ.get("KG_HALO_WC", "0"))   # tuning override (0 = library default)
+
+
 def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, flip=False, wc=0):
     """Stride-1 "same" KSxKS conv (or its input gradient when flip) with the input halo resident in LDS."""
+    wc = wc or HALO_WC
     f32_C = 0
     if y_f32 is not None:
         f32_C = y_f32.shape[1] if y_f32.dim() == 4 else 1

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Micro-benchmark of single conv kernels at KGnet's shapes (used for rocprofv3 --pmc runs and tuning).
+    python tools/kbench.py halo7_c0 [reps]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from kg_instance_segmentation_amd import ops
+from kg_instance_segmentation_amd.ops import BF16, PackedWeight
+
+CASES = {
+    # name: (kind, N, H, cin, cout, k)
+    "halo7_c0": ("fwd", 8, 512, 64, 192, 7),
+    "halo7_c0_64": ("fwd", 8, 512, 192, 64, 7),
+    "halo7_c2": ("fwd", 8, 128, 256, 768, 7),
+    "halo7_c3": ("fwd", 8, 64, 512, 1536, 7),
+    "halo7_c3d": ("fwd", 8, 64, 1536, 512, 7),
+    "halo3_c0": ("fwd", 8, 512, 64, 64, 3),
+    "wg7_c0": ("wgrad", 8, 512, 64, 192, 7),
+    "wg7_c3": ("wgrad", 8, 64, 512, 1536, 7),
+    "wg3_c0": ("wgrad", 8, 512, 64, 64, 3),
+    "igemm1_c0": ("igemm", 8, 512, 128, 64, 1),
+}
+
+
+def main():
+    name = sys.argv[1]
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    kind, N, H, cin, cout, k = CASES[name]
+    dev = "cuda"
+    M = N * H * H
+    x = (torch.randn(M, cin, device=dev) * 0.5).to(BF16)
+    geom = (M, H, H, H, H, k, k, 1, k // 2)
+    flops = 2.0 * M * cout * k * k * cin
+    if kind in ("fwd", "igemm"):
+        pw = PackedWeight(cout, k * k, cin, dev)
+        pw.buf.copy_((torch.randn_like(pw.buf.float()) * 0.05).to(BF16))
+        y = torch.empty(M, cout, dtype=BF16, device=dev)
+        bias = torch.zeros(cout, device=dev)
+        if kind == "fwd":
+            fn = lambda: ops.conv_halo(x, pw, cout, N, H, H, k, y=y, bias=bias, relu=True)
+        else:
+            fn = lambda: ops.conv_igemm(x, pw, cout, geom, y=y, bias=bias, relu=True)
+    else:
+        dy = (torch.randn(M, cout, device=dev) * 0.5).to(BF16)
+        gw = torch.empty(cout, cin, k, k, device=dev)
+        fn = lambda: ops.conv_wgrad(x, dy, cin, cout, geom, [(gw, 0, cout)], N=N)
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / reps
+    print(f"{name}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
