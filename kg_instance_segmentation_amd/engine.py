@@ -72,6 +72,8 @@ class Engine:
         self.specs = {}
         self.tape = None
         self.param_grads = None
+        self.fusedT = {}
+        self.head_slots = []
 
     # ---- parameters ---------------------------------------------------------------------------
     def P(self, key):
@@ -306,40 +308,89 @@ class Engine:
             catv[lvl] = cur
         # heads (KGnet.py:300-316): three first 7x7 convs fused along Cout, three second convs
         maps = []
-        self.head_vars = []
+        self.head_slots = []
         for lvl in range(4):
             C = arch.HEAD_CH[lvl]
             Hh, Wh = dims[lvl]
             fused = [f"{h}_head_c{lvl}.0" for h, _ in arch.HEADS]
             hid, _, _ = self.conv(catv[lvl], self.spec(f"heads_c{lvl}.0", C, C, 7, 1, 3, fused=fused), N, Hh, Wh, True)
-            for k, (h, co) in enumerate(arch.HEADS):
-                hv = Var(hid.t[:, k * C:(k + 1) * C], C, relu=True, parent=hid, c0=k * C)
-                o = torch.empty(N, co, Hh, Wh, dtype=torch.float32, device=dev)
-                ov, _, _ = self.conv(hv, self.spec(f"{h}_head_c{lvl}.2", C, co, 7, 1, 3), N, Hh, Wh, False, y_f32=o)
-                ov.C = co
-                if h == "kp":
-                    ops.sigmoid_(o)
-                maps.append(o)
-                self.head_vars.append(ov)
+            outs = self.heads_second(hid, lvl, C, N, Hh, Wh)
+            maps.extend(outs)
         self.feats, self.dims, self.N, self.maps = feats, dims, N, maps
         return maps, feats, dims
 
+    HEAD_OFF = (0, 8, 24)      # channel offsets of the kp / short / mid gradients in the fused [rows, 64] dY buffer
+    HEAD_PAD = (8, 16, 40)
+
+    def heads_second(self, hid, lvl, C, N, H, W):
+        """The three second 7x7 head convs (KGnet.py:161-209, `.2` layers) on the slices of the fused hidden tensor
+        hid [rows, 3C].  Forward: three fp32-NCHW-exporting convs.  Backward: per-head weight/bias gradients, and ONE
+        fused input-gradient conv: the three map gradients are packed side by side into a [rows, 64] buffer
+        (8 | 16 | 40 channels) and multiplied by a block-structured transposed weight matrix [3C][49][64], which
+        runs on the fast LDS-halo kernel instead of three tiny-K gather convs."""
+        dev = hid.t.device
+        train = self.tape is not None
+        specs, outs = [], []
+        for k, (h, co) in enumerate(arch.HEADS):
+            s = self.spec(f"{h}_head_c{lvl}.2", C, co, 7, 1, 3)
+            self.prepare(s, need_T=False)
+            o = torch.empty(N, co, H, W, dtype=torch.float32, device=dev)
+            geom = (N * H * W, H, W, H, W, 7, 7, 1, 3)
+            ops.conv_auto(hid.t[:, k * C:(k + 1) * C], s.pw, co, geom, N, y_f32=o, bias=s.bias_cat)
+            if h == "kp":
+                ops.sigmoid_(o)
+            specs.append(s); outs.append(o)
+        slot = {"grad": None}
+        self.head_slots.append((slot, lvl, N, H, W))
+        if train:
+            key = f"heads_c{lvl}.2T"
+            ent = self.fusedT.get(key)
+            ws = [self.P(s.names[0] + ".weight") for s in specs]
+            ver = tuple(w._version for w in ws) + tuple(w.data_ptr() for w in ws)
+            if ent is None or ent[0] != ver or ent[1].buf.device != dev:
+                pwT = ent[1] if ent is not None and ent[1].buf.device == dev else PackedWeight(3 * C, 49, 64, dev)
+                for k, w in enumerate(ws):
+                    pwT.pack(w.detach(), row0=k * C, c0=self.HEAD_OFF[k], transposed=True)
+                self.fusedT[key] = (ver, pwT)
+            pwT = self.fusedT[key][1]
+            geom = (N * H * W, H, W, H, W, 7, 7, 1, 3)
+
+            def bwd():
+                g = slot["grad"]      # [rows, 64] packed map gradients (set by backward_dec)
+                if g is None:
+                    return
+                for k, ((h, co), s) in enumerate(zip(arch.HEADS, specs)):
+                    gk = g[:, self.HEAD_OFF[k]:self.HEAD_OFF[k] + self.HEAD_PAD[k]]
+                    w = self.P(s.names[0] + ".weight")
+                    gw = torch.empty_like(w)
+                    ops.conv_wgrad(hid.t[:, k * C:(k + 1) * C], gk, C, co, geom, [(gw, 0, co)], N=N)
+                    db = torch.empty(co, dtype=torch.float32, device=dev)
+                    ops.bias_grad(gk, co, db)
+                    self.param_grads[s.names[0] + ".weight"] = gw
+                    self.param_grads[s.names[0] + ".bias"] = db
+                dh = torch.empty(hid.rows, 3 * C, dtype=BF16, device=dev)
+                ops.conv_auto(g, pwT, 3 * C, geom, N, y=dh, mask=hid.t, transposed=True)
+                hid.add_grad(dh, masked=True)
+            self.tape.append(bwd)
+        return outs
+
     def backward_dec(self, map_grads, feat_grads):
         """map_grads: 12 fp32 NCHW (or None); feat_grads: 5 bf16 rows tensors (or None)."""
-        N = self.N
-        for i, (ov, g) in enumerate(zip(self.head_vars, map_grads)):
-            lvl, k = divmod(i, 3)
-            Hh, Wh = self.dims[lvl]
-            co = arch.HEADS[k][1]
-            cpad = ops.round_up(co, 8)
-            dev = self.maps[i].device
-            if g is None:   # no gradient reaches this map: its slice of the fused hidden gradient must still be defined
-                packed = torch.zeros(N * Hh * Wh, cpad, dtype=BF16, device=dev)
-            else:
-                packed = torch.empty(N * Hh * Wh, cpad, dtype=BF16, device=dev)
-                prob = self.maps[i] if k == 0 else None
-                ops.grad_pack(g.contiguous().float(), prob, packed, N, co, Hh, Wh, cpad)
-            ov.grad, ov.masked = packed, True
+        for (slot, lvl, N, Hh, Wh) in self.head_slots:
+            gs = map_grads[3 * lvl:3 * lvl + 3]
+            if all(g is None for g in gs):
+                continue
+            dev = self.maps[3 * lvl].device
+            packed = torch.empty(N * Hh * Wh, 64, dtype=BF16, device=dev)
+            for k, g in enumerate(gs):
+                co = arch.HEADS[k][1]
+                view = packed[:, self.HEAD_OFF[k]:self.HEAD_OFF[k] + self.HEAD_PAD[k]]
+                if g is None:
+                    view.zero_()
+                else:
+                    prob = self.maps[3 * lvl] if k == 0 else None
+                    ops.grad_pack(g.contiguous().float(), prob, view, N, co, Hh, Wh, self.HEAD_PAD[k])
+            slot["grad"] = packed
         for fv, g in zip(self.feats, feat_grads):
             if g is not None:
                 fv.add_grad(g, masked=False)

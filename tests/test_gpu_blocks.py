@@ -135,40 +135,30 @@ def test_heads_level(model, state_dict0):
     eng.tape, eng.param_grads = [], {}
     from kg_instance_segmentation_amd import arch, ops
     xv = Var(rows_of(x).to(DEV), C, relu=True, req=True)
-    fused = [f"{h}_head_c1.0" for h, _ in arch.HEADS]
-    hid, _, _ = eng.conv(xv, eng.spec("heads_c1.0", C, C, 7, 1, 3, fused=fused), N, H, W, True)
-    outs, ovs = [], []
-    for k, (h, co) in enumerate(arch.HEADS):
-        hv = Var(hid.t[:, k * C:(k + 1) * C], C, relu=True, parent=hid, c0=k * C)
-        o = torch.empty(N, co, H, W, dtype=torch.float32, device=DEV)
-        ov, _, _ = eng.conv(hv, eng.spec(f"{h}_head_c1.2", C, co, 7, 1, 3), N, H, W, False, y_f32=o)
-        outs.append(o); ovs.append((ov, co))
-    ops.sigmoid_(outs[0])
+    fused = [f"{h}_head_c0.0" for h, _ in arch.HEADS]
+    eng.head_slots = []
+    hid, _, _ = eng.conv(xv, eng.spec("heads_c0.0", C, C, 7, 1, 3, fused=fused), N, H, W, True)
+    outs = eng.heads_second(hid, 0, C, N, H, W)
     gm = [torch.randn(N, co, H, W, generator=g) * 1e-3 for _, co in arch.HEADS]
-    for k, ((ov, co), gk) in enumerate(zip(ovs, gm)):
-        cpad = ops.round_up(co, 8)
-        packed = torch.empty(N * H * W, cpad, dtype=BF16, device=DEV)
-        ops.grad_pack(gk.to(DEV), outs[0] if k == 0 else None, packed, N, co, H, W, cpad)
-        ov.grad, ov.masked = packed, True
-    for fn in reversed(eng.tape):
-        fn()
+    eng.maps, eng.feats = outs, []
+    pgrads = eng.backward_dec([t.to(DEV) for t in gm], [])
     gx = xv.take_grad()
     torch.cuda.synchronize()
-    sd = oracle_params(state_dict0, [f"{h}_head_c1." for h, _ in arch.HEADS])
+    sd = oracle_params(state_dict0, [f"{h}_head_c0." for h, _ in arch.HEADS])
     net = onet.Net(sd, training=True)
     xd = x.clone().requires_grad_(True)
     xin = F.relu(xd)
     ref = []
     for h, co in arch.HEADS:
-        y = net.conv(net.conv(xin, f"{h}_head_c1.0", 1, 3, True), f"{h}_head_c1.2", 1, 3)
+        y = net.conv(net.conv(xin, f"{h}_head_c0.0", 1, 3, True), f"{h}_head_c0.2", 1, 3)
         ref.append(torch.sigmoid(y) if h == "kp" else y)
     torch.autograd.backward(ref, gm)
     for (h, _), o, r in zip(arch.HEADS, outs, ref):
         check(f"head.{h}.out", o.cpu(), r)
     check("head.dx", nchw_of(gx, N, H, W), xd.grad)
-    for k, gg in eng.param_grads.items():
+    assert len(pgrads) == 12
+    for k, gg in pgrads.items():
         check(k, gg, sd[k].grad)
-    eng.tape = None
 
 
 def test_seg_branch_forward_backward(model, state_dict0):
