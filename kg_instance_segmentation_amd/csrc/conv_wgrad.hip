@@ -199,8 +199,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int tap = e / CH, ci = e - tap * CH;
         float s = 0.f;
         if (ci < nci) {
-            const long src = ((long)co * taps + tap) * Cin + ci0 + ci;
-            for (int k = 0; k < S; ++k) s += part[k * split_stride + src];
+            const float* src = part + ((long)co * taps + tap) * Cin + ci0 + ci;
+            int k = 0;
+            for (; k + 8 <= S; k += 8) {   // 8 independent loads in flight; the adds keep the fixed k order
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(long)(k + u) * split_stride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; k < S; ++k) s += src[(long)k * split_stride];
         }
         tile[tap * (CH + 1) + ci] = s;
     }

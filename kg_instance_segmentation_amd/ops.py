@@ -120,7 +120,7 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
         cit = 16 if KH == 7 else 64
         nblk = math.ceil(cin_lim / cit) * math.ceil(cout_lim / 64)
         tiles = N * math.ceil(H / 16) * math.ceil(W / 16)
-        S = max(1, min(math.ceil(768 / nblk), tiles))
+        S = max(1, min(512 // nblk if nblk <= 512 else 1, tiles))   # ~2 resident rounds of 1-block-per-CU workgroups
         while S > 1 and S * nelem * 4 > (768 << 20):
             S -= 1
         part = scratch_f32(S * nelem, x.device, "wgrad")
