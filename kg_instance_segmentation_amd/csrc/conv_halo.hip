@@ -46,18 +46,23 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // weight fragment rows (cout permutation: lane ends with 16 consecutive couts) and their swizzle keys
-    int a_row_off[4], a_key[4];
+    // Fragment byte offsets.  Everything lane-dependent is hoisted out of the tap loop: the inner loop was VALU-issue
+    // bound (3.5 VALU per MFMA) when these were recomputed per tap.
+    // weights: row permutation (lane ends with 16 consecutive couts), swizzle key from the row -> constant per (i, s)
+    int a_off[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int r = wc * 64 + (lm >> 2) * 16 + i * 4 + (lm & 3);
-        a_row_off[i] = r * 128;
-        a_key[i] = 2 * ((r >> 4) & 3) + ((r >> 1) & 1);
-    }
-    // pixel fragment base halo index (tap offset added per tap)
-    int p_base[4];
+        const int r = wc * 64 + (lm >> 2) * 16 + i * 4 + (lm & 3);
+        const int key = 2 * ((r >> 4) & 3) + ((r >> 1) & 1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p_base[j] = ((wp & 3) * 4 + j) * HWD + (wp >> 2) * 16 + lm;
+        for (int s = 0; s < 2; ++s) a_off[i][s] = r * 128 + (((4 * s + g) ^ key) * 16);
+    }
+    // pixels: halo byte offset of the lane's pixel for fragment j at tap (0,0); the swizzle key depends on the halo
+    // x coordinate only ( = xb + kx ), so it is computed once per tap and shared by the 4 rows and 2 k-steps.
+    const int xb = (wp >> 2) * 16 + lm;
+    int p_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p_off[j] = (((wp & 3) * 4 + j) * HWD + xb) * 128;
 
     // weight staging assignment
     int w_row[WPT], w_lds[WPT];
@@ -74,17 +79,15 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     auto load_a = [&](bf16x8 (&af)[4], int slot, int s) {
         const unsigned char* wb = wbuf + slot * WBUF_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            af[i] = *reinterpret_cast<const bf16x8*>(wb + a_row_off[i] + (((4 * s + g) ^ a_key[i]) * 16));
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wb + a_off[i][s]);
     };
     auto load_b = [&](bf16x8 (&bfr)[4], int t, int s) {
         const int ky = t / KS, kx = t - ky * KS;
-        const int tapoff = a.flip ? ((KS - 1 - ky) * HWD + (KS - 1 - kx)) : (ky * HWD + kx);
+        const int fy = a.flip ? KS - 1 - ky : ky, fx = a.flip ? KS - 1 - kx : kx;
+        const int key = ((xb + fx) >> 1) & 7;
+        const unsigned char* hb = halo + (fy * HWD + fx) * 128 + (((4 * s + g) ^ key) * 16);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = p_base[j] + tapoff;
-            bfr[j] = *reinterpret_cast<const bf16x8*>(halo + p * 128 + (((4 * s + g) ^ ((p >> 1) & 7)) * 16));
-        }
+        for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(hb + p_off[j]);
     };
     auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[4]) {
         __builtin_amdgcn_s_setprio(1);
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
             uint4 v = make_uint4(0, 0, 0, 0);
             if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                 v = *reinterpret_cast<const uint4*>(a.x + ((long)(n * a.H + iy) * a.W + ix) * a.ldx + cc * 64 + c * 8);
-            *reinterpret_cast<uint4*>(halo + p * 128 + ((c ^ ((p >> 1) & 7)) * 16)) = v;
+            *reinterpret_cast<uint4*>(halo + p * 128 + ((c ^ ((hx >> 1) & 7)) * 16)) = v;
         }
         auto wload = [&](int tap) {
 #pragma unroll
