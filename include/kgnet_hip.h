@@ -38,7 +38,8 @@ int kg_conv2d_igemm(const void* x, const void* w, const float* bias, void* y, fl
  * (the 7x7 head convolutions of KGnet.py:161-209 are 86 % of the network's FLOPs).  flip = 1: input gradient. */
 int kg_conv2d_halo(const void* x, const void* w, const float* bias, void* y, float* y_f32, const void* res,
                    const void* mask, int N, int H, int W, int cin_pad, int ldx, int Cout, int ldy, int ldres, int ldmask,
-                   int K, int KS, int flip, int relu, int f32_C, int wc, void* stream);
+                   int K, int KS, int flip, int relu, int f32_C, int wc, const int* tiletab, int ntiles, int total_rows,
+                   void* stream);   /* tiletab != NULL: ragged boxes, one {row0,(h<<16)|w,(oy0<<16)|ox0,0} entry per workgroup */
 /* fp32 OIHW parameter -> packed bf16 matrix rows (forward) or its transpose (data gradient). */
 int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad, int row0, int c0,
                    int transposed, void* stream);
@@ -48,7 +49,8 @@ int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const int* rowdes
                     int dil, int mode, int nsplit, long split_stride, void* stream);
 /* weight gradient of a dense stride-1 "same" 3x3 / 7x7 conv with dY tile + X halo resident in LDS (all taps per staging pass) */
 int kg_conv2d_wgrad_halo(const void* x, const void* dy, float* dwp, int N, int H, int W, int ldx, int lddy, int Cin, int Cout,
-                         int cin_lim, int cout_lim, int KS, int nsplit, long split_stride, void* stream);
+                         int cin_lim, int cout_lim, int KS, int nsplit, long split_stride, const int* tiletab16, int ntiles,
+                         void* stream);   /* tiletab16 != NULL: ragged boxes, one entry per 16x16 tile */
 int kg_wgrad_reduce(const float* part, float* grad_oihw, int Cout, int Cin, int KH, int KW, int nsplit, long split_stride,
                     int accumulate, void* stream);
 int kg_bias_grad(const void* dy, float* db, float* scratch, int scratch_floats, int M, int C, int ld, int accumulate,

@@ -18,11 +18,11 @@ _SIGS = {
     "kg_device_arch": [ctypes.c_char_p, c_int],
     "kg_tr_probe": [P, P],
     "kg_conv2d_igemm": [P, P, P, P, P, P, P, P] + [c_int] * 21 + [P],
-    "kg_conv2d_halo": [P, P, P, P, P, P, P] + [c_int] * 15 + [P],
+    "kg_conv2d_halo": [P, P, P, P, P, P, P] + [c_int] * 15 + [P, c_int, c_int, P],
     "kg_pack_weight": [P, P] + [c_int] * 9 + [P],
     "kg_set_wgrad_tr": [c_int],
     "kg_conv2d_wgrad": [P, P, P, P] + [c_int] * 18 + [c_long, P],
-    "kg_conv2d_wgrad_halo": [P, P, P] + [c_int] * 11 + [c_long, P],
+    "kg_conv2d_wgrad_halo": [P, P, P] + [c_int] * 11 + [c_long, P, c_int, P],
     "kg_wgrad_reduce": [P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, P],
     "kg_bias_grad": [P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "kg_img_pack": [P, P, c_int, c_int, c_int, c_int, P],

@@ -17,8 +17,10 @@
 struct HaloArgs {
     const bf16_t* x; const bf16_t* w; const float* bias;
     bf16_t* y; float* y_f32; const bf16_t* res; const bf16_t* mask;
+    const int4* tiletab;   // ragged mode: one entry per workgroup {row0, (h<<16)|w, (oy0<<16)|ox0, 0}; rows of a box are raster-contiguous
+    int ntiles;
     int N, H, W, tiles_x, tiles_y;
-    int cin_pad, ldx, Cout, ldy, ldres, ldmask, K, flip, relu, f32_C;
+    int cin_pad, ldx, Cout, ldy, ldres, ldmask, K, flip, relu, f32_C, f32_hw;
 };
 
 // WPX = pixel waves: 4 -> 16x16 output tile, 8 -> 16 rows x 32 columns (two 16x16 halves side by side)
@@ -34,10 +36,17 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave / WPX, wp = wave % WPX;
     const int lm = lane & 15, g = lane >> 4;
-    int bt = blockIdx.x;
-    const int tx = bt % a.tiles_x; bt /= a.tiles_x;
-    const int ty = bt % a.tiles_y; const int n = bt / a.tiles_y;
-    const int oy0 = ty * 16, ox0 = tx * TW;
+    int oy0, ox0, Hd, Wd;
+    long rowbase;   // row index of pixel (0,0) of this tile's image / box
+    if (a.tiletab) {
+        const int4 tt = a.tiletab[blockIdx.x];
+        rowbase = tt.x; Hd = tt.y >> 16; Wd = tt.y & 0xffff; oy0 = tt.z >> 16; ox0 = tt.z & 0xffff;
+    } else {
+        int bt = blockIdx.x;
+        const int tx = bt % a.tiles_x; bt /= a.tiles_x;
+        const int ty = bt % a.tiles_y; const int n = bt / a.tiles_y;
+        oy0 = ty * 16; ox0 = tx * TW; Hd = a.H; Wd = a.W; rowbase = (long)n * a.H * a.W;
+    }
     const int c0 = blockIdx.y * TC;
 
     f32x4 acc[4][4];
@@ -108,8 +117,8 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
             const int hy = p / HWD, hx = p - hy * HWD;
             const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                v = *reinterpret_cast<const uint4*>(a.x + ((long)(n * a.H + iy) * a.W + ix) * a.ldx + cc * 64 + c * 8);
+            if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd)
+                v = *reinterpret_cast<const uint4*>(a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + cc * 64 + c * 8);
             *reinterpret_cast<uint4*>(halo + p * 128 + ((c ^ ((hx >> 1) & 7)) * 16)) = v;
         }
         auto wload = [&](int tap) {
@@ -156,8 +165,8 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int oy = oy0 + (wp & 3) * 4 + j;
-        if (oy >= a.H || ox >= a.W) continue;
-        const long m = (long)(n * a.H + oy) * a.W + ox;
+        if (oy >= Hd || ox >= Wd) continue;
+        const long m = rowbase + (long)oy * Wd + ox;
         float v[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -201,10 +210,12 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
             }
         }
         if (a.y_f32) {
-            const long hw = (long)a.H * a.W, pix = (long)oy * a.W + ox;
+            // dense: NCHW [N][f32_C][H*W]; ragged: [f32_C][total rows] (f32_hw = total rows, image index 0)
+            const long hw = a.tiletab ? (long)a.f32_hw : (long)a.H * a.W;
+            const long nimg = a.tiletab ? 0 : rowbase / hw, pix = a.tiletab ? m : (long)oy * Wd + ox;
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                if (cb + e < a.Cout) a.y_f32[((long)n * a.f32_C + cb + e) * hw + pix] = v[e];
+                if (cb + e < a.Cout) a.y_f32[(nimg * a.f32_C + cb + e) * hw + pix] = v[e];
         }
     }
 }
@@ -219,7 +230,7 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
         KG_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<KS, WC, WPX>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
-    dim3 grid(a.N * a.tiles_x * a.tiles_y, kg_cdiv(a.Cout, TC));
+    dim3 grid(a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y, kg_cdiv(a.Cout, TC));
     hipLaunchKernelGGL((conv_halo_kernel<KS, WC, WPX>), grid, dim3(WC * WPX * 64), smem, st, a);
     KG_CHECK_LAUNCH("conv_halo");
     return KG_OK;
@@ -227,21 +238,24 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
 
 // Stride-1 "same" convolution, KS in {3,7}; cin_pad % 64 == 0; weight rows padded to a multiple of 64*wc.
 // wc: couts per workgroup / 64; 0 = default (1: 16x32-pixel tile, 8 waves); 2, 3: 16x16-pixel tile with 128 / 192 couts.
+// Ragged mode (tiletab != null): the "images" are boxes of a ragged pixel list; the caller supplies one tile entry per
+// workgroup (tile = 16 rows x 32 columns for wc == 1, 16 x 16 otherwise) and total_rows for the fp32 export.
 extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, void* y, float* y_f32, const void* res,
                               const void* mask, int N, int H, int W, int cin_pad, int ldx, int Cout, int ldy, int ldres,
-                              int ldmask, int K, int KS, int flip, int relu, int f32_C, int wc, void* stream) {
+                              int ldmask, int K, int KS, int flip, int relu, int f32_C, int wc, const int* tiletab,
+                              int ntiles, int total_rows, void* stream) {
     HaloArgs a;
     memset(&a, 0, sizeof(a));
     KG_CHECK_ARG(x && w && (y || y_f32), "kg_conv2d_halo: null pointer");
     KG_CHECK_ARG(KS == 3 || KS == 7, "kg_conv2d_halo: kernel size must be 3 or 7");
     KG_CHECK_ARG(cin_pad % 64 == 0 && ldx % 8 == 0, "kg_conv2d_halo: cin_pad must be a multiple of 64 (got %d)", cin_pad);
     KG_CHECK_ARG(K >= KS * KS * cin_pad, "kg_conv2d_halo: K too small");
-    KG_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cout > 0, "kg_conv2d_halo: empty problem");
+    KG_CHECK_ARG((tiletab && ntiles > 0 && Cout > 0) || (N > 0 && H > 0 && W > 0 && Cout > 0), "kg_conv2d_halo: empty problem");
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.y_f32 = y_f32;
     a.res = (const bf16_t*)res; a.mask = (const bf16_t*)mask;
     a.N = N; a.H = H; a.W = W; a.tiles_x = kg_cdiv(W, 16); a.tiles_y = kg_cdiv(H, 16);
     a.cin_pad = cin_pad; a.ldx = ldx; a.Cout = Cout; a.ldy = ldy; a.ldres = ldres; a.ldmask = ldmask; a.K = K;
-    a.flip = flip; a.relu = relu; a.f32_C = f32_C;
+    a.flip = flip; a.relu = relu; a.f32_C = f32_C; a.tiletab = (const int4*)tiletab; a.ntiles = ntiles; a.f32_hw = total_rows;
     if (wc == 0) wc = 1;   // measured on MI355X: the 16x32-pixel x 64-cout tile (8 waves) beats the 16x16 x 128/192-cout tiles at every KGnet shape
     hipStream_t st = (hipStream_t)stream;
     if (KS == 7) {

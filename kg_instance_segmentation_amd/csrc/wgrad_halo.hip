@@ -15,6 +15,8 @@
 
 struct WgHaloArgs {
     const bf16_t* x; const bf16_t* dy; float* dwp;
+    const int4* tiletab;   // ragged mode: {row0, (h<<16)|w, (oy0<<16)|ox0, 0} per 16x16 tile
+    int ntiles;
     int N, H, W, tiles_x, tiles_y, ldx, lddy;
     int Cin, Cout, cin_lim, cout_lim, nsplit;
     long split_stride;
@@ -46,20 +48,26 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
         for (int c = 0; c < 4; ++c) acc[q][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 dyr[DYPT], xr[XPT];
-    const int tiles_total = a.N * a.tiles_x * a.tiles_y;
+    const int tiles_total = a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y;
 
     auto load_tile = [&](int t) {
-        int bt = t;
-        const int tx = bt % a.tiles_x; bt /= a.tiles_x;
-        const int ty = bt % a.tiles_y; const int n = bt / a.tiles_y;
-        const int oy0 = ty * 16, ox0 = tx * 16;
+        int oy0, ox0, Hd, Wd; long rowbase;
+        if (a.tiletab) {
+            const int4 tt = a.tiletab[t];
+            rowbase = tt.x; Hd = tt.y >> 16; Wd = tt.y & 0xffff; oy0 = tt.z >> 16; ox0 = tt.z & 0xffff;
+        } else {
+            int bt = t;
+            const int tx = bt % a.tiles_x; bt /= a.tiles_x;
+            const int ty = bt % a.tiles_y; const int n = bt / a.tiles_y;
+            oy0 = ty * 16; ox0 = tx * 16; Hd = a.H; Wd = a.W; rowbase = (long)n * a.H * a.W;
+        }
 #pragma unroll
         for (int k = 0; k < DYPT; ++k) {
             const int e = tid + k * 512, r = e >> 3, c8 = e & 7;
             const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (oy < a.H && ox < a.W && co0 + c8 * 8 < a.cout_lim)
-                v = *reinterpret_cast<const uint4*>(a.dy + ((long)(n * a.H + oy) * a.W + ox) * a.lddy + co0 + c8 * 8);
+            if (oy < Hd && ox < Wd && co0 + c8 * 8 < a.cout_lim)
+                v = *reinterpret_cast<const uint4*>(a.dy + (rowbase + (long)oy * Wd + ox) * a.lddy + co0 + c8 * 8);
             dyr[k] = v;
         }
 #pragma unroll
@@ -70,8 +78,8 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
                 const int p = e / (2 * CIF), c = e - p * (2 * CIF);
                 const int hy = p / HWD, hx = p - hy * HWD;
                 const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
-                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && ci0 + c * 8 < a.cin_lim)
-                    v = *reinterpret_cast<const uint4*>(a.x + ((long)(n * a.H + iy) * a.W + ix) * a.ldx + ci0 + c * 8);
+                if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd && ci0 + c * 8 < a.cin_lim)
+                    v = *reinterpret_cast<const uint4*>(a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + ci0 + c * 8);
             }
             xr[k] = v;
         }
@@ -184,16 +192,17 @@ static int launch_wg(const WgHaloArgs& a, hipStream_t st) {
 // dwp receives nsplit partial tensors [Cout][KS*KS][Cin] (fp32), split_stride elements apart.
 extern "C" int kg_conv2d_wgrad_halo(const void* x, const void* dy, float* dwp, int N, int H, int W, int ldx, int lddy,
                                     int Cin, int Cout, int cin_lim, int cout_lim, int KS, int nsplit, long split_stride,
-                                    void* stream) {
+                                    const int* tiletab, int ntiles, void* stream) {
     WgHaloArgs a;
     memset(&a, 0, sizeof(a));
     KG_CHECK_ARG(x && dy && dwp, "kg_conv2d_wgrad_halo: null pointer");
     KG_CHECK_ARG(KS == 3 || KS == 7, "kg_conv2d_wgrad_halo: kernel size must be 3 or 7");
     KG_CHECK_ARG(ldx % 8 == 0 && lddy % 8 == 0 && cin_lim % 8 == 0 && cout_lim % 8 == 0, "kg_conv2d_wgrad_halo: ld/lim must be multiples of 8");
-    KG_CHECK_ARG(nsplit >= 1 && N > 0 && H > 0 && W > 0, "kg_conv2d_wgrad_halo: bad sizes");
+    KG_CHECK_ARG(nsplit >= 1 && ((tiletab && ntiles > 0) || (N > 0 && H > 0 && W > 0)), "kg_conv2d_wgrad_halo: bad sizes");
     a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dwp = dwp; a.N = N; a.H = H; a.W = W;
     a.tiles_x = kg_cdiv(W, 16); a.tiles_y = kg_cdiv(H, 16); a.ldx = ldx; a.lddy = lddy; a.Cin = Cin; a.Cout = Cout;
     a.cin_lim = cin_lim; a.cout_lim = cout_lim; a.nsplit = nsplit; a.split_stride = split_stride;
+    a.tiletab = (const int4*)tiletab; a.ntiles = ntiles;
     hipStream_t st = (hipStream_t)stream;
     if (KS == 7) return launch_wg<7, 1>(a, st);
     return launch_wg<3, 4>(a, st);

@@ -25,6 +25,16 @@ def scratch_f32(nfloats, dev, tag="default"):
     return t
 
 
+def h2d(arr, dev):
+    """numpy -> device through a pinned staging tensor, truly asynchronous.  (A pageable-memory copy blocks the host
+    until all earlier work on the stream has drained, which serialises host glue and GPU kernels.)"""
+    import numpy as np
+    arr = np.ascontiguousarray(arr)
+    st = torch.empty(arr.shape, dtype=torch.from_numpy(arr[:0] if arr.ndim else arr).dtype, pin_memory=True)
+    st.numpy()[...] = arr
+    return st.to(dev, non_blocking=True)
+
+
 def _rows(t):
     assert t.dim() == 2 and t.dtype == BF16 and (t.shape[1] == 1 or t.stride(1) == 1), (t.shape, t.stride(), t.dtype)
     return t
@@ -75,15 +85,18 @@ USE_HALO = True
 HALO_WC = int(__import__("os").environ.get("KG_HALO_WC", "0"))   # tuning override (0 = library default)
 
 
-def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, flip=False, wc=0):
-    """Stride-1 "same" KSxKS conv (or its input gradient when flip) with the input halo resident in LDS."""
+def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, flip=False, wc=0,
+              tiletab=None, total_rows=0):
+    """Stride-1 "same" KSxKS conv (or its input gradient when flip) with the input halo resident in LDS.
+    tiletab (int32 [ntiles,4] device tensor): ragged boxes instead of N images of HxW."""
     wc = wc or HALO_WC
     f32_C = 0
     if y_f32 is not None:
         f32_C = y_f32.shape[1] if y_f32.dim() == 4 else 1
     _lib.call("kg_conv2d_halo", ptr(_rows(x)), ptr(pw.buf), ptr(bias), ptr(y), ptr(y_f32), ptr(res), ptr(mask), N, H, W,
               pw.cin_pad, ld(x), cout, ld(y) if y is not None else 0, ld(res) if res is not None else 0,
-              ld(mask) if mask is not None else 0, pw.K, KS, 1 if flip else 0, 1 if relu else 0, f32_C, wc, stream_ptr())
+              ld(mask) if mask is not None else 0, pw.K, KS, 1 if flip else 0, 1 if relu else 0, f32_C, wc, ptr(tiletab),
+              tiletab.shape[0] if tiletab is not None else 0, total_rows, stream_ptr())
 
 
 def conv_auto(x, pw, cout, geom, N, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, transposed=False, tile=0):
@@ -107,7 +120,7 @@ def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):
     return s
 
 
-def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=False, N=None):
+def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=False, N=None, tiletab16=None):
     """grads: list of (fp32 OIHW grad tensor, cout_offset, cout_count) sharing x (fused heads) or one entry.
     Dense stride-1 "same" 3x3/7x7 convs (N given) use the LDS-halo kernel, everything else the gather kernel."""
     M, H, W, OH, OW, KH, KW, stride, pad = geom
@@ -115,16 +128,17 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
     cin_lim = min(round_up(cin, 8), x.shape[1])
     cout_lim = min(round_up(cout, 8), dy.shape[1])
     nelem = cout * KH * KW * cin
-    halo = USE_HALO and mode == 0 and N is not None and stride == 1 and KH == KW and KH in (3, 7) and pad == KH // 2
+    halo = (USE_HALO and stride == 1 and KH == KW and KH in (3, 7) and pad == KH // 2
+            and ((mode == 0 and N is not None) or (mode == 2 and tiletab16 is not None)))
     if halo:
         cit = 16 if KH == 7 else 64
         nblk = math.ceil(cin_lim / cit) * math.ceil(cout_lim / 64)
-        tiles = N * math.ceil(H / 16) * math.ceil(W / 16)
+        tiles = tiletab16.shape[0] if tiletab16 is not None else N * math.ceil(H / 16) * math.ceil(W / 16)
         S = max(1, min(512 // nblk if nblk <= 512 else 1, tiles))   # ~2 resident rounds of 1-block-per-CU workgroups
         while S > 1 and S * nelem * 4 > (768 << 20):
             S -= 1
         part = scratch_f32(S * nelem, x.device, "wgrad")
-        wgrad_halo(x, dy, part, N, H, W, cin, cout, cin_lim, cout_lim, KH, S, nelem)
+        wgrad_halo(x, dy, part, N or 0, H, W, cin, cout, cin_lim, cout_lim, KH, S, nelem, tiletab16)
     else:
         S = wgrad_splits(M, cin_lim, cout_lim, KH * KW, nelem)
         part = scratch_f32(S * nelem, x.device, "wgrad")
@@ -136,9 +150,9 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
     return "halo" if halo else "gather"
 
 
-def wgrad_halo(x, dy, part, N, H, W, cin, cout, cin_lim, cout_lim, KS, S, nelem):
+def wgrad_halo(x, dy, part, N, H, W, cin, cout, cin_lim, cout_lim, KS, S, nelem, tiletab16=None):
     _lib.call("kg_conv2d_wgrad_halo", ptr(x), ptr(dy), ptr(part), N, H, W, ld(x), ld(dy), cin, cout, cin_lim, cout_lim, KS, S,
-              c_long(nelem), stream_ptr())
+              c_long(nelem), ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, stream_ptr())
 
 
 def ctypes_offset(t, elem_off):

@@ -141,14 +141,41 @@ class SegBranch:
             (hi, wi), (ho, wo) = p.hw[l + 1], p.hw[l]
             bil.append(np.stack([p.row0[l + 1][:nc].astype(np.int32), hi[:nc], wi[:nc], p.row0[l][:nc].astype(np.int32),
                                  ho[:nc], wo[:nc]], 1).astype(np.int32))
-        blob = np.concatenate([t.ravel() for t in tabs] + [b.ravel() for b in bil]).astype(np.int32)
-        dblob = torch.from_numpy(blob).to(dev, non_blocking=True)
+        # tile tables for the LDS-halo kernels: one {row0, (h<<16)|w, (oy0<<16)|ox0, 0} entry per tile of every box
+        def tile_table(l, th, tw):
+            h, w = p.hw[l]
+            r0 = p.row0[l][:-1]
+            ny, nx = (h + th - 1) // th, (w + tw - 1) // tw
+            cnt = ny * nx
+            if cnt.sum() == 0:
+                return np.zeros((0, 4), np.int32)
+            b = np.repeat(np.arange(len(h)), cnt)
+            k = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+            ty, tx = k // nx[b], k % nx[b]
+            return np.stack([r0[b].astype(np.int64), (h[b].astype(np.int64) << 16) | w[b], ((ty * th).astype(np.int64) << 16) | (tx * tw),
+                             np.zeros(len(b), np.int64)], 1).astype(np.int32)
+        t32 = [tile_table(l, 16, 32) for l in range(5)]
+        t16 = [tile_table(l, 16, 16) for l in range(5)]
+
+        def cum(l, th, tw):
+            h, w = p.hw[l]
+            c = np.zeros(len(h) + 1, np.int64)
+            np.cumsum(((h + th - 1) // th) * ((w + tw - 1) // tw), out=c[1:])
+            return c
+        p.t32_cum = [cum(l, 16, 32) for l in range(5)]; p.t16_cum = [cum(l, 16, 16) for l in range(5)]
+        blob = np.concatenate([t.ravel() for t in tabs] + [b.ravel() for b in bil] + [t.ravel() for t in t32] + [t.ravel() for t in t16]).astype(np.int32)
+        dblob = ops.h2d(blob, dev)
         off = 0
         p.tab_d, p.bil_d = [], []
         for t in tabs:
             p.tab_d.append(dblob[off:off + t.size]); off += t.size
         for b in bil:
             p.bil_d.append(dblob[off:off + b.size]); off += b.size
+        p.t32_d, p.t16_d = [], []
+        for t in t32:
+            p.t32_d.append(dblob[off:off + t.size].view(-1, 4)); off += t.size
+        for t in t16:
+            p.t16_d.append(dblob[off:off + t.size].view(-1, 4)); off += t.size
         p.rows = [int(p.row0[l][-1]) for l in range(5)]
         p.rowdesc, p.row2box, p.srcrow = [], [], []
         for l in range(5):
@@ -175,9 +202,25 @@ class SegBranch:
             _lib.call("kg_rows_gather", ptr(frows), ops.ld(frows), _lib.c_void_p(srcrow.data_ptr() + 4 * row_off),
                       ptr(dst), ops.ld(dst), c_long(nrows), C, stream_ptr())
 
-    def rconv(self, x, pw, cout, rowdesc, M, k, y=None, y_f32=None, bias=None, relu=False, mask=None, mode=2):
+    def rconv(self, x, pw, cout, rowdesc, M, k, y=None, y_f32=None, bias=None, relu=False, mask=None, mode=2, tiles=None):
+        """Ragged conv (mode 2) or its input gradient (mode 3).  3x3 convs over 64-channel-aligned inputs run on the
+        LDS-halo kernel with one (box, 16x32 tile) entry per workgroup; the rest on the gather implicit GEMM.
+        `tiles` = (tile table of the first `M` rows' boxes); boxes are a prefix, so a prefix of the table is used."""
+        if (ops.USE_HALO and k == 3 and tiles is not None and tiles.shape[0] > 0 and pw.cin_pad % 64 == 0 and x.shape[1] >= pw.cin_pad
+                and M >= 0.35 * tiles.shape[0] * 512):     # tiles mostly full: tiny deep-level crops stay on the gather kernel
+            ops.conv_halo(x, pw, cout, 0, 0, 0, 3, y=y, y_f32=y_f32, bias=bias, relu=relu, mask=mask, flip=(mode == 3),
+                          tiletab=tiles, total_rows=M)
+            return
         geom = (M, 0, 0, M, 1, k, k, 1, (k - 1) // 2)
         ops.conv_igemm(x, pw, cout, geom, y=y, y_f32=y_f32, bias=bias, relu=relu, mask=mask, mode=mode, rowdesc=rowdesc)
+
+    @staticmethod
+    def T32(plan, l, nboxes):
+        return plan.t32_d[l][:int(plan.t32_cum[l][nboxes])]
+
+    @staticmethod
+    def T16(plan, l, nboxes):
+        return plan.t16_d[l][:int(plan.t16_cum[l][nboxes])]
 
     def run_forward(self, plan, feats, record):
         dev = feats[0].device
@@ -201,7 +244,8 @@ class SegBranch:
                 ops.bilinear_fwd(pre[l + 1], uin, 0, 0, 0, 0, 0, CH[l + 1], boxdesc=plan.bil_d[l], row2box=plan.row2box[l])
                 cat = torch.empty(rowsC, ccat, dtype=BF16, device=dev)
                 pw, _, b = self.packw(f"skip_combine.{l}.up.0", record)
-                self.rconv(uin, pw, cout, plan.rowdesc[l], rowsC, 3, y=cat[:, CH[l]:CH[l] + cout], bias=b, relu=True)
+                self.rconv(uin, pw, cout, plan.rowdesc[l], rowsC, 3, y=cat[:, CH[l]:CH[l] + cout], bias=b, relu=True,
+                           tiles=self.T32(plan, l, nc))
                 self.gather(fr[l], plan.srcrow[l], cat[:, 0:CH[l]], rowsC, CH[l])
                 pw, _, b = self.packw(f"skip_combine.{l}.cat_conv.0", record)
                 self.rconv(cat, pw, cout, plan.rowdesc[l], rowsC, 1, y=pre[l][:rowsC], bias=b, relu=True)
@@ -210,27 +254,28 @@ class SegBranch:
         rows0 = plan.rows[0]
         hid = torch.empty(rows0, 64, dtype=BF16, device=dev)
         pw, _, b = self.packw("seg_head.0", record)
-        self.rconv(pre[0], pw, 64, plan.rowdesc[0], rows0, 3, y=hid, bias=b, relu=True)
+        self.rconv(pre[0], pw, 64, plan.rowdesc[0], rows0, 3, y=hid, bias=b, relu=True, tiles=self.T32(plan, 0, plan.nb[0]))
         flat = torch.empty(rows0, dtype=torch.float32, device=dev)
         pw, _, b = self.packw("seg_head.2", record)
-        self.rconv(hid, pw, 1, plan.rowdesc[0], rows0, 3, y_f32=flat, bias=b)
+        self.rconv(hid, pw, 1, plan.rowdesc[0], rows0, 3, y_f32=flat, bias=b, tiles=self.T32(plan, 0, plan.nb[0]))
         ops.sigmoid_(flat)
         saved = (pre, cats, uins, hid, flat, top) if record else None
         return flat, saved
 
-    def conv_bwd(self, key, x, g, rowdesc, M, k, pgrads, dx=None, mask=None):
+    def conv_bwd(self, key, x, g, rowdesc, M, k, pgrads, dx=None, mask=None, t32=None, t16=None):
         """wgrad + bias grad (+ dgrad into dx) of one ragged conv; g must already be pre-activation."""
         w = self.P(key + ".weight")
         cout, cin = w.shape[0], w.shape[1]
         geom = (M, 0, 0, M, 1, k, k, 1, (k - 1) // 2)
         gw = torch.empty_like(w)
-        ops.conv_wgrad(x, g, cin, cout, geom, [(gw, 0, cout)], mode=2, rowdesc=rowdesc)
+        use16 = t16 if (k == 3 and t16 is not None and M >= 0.35 * t16.shape[0] * 256) else None
+        ops.conv_wgrad(x, g, cin, cout, geom, [(gw, 0, cout)], mode=2, rowdesc=rowdesc, tiletab16=use16)
         db = torch.empty(cout, dtype=torch.float32, device=w.device)
         ops.bias_grad(g, cout, db)
         pgrads[key + ".weight"], pgrads[key + ".bias"] = gw, db
         if dx is not None:
             _, pwT, _ = self.packw(key, True)
-            self.rconv(g, pwT, cin, rowdesc, M, k, y=dx, mask=mask, mode=3)
+            self.rconv(g, pwT, cin, rowdesc, M, k, y=dx, mask=mask, mode=3, tiles=t32)
 
     def run_backward(self, plan, saved, gflat, feat_shapes):
         pre, cats, uins, hid, flat, top = saved
@@ -241,9 +286,10 @@ class SegBranch:
         gz = torch.empty(rows0, 8, dtype=BF16, device=dev)
         ops.grad_pack(gflat, flat, gz, 1, 1, rows0, 1, 8)
         dhid = torch.empty(rows0, 64, dtype=BF16, device=dev)
-        self.conv_bwd("seg_head.2", hid, gz, plan.rowdesc[0], rows0, 3, pgrads, dx=dhid, mask=hid)
+        t32_0, t16_0 = self.T32(plan, 0, plan.nb[0]), self.T16(plan, 0, plan.nb[0])
+        self.conv_bwd("seg_head.2", hid, gz, plan.rowdesc[0], rows0, 3, pgrads, dx=dhid, mask=hid, t32=t32_0, t16=t16_0)
         dpre = torch.empty(rows0, 64, dtype=BF16, device=dev)
-        self.conv_bwd("seg_head.0", pre[0], dhid, plan.rowdesc[0], rows0, 3, pgrads, dx=dpre, mask=pre[0])
+        self.conv_bwd("seg_head.0", pre[0], dhid, plan.rowdesc[0], rows0, 3, pgrads, dx=dpre, mask=pre[0], t32=t32_0, t16=t16_0)
         acc = []
         for l in range(5):
             n, c, h, w = feat_shapes[l]
@@ -267,7 +313,8 @@ class SegBranch:
                 self.conv_bwd(f"skip_combine.{l}.cat_conv.0", cat, dpre[:rowsC], plan.rowdesc[l], rowsC, 1, pgrads, dx=dcat, mask=cat)
                 scatter(dcat[:, 0:CH[l]], l, rowsC)
                 duin = torch.empty(rowsC, CH[l + 1], dtype=BF16, device=dev)
-                self.conv_bwd(f"skip_combine.{l}.up.0", uin, dcat[:, CH[l]:CH[l] + cout], plan.rowdesc[l], rowsC, 3, pgrads, dx=duin)
+                self.conv_bwd(f"skip_combine.{l}.up.0", uin, dcat[:, CH[l]:CH[l] + cout], plan.rowdesc[l], rowsC, 3, pgrads, dx=duin,
+                              t32=self.T32(plan, l, nc), t16=self.T16(plan, l, nc))
                 nxt = torch.empty(plan.rows[l + 1], CH[l + 1], dtype=BF16, device=dev)
                 ops.bilinear_bwd(duin, nxt, 0, 0, 0, 0, 0, CH[l + 1], boxdesc=plan.bil_d[l], row2box=plan.row2box[l + 1])
                 ops.add_rows(nxt, None, nxt, CH[l + 1], mask=pre[l + 1])

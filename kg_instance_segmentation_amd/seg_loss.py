@@ -126,7 +126,7 @@ class SEG_loss(nn.Module):
         ptab = np.array([[o, r[2], r[3], r[4]] for o, r in zip(offs, recs)], np.int32)
         pair_t = np.zeros(len(pairs), dtype=[("off", np.int32), ("w", np.float32)])
         pair_t["off"] = [p[0] for p in pairs]; pair_t["w"] = [p[1] for p in pairs]
-        tgt = torch.from_numpy(np.concatenate(tgts)).to(dev)
-        ptab_d = torch.from_numpy(ptab).to(dev)
-        pairs_d = torch.from_numpy(pair_t.view(np.uint8)).to(dev)
+        tgt = ops.h2d(np.concatenate(tgts), dev)
+        ptab_d = ops.h2d(ptab, dev)
+        pairs_d = ops.h2d(pair_t.view(np.uint8), dev)
         return _SegLossFn.apply(flat, tgt, ptab_d, pairs_d, len(recs))

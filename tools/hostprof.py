@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Host-vs-GPU time per phase of the train step (tuning aid): for each phase, host enqueue time and time until the GPU
+drains (a synchronize after every phase, so phases do not overlap here)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from kg_instance_segmentation_amd import KGnet
+from kg_instance_segmentation_amd.loss import DetectionLossAll
+from kg_instance_segmentation_amd.seg_loss import SEG_loss
+
+dev = torch.device("cuda", 0)
+model = KGnet.resnet50(pretrained=False).to(dev).train()
+opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+ldec, lseg = DetectionLossAll(5), SEG_loss(512, 512)
+x, gt, gt_masks, gt_boxes = bench.make_batch(8, 512, 300, 100, dev)
+acc = {}
+
+def phase(name, fn):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    r = fn(); t1 = time.perf_counter()
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    a = acc.setdefault(name, [0.0, 0.0]); a[0] += t1 - t0; a[1] += t2 - t0
+    return r
+
+for it in range(4):
+    if it == 1:
+        acc.clear()
+    phase("zero_grad", lambda: opt.zero_grad())
+    d = phase("forward_dec", lambda: model.forward_dec(x))
+    plan = phase("seg.make_plan", lambda: model._seg.make_plan(d[4], gt_boxes))
+    pred = phase("forward_seg", lambda: model.forward_seg(d[4], gt_boxes))
+    l1 = phase("loss_dec", lambda: sum(ldec(p, g) for p, g in zip(d[:4], gt)))
+    l2 = phase("loss_seg", lambda: lseg(pred, gt_masks, gt_boxes))
+    loss = l1 + l2
+    phase("backward", lambda: loss.backward())
+    phase("opt.step", lambda: opt.step())
+    phase("loss.item", lambda: loss.item())
+n = 3
+print(f"{'phase':16s} {'host ms':>9s} {'host+gpu ms':>12s}")
+th = tg = 0
+for k, (h, g) in acc.items():
+    print(f"{k:16s} {1e3*h/n:9.2f} {1e3*g/n:12.2f}"); th += h; tg += g
+print(f"{'sum':16s} {1e3*th/n:9.2f} {1e3*tg/n:12.2f}   (forward_seg includes its own make_plan)")
