@@ -86,8 +86,17 @@ class KernelTimer:
             s.record(); r = orig_halo(x, pw, cout, N, H, W, KS, *a, **k); e.record()
             timer.rec.append((f"conv_halo<{KS},{wc}>", 2.0 * N * H * W * cout * KS * KS * pw.cin_pad, s, e, f"N={N} H={H} cout={cout} cinp={pw.cin_pad}"))
             return r
+        orig_1x1 = ops.conv1x1
+
+        def c1x1(x, pw, cout, y, *a, **k):
+            if not timer.on:
+                return orig_1x1(x, pw, cout, y, *a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); r = orig_1x1(x, pw, cout, y, *a, **k); e.record()
+            timer.rec.append(("conv1x1", 2.0 * x.shape[0] * cout * pw.cin_pad, s, e, f"M={x.shape[0]} cout={cout} K={pw.cin_pad}"))
+            return r
         # engine/seg call through `ops.<fn>` (and conv_auto resolves these names at call time)
-        ops.conv_igemm, ops.conv_wgrad, ops.conv_halo = conv, wgrad, halo
+        ops.conv_igemm, ops.conv_wgrad, ops.conv_halo, ops.conv1x1 = conv, wgrad, halo, c1x1
 
     def dump(self, path, steps):
         rows = {}

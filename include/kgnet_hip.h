@@ -40,6 +40,10 @@ int kg_conv2d_halo(const void* x, const void* w, const float* bias, void* y, flo
                    const void* mask, int N, int H, int W, int cin_pad, int ldx, int Cout, int ldy, int ldres, int ldmask,
                    int K, int KS, int flip, int relu, int f32_C, int wc, const int* tiletab, int ntiles, int total_rows,
                    void* stream);   /* tiletab != NULL: ragged boxes, one {row0,(h<<16)|w,(oy0<<16)|ox0,0} entry per workgroup */
+/* 1x1 stride-1 convolution / its input gradient as a streaming GEMM over rows (dense or ragged): weight slab resident in
+ * LDS, pixel fragments straight from global memory, persistent workgroups (KGnet.py:64-99,101-111,155-158) */
+int kg_conv1x1(const void* x, const void* w, const float* bias, void* y, const void* res, const void* mask, long M, int K,
+               int wK, int ldx, int Cout, int ldy, int ldres, int ldmask, int relu, void* stream);
 /* fp32 OIHW parameter -> packed bf16 matrix rows (forward) or its transpose (data gradient). */
 int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad, int row0, int c0,
                    int transposed, void* stream);

@@ -19,6 +19,7 @@ _SIGS = {
     "kg_tr_probe": [P, P],
     "kg_conv2d_igemm": [P, P, P, P, P, P, P, P] + [c_int] * 21 + [P],
     "kg_conv2d_halo": [P, P, P, P, P, P, P] + [c_int] * 15 + [P, c_int, c_int, P],
+    "kg_conv1x1": [P, P, P, P, P, P, c_long] + [c_int] * 8 + [P],
     "kg_pack_weight": [P, P] + [c_int] * 9 + [P],
     "kg_set_wgrad_tr": [c_int],
     "kg_conv2d_wgrad": [P, P, P, P] + [c_int] * 18 + [c_long, P],

@@ -99,6 +99,21 @@ def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None,
               tiletab.shape[0] if tiletab is not None else 0, total_rows, stream_ptr())
 
 
+USE_1X1 = True
+
+
+def conv1x1(x, pw, cout, y, bias=None, res=None, mask=None, relu=False):
+    """1x1 stride-1 conv / input gradient as a streaming GEMM over the rows of x (kg_conv1x1)."""
+    _lib.call("kg_conv1x1", ptr(_rows(x)), ptr(pw.buf), ptr(bias), ptr(_rows(y)), ptr(res), ptr(mask), c_long(x.shape[0]),
+              pw.cin_pad, pw.K, ld(x), cout, ld(y), ld(res) if res is not None else 0, ld(mask) if mask is not None else 0,
+              1 if relu else 0, stream_ptr())
+
+
+def can_1x1(x, pw, KH, stride, pad, y, y_f32):
+    return (USE_1X1 and KH == 1 and stride == 1 and pad == 0 and y is not None and y_f32 is None and pw.cin_pad % 64 == 0
+            and 64 <= pw.cin_pad <= 1024 and x.shape[1] >= pw.cin_pad and y.shape[0] == x.shape[0])
+
+
 def conv_auto(x, pw, cout, geom, N, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, transposed=False, tile=0):
     """Dense conv forward (transposed=False) or input gradient (True): picks the LDS-halo kernel for stride-1
     "same" 3x3/7x7 convs over 64-channel-aligned inputs, else the gather implicit GEMM."""
@@ -107,6 +122,9 @@ def conv_auto(x, pw, cout, geom, N, y=None, y_f32=None, bias=None, res=None, mas
             and x.shape[1] >= pw.cin_pad):
         conv_halo(x, pw, cout, N, OH, OW, KH, y=y, y_f32=y_f32, bias=bias, res=res, mask=mask, relu=relu, flip=transposed)
         return "halo"
+    if KH == KW and can_1x1(x, pw, KH, stride, pad, y, y_f32):
+        conv1x1(x, pw, cout, y, bias=bias, res=res, mask=mask, relu=relu)
+        return "1x1"
     conv_igemm(x, pw, cout, geom, y=y, y_f32=y_f32, bias=bias, res=res, mask=mask, relu=relu, mode=1 if transposed else 0, tile=tile)
     return "igemm"
 

@@ -211,6 +211,9 @@ class SegBranch:
             ops.conv_halo(x, pw, cout, 0, 0, 0, 3, y=y, y_f32=y_f32, bias=bias, relu=relu, mask=mask, flip=(mode == 3),
                           tiletab=tiles, total_rows=M)
             return
+        if k == 1 and y is not None and ops.can_1x1(x[:M], pw, 1, 1, 0, y[:M], y_f32):
+            ops.conv1x1(x[:M], pw, cout, y[:M], bias=bias, mask=mask[:M] if mask is not None else None, relu=relu)
+            return
         geom = (M, 0, 0, M, 1, k, k, 1, (k - 1) // 2)
         ops.conv_igemm(x, pw, cout, geom, y=y, y_f32=y_f32, bias=bias, relu=relu, mask=mask, mode=mode, rowdesc=rowdesc)
 

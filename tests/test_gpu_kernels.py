@@ -401,3 +401,30 @@ def test_conv_wgrad_halo(case):
     torch.cuda.synchronize()
     scale = float(w.grad.abs().max())
     report(f"wgrad_halo{case}", gw.cpu(), w.grad, atol=2e-4 * scale, rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", [(128, 64, 5000, True, True), (64, 128, 4096, False, False), (1024, 512, 777, True, True),
+                                  (256, 100, 300, False, True), (64, 64, 70000, True, False)])
+def test_conv1x1_streaming(case):
+    """kg_conv1x1 (persistent streaming GEMM) vs fp64 matmul, incl. residual / mask epilogue and channel-slice I/O."""
+    K, cout, M, relu, bias = case
+    g = torch.Generator().manual_seed(K + cout)
+    x = bfr(torch.randn(M, K + 64, generator=g))          # consume a K-wide slice of a wider buffer
+    w = bfr(torch.randn(cout, K, 1, 1, generator=g) / math.sqrt(K))
+    b = torch.randn(cout, generator=g) if bias else None
+    res = bfr(torch.randn(M, cout, generator=g)); msk = bfr(torch.randn(M, cout, generator=g))
+    ref = x[:, 64:].double() @ w.view(cout, K).double().t()
+    if bias:
+        ref = ref + b.double()
+    ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    ref = ref * (msk > 0)
+    pw = PackedWeight(cout, 1, K, DEV); pw.pack(w.to(DEV))
+    xd = x.to(BF16).to(DEV)
+    ybuf = torch.zeros(M, cout + 32, dtype=BF16, device=DEV)
+    assert ops.can_1x1(xd[:, 64:], pw, 1, 1, 0, ybuf[:, 32:], None)
+    ops.conv1x1(xd[:, 64:], pw, cout, ybuf[:, 32:], bias=b.to(DEV) if bias else None, res=res.to(BF16).to(DEV),
+                mask=msk.to(BF16).to(DEV), relu=relu)
+    report(f"conv1x1{case}", ybuf[:, 32:].float().cpu(), ref, atol=3e-2, rtol=1e-2)
+    assert float(ybuf[:, :32].abs().max()) == 0.0
