@@ -13,6 +13,9 @@
 // The same kernel computes the input gradient of such a conv (flip = 1, transposed-packed weights).
 // Wave tile = 64 couts x 64 pixels (4 rows of the 16x16 tile), 16 v_mfma_f32_16x16x32_bf16 per 32-wide k-step.
 #include "kg_common.h"
+#ifndef KG_HALO_SETPRIO
+#define KG_HALO_SETPRIO 1
+#endif
 
 struct HaloArgs {
     const bf16_t* x; const bf16_t* w; const float* bias;
@@ -66,12 +69,24 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 #pragma unroll
         for (int s = 0; s < 2; ++s) a_off[i][s] = r * 128 + (((4 * s + g) ^ key) * 16);
     }
-    // pixels: halo byte offset of the lane's pixel for fragment j at tap (0,0); the swizzle key depends on the halo
-    // x coordinate only ( = xb + kx ), so it is computed once per tap and shared by the 4 rows and 2 k-steps.
+    // pixels: kb[kx][s] = halo byte offset of the lane's pixel for fragment 0 + swizzled 16-byte chunk of k-step s for a
+    // tap whose halo-x shift is fx(kx); fragment j adds the immediate j*HWD*128, the tap adds a scalar.
     const int xb = (wp >> 2) * 16 + lm;
-    int p_off[4];
+    int kb[KS][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p_off[j] = (((wp & 3) * 4 + j) * HWD + xb) * 128;
+    for (int kx = 0; kx < KS; ++kx) {
+        const int fx = a.flip ? KS - 1 - kx : kx;
+        const int key = ((xb + fx) >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) kb[kx][s] = (((wp & 3) * 4) * HWD + xb) * 128 + (((4 * s + g) ^ key) * 16);
+    }
+    // weights: ab[slot][s] = ring slot base + row/chunk offset of fragment 0 (fragment i adds the immediate i*512: the
+    // swizzle key of row r = (lm>>2)*16 + i*4 + (lm&3) does not depend on i)
+    int ab[3][2];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) ab[q][s] = q * WBUF_BYTES + a_off[0][s];
 
     // weight staging assignment
     int w_row[WPT], w_lds[WPT];
@@ -84,28 +99,14 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     const int wc8 = (tid & 7) * 8;  // NT % 8 == 0: the channel chunk of a thread is the same for every i
     uint4 wreg[WPT];
 
-    // Fragment loaders.  A: weight rows of ring slot `slot`; B: halo pixels shifted by the tap offset.
-    auto load_a = [&](bf16x8 (&af)[4], int slot, int s) {
-        const unsigned char* wb = wbuf + slot * WBUF_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wb + a_off[i][s]);
-    };
-    auto load_b = [&](bf16x8 (&bfr)[4], int t, int s) {
-        const int ky = t / KS, kx = t - ky * KS;
-        const int fy = a.flip ? KS - 1 - ky : ky, fx = a.flip ? KS - 1 - kx : kx;
-        const int key = ((xb + fx) >> 1) & 7;
-        const unsigned char* hb = halo + (fy * HWD + fx) * 128 + (((4 * s + g) ^ key) * 16);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(hb + p_off[j]);
-    };
     auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[4]) {
-        __builtin_amdgcn_s_setprio(1);
+        if (KG_HALO_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (KG_HALO_SETPRIO) __builtin_amdgcn_s_setprio(0);
     };
 
     const int nchunks = a.cin_pad / 64;
@@ -130,27 +131,62 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 #pragma unroll
             for (int i = 0; i < WPT; ++i) *reinterpret_cast<uint4*>(wbuf + slot * WBUF_BYTES + w_lds[i]) = wreg[i];
         };
+        auto wstore_at = [&](int slot_bytes) {
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) *reinterpret_cast<uint4*>(wbuf + slot_bytes + w_lds[i]) = wreg[i];
+        };
         // Weight ring of 3 slots: at the start of tap t slots t%3 and (t+1)%3 are visible, W(t+2) is in registers.
         wload(0); wstore(0);
         if (T > 1) { wload(1); wstore(1); }
         if (T > 2) wload(2);
         __syncthreads();
         // Software pipeline over (tap, k-step): the fragments of the NEXT k-step are fetched from LDS while the 16
-        // MFMAs of the current one run, so no wave waits on LDS right after the per-tap barrier.
+        // MFMAs of the current one run, so no wave waits on LDS right after the per-tap barrier.  The tap loop is
+        // ky (rolled) x kx (unrolled): every lane-dependent address term is a precomputed register (kb / ab), the tap
+        // offset is a scalar, fragment j / i offsets are instruction immediates -> ~4 VALU per tap.
         bf16x8 a0[4], b0[4], a1[4], b1[4];
-        load_a(a0, 0, 0); load_b(b0, 0, 0);
+        int abr[3][2];                 // ab rotated so that index kx%3 is the ring slot of tap (ky,kx)
+        int sbr[3] = {0, WBUF_BYTES, 2 * WBUF_BYTES};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { abr[q][0] = ab[q][0]; abr[q][1] = ab[q][1]; }
+        int tapb = a.flip ? ((KS - 1) * HWD + (KS - 1)) * 128 : 0;   // halo byte offset of tap (ky, kx = 0)
+        const int sx = a.flip ? -128 : 128, sy = a.flip ? -HWD * 128 : HWD * 128;
+        auto ldA = [&](bf16x8 (&af)[4], int base) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wbuf + base + i * 512);
+        };
+        auto ldB = [&](bf16x8 (&bfr)[4], int tb, int kbv) {
+            const unsigned char* hb = halo + tb + kbv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(hb + j * (HWD * 128));
+        };
+        ldA(a0, abr[0][0]); ldB(b0, tapb, kb[0][0]);
+        int t = 0;
 #pragma unroll 1
-        for (int t = 0; t < T; ++t) {
-            const int slot = t % 3;
-            load_a(a1, slot, 1); load_b(b1, t, 1);
-            mma(a0, b0);
-            if (t + 1 < T) { load_a(a0, (t + 1) % 3, 0); load_b(b0, t + 1, 0); }
-            mma(a1, b1);
-            if (t + 2 < T) {
-                wstore((t + 2) % 3);
-                if (t + 3 < T) wload(t + 3);
+        for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx, ++t) {
+                constexpr int dummy = 0; (void)dummy;
+                const int cur = kx % 3, nxt = (kx + 1) % 3, st = (kx + 2) % 3;
+                const int nkx = (kx + 1 == KS) ? 0 : kx + 1;
+                const int tb = tapb + kx * sx;
+                const int ntb = (kx + 1 == KS) ? tapb + sy : tapb + (kx + 1) * sx;
+                ldA(a1, abr[cur][1]); ldB(b1, tb, kb[kx][1]);
+                mma(a0, b0);
+                if (t + 1 < T) { ldA(a0, abr[nxt][0]); ldB(b0, ntb, kb[nkx][0]); }
+                mma(a1, b1);
+                if (t + 2 < T) {
+                    wstore_at(sbr[st]);
+                    if (t + 3 < T) wload(t + 3);
+                }
+                __syncthreads();
             }
-            __syncthreads();
+            tapb += sy;
+            if (KS % 3 == 1) {   // 7 taps per row: the ring slot of (ky+1, 0) is one further
+                const int s0 = sbr[0]; sbr[0] = sbr[1]; sbr[1] = sbr[2]; sbr[2] = s0;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) { const int v0 = abr[0][s2]; abr[0][s2] = abr[1][s2]; abr[1][s2] = abr[2][s2]; abr[2][s2] = v0; }
+            }
         }
     }
 
