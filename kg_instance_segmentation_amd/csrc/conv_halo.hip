@@ -113,14 +113,37 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     for (int cc = 0; cc < nchunks; ++cc) {
         __syncthreads();
         // ---- stage the halo of this 64-channel chunk ------------------------------------------------
-        for (int e = tid; e < HPIX * 8; e += NT) {
-            const int p = e >> 3, c = e & 7;
-            const int hy = p / HWD, hx = p - hy * HWD;
-            const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd)
-                v = *reinterpret_cast<const uint4*>(a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + cc * 64 + c * 8);
-            *reinterpret_cast<uint4*>(halo + p * 128 + ((c ^ ((hx >> 1) & 7)) * 16)) = v;
+        if (KS != 3) {   // 7x7: 49 taps amortise the staging; a simple load->store loop keeps register pressure low
+            for (int e = tid; e < HPIX * 8; e += NT) {
+                const int p = e >> 3, c = e & 7;
+                const int hy = p / HWD, hx = p - hy * HWD;
+                const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd)
+                    v = *reinterpret_cast<const uint4*>(a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + cc * 64 + c * 8);
+                *reinterpret_cast<uint4*>(halo + p * 128 + ((c ^ ((hx >> 1) & 7)) * 16)) = v;
+            }
+        } else {   // 3x3: all global loads of the halo are issued before the first LDS store (one HBM round trip per chunk)
+            constexpr int HPT = (HPIX * 8 + NT - 1) / NT;
+            uint4 hreg[HPT];
+#pragma unroll
+            for (int q = 0; q < HPT; ++q) {
+                const int e = tid + q * NT;
+                const int p = e >> 3, c = e & 7;
+                const int hy = p / HWD, hx = p - hy * HWD;
+                const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (e < HPIX * 8 && (unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd)
+                    v = *reinterpret_cast<const uint4*>(a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + cc * 64 + c * 8);
+                hreg[q] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < HPT; ++q) {
+                const int e = tid + q * NT;
+                const int p = e >> 3, c = e & 7;
+                const int hx = p % HWD;
+                if (e < HPIX * 8) *reinterpret_cast<uint4*>(halo + p * 128 + ((c ^ ((hx >> 1) & 7)) * 16)) = hreg[q];
+            }
         }
         auto wload = [&](int tap) {
 #pragma unroll

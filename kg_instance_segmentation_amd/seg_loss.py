@@ -89,7 +89,8 @@ class SEG_loss(nn.Module):
                     continue
                 pb = np.stack([np.asarray(d[:4].detach().cpu().numpy() if hasattr(d, "detach") else d[:4], np.float32) for d in mask_dets[i]])
                 per_img.append((pb, np.array([p.shape[0] for p in pl]), np.array([p.shape[1] for p in pl]), None, pl))
-        recs, pairs, tgts, toff = [], [], [], 0   # recs: (img, patch index in image, npix, first pair, npairs)
+        # pass 1: match (vectorised); pass 2: crop the GT masks straight into ONE pinned uint8 staging buffer
+        recs, pairs, work, toff = [], [], [], 0   # recs: (img, patch index in image, npix, first pair, npairs)
         for i, (pb, hs, ws, offs, pl) in enumerate(per_img):
             gb = np.asarray(gt_boxes[i], np.float32).reshape(-1, 5) if len(gt_boxes[i]) else np.zeros((0, 5), np.float32)
             if len(pb) == 0 or len(gb) == 0:
@@ -101,19 +102,29 @@ class SEG_loss(nn.Module):
             y1 = np.maximum(0, np.round(pb[:, 0]).astype(np.int32)); x1 = np.maximum(0, np.round(pb[:, 1]).astype(np.int32))
             y2 = np.minimum(np.round(pb[:, 2]).astype(np.int32), self.height - 1)
             x2 = np.minimum(np.round(pb[:, 3]).astype(np.int32), self.width - 1)
-            gm_all = gt_masks[i]
-            for j in np.nonzero(match.any(1))[0]:
+            js, gs_all = np.nonzero(match)                                      # row-major: patch asc, gt asc
+            first = np.searchsorted(js, np.unique(js))
+            ujs = js[first]
+            counts = np.diff(np.append(first, len(js)))
+            w_img = 1.0 / nobj / nimg
+            for j, f0, cnt in zip(ujs.tolist(), first.tolist(), counts.tolist()):
                 h1, w1 = int(hs[j]), int(ws[j])
-                gs = np.nonzero(match[j])[0]
-                recs.append((i, int(j), h1 * w1, len(pairs), len(gs)))
-                for g in gs:
-                    gm = nearest_resize(np.asarray(gm_all[g])[y1[j]:y2[j], x1[j]:x2[j]], h1, w1)   # seg_loss.py:64,77
-                    assert gm.shape == (h1, w1), "[loss.py] mask size does not match!"
-                    tgts.append(gm.astype(np.uint8).ravel())
-                    pairs.append((toff, 1.0 / (h1 * w1) / nobj / nimg))
-                    toff += h1 * w1
+                npx = h1 * w1
+                recs.append((i, j, npx, len(pairs), cnt))
+                for g in gs_all[f0:f0 + cnt].tolist():
+                    pairs.append((toff, w_img / npx))
+                    work.append((i, g, int(y1[j]), int(y2[j]), int(x1[j]), int(x2[j]), h1, w1, toff))
+                    toff += npx
         if not recs:
             return None                      # seg_loss.py:93-96
+        tgt_host = torch.empty(toff, dtype=torch.uint8, pin_memory=True)
+        tnp = tgt_host.numpy()
+        for (i, g, ya, yb, xa, xb_, h1, w1, off) in work:
+            crop = gt_masks[i][g][ya:yb, xa:xb_]                               # seg_loss.py:64
+            if crop.shape != (h1, w1):
+                crop = nearest_resize(np.asarray(crop), h1, w1)                 # seg_loss.py:77
+                assert crop.shape == (h1, w1), "[loss.py] mask size does not match!"
+            tnp[off:off + h1 * w1].reshape(h1, w1)[...] = crop
         if meta is not None:
             flat = meta["flat"]
             offs = [int(per_img[i][3][j]) for i, j, _, _, _ in recs]
@@ -126,7 +137,7 @@ class SEG_loss(nn.Module):
         ptab = np.array([[o, r[2], r[3], r[4]] for o, r in zip(offs, recs)], np.int32)
         pair_t = np.zeros(len(pairs), dtype=[("off", np.int32), ("w", np.float32)])
         pair_t["off"] = [p[0] for p in pairs]; pair_t["w"] = [p[1] for p in pairs]
-        tgt = ops.h2d(np.concatenate(tgts), dev)
+        tgt = tgt_host.to(dev, non_blocking=True)
         ptab_d = ops.h2d(ptab, dev)
         pairs_d = ops.h2d(pair_t.view(np.uint8), dev)
         return _SegLossFn.apply(flat, tgt, ptab_d, pairs_d, len(recs))
