@@ -3,14 +3,21 @@
 //   dW[co][tap][ci] = sum over pixels  dY[px][co] * X[px + d(tap)][ci]
 //
 // One workgroup (8 waves) owns 64 output channels x CI = 16*CIF input channels x ALL KS*KS taps and walks over
-// 16x16 pixel tiles (its "split" of the image batch).  Per tile it stages the dY tile [256 px][64 co] and the X
-// halo [(16+KS-1)^2 px][CI] into LDS once; every tap re-reads the halo with a shifted window, so the 49 taps of
-// a 7x7 conv cost one staging pass instead of 49.  The reduction dimension (pixels) is the strided one in NHWC,
-// so both MFMA operands come from ds_read_b64_tr_b16 transpose reads.  Work split inside the workgroup: the
-// (tap, ci-fragment) units are dealt round-robin to the 8 waves; each wave keeps its <= 7 units x 4 co-fragments
-// of fp32 accumulators in registers across all tiles and writes them once at the end to the
+// 16x16 pixel tiles (its "split" of the image batch, or of the ragged box tiles).  Per tile it stages the dY tile
+// [256 px][64 co] and the X halo [(16+KS-1)^2 px][CI] into LDS once; every tap re-reads the halo with a shifted
+// window, so the 49 taps of a 7x7 conv cost one staging pass instead of 49.  The reduction dimension (pixels) is the
+// strided one in NHWC, so both MFMA operands come from ds_read_b64_tr_b16 transpose reads.  Work split inside the
+// workgroup: the (tap, ci-fragment) units are dealt round-robin to the 8 waves; each wave keeps its <= 7 units x 4
+// co-fragments of fp32 accumulators in registers across all tiles and writes them once at the end to the
 // [split][co][tap][ci] partial buffer that kg_wgrad_reduce sums (fixed order => reproducible).
 // Tiles are double-buffered through registers (loads of tile t+1 are in flight while tile t is multiplied).
+//
+// LDS layouts are chosen so that (a) the 32-lane halves of a transpose read hit disjoint banks and (b) every fragment
+// address is  lane-constant register + k-step immediate:  the k-step loop contains no address arithmetic.
+//   k-step s = tile rows 2s, 2s+1; lane group G reads row 2s + (G&1), columns (G>>1)*8 + h*4 + (i>>2)   (h = 0,1)
+//   dY tile : [256 px][128 B], 32-byte unit index XOR f(r), f(r) = ((r>>1)&1) | (((r>>4)&1)<<1)
+//   X halo  : [HWD rows][PITCH], PITCH = HWD*32*CIF rounded up to 128 (mod 256) so consecutive rows alternate bank
+//             halves; CIF == 4: 32-byte unit XOR (x & 3)
 #include "kg_common.h"
 
 struct WgHaloArgs {
@@ -23,14 +30,23 @@ struct WgHaloArgs {
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-__device__ __forceinline__ int trf(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); }
+__device__ __forceinline__ int dyf(int r) { return ((r >> 1) & 1) | (((r >> 4) & 1) << 1); }
+
+template <int KS, int CIF>
+struct WgGeom {
+    static constexpr int PAD = KS / 2, HWD = 16 + KS - 1, T = KS * KS;
+    static constexpr int XB = 32 * CIF;                                    // bytes per halo pixel
+    static constexpr int RAW = HWD * XB;
+    static constexpr int PITCH = ((RAW - 128 + 255) / 256) * 256 + 128;     // >= RAW and == 128 (mod 256)
+    static constexpr int DY_BYTES = 256 * 128, X_BYTES = HWD * PITCH, BUF = DY_BYTES + X_BYTES;
+    static constexpr int UNITS = T * CIF, UPW = (UNITS + 7) / 8;
+};
 
 template <int KS, int CIF>
 __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
-    constexpr int PAD = KS / 2, HWD = 16 + KS - 1, HPIX = HWD * HWD, T = KS * KS;
-    constexpr int XB = 32 * CIF;                       // bytes per halo pixel
-    constexpr int DY_BYTES = 256 * 128, X_BYTES = HPIX * XB, BUF = DY_BYTES + X_BYTES;
-    constexpr int UNITS = T * CIF, UPW = (UNITS + 7) / 8;
+    using GE = WgGeom<KS, CIF>;
+    constexpr int PAD = GE::PAD, HWD = GE::HWD, HPIX = HWD * HWD, T = GE::T, XB = GE::XB, PITCH = GE::PITCH;
+    constexpr int DY_BYTES = GE::DY_BYTES, BUF = GE::BUF, UNITS = GE::UNITS, UPW = GE::UPW;
     constexpr int DYPT = 256 * 8 / 512;                // dY 16-byte chunks per thread (4)
     constexpr int XCH = HPIX * 2 * CIF, XPT = (XCH + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -46,6 +62,31 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     for (int q = 0; q < UPW; ++q)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[q][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- lane-constant fragment addresses (k-step 0); k-step s adds an immediate ------------------------------------
+    // dY^T fragment c (co block), half h: tile row r = (G&1)*16 + (G>>1)*8 + h*4 + (i16>>2)   (+ s*32)
+    int ay[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = (G & 1) * 16 + (G >> 1) * 8 + h * 4 + (i16 >> 2);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ay[c][h] = r * 128 + ((c ^ dyf(r)) * 32) + (i16 & 3) * 8;
+    }
+    // X^T fragment of unit q (tap, ci block f), half h: halo row (G&1) + ky (+ 2s), column (G>>1)*8 + h*4 + (i16>>2) + kx
+    int bx[UPW][2];
+#pragma unroll
+    for (int q = 0; q < UPW; ++q) {
+        int u = wave + 8 * q;
+        if (u >= UNITS) u = UNITS - 1;          // idle slot: any valid address
+        const int tap = u / CIF, f = u - tap * CIF;
+        const int ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int xh = (G >> 1) * 8 + h * 4 + (i16 >> 2) + kx;
+            const int unit = CIF == 1 ? 0 : (f ^ (xh & (CIF - 1)));
+            bx[q][h] = ((G & 1) + ky) * PITCH + xh * XB + unit * 32 + (i16 & 3) * 8;
+        }
+    }
 
     uint4 dyr[DYPT], xr[XPT];
     const int tiles_total = a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y;
@@ -84,25 +125,22 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
             xr[k] = v;
         }
     };
-    // halo byte address of 16-byte chunk c (8 channels) of halo pixel p
-    auto xaddr = [&](int p, int c) -> int {
-        if (CIF == 1) return ((p * 32) ^ (((p >> 3) & 1) << 7)) + c * 16;
-        return p * XB + (((c >> 1) ^ (trf(p) & (CIF - 1))) * 32) + (c & 1) * 16;
-    };
     auto store_tile = [&](int buf) {
         unsigned char* sy = smem + buf * BUF;
         unsigned char* sx = sy + DY_BYTES;
 #pragma unroll
         for (int k = 0; k < DYPT; ++k) {
             const int e = tid + k * 512, r = e >> 3, c8 = e & 7;
-            *reinterpret_cast<uint4*>(sy + r * 128 + (((c8 >> 1) ^ trf(r)) * 32) + (c8 & 1) * 16) = dyr[k];
+            *reinterpret_cast<uint4*>(sy + r * 128 + (((c8 >> 1) ^ dyf(r)) * 32) + (c8 & 1) * 16) = dyr[k];
         }
 #pragma unroll
         for (int k = 0; k < XPT; ++k) {
             const int e = tid + k * 512;
             if (e < XCH) {
                 const int p = e / (2 * CIF), c = e - p * (2 * CIF);
-                *reinterpret_cast<uint4*>(sx + xaddr(p, c)) = xr[k];
+                const int hy = p / HWD, hx = p - hy * HWD;
+                const int unit = CIF == 1 ? 0 : ((c >> 1) ^ (hx & (CIF - 1)));
+                *reinterpret_cast<uint4*>(sx + hy * PITCH + hx * XB + unit * 32 + (c & 1) * 16) = xr[k];
             }
         }
     };
@@ -116,34 +154,23 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
         if (tn < tiles_total) load_tile(tn);
         const unsigned char* sy = smem + cur * BUF;
         const unsigned char* sx = sy + DY_BYTES;
-#pragma unroll 1
-        for (int s = 0; s < 8; ++s) {       // k-step: the 32 pixels of tile rows 2s, 2s+1
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {       // k-step: the 32 pixels of tile rows 2s, 2s+1 (all offsets are immediates)
             bf16x8 af[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {   // dY^T fragments: row = co, k = pixel
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int r = s * 32 + G * 8 + h * 4 + (i16 >> 2);
-                    const int off = r * 128 + ((c ^ trf(r)) * 32) + (i16 & 3) * 8;
-                    bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sy + off));
+                    bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sy + ay[c][h] + s * 32 * 128));
                     af[c][h * 4 + 0] = v[0]; af[c][h * 4 + 1] = v[1]; af[c][h * 4 + 2] = v[2]; af[c][h * 4 + 3] = v[3];
                 }
-            }
 #pragma unroll
             for (int q = 0; q < UPW; ++q) {
-                const int u = wave + 8 * q;
-                if (u < UNITS) {            // wave-uniform
-                    const int tap = u / CIF, f = u - tap * CIF;
-                    const int ky = tap / KS, kx = tap - ky * KS;
+                if (wave + 8 * q < UNITS) {            // wave-uniform
                     bf16x8 bfr;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const int k = G * 8 + h * 4 + (i16 >> 2);
-                        const int p = (2 * s + (k >> 4) + ky) * HWD + (k & 15) + kx;
-                        int off;
-                        if (CIF == 1) off = ((p * 32) ^ (((p >> 3) & 1) << 7)) + (i16 & 3) * 8;
-                        else off = p * XB + ((f ^ (trf(p) & (CIF - 1))) * 32) + (i16 & 3) * 8;
-                        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sx + off));
+                        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sx + bx[q][h] + s * 2 * PITCH));
                         bfr[h * 4 + 0] = v[0]; bfr[h * 4 + 1] = v[1]; bfr[h * 4 + 2] = v[2]; bfr[h * 4 + 3] = v[3];
                     }
 #pragma unroll
@@ -175,8 +202,7 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
 
 template <int KS, int CIF>
 static int launch_wg(const WgHaloArgs& a, hipStream_t st) {
-    constexpr int HWD = 16 + KS - 1;
-    constexpr int smem = 2 * (256 * 128 + HWD * HWD * 32 * CIF);
+    constexpr int smem = 2 * WgGeom<KS, CIF>::BUF;
     static bool attr_done = false;
     if (!attr_done) {
         KG_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<KS, CIF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
