@@ -40,6 +40,11 @@ int kg_conv2d_halo(const void* x, const void* w, const float* bias, void* y, flo
                    const void* mask, int N, int H, int W, int cin_pad, int ldx, int Cout, int ldy, int ldres, int ldmask,
                    int K, int KS, int flip, int relu, int f32_C, int wc, const int* tiletab, int ntiles, int total_rows,
                    void* stream);   /* tiletab != NULL: ragged boxes, one {row0,(h<<16)|w,(oy0<<16)|ox0,0} entry per workgroup */
+/* the three second-layer 7x7 head convolutions of one scale (KGnet.py:161-209 `.2` layers, sigmoid on kp :300) in one launch
+ * over the fused hidden rows [N*H*W][>=3C]: w = packed [64 virtual couts][49][3C] (kg_pack_weight_rows), bias64 / vmap[64]
+ * indexed by virtual cout (vmap: channel of kp 0-4 | short 5-14 | mid 15-54, or -1); fp32 NCHW outputs */
+int kg_conv2d_halo_heads2(const void* x, const void* w, const float* bias64, const int* vmap, float* kp, float* sh, float* md,
+                          int N, int H, int W, int C, int ldx, int K, void* stream);
 /* 1x1 stride-1 convolution / its input gradient as a streaming GEMM over rows (dense or ragged): weight slab resident in
  * LDS, pixel fragments straight from global memory, persistent workgroups (KGnet.py:64-99,101-111,155-158) */
 int kg_conv1x1(const void* x, const void* w, const float* bias, void* y, const void* res, const void* mask, long M, int K,
@@ -47,6 +52,9 @@ int kg_conv1x1(const void* x, const void* w, const float* bias, void* y, const v
 /* fp32 OIHW parameter -> packed bf16 matrix rows (forward) or its transpose (data gradient). */
 int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad, int row0, int c0,
                    int transposed, void* stream);
+/* forward packing with a row table: packed row of output channel co = rowmap[co] (device int array) */
+int kg_pack_weight_rows(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad, const int* rowmap,
+                        int c0, void* stream);
 /* weight gradient (autograd of nn.Conv2d at train.py:153): partial sums [nsplit][Cout][taps][Cin] fp32 */
 int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const int* rowdesc, int M, int H, int W, int OH, int OW,
                     int ldx, int lddy, int Cin, int Cout, int cin_lim, int cout_lim, int KH, int KW, int stride, int pad,

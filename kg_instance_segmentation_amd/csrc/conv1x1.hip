@@ -16,8 +16,10 @@ struct C1Args {
     bf16_t* y; const bf16_t* res; const bf16_t* mask;
     long M;
     int K, ldx, Cout, ldy, ldres, ldmask, relu, wK;   // wK: row pitch (elements) of the packed weight matrix
+    int wrows;                                        // rows of the packed weight matrix that may be read
 };
 
+template <int KU>   // k-steps (of 32 channels) fetched per prefetch group: the loads of KU k-steps are in flight together
 __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [K/64][64 rows][128 B], swizzled
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -26,11 +28,22 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
     const int nk64 = a.K / 64;
 
     // ---- stage the weight slab once ---------------------------------------------------------------------------
-    for (int e = tid; e < nk64 * 64 * 8; e += 256) {
-        const int c = e & 7, r = (e >> 3) & 63, kc = e >> 9;
-        const uint4 v = *reinterpret_cast<const uint4*>(a.w + (long)(c0 + r) * a.wK + kc * 64 + c * 8);
-        const int key = 2 * ((r >> 4) & 3) + ((r >> 1) & 1);
-        *reinterpret_cast<uint4*>(smem + kc * 8192 + r * 128 + ((c ^ key) * 16)) = v;
+    // (8 loads in flight per thread: the slab is up to 128 KB and only one workgroup fits a CU at that size)
+    for (int e0 = tid; e0 < nk64 * 64 * 8; e0 += 256 * 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + q * 256;
+            const int c = e & 7, r = (e >> 3) & 63, kc = e >> 9;
+            v[q] = e < nk64 * 64 * 8 ? *reinterpret_cast<const uint4*>(a.w + (long)(c0 + r) * a.wK + kc * 64 + c * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + q * 256;
+            const int c = e & 7, r = (e >> 3) & 63, kc = e >> 9;
+            const int key = 2 * ((r >> 4) & 3) + ((r >> 1) & 1);
+            if (e < nk64 * 64 * 8) *reinterpret_cast<uint4*>(smem + kc * 8192 + r * 128 + ((c ^ key) * 16)) = v[q];
+        }
     }
     __syncthreads();
 
@@ -49,17 +62,19 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
     for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
 
     const long ntiles = (a.M + 255) / 256;
-    const int nks = a.K / 32;
+    const int ngr = a.K / (32 * KU);
     auto rowptr = [&](long tile, int j) -> const bf16_t* {
         long m = tile * 256 + wave * 64 + j * 16 + lm;
         if (m >= a.M) m = a.M - 1;   // clamped rows are computed and discarded
         return a.x + m * a.ldx + g * 8;
     };
-    bf16x8 bcur[4], bnxt[4];
+    bf16x8 bcur[KU][4], bnxt[KU][4];
     long tile = blockIdx.x;
     if (tile < ntiles) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bcur[j] = *reinterpret_cast<const bf16x8*>(rowptr(tile, j));
+        for (int u = 0; u < KU; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bcur[u][j] = *reinterpret_cast<const bf16x8*>(rowptr(tile, j) + u * 32);
     }
     for (; tile < ntiles; tile += gridDim.x) {
         f32x4 acc[4][4];
@@ -71,26 +86,36 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) rp[j] = rowptr(tile, j);
         const long tnext = tile + gridDim.x;
-        for (int ks = 0; ks < nks; ++ks) {
-            // prefetch the next k-step's pixel fragments (next tile's first k-step at the end)
-            if (ks + 1 < nks) {
+        for (int gr = 0; gr < ngr; ++gr) {
+            // prefetch the next group's pixel fragments (next tile's first group at the end)
+            if (gr + 1 < ngr) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bnxt[j] = *reinterpret_cast<const bf16x8*>(rp[j] + (ks + 1) * 32);
+                for (int u = 0; u < KU; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bnxt[u][j] = *reinterpret_cast<const bf16x8*>(rp[j] + ((gr + 1) * KU + u) * 32);
             } else if (tnext < ntiles) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bnxt[j] = *reinterpret_cast<const bf16x8*>(rowptr(tnext, j));
+                for (int u = 0; u < KU; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bnxt[u][j] = *reinterpret_cast<const bf16x8*>(rowptr(tnext, j) + u * 32);
             }
-            bf16x8 af[4];
-            const unsigned char* wb = smem + (ks >> 1) * 8192;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wb + a_off[i][ks & 1]);
+            for (int u = 0; u < KU; ++u) {
+                const int ks = gr * KU + u;
+                bf16x8 af[4];
+                const unsigned char* wb = smem + (ks >> 1) * 8192;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wb + a_off[i][u & 1]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bcur[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bcur[j] = bnxt[j];
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bcur[u][j], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bcur[u][j] = bnxt[u][j];
         }
         // ---- epilogue ---------------------------------------------------------------------------------------
         if (cb < a.Cout) {
@@ -105,9 +130,17 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
                     for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bv[i * 4 + r];
                 if (a.res) {
                     const bf16_t* rq = a.res + m * a.ldres + cb;
+                    if (full && ((reinterpret_cast<uintptr_t>(rq) & 15) == 0)) {
+                        uint4 r0 = *reinterpret_cast<const uint4*>(rq), r1 = *reinterpret_cast<const uint4*>(rq + 8);
+                        const bf16_t* rs0 = reinterpret_cast<const bf16_t*>(&r0);
+                        const bf16_t* rs1 = reinterpret_cast<const bf16_t*>(&r1);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        if (full || cb + e < a.Cout) v[e] += bf2f(rq[e]);
+                        for (int e = 0; e < 8; ++e) { v[e] += bf2f(rs0[e]); v[8 + e] += bf2f(rs1[e]); }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            if (full || cb + e < a.Cout) v[e] += bf2f(rq[e]);
+                    }
                 }
                 if (a.relu) {
 #pragma unroll
@@ -143,6 +176,141 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
     }
 }
 
+
+// ---- HBM-bound shapes (K <= 128): fully coalesced variant -----------------------------------------------------------
+// The fragment-shaped accesses of conv1x1_kernel (16 rows x 64 B per load, 16-byte pieces at a 32-byte stride per store)
+// cap it at ~1.5-2.5 TB/s.  Here every global access is a full 128-byte line per 8 lanes:
+//   * the X tile [128 rows][K] is fetched with row-contiguous 16-byte loads (next tile in flight during the MFMAs) and
+//     written to swizzled LDS, from which the MFMA B fragments are read;
+//   * the fp32 accumulators (+bias) go through an LDS transpose tile [128][64] (aliasing the X tile), and the epilogue
+//     (residual add, ReLU, ReLU-mask, bf16 rounding: one rounding, as in the other kernels) runs on 8-cout pieces with
+//     coalesced 16-byte residual / mask loads and stores.
+template <int KC>
+__global__ __launch_bounds__(256) void conv1x1_stream_kernel(const C1Args a) {
+    constexpr int TM = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wl = smem;                       // [KC][64 couts][128 B]
+    unsigned char* xl = smem + KC * 8192;           // [KC][TM][128 B]  (X tile)  /  [TM][256 B] fp32 (output tile)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 15, g = lane >> 4;
+    const int c0 = blockIdx.y * 64;
+
+    for (int e = tid; e < KC * 64 * 8; e += 256) {
+        const int c = e & 7, r = (e >> 3) & 63, kc = e >> 9;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c0 + r < a.wrows) v = *reinterpret_cast<const uint4*>(a.w + (long)(c0 + r) * a.wK + kc * 64 + c * 8);
+        const int key = 2 * ((r >> 4) & 3) + ((r >> 1) & 1);
+        *reinterpret_cast<uint4*>(wl + kc * 8192 + r * 128 + ((c ^ key) * 16)) = v;
+    }
+    int a_off[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (lm >> 2) * 16 + i * 4 + (lm & 3);
+        const int key = 2 * ((r >> 4) & 3) + ((r >> 1) & 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) a_off[i][s] = r * 128 + (((4 * s + g) ^ key) * 16);
+    }
+    float bv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bv[e] = (a.bias && c0 + g * 16 + e < a.Cout) ? a.bias[c0 + g * 16 + e] : 0.f;
+
+    // X staging: thread -> (row, 16-byte chunk) pairs, 8 (KC=1) or 16 (KC=2) consecutive lanes per row
+    constexpr int XPT = TM * KC * 8 / 256;
+    int x_row[XPT], x_col[XPT], x_lds[XPT];
+#pragma unroll
+    for (int q = 0; q < XPT; ++q) {
+        const int e = tid + q * 256;
+        const int cw = e % (KC * 8), r = e / (KC * 8);
+        x_row[q] = r; x_col[q] = cw * 8;
+        x_lds[q] = (cw >> 3) * (TM * 128) + r * 128 + (((cw & 7) ^ ((r >> 1) & 7)) * 16);
+    }
+    const long ntiles = (a.M + TM - 1) / TM;
+    uint4 xr[XPT];
+    auto xload = [&](long tile) {
+#pragma unroll
+        for (int q = 0; q < XPT; ++q) {
+            const long m = tile * TM + x_row[q];
+            xr[q] = m < a.M ? *reinterpret_cast<const uint4*>(a.x + m * a.ldx + x_col[q]) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    // B fragment offsets: wave rows 32*wave + 16*j + lm
+    int b_off[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = wave * 32 + j * 16 + lm;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) b_off[j][s] = r * 128 + (((4 * s + g) ^ ((r >> 1) & 7)) * 16);
+    }
+    // epilogue pieces: thread -> (row, 8-cout piece)
+    const int e_c8 = tid & 7, e_r0 = tid >> 3;   // rows e_r0 + 32*q
+    const int cpiece = c0 + e_c8 * 8;
+    const bool piece_ok = cpiece < a.Cout;       // Cout % 8 == 0 on this path
+
+    long tile = blockIdx.x;
+    if (tile < ntiles) xload(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                          // previous tile's output reads are done (xl is reused)
+#pragma unroll
+        for (int q = 0; q < XPT; ++q) *reinterpret_cast<uint4*>(xl + x_lds[q]) = xr[q];
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) xload(tile + gridDim.x);
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{bv[i * 4 + 0], bv[i * 4 + 1], bv[i * 4 + 2], bv[i * 4 + 3]};
+#pragma unroll
+        for (int ks = 0; ks < 2 * KC; ++ks) {
+            bf16x8 af[4], bf[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wl + (ks >> 1) * 8192 + a_off[i][ks & 1]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(xl + (ks >> 1) * (TM * 128) + b_off[j][ks & 1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                          // all B fragments read: xl becomes the fp32 output tile
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = wave * 32 + j * 16 + lm;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(xl + r * 256 + (((g * 4 + i) ^ (r & 15)) * 16)) = acc[i][j];
+        }
+        __syncthreads();
+        if (piece_ok) {
+#pragma unroll
+            for (int q = 0; q < TM / 32; ++q) {
+                const int r = e_r0 + 32 * q;
+                const long m = tile * TM + r;
+                if (m >= a.M) continue;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(xl + r * 256 + (((2 * e_c8) ^ (r & 15)) * 16));
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(xl + r * 256 + (((2 * e_c8 + 1) ^ (r & 15)) * 16));
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (a.res) {
+                    const uint4 rv = *reinterpret_cast<const uint4*>(a.res + m * a.ldres + cpiece);
+                    const bf16_t* rs = reinterpret_cast<const bf16_t*>(&rv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bf2f(rs[e]);
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                }
+                if (a.mask) {
+                    const uint4 mv = *reinterpret_cast<const uint4*>(a.mask + m * a.ldmask + cpiece);
+                    const bf16_t* ms = reinterpret_cast<const bf16_t*>(&mv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = bf2f(ms[e]) > 0.f ? v[e] : 0.f;
+                }
+                *reinterpret_cast<uint4*>(a.y + m * a.ldy + cpiece) =
+                    make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+            }
+        }
+    }
+}
+
 // Y[M][Cout] = act(X[M][K] . W^T + bias + res) (* mask > 0).  K % 64 == 0, K <= 1024; packed weight rows padded to 64.
 extern "C" int kg_conv1x1(const void* x, const void* w, const float* bias, void* y, const void* res, const void* mask, long M,
                           int K, int wK, int ldx, int Cout, int ldy, int ldres, int ldmask, int relu, void* stream) {
@@ -154,10 +322,27 @@ extern "C" int kg_conv1x1(const void* x, const void* w, const float* bias, void*
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.res = (const bf16_t*)res;
     a.mask = (const bf16_t*)mask; a.M = M; a.K = K; a.wK = wK; a.ldx = ldx; a.Cout = Cout; a.ldy = ldy; a.ldres = ldres;
     a.ldmask = ldmask; a.relu = relu;
+    a.wrows = kg_cdiv(Cout, 64) * 64;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (K <= 128 && Cout % 8 == 0 && ldy % 8 == 0 && al16(y) && al16(x) && (!res || (ldres % 8 == 0 && al16(res))) &&
+        (!mask || (ldmask % 8 == 0 && al16(mask)))) {
+        const int kc = K / 64;
+        const int smem_s = kc * 8192 + (kc == 1 ? 32768 : 32768);   // X tile (16/32 KB) aliased with the 32 KB fp32 output tile
+        const long nt = (M + 127) / 128;
+        const int nyb = kg_cdiv(Cout, 64);
+        long gxs = (long)256 * (kc == 1 ? 4 : 3) / nyb;
+        if (gxs < 64) gxs = 64;
+        if (gxs > nt) gxs = nt;
+        if (kc == 1) hipLaunchKernelGGL(conv1x1_stream_kernel<1>, dim3((unsigned)gxs, nyb), dim3(256), smem_s, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(conv1x1_stream_kernel<2>, dim3((unsigned)gxs, nyb), dim3(256), smem_s, (hipStream_t)stream, a);
+        KG_CHECK_LAUNCH("conv1x1_stream");
+        return KG_OK;
+    }
     const int smem = (K / 64) * 8192;
     static int attr_done = 0;
     if (!attr_done) {
-        KG_HIP(hipFuncSetAttribute((const void*)conv1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        KG_HIP(hipFuncSetAttribute((const void*)conv1x1_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        KG_HIP(hipFuncSetAttribute((const void*)conv1x1_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         attr_done = 1;
     }
     const long ntiles = (M + 255) / 256;
@@ -166,7 +351,8 @@ extern "C" int kg_conv1x1(const void* x, const void* w, const float* bias, void*
     long gx = (long)256 * per_cu / ny;
     if (gx < 64) gx = 64;
     if (gx > ntiles) gx = ntiles;
-    hipLaunchKernelGGL(conv1x1_kernel, dim3((unsigned)gx, ny), dim3(256), smem, (hipStream_t)stream, a);
+    if (K % 128 == 0) hipLaunchKernelGGL(conv1x1_kernel<4>, dim3((unsigned)gx, ny), dim3(256), smem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv1x1_kernel<2>, dim3((unsigned)gx, ny), dim3(256), smem, (hipStream_t)stream, a);
     KG_CHECK_LAUNCH("conv1x1");
     return KG_OK;
 }

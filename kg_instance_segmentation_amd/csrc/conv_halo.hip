@@ -13,9 +13,12 @@
 // The same kernel computes the input gradient of such a conv (flip = 1, transposed-packed weights).
 // Wave tile = 64 couts x 64 pixels (4 rows of the 16x16 tile), 16 v_mfma_f32_16x16x32_bf16 per 32-wide k-step.
 #include "kg_common.h"
+#include <type_traits>
 #ifndef KG_HALO_SETPRIO
 #define KG_HALO_SETPRIO 1
 #endif
+
+__device__ uint4 kg_halo_zero_line[8];   // 128 zero bytes: source of the padding pixels of a halo
 
 struct HaloArgs {
     const bf16_t* x; const bf16_t* w; const float* bias;
@@ -24,10 +27,19 @@ struct HaloArgs {
     int ntiles;
     int N, H, W, tiles_x, tiles_y;
     int cin_pad, ldx, Cout, ldy, ldres, ldmask, K, flip, relu, f32_C, f32_hw;
+    // grouped second-layer heads (GM = 1): per-head channel chunks, virtual-cout -> map-channel table, the 3 fp32 outputs
+    int grp_chunks; const int* vmap; float* f32_b; float* f32_c;
+    int dbg;
+    int head_split;   // GM: 1 = blockIdx.y is the head (small images: 3x the workgroups), 0 = one workgroup walks all heads
 };
 
 // WPX = pixel waves: 4 -> 16x16 output tile, 8 -> 16 rows x 32 columns (two 16x16 halves side by side)
-template <int KS, int WC, int WPX>
+// GM = 1: the three second-layer head convs (KGnet.py:161-209 `.2`: C -> 5 / 10 / 40) as ONE launch over the fused hidden
+// tensor [rows][3C].  The 64 "virtual" output channels are dealt to the four MFMA row groups i (couts 16q + 4i + r):
+// kp -> group 0, short -> group 1, mid -> groups 2, 3 and the rest of group 0; a 64-channel input chunk that belongs to
+// head h only runs the MFMA row groups of that head (1, 1 and 3 of 4), instead of three launches that each pad their
+// 5 / 10 / 40 couts to a 64-cout tile.  Small images (head_split): blockIdx.y = head, a workgroup walks the chunks of one head and writes only its maps.
+template <int KS, int WC, int WPX, int GM = 0>
 __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs a) {
     constexpr int PAD = KS / 2, TW = 4 * WPX, HWD = TW + KS - 1, HPIX = (16 + KS - 1) * HWD, TC = WC * 64, NT = WC * WPX * 64, T = KS * KS;
     constexpr int HALO_BYTES = HPIX * 128, WBUF_BYTES = TC * 128;
@@ -50,7 +62,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
         const int ty = bt % a.tiles_y; const int n = bt / a.tiles_y;
         oy0 = ty * 16; ox0 = tx * TW; Hd = a.H; Wd = a.W; rowbase = (long)n * a.H * a.W;
     }
-    const int c0 = blockIdx.y * TC;
+    const int c0 = GM == 1 ? 0 : blockIdx.y * TC;   // GM: blockIdx.y = head (kp / short / mid), all on the one 64-row weight tile
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -99,31 +111,24 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     const int wc8 = (tid & 7) * 8;  // NT % 8 == 0: the channel chunk of a thread is the same for every i
     uint4 wreg[WPT];
 
-    auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[4]) {
+    auto mma = [&](auto mk, const bf16x8 (&af)[4], const bf16x8 (&bfr)[4]) {
+        constexpr int MK = decltype(mk)::value;
         if (KG_HALO_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
+            if ((MK >> i) & 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
         if (KG_HALO_SETPRIO) __builtin_amdgcn_s_setprio(0);
     };
 
-    const int nchunks = a.cin_pad / 64;
-    for (int cc = 0; cc < nchunks; ++cc) {
+    const int nchunks = (GM == 1 && a.head_split) ? (blockIdx.y + 1) * a.grp_chunks : a.cin_pad / 64;
+    for (int cc = (GM == 1 && a.head_split) ? blockIdx.y * a.grp_chunks : 0; cc < nchunks; ++cc) {
         __syncthreads();
         // ---- stage the halo of this 64-channel chunk ------------------------------------------------
-        if (KS != 3) {   // 7x7: 49 taps amortise the staging; a simple load->store loop keeps register pressure low
-            for (int e = tid; e < HPIX * 8; e += NT) {
-                const int p = e >> 3, c = e & 7;
-                const int hy = p / HWD, hx = p - hy * HWD;
-                const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd)
-                    v = *reinterpret_cast<const uint4*>(a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + cc * 64 + c * 8);
-                *reinterpret_cast<uint4*>(halo + p * 128 + ((c ^ ((hx >> 1) & 7)) * 16)) = v;
-            }
-        } else {   // 3x3: all global loads of the halo are issued before the first LDS store (one HBM round trip per chunk)
+        if (KS == 3) {   // 3x3 (9 taps per staging): all global loads of the halo are issued before the first LDS store
             constexpr int HPT = (HPIX * 8 + NT - 1) / NT;
             uint4 hreg[HPT];
 #pragma unroll
@@ -143,6 +148,28 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                 const int p = e >> 3, c = e & 7;
                 const int hx = p % HWD;
                 if (e < HPIX * 8) *reinterpret_cast<uint4*>(halo + p * 128 + ((c ^ ((hx >> 1) & 7)) * 16)) = hreg[q];
+            }
+        } else
+        {   // 7x7: LDS-direct loads (global_load_lds_dwordx4): the whole halo is in flight at once and needs no staging
+            // registers next to the ~250 live ones of the tap loop.  The destination of a wave's load is lane-linear
+            // (M0 base + lane * 16), so the XOR swizzle of the 16-byte channel slots is applied to the SOURCE slot
+            // (an involution inside the pixel's 128-byte line); padding pixels read a zero line.
+            constexpr int HPT = (HPIX * 8 + NT - 1) / NT;
+            const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll 1
+            for (int q = 0; q < HPT; ++q) {   // rolled: an unrolled loop materialises all 14 source addresses at once (spills)
+                const int e = tid + q * NT;
+                if (e < HPIX * 8) {
+                    const int p = e >> 3, cs = e & 7;
+                    const int hy = p / HWD, hx = p - hy * HWD;
+                    const int c = cs ^ ((hx >> 1) & 7);
+                    const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
+                    const bf16_t* src = reinterpret_cast<const bf16_t*>(kg_halo_zero_line) + c * 8;
+                    if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd)
+                        src = a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + cc * 64 + c * 8;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(halo + (q * NT + wave_u * 64) * 16), 16, 0, 0);
+                }
             }
         }
         auto wload = [&](int tap) {
@@ -174,16 +201,19 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
         for (int q = 0; q < 3; ++q) { abr[q][0] = ab[q][0]; abr[q][1] = ab[q][1]; }
         int tapb = a.flip ? ((KS - 1) * HWD + (KS - 1)) * 128 : 0;   // halo byte offset of tap (ky, kx = 0)
         const int sx = a.flip ? -128 : 128, sy = a.flip ? -HWD * 128 : HWD * 128;
-        auto ldA = [&](bf16x8 (&af)[4], int base) {
+        auto ldA = [&](auto mk, bf16x8 (&af)[4], int base) {
+            constexpr int MK = decltype(mk)::value;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wbuf + base + i * 512);
+            for (int i = 0; i < 4; ++i)
+                if ((MK >> i) & 1) af[i] = *reinterpret_cast<const bf16x8*>(wbuf + base + i * 512);
         };
         auto ldB = [&](bf16x8 (&bfr)[4], int tb, int kbv) {
             const unsigned char* hb = halo + tb + kbv;
 #pragma unroll
             for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(hb + j * (HWD * 128));
         };
-        ldA(a0, abr[0][0]); ldB(b0, tapb, kb[0][0]);
+        auto run_taps = [&](auto mk) {
+        ldA(mk, a0, abr[0][0]); ldB(b0, tapb, kb[0][0]);
         int t = 0;
 #pragma unroll 1
         for (int ky = 0; ky < KS; ++ky) {
@@ -194,10 +224,23 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                 const int nkx = (kx + 1 == KS) ? 0 : kx + 1;
                 const int tb = tapb + kx * sx;
                 const int ntb = (kx + 1 == KS) ? tapb + sy : tapb + (kx + 1) * sx;
-                ldA(a1, abr[cur][1]); ldB(b1, tb, kb[kx][1]);
-                mma(a0, b0);
-                if (t + 1 < T) { ldA(a0, abr[nxt][0]); ldB(b0, ntb, kb[nkx][0]); }
-                mma(a1, b1);
+                if constexpr ((decltype(mk)::value & 16) == 0) {
+                    ldA(mk, a1, abr[cur][1]); ldB(b1, tb, kb[kx][1]);
+                    mma(mk, a0, b0);
+                    if (t + 1 < T) { ldA(mk, a0, abr[nxt][0]); ldB(b0, ntb, kb[nkx][0]); }
+                    mma(mk, a1, b1);
+                } else {   // only k-step 0 of the chunk is non-zero: taps alternate between the two fragment buffers
+                    if (kx + 1 == KS) {
+                        mma(mk, a0, b0);
+                        if (t + 1 < T) { ldA(mk, a0, abr[nxt][0]); ldB(b0, ntb, kb[nkx][0]); }
+                    } else if (kx % 2 == 0) {
+                        ldA(mk, a1, abr[nxt][0]); ldB(b1, ntb, kb[nkx][0]);
+                        mma(mk, a0, b0);
+                    } else {
+                        ldA(mk, a0, abr[nxt][0]); ldB(b0, ntb, kb[nkx][0]);
+                        mma(mk, a1, b1);
+                    }
+                }
                 if (t + 2 < T) {
                     wstore_at(sbr[st]);
                     if (t + 3 < T) wload(t + 3);
@@ -211,6 +254,20 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                 for (int s2 = 0; s2 < 2; ++s2) { const int v0 = abr[0][s2]; abr[0][s2] = abr[1][s2]; abr[1][s2] = abr[2][s2]; abr[2][s2] = v0; }
             }
         }
+        };
+        if constexpr (GM == 2) {
+            // the kp / short cout blocks of the fused second-layer head dgrad (engine.heads_second): their weights are zero
+            // for dY channels 32..63, so k-step 1 of the (single) chunk is skipped
+            run_taps(std::integral_constant<int, 31>{});
+        } else if constexpr (GM == 1) {
+            const int head = cc / a.grp_chunks;
+            if (head == 0) run_taps(std::integral_constant<int, 1>{});
+            else if (head == 1) run_taps(std::integral_constant<int, 2>{});
+            else run_taps(std::integral_constant<int, 13>{});
+        } else {
+            // fused second-layer head dgrad (engine.heads_second): the kp / short cout blocks only see dY channels 0..31
+            run_taps(std::integral_constant<int, 15>{});
+        }
     }
 
     // ---- epilogue: lane owns pixel (oy0 + wp*4 + j, ox0 + lm) and couts cb .. cb+15 ----------------------
@@ -221,6 +278,11 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 #pragma unroll
     for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
     const int ox = ox0 + (wp >> 2) * 16 + lm;
+    int vm[16];
+    if constexpr (GM == 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) vm[e] = a.vmap[cb + e];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int oy = oy0 + (wp & 3) * 4 + j;
@@ -231,6 +293,19 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bv[i * 4 + r];
+        if constexpr (GM == 1) {   // fp32 NCHW export to the kp (sigmoid, KGnet.py:300) / short / mid maps
+            const long hw = (long)a.H * a.W;
+            const long nimg = rowbase / hw, pix = (long)oy * Wd + ox;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ch = vm[e];
+                if (ch < 0 || (a.head_split && (ch < 5 ? 0 : ch < 15 ? 1 : 2) != (int)blockIdx.y)) continue;
+                if (ch < 5) a.y_f32[(nimg * 5 + ch) * hw + pix] = 1.f / (1.f + expf(-v[e]));
+                else if (ch < 15) a.f32_b[(nimg * 10 + ch - 5) * hw + pix] = v[e];
+                else a.f32_c[(nimg * 40 + ch - 15) * hw + pix] = v[e];
+            }
+            continue;
+        }
         if (a.res) {
             const bf16_t* rp = a.res + m * a.ldres + cb;
 #pragma unroll
@@ -279,18 +354,19 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     }
 }
 
-template <int KS, int WC, int WPX>
+template <int KS, int WC, int WPX, int GM = 0>
 static int launch_halo(HaloArgs a, hipStream_t st) {
     constexpr int TW = 4 * WPX, HWD = TW + KS - 1, TC = WC * 64;
     constexpr int smem = (16 + KS - 1) * HWD * 128 + 3 * TC * 128;
     a.tiles_x = kg_cdiv(a.W, TW);
+    { const char* d = getenv("KG_HALO_DBG"); a.dbg = d ? atoi(d) : 0; }
     static bool attr_done = false;
     if (!attr_done) {
-        KG_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<KS, WC, WPX>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        KG_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<KS, WC, WPX, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
-    dim3 grid(a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y, kg_cdiv(a.Cout, TC));
-    hipLaunchKernelGGL((conv_halo_kernel<KS, WC, WPX>), grid, dim3(WC * WPX * 64), smem, st, a);
+    dim3 grid(a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y, GM == 1 ? (a.head_split ? 3 : 1) : kg_cdiv(a.Cout, TC));
+    hipLaunchKernelGGL((conv_halo_kernel<KS, WC, WPX, GM>), grid, dim3(WC * WPX * 64), smem, st, a);
     KG_CHECK_LAUNCH("conv_halo");
     return KG_OK;
 }
@@ -315,11 +391,12 @@ extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, v
     a.N = N; a.H = H; a.W = W; a.tiles_x = kg_cdiv(W, 16); a.tiles_y = kg_cdiv(H, 16);
     a.cin_pad = cin_pad; a.ldx = ldx; a.Cout = Cout; a.ldy = ldy; a.ldres = ldres; a.ldmask = ldmask; a.K = K;
     a.flip = flip; a.relu = relu; a.f32_C = f32_C; a.tiletab = (const int4*)tiletab; a.ntiles = ntiles; a.f32_hw = total_rows;
+    const int k1skip = wc >> 8; wc &= 255;   // bit 8: the weights are zero for channels 32..63 of every chunk -> k-step 1 is skipped
     if (wc == 0) wc = 1;   // measured on MI355X: the 16x32-pixel x 64-cout tile (8 waves) beats the 16x16 x 128/192-cout tiles at every KGnet shape
     hipStream_t st = (hipStream_t)stream;
     if (KS == 7) {
         switch (wc) {
-            case 1: return launch_halo<7, 1, 8>(a, st);
+            case 1: return k1skip ? launch_halo<7, 1, 8, 2>(a, st) : launch_halo<7, 1, 8>(a, st);
             case 2: return launch_halo<7, 2, 4>(a, st);
             case 3: return launch_halo<7, 3, 4>(a, st);
         }
@@ -332,4 +409,23 @@ extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, v
     }
     kg_set_error("kg_conv2d_halo: bad wc %d", wc);
     return KG_ERR_ARG;
+}
+
+// The three second-layer 7x7 head convolutions of one scale (KGnet.py:161-209 `.2` layers + torch.sigmoid on kp :300) in
+// one launch.  x: fused hidden rows [N*H*W][ldx] = kp | short | mid hidden, C channels each (C % 64 == 0);
+// w: packed [64 virtual couts][49][3C] (kg_pack_weight_rows with the virtual row of every map channel; blocks of other
+// heads zero); bias64: bias per virtual cout; vmap[64] (device): virtual cout -> channel of (kp 0-4 | short 5-14 |
+// mid 15-54) or -1.  kp / sh / md: fp32 NCHW outputs [N][5|10|40][H][W].
+extern "C" int kg_conv2d_halo_heads2(const void* x, const void* w, const float* bias64, const int* vmap, float* kp, float* sh,
+                                     float* md, int N, int H, int W, int C, int ldx, int K, void* stream) {
+    HaloArgs a;
+    memset(&a, 0, sizeof(a));
+    KG_CHECK_ARG(x && w && vmap && kp && sh && md, "kg_conv2d_halo_heads2: null pointer");
+    KG_CHECK_ARG(C % 64 == 0 && C > 0 && ldx % 8 == 0 && ldx >= 3 * C, "kg_conv2d_halo_heads2: C must be a multiple of 64 (got %d)", C);
+    KG_CHECK_ARG(K >= 49 * 3 * C && N > 0 && H > 0 && W > 0, "kg_conv2d_halo_heads2: bad sizes");
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias64; a.y_f32 = kp; a.f32_b = sh; a.f32_c = md; a.vmap = vmap;
+    a.N = N; a.H = H; a.W = W; a.tiles_y = kg_cdiv(H, 16); a.cin_pad = 3 * C; a.ldx = ldx; a.Cout = 64; a.K = K;
+    a.grp_chunks = C / 64;
+    a.head_split = (long)N * kg_cdiv(H, 16) * kg_cdiv(W, 32) < 256;   // too few pixel tiles to fill 256 CUs
+    return launch_halo<7, 1, 8, 1>(a, (hipStream_t)stream);
 }

@@ -302,7 +302,7 @@ extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, 
 // writes 128-byte bf16 runs along co for every tap.
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int Cout,
                                                           int Cin, int taps, int K, int cin_pad, int row0, int c0,
-                                                          int transposed) {
+                                                          int transposed, const int* __restrict__ rowmap) {
     __shared__ float tile[64 * 50];
     if (!transposed) {
         const int co = blockIdx.x, ci0 = blockIdx.y * 64;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
         __syncthreads();
         for (int e = threadIdx.x; e < taps * 64; e += 256) {
             const int tap = e >> 6, ci = e & 63;
-            if (ci < nci) dst[(long)(row0 + co) * K + (long)tap * cin_pad + c0 + ci0 + ci] = f2bf(tile[ci * 50 + tap]);
+            if (ci < nci) dst[(long)(rowmap ? rowmap[co] : row0 + co) * K + (long)tap * cin_pad + c0 + ci0 + ci] = f2bf(tile[ci * 50 + tap]);
         }
     } else {
         const int co0 = blockIdx.x * 64, ci = blockIdx.y;
@@ -335,7 +335,18 @@ extern "C" int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int 
     KG_CHECK_ARG(KH * KW <= 49, "kg_pack_weight: at most 49 taps");
     dim3 grid = transposed ? dim3((Cout + 63) / 64, Cin) : dim3(Cout, (Cin + 63) / 64);
     hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, Cout,
-                       Cin, KH * KW, K, cin_pad, row0, c0, transposed);
+                       Cin, KH * KW, K, cin_pad, row0, c0, transposed, (const int*)nullptr);
     KG_CHECK_LAUNCH("pack_weight");
+    return KG_OK;
+}
+
+// forward packing with a row table: dst row of output channel co = rowmap[co] (device int array)
+extern "C" int kg_pack_weight_rows(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad,
+                                   const int* rowmap, int c0, void* stream) {
+    KG_CHECK_ARG(w && dst && rowmap, "kg_pack_weight_rows: null pointer");
+    KG_CHECK_ARG(KH * KW <= 49, "kg_pack_weight_rows: at most 49 taps");
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(Cout, (Cin + 63) / 64), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst,
+                       Cout, Cin, KH * KW, K, cin_pad, 0, c0, 0, rowmap);
+    KG_CHECK_LAUNCH("pack_weight_rows");
     return KG_OK;
 }

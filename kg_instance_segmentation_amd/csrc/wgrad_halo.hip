@@ -42,7 +42,9 @@ struct WgGeom {
     static constexpr int UNITS = T * CIF, UPW = (UNITS + 7) / 8;
 };
 
-template <int KS, int CIF>
+// NCF = 16-wide output-channel fragments that are computed (4 = all 64; 1 / 3 for the 5-, 10- and 40-channel second
+// head convs, whose dY tile is mostly padding: KGnet.py:161-209 `.2` layers)
+template <int KS, int CIF, int NCF = 4>
 __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     using GE = WgGeom<KS, CIF>;
     constexpr int PAD = GE::PAD, HWD = GE::HWD, HPIX = HWD * HWD, T = GE::T, XB = GE::XB, PITCH = GE::PITCH;
@@ -57,11 +59,11 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     const int split = blockIdx.y;
     const int G = lane >> 4, i16 = lane & 15;
 
-    f32x4 acc[UPW][4];
+    f32x4 acc[UPW][NCF];
 #pragma unroll
     for (int q = 0; q < UPW; ++q)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[q][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < NCF; ++c) acc[q][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- lane-constant fragment addresses (k-step 0); k-step s adds an immediate ------------------------------------
     // dY^T fragment c (co block), half h: tile row r = (G&1)*16 + (G>>1)*8 + h*4 + (i16>>2)   (+ s*32)
@@ -156,9 +158,9 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
         const unsigned char* sx = sy + DY_BYTES;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {       // k-step: the 32 pixels of tile rows 2s, 2s+1 (all offsets are immediates)
-            bf16x8 af[4];
+            bf16x8 af[NCF];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < NCF; ++c)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sy + ay[c][h] + s * 32 * 128));
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
                         bfr[h * 4 + 0] = v[0]; bfr[h * 4 + 1] = v[1]; bfr[h * 4 + 2] = v[2]; bfr[h * 4 + 3] = v[3];
                     }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
+                    for (int c = 0; c < NCF; ++c)
                         acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfr, acc[q][c], 0, 0, 0);
                 }
             }
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
         const int tap = u / CIF, f = u - tap * CIF;
         const int ci = ci0 + f * 16 + i16;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < NCF; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + c * 16 + G * 4 + r;
@@ -200,16 +202,16 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     }
 }
 
-template <int KS, int CIF>
+template <int KS, int CIF, int NCF = 4>
 static int launch_wg(const WgHaloArgs& a, hipStream_t st) {
     constexpr int smem = 2 * WgGeom<KS, CIF>::BUF;
     static bool attr_done = false;
     if (!attr_done) {
-        KG_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<KS, CIF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        KG_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<KS, CIF, NCF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
     const int n_ci = (a.cin_lim + 16 * CIF - 1) / (16 * CIF), n_co = (a.cout_lim + 63) / 64;
-    hipLaunchKernelGGL((wgrad_halo_kernel<KS, CIF>), dim3(n_ci * n_co, a.nsplit), dim3(512), smem, st, a);
+    hipLaunchKernelGGL((wgrad_halo_kernel<KS, CIF, NCF>), dim3(n_ci * n_co, a.nsplit), dim3(512), smem, st, a);
     KG_CHECK_LAUNCH("wgrad_halo");
     return KG_OK;
 }
@@ -230,6 +232,11 @@ extern "C" int kg_conv2d_wgrad_halo(const void* x, const void* dy, float* dwp, i
     a.cin_lim = cin_lim; a.cout_lim = cout_lim; a.nsplit = nsplit; a.split_stride = split_stride;
     a.tiletab = (const int4*)tiletab; a.ntiles = ntiles;
     hipStream_t st = (hipStream_t)stream;
-    if (KS == 7) return launch_wg<7, 1>(a, st);
+    if (KS == 7) {
+        if (cout_lim <= 16) return launch_wg<7, 1, 1>(a, st);
+        if (cout_lim <= 48) return launch_wg<7, 1, 3>(a, st);
+        return launch_wg<7, 1>(a, st);
+    }
+    if (cout_lim <= 16) return launch_wg<3, 4, 1>(a, st);   // seg_head.2 (64 -> 1)
     return launch_wg<3, 4>(a, st);
 }

@@ -322,24 +322,42 @@ class Engine:
     HEAD_OFF = (0, 8, 24)      # channel offsets of the kp / short / mid gradients in the fused [rows, 64] dY buffer
     HEAD_PAD = (8, 16, 40)
 
+    def heads2_tables(self, dev):
+        """Device tables of the fused second-layer head conv (ops.heads2_layout)."""
+        t = getattr(self, "_heads2", None)
+        if t is None or t["vmap"].device != dev:
+            rows, vmap = ops.heads2_layout()
+            vm = torch.tensor(vmap, dtype=torch.int32)
+            t = {"rows": [torch.tensor(r, dtype=torch.int32, device=dev) for r in rows], "vmap": vm.to(dev),
+                 "bias_idx": torch.where(vm < 0, torch.full_like(vm, 55), vm).long().to(dev),
+                 "zero1": torch.zeros(1, dtype=torch.float32, device=dev)}
+            self._heads2 = t
+        return t
+
     def heads_second(self, hid, lvl, C, N, H, W):
         """The three second 7x7 head convs (KGnet.py:161-209, `.2` layers) on the slices of the fused hidden tensor
-        hid [rows, 3C].  Forward: three fp32-NCHW-exporting convs.  Backward: per-head weight/bias gradients, and ONE
+        hid [rows, 3C].  Forward: ONE grouped launch (kg_conv2d_halo_heads2) exporting the three fp32 NCHW maps.  Backward: per-head weight/bias gradients, and ONE
         fused input-gradient conv: the three map gradients are packed side by side into a [rows, 64] buffer
         (8 | 16 | 40 channels) and multiplied by a block-structured transposed weight matrix [3C][49][64], which
         runs on the fast LDS-halo kernel instead of three tiny-K gather convs."""
         dev = hid.t.device
         train = self.tape is not None
-        specs, outs = [], []
-        for k, (h, co) in enumerate(arch.HEADS):
-            s = self.spec(f"{h}_head_c{lvl}.2", C, co, 7, 1, 3)
-            self.prepare(s, need_T=False)
-            o = torch.empty(N, co, H, W, dtype=torch.float32, device=dev)
-            geom = (N * H * W, H, W, H, W, 7, 7, 1, 3)
-            ops.conv_auto(hid.t[:, k * C:(k + 1) * C], s.pw, co, geom, N, y_f32=o, bias=s.bias_cat)
-            if h == "kp":
-                ops.sigmoid_(o)
-            specs.append(s); outs.append(o)
+        specs = [self.spec(f"{h}_head_c{lvl}.2", C, co, 7, 1, 3) for h, co in arch.HEADS]
+        ws = [self.P(s.names[0] + ".weight") for s in specs]
+        bs = [self.P(s.names[0] + ".bias") for s in specs]
+        ver = tuple(t._version for t in ws + bs) + tuple(t.data_ptr() for t in ws + bs)
+        key = f"heads_c{lvl}.2F"
+        ent = self.fusedT.get(key)
+        if ent is None or ent[0] != ver or ent[1].buf.device != dev:
+            lay = self.heads2_tables(dev)
+            pwF = ent[1] if ent is not None and ent[1].buf.device == dev else PackedWeight(64, 49, 3 * C, dev)
+            for k, w in enumerate(ws):
+                pwF.pack_rows(w.detach(), lay["rows"][k], c0=k * C)
+            bias64 = torch.cat([b.detach() for b in bs] + [lay["zero1"]])[lay["bias_idx"]]
+            self.fusedT[key] = (ver, pwF, bias64)
+        _, pwF, bias64 = self.fusedT[key]
+        outs = [torch.empty(N, co, H, W, dtype=torch.float32, device=dev) for _, co in arch.HEADS]
+        ops.conv_halo_heads2(hid.t, pwF, bias64, self.heads2_tables(dev)["vmap"], outs[0], outs[1], outs[2], N, H, W, C)
         slot = {"grad": None}
         self.head_slots.append((slot, lvl, N, H, W))
         if train:
@@ -369,7 +387,9 @@ class Engine:
                     self.param_grads[s.names[0] + ".weight"] = gw
                     self.param_grads[s.names[0] + ".bias"] = db
                 dh = torch.empty(hid.rows, 3 * C, dtype=BF16, device=dev)
-                ops.conv_auto(g, pwT, 3 * C, geom, N, y=dh, mask=hid.t, transposed=True)
+                # kp / short cout blocks only see dY channels 0..23 (k-step 1 of the chunk skipped); mid sees 24..63
+                ops.conv_halo(g, pwT, 2 * C, N, H, W, 7, y=dh[:, :2 * C], mask=hid.t[:, :2 * C], flip=True, k1skip=True)
+                ops.conv_halo(g, pwT.rows_from(2 * C), C, N, H, W, 7, y=dh[:, 2 * C:], mask=hid.t[:, 2 * C:], flip=True)
                 hid.add_grad(dh, masked=True)
             self.tape.append(bwd)
         return outs

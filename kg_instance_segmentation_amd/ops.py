@@ -64,6 +64,42 @@ class PackedWeight:
                   1 if transposed else 0, stream_ptr())
 
 
+    def rows_from(self, r0):
+        """View of the packed matrix starting at row r0 (a cout-block-aligned slice of a fused weight)."""
+        v = PackedWeight.__new__(PackedWeight)
+        v.rows, v.taps, v.cin_pad, v.K, v.buf = self.rows - r0, self.taps, self.cin_pad, self.K, self.buf[r0:]
+        return v
+
+    def pack_rows(self, w, rowmap, c0=0):
+        """forward packing of w (fp32 OIHW) with output channel co going to packed row rowmap[co] (device int32)."""
+        Cout, Cin, KH, KW = w.shape
+        assert w.dtype == torch.float32 and w.is_contiguous() and rowmap.dtype == torch.int32 and rowmap.numel() == Cout
+        _lib.call("kg_pack_weight_rows", ptr(w), ptr(self.buf), Cout, Cin, KH, KW, self.K, self.cin_pad, ptr(rowmap), c0,
+                  stream_ptr())
+
+
+def heads2_layout():
+    """Virtual-cout layout of the fused second-layer head conv (conv_halo.hip GM = 1): MFMA row group i owns the virtual
+    couts 16q + 4i + r.  Returns (rows, vmap): rows[h] = virtual cout of every channel of head h (kp 5, short 10, mid 40),
+    vmap[v] = channel in (kp 0-4 | short 5-14 | mid 15-54) or -1."""
+    grp = [[16 * q + 4 * i + r for q in range(4) for r in range(4)] for i in range(4)]
+    rows = [grp[0][:5], grp[1][:10], grp[2] + grp[3] + grp[0][5:13]]
+    vmap = [-1] * 64
+    base = (0, 5, 15)
+    for h in range(3):
+        for c, v in enumerate(rows[h]):
+            vmap[v] = base[h] + c
+    return rows, vmap
+
+
+def conv_halo_heads2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C):
+    """kg_conv2d_halo_heads2: x = fused hidden rows [N*H*W, >=3C]; kp/sh/md fp32 NCHW outputs (kp gets the sigmoid)."""
+    _rows(x)
+    assert kp.is_contiguous() and sh.is_contiguous() and md.is_contiguous() and vmap.dtype == torch.int32
+    _lib.call("kg_conv2d_halo_heads2", ptr(x), ptr(pw.buf), ptr(bias64), ptr(vmap), ptr(kp), ptr(sh), ptr(md), N, H, W, C,
+              ld(x), pw.K, stream_ptr())
+
+
 def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, mode=0,
                rowdesc=None, tile=0):
     """geom = (M, H, W, OH, OW, KH, KW, stride, pad): H, W = gathered tensor's dims, OH, OW = output dims."""
@@ -86,10 +122,14 @@ HALO_WC = int(__import__("os").environ.get("KG_HALO_WC", "0"))   # tuning overri
 
 
 def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, flip=False, wc=0,
-              tiletab=None, total_rows=0):
+              tiletab=None, total_rows=0, k1skip=False):
     """Stride-1 "same" KSxKS conv (or its input gradient when flip) with the input halo resident in LDS.
-    tiletab (int32 [ntiles,4] device tensor): ragged boxes instead of N images of HxW."""
+    tiletab (int32 [ntiles,4] device tensor): ragged boxes instead of N images of HxW.
+    k1skip (7x7 only): the packed weights are zero for channels 32..63 of every 64-channel chunk."""
     wc = wc or HALO_WC
+    if k1skip:
+        assert KS == 7 and wc in (0, 1)
+        wc = 1 | 256
     f32_C = 0
     if y_f32 is not None:
         f32_C = y_f32.shape[1] if y_f32.dim() == 4 else 1

@@ -379,7 +379,8 @@ def test_conv_halo_forward_and_dgrad(case):
 
 
 WGRAD_HALO_CASES = [(64, 64, 3, 2, 20, 28), (64, 192, 7, 1, 32, 32), (64, 5, 7, 1, 16, 24), (3, 64, 3, 1, 24, 24),
-                    (256, 128, 3, 1, 16, 16), (128, 64, 7, 2, 18, 21), (1024, 512, 3, 1, 8, 8)]
+                    (256, 128, 3, 1, 16, 16), (128, 64, 7, 2, 18, 21), (1024, 512, 3, 1, 8, 8),
+                    (64, 10, 7, 1, 20, 20), (128, 40, 7, 1, 17, 33), (64, 1, 3, 2, 19, 23)]
 
 
 @pytest.mark.parametrize("case", WGRAD_HALO_CASES)
@@ -404,7 +405,8 @@ def test_conv_wgrad_halo(case):
 
 
 @pytest.mark.parametrize("case", [(128, 64, 5000, True, True), (64, 128, 4096, False, False), (1024, 512, 777, True, True),
-                                  (256, 100, 300, False, True), (64, 64, 70000, True, False)])
+                                  (256, 100, 300, False, True), (64, 64, 70000, True, False), (64, 40, 1000, True, True),
+                                  (128, 256, 3333, False, True), (64, 12, 500, False, True)])
 def test_conv1x1_streaming(case):
     """kg_conv1x1 (persistent streaming GEMM) vs fp64 matmul, incl. residual / mask epilogue and channel-slice I/O."""
     K, cout, M, relu, bias = case
@@ -428,3 +430,30 @@ def test_conv1x1_streaming(case):
                 mask=msk.to(BF16).to(DEV), relu=relu)
     report(f"conv1x1{case}", ybuf[:, 32:].float().cpu(), ref, atol=3e-2, rtol=1e-2)
     assert float(ybuf[:, :32].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", [(64, 2, 40, 44), (128, 1, 16, 32), (256, 1, 33, 20)])
+def test_conv_halo_heads2(case):
+    """kg_conv2d_halo_heads2 (the three second-layer 7x7 head convs of one scale as ONE grouped launch, KGnet.py:161-209
+    `.2` + sigmoid :300) vs three fp64 F.conv2d on the slices of the fused hidden tensor."""
+    C, N, H, W = case
+    g = torch.Generator().manual_seed(C + H)
+    hid = bfr(torch.randn(N, 3 * C, H, W, generator=g).clamp_min(0))
+    rows, vmap = ops.heads2_layout()
+    assert sorted(v for v in vmap if v >= 0) == list(range(55)) and [len(r) for r in rows] == [5, 10, 40]
+    pw = PackedWeight(64, 49, 3 * C, DEV)
+    vm = torch.tensor(vmap, dtype=torch.int32, device=DEV)
+    bias64 = torch.zeros(64, device=DEV)
+    refs, outs = [], []
+    for k, co in enumerate((5, 10, 40)):
+        w = bfr(torch.randn(co, C, 7, 7, generator=g) / math.sqrt(49 * C))
+        b = torch.randn(co, generator=g)
+        r = F.conv2d(hid[:, k * C:(k + 1) * C].double(), w.double(), b.double(), 1, 3)
+        refs.append(torch.sigmoid(r) if k == 0 else r)
+        rm = torch.tensor(rows[k], dtype=torch.int32, device=DEV)
+        pw.pack_rows(w.to(DEV), rm, c0=k * C)
+        bias64[rm.long()] = b.to(DEV)
+        outs.append(torch.full((N, co, H, W), float("nan"), dtype=torch.float32, device=DEV))
+    ops.conv_halo_heads2(rows_of(hid).to(DEV), pw, bias64, vm, outs[0], outs[1], outs[2], N, H, W, C)
+    for name, o, r in zip(("kp", "short", "mid"), outs, refs):
+        report(f"heads2{case}.{name}", o.cpu(), r, atol=2e-3, rtol=2e-3)

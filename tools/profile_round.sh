@@ -1,0 +1,20 @@
+#!/bin/bash
+# Regenerates the measurement artefacts of a round on a GPU box (run through gpurun from the repo root):
+#   bash tools/profile_round.sh r01
+# Writes gpurun_out/<tag>_*: bench JSON (with cpu_baseline), rocprofv3 kernel-trace summary of the same command,
+# per-launch dump, and two separate PMC passes (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md prescribes.
+tag=${1:-r01}
+R=$PWD
+O=$R/gpurun_out
+mkdir -p $O
+export TMPDIR=/tmp
+python bench.py --steps 10 --warmup 3 > $O/${tag}_bench_n1.json 2> $O/${tag}_bench.err
+KG_BENCH_DUMP=$O/${tag}_bench_launches.txt python bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/${tag}_prof -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timer > $O/${tag}_prof.log 2>&1
+python $R/tools/rocprof_summary.py $(find $O/${tag}_prof -name "*.db" | head -1) $O/${tag}_bench_kernel_stats.csv 13 >> $O/${tag}_prof.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${tag}_pmc_rd -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer > $O/${tag}_pmc_rd.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${tag}_pmc_wr -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer > $O/${tag}_pmc_wr.log 2>&1
+python $R/tools/pmc_summary.py $O/${tag}_pmc_hbm.json $(find $O/${tag}_pmc_rd $O/${tag}_pmc_wr -name "*counter_collection.csv") >> $O/${tag}_prof.log 2>&1
+rm -rf $O/${tag}_pmc_rd $O/${tag}_pmc_wr   # raw per-dispatch CSVs are large
+tail -3 $O/${tag}_prof.log; cat $O/${tag}_bench_n1.json | cut -c1-600
