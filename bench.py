@@ -88,7 +88,8 @@ class KernelTimer:
             wc = 1
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); r = orig_halo(x, pw, cout, N, H, W, KS, *a, **k); e.record()
-            timer.rec.append((f"conv_halo<{KS},{wc}>", 2.0 * N * H * W * cout * KS * KS * pw.cin_pad, s, e, f"N={N} H={H} cout={cout} cinp={pw.cin_pad}"))
+            cin = k.get("algo_cin") or pw.cin_pad     # fused second-layer head dgrad: 5 / 10 / 40 real dY channels per head
+            timer.rec.append((f"conv_halo<{KS},{wc}>", 2.0 * N * H * W * cout * KS * KS * cin, s, e, f"N={N} H={H} cout={cout} cinp={pw.cin_pad}" + (f" algo_cin={cin}" if "algo_cin" in k else "")))
             return r
         orig_1x1 = ops.conv1x1
 
@@ -205,7 +206,7 @@ def main():
     ldec, lseg = DetectionLossAll(kp_radius=5), SEG_loss(height=args.size, width=args.size)
     x, gt, gt_masks, gt_boxes = make_batch(args.batch, args.size, args.boxes, 100 + rank, dev)
     den = parallel.detection_denominators(gt) if world > 1 else None
-    reducer = parallel.GradReducer(model.parameters()) if world > 1 else None
+    reducer = parallel.GradReducer(model.parameters()).attach(model) if world > 1 else None
     timer = KernelTimer()
     if not args.no_kernel_timer:
         timer.install()

@@ -74,6 +74,7 @@ class Engine:
         self.param_grads = None
         self.fusedT = {}
         self.head_slots = []
+        self.grad_hook = None      # parallel.GradReducer.attach: called with [(key, grad)] as backward produces them
 
     # ---- parameters ---------------------------------------------------------------------------
     def P(self, key):
@@ -388,8 +389,8 @@ class Engine:
                     self.param_grads[s.names[0] + ".bias"] = db
                 dh = torch.empty(hid.rows, 3 * C, dtype=BF16, device=dev)
                 # kp / short cout blocks only see dY channels 0..23 (k-step 1 of the chunk skipped); mid sees 24..63
-                ops.conv_halo(g, pwT, 2 * C, N, H, W, 7, y=dh[:, :2 * C], mask=hid.t[:, :2 * C], flip=True, k1skip=True)
-                ops.conv_halo(g, pwT.rows_from(2 * C), C, N, H, W, 7, y=dh[:, 2 * C:], mask=hid.t[:, 2 * C:], flip=True)
+                ops.conv_halo(g, pwT, 2 * C, N, H, W, 7, y=dh[:, :2 * C], mask=hid.t[:, :2 * C], flip=True, k1skip=True, algo_cin=7.5)
+                ops.conv_halo(g, pwT.rows_from(2 * C), C, N, H, W, 7, y=dh[:, 2 * C:], mask=hid.t[:, 2 * C:], flip=True, algo_cin=40)
                 hid.add_grad(dh, masked=True)
             self.tape.append(bwd)
         return outs
@@ -414,8 +415,14 @@ class Engine:
         for fv, g in zip(self.feats, feat_grads):
             if g is not None:
                 fv.add_grad(g, masked=False)
+        hook = self.grad_hook
         for fn in reversed(self.tape):
+            n0 = len(self.param_grads)
             fn()
+            if hook is not None and len(self.param_grads) > n0:      # data-parallel: parameter gradients whose kernels are
+                hook(list(self.param_grads.items())[n0:], False)    # enqueued go to the bucketed all-reduce right away
+        if hook is not None:
+            hook([], True)
         self.tape = None
         grads = self.param_grads
         self.param_grads = {}

@@ -122,10 +122,11 @@ HALO_WC = int(__import__("os").environ.get("KG_HALO_WC", "0"))   # tuning overri
 
 
 def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, flip=False, wc=0,
-              tiletab=None, total_rows=0, k1skip=False):
+              tiletab=None, total_rows=0, k1skip=False, algo_cin=None):
     """Stride-1 "same" KSxKS conv (or its input gradient when flip) with the input halo resident in LDS.
     tiletab (int32 [ntiles,4] device tensor): ragged boxes instead of N images of HxW.
-    k1skip (7x7 only): the packed weights are zero for channels 32..63 of every 64-channel chunk."""
+    k1skip (7x7 only): the packed weights are zero for channels 32..63 of every 64-channel chunk.
+    algo_cin: number of input channels that carry data (FLOP accounting of bench.py's timer; unused here)."""
     wc = wc or HALO_WC
     if k1skip:
         assert KS == 7 and wc in (0, 1)
