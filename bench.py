@@ -49,7 +49,7 @@ def make_batch(N, S, nboxes, seed, dev):
 class KernelTimer:
     """HIP-event brackets around every kg_conv2d_igemm / kg_conv2d_wgrad launch on the launch stream."""
 
-    DOMINANT = "conv_halo<7,1>"    # the 7x7 LDS-halo kernel (forward + input gradient of the head convs)
+    DOMINANT = "conv_halo<7,1>"    # conv_halo_kernel<7,1,8,0>: the 7x7 LDS-halo kernel (forward + input gradient of the head convs)
 
     def __init__(self):
         self.rec = []
@@ -89,7 +89,7 @@ class KernelTimer:
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); r = orig_halo(x, pw, cout, N, H, W, KS, *a, **k); e.record()
             cin = k.get("algo_cin") or pw.cin_pad     # fused second-layer head dgrad: 5 / 10 / 40 real dY channels per head
-            timer.rec.append((f"conv_halo<{KS},{wc}>", 2.0 * N * H * W * cout * KS * KS * cin, s, e, f"N={N} H={H} cout={cout} cinp={pw.cin_pad}" + (f" algo_cin={cin}" if "algo_cin" in k else "")))
+            timer.rec.append((f"conv_halo<{KS},{wc}>" + ("k1skip" if k.get("k1skip") else ""), 2.0 * N * H * W * cout * KS * KS * cin, s, e, f"N={N} H={H} cout={cout} cinp={pw.cin_pad}" + (f" algo_cin={cin}" if "algo_cin" in k else "")))
             return r
         orig_1x1 = ops.conv1x1
 
@@ -269,7 +269,7 @@ def main():
         dom = timer.summary(dom_rec).get(KernelTimer.DOMINANT)
         if dom:
             ach = dom["flops"] / dom["seconds"] / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel<7,1,8> (7x7 head convs, forward + input gradient)",
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel<7,1,8,0> (7x7 head convs, forward + input gradient)",
                                "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
                                "traffic": pmc_traffic(), "avg_launch_ms": 1e3 * dom["seconds"] / dom["launches"],
                                "launches": dom["launches"], "share_of_step": dom["seconds"] / dt,
