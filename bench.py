@@ -202,7 +202,8 @@ def main():
     torch.manual_seed(1234)
     model = KGnet.resnet50(pretrained=False).to(dev).train()
     parallel.broadcast_parameters(model)
-    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4)   # train.py:71
+    # train.py:71 (torch.optim.Adam is caller code; `fused=True` selects PyTorch's single-kernel multi-tensor implementation)
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4, fused=os.environ.get("KG_ADAM_FUSED", "1") == "1")
     ldec, lseg = DetectionLossAll(kp_radius=5), SEG_loss(height=args.size, width=args.size)
     x, gt, gt_masks, gt_boxes = make_batch(args.batch, args.size, args.boxes, 100 + rank, dev)
     den = parallel.detection_denominators(gt) if world > 1 else None

@@ -263,10 +263,72 @@ __global__ void bias_grad_final_kernel(const float* __restrict__ part, float* __
     if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
 }
 
+// Vector variant (C % 8 == 0, 16-byte aligned rows): a thread owns one 16-byte channel chunk and a row lane, keeps 4 row
+// loads in flight, and the row lanes of a workgroup are combined through LDS in fixed order.
+__global__ __launch_bounds__(256) void bias_grad_vec_kernel(const bf16_t* __restrict__ dy, float* __restrict__ part, int M, int C8,
+                                                            int ld, int rows_per_block, int nrl) {
+    __shared__ float red[256 * 8];
+    const int c8 = threadIdx.x % C8, rl = threadIdx.x / C8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int r0 = blockIdx.x * rows_per_block, r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    if (rl < nrl) {
+        const bf16_t* p = dy + c8 * 8;
+        int r = r0 + rl;
+        for (; r + 3 * nrl < r1; r += 4 * nrl) {
+            uint4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const uint4*>(p + (long)(r + q * nrl) * ld);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16_t* e = reinterpret_cast<const bf16_t*>(&v[q]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += bf2f(e[k]);
+            }
+        }
+        for (; r < r1; r += nrl) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p + (long)r * ld);
+            const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += bf2f(e[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[k * 256 + threadIdx.x] = acc[k];
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float t = 0.f;
+            for (int q = 0; q < nrl; ++q) t += red[k * 256 + q * C8 + c8];
+            part[(long)blockIdx.x * (C8 * 8) + c8 * 8 + k] = t;
+        }
+    }
+}
+
 extern "C" int kg_bias_grad(const void* dy, float* db, float* scratch, int scratch_floats, int M, int C, int ld,
                             int accumulate, void* stream) {
     KG_CHECK_ARG(dy && db && scratch, "kg_bias_grad: null pointer");
     KG_CHECK_ARG(C >= 1 && M >= 1, "kg_bias_grad: empty problem");
+    if (C % 8 == 0 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
+        for (int c0 = 0; c0 < C; c0 += 2048) {   // slabs of <= 256 chunks
+            const int Cs = C - c0 < 2048 ? C - c0 : 2048, C8 = Cs / 8;
+            const int nrl = 256 / C8;
+            int nb = scratch_floats / Cs;
+            if (nb > 2048) nb = 2048;
+            int need = (M + 4 * nrl - 1) / (4 * nrl);
+            if (nb > need) nb = need;
+            KG_CHECK_ARG(nb >= 1, "kg_bias_grad: scratch too small");
+            int rpb = (M + nb - 1) / nb;
+            nb = (M + rpb - 1) / rpb;
+            hipLaunchKernelGGL(bias_grad_vec_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy + c0, scratch, M,
+                               C8, ld, rpb, nrl);
+            hipLaunchKernelGGL(bias_grad_final_kernel, dim3(Cs), dim3(64), 0, (hipStream_t)stream, scratch, db + c0, nb, Cs,
+                               accumulate);
+        }
+        KG_CHECK_LAUNCH("bias_grad");
+        return KG_OK;
+    }
     for (int c0 = 0; c0 < C; c0 += 1024) {   // channel slabs of <= 1024 (one thread per channel and row lane)
         const int Cs = C - c0 < 1024 ? C - c0 : 1024;
         int nrl = 1024 / Cs;

@@ -378,15 +378,15 @@ class Engine:
                 g = slot["grad"]      # [rows, 64] packed map gradients (set by backward_dec)
                 if g is None:
                     return
+                db64 = torch.empty(64, dtype=torch.float32, device=dev)
+                ops.bias_grad(g, 64, db64)           # one pass over the packed buffer for the three bias gradients
                 for k, ((h, co), s) in enumerate(zip(arch.HEADS, specs)):
                     gk = g[:, self.HEAD_OFF[k]:self.HEAD_OFF[k] + self.HEAD_PAD[k]]
                     w = self.P(s.names[0] + ".weight")
                     gw = torch.empty_like(w)
                     ops.conv_wgrad(hid.t[:, k * C:(k + 1) * C], gk, C, co, geom, [(gw, 0, co)], N=N)
-                    db = torch.empty(co, dtype=torch.float32, device=dev)
-                    ops.bias_grad(gk, co, db)
                     self.param_grads[s.names[0] + ".weight"] = gw
-                    self.param_grads[s.names[0] + ".bias"] = db
+                    self.param_grads[s.names[0] + ".bias"] = db64[self.HEAD_OFF[k]:self.HEAD_OFF[k] + co]
                 dh = torch.empty(hid.rows, 3 * C, dtype=BF16, device=dev)
                 # kp / short cout blocks only see dY channels 0..23 (k-step 1 of the chunk skipped); mid sees 24..63
                 ops.conv_halo(g, pwT, 2 * C, N, H, W, 7, y=dh[:, :2 * C], mask=hid.t[:, :2 * C], flip=True, k1skip=True, algo_cin=7.5)

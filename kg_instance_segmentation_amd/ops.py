@@ -220,7 +220,7 @@ def ctypes_offset(t, elem_off):
 
 def bias_grad(dy, C, db, accumulate=False):
     _rows(dy)
-    sc = scratch_f32(1024 * max(C, 1), dy.device, "bias")
+    sc = scratch_f32(2048 * max(C, 1), dy.device, "bias")
     _lib.call("kg_bias_grad", ptr(dy), ptr(db), ptr(sc), sc.numel(), dy.shape[0], C, ld(dy), 1 if accumulate else 0, stream_ptr())
 
 
