@@ -236,8 +236,10 @@ def main():
     timer.only_dominant = True
     t0 = time.perf_counter()
     last = None
+    marks = []
     for _ in range(args.steps):
         last = step()
+        marks.append(time.perf_counter())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -257,6 +259,8 @@ def main():
         timer.on = False
     if rank != 0:
         return
+    if os.environ.get("KG_BENCH_VERBOSE"):
+        print("per-step host ms:", [round(1e3 * (b - a), 1) for a, b in zip([t0] + marks[:-1], marks)], file=sys.stderr)
     imgs = args.batch * world * args.steps
     out = {"metric": "imgs/s (train fwd+bwd) at 512x512", "value": imgs / dt, "unit": "imgs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,

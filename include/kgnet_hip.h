@@ -55,6 +55,10 @@ int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW,
 /* forward packing with a row table: packed row of output channel co = rowmap[co] (device int array) */
 int kg_pack_weight_rows(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad, const int* rowmap,
                         int c0, void* stream);
+/* all (re)packs of a step in one launch: jobs = device array of 64-byte records {const float* w; void* dst; const int* rowmap;
+ * int Cout, Cin, taps, K, cin_pad, row0, c0, transposed, gx, blk0;} (gx = Cout, or ceil(Cout/64) when transposed; blk0 = first
+ * workgroup of the job); total_blocks = sum of gx * gy over the jobs */
+int kg_pack_weight_batch(const void* jobs, int njobs, int total_blocks, void* stream);
 /* weight gradient (autograd of nn.Conv2d at train.py:153): partial sums [nsplit][Cout][taps][Cin] fp32 */
 int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const int* rowdesc, int M, int H, int W, int OH, int OW,
                     int ldx, int lddy, int Cin, int Cout, int cin_lim, int cout_lim, int KH, int KW, int stride, int pad,

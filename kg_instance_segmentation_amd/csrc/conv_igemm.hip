@@ -300,12 +300,11 @@ extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, 
 // forward: one block per (co, 64-ci chunk): contiguous fp32 reads [ci][tap], LDS transpose, 128-byte bf16 writes
 // along ci for every tap.  transposed: one block per (64-co chunk, ci): reads `taps` contiguous floats per co,
 // writes 128-byte bf16 runs along co for every tap.
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int Cout,
-                                                          int Cin, int taps, int K, int cin_pad, int row0, int c0,
-                                                          int transposed, const int* __restrict__ rowmap) {
-    __shared__ float tile[64 * 50];
+__device__ __forceinline__ void pack_weight_block(float* tile, const float* __restrict__ w, bf16_t* __restrict__ dst, int Cout, int Cin,
+                                                  int taps, int K, int cin_pad, int row0, int c0, int transposed,
+                                                  const int* __restrict__ rowmap, int bx, int by) {
     if (!transposed) {
-        const int co = blockIdx.x, ci0 = blockIdx.y * 64;
+        const int co = bx, ci0 = by * 64;
         const int nci = Cin - ci0 < 64 ? Cin - ci0 : 64;
         const float* src = w + ((long)co * Cin + ci0) * taps;
         for (int j = threadIdx.x; j < nci * taps; j += 256) { int ci = j / taps, tap = j - ci * taps; tile[ci * 50 + tap] = src[j]; }
@@ -315,7 +314,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
             if (ci < nci) dst[(long)(rowmap ? rowmap[co] : row0 + co) * K + (long)tap * cin_pad + c0 + ci0 + ci] = f2bf(tile[ci * 50 + tap]);
         }
     } else {
-        const int co0 = blockIdx.x * 64, ci = blockIdx.y;
+        const int co0 = bx * 64, ci = by;
         const int nco = Cout - co0 < 64 ? Cout - co0 : 64;
         for (int j = threadIdx.x; j < nco * taps; j += 256) {
             int co = j / taps, tap = j - co * taps;
@@ -327,6 +326,30 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
             if (co < nco) dst[(long)(row0 + ci) * K + (long)tap * cin_pad + c0 + co0 + co] = f2bf(tile[co * 50 + tap]);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int Cout,
+                                                          int Cin, int taps, int K, int cin_pad, int row0, int c0,
+                                                          int transposed, const int* __restrict__ rowmap) {
+    __shared__ float tile[64 * 50];
+    pack_weight_block(tile, w, dst, Cout, Cin, taps, K, cin_pad, row0, c0, transposed, rowmap, blockIdx.x, blockIdx.y);
+}
+
+// All weight (re)packs of a training step in ONE launch: the 170+ per-tensor launches were launch-bound (5 us each).
+struct PackJob {   // 64 bytes, mirrored by ops.PackQueue
+    const float* w; bf16_t* dst; const int* rowmap;
+    int Cout, Cin, taps, K, cin_pad, row0, c0, transposed, gx, blk0;
+};
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    __shared__ float tile[64 * 50];
+    int lo = 0, hi = njobs - 1;          // last job whose first block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJob j = jobs[lo];
+    const int b = blockIdx.x - j.blk0;
+    pack_weight_block(tile, j.w, j.dst, j.Cout, j.Cin, j.taps, j.K, j.cin_pad, j.row0, j.c0, j.transposed, j.rowmap, b % j.gx, b / j.gx);
 }
 
 extern "C" int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad,
@@ -348,5 +371,15 @@ extern "C" int kg_pack_weight_rows(const float* w, void* dst, int Cout, int Cin,
     hipLaunchKernelGGL(pack_weight_kernel, dim3(Cout, (Cin + 63) / 64), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst,
                        Cout, Cin, KH * KW, K, cin_pad, 0, c0, 0, rowmap);
     KG_CHECK_LAUNCH("pack_weight_rows");
+    return KG_OK;
+}
+
+// jobs: device array of njobs PackJob records (see struct PackJob: {w, dst, rowmap, Cout, Cin, taps, K, cin_pad, row0, c0,
+// transposed, gx, blk0}; gx = grid x of the job = Cout (forward) or ceil(Cout/64) (transposed), blk0 = first block of the
+// job in this launch); total_blocks = sum of the jobs' gx * gy.
+extern "C" int kg_pack_weight_batch(const void* jobs, int njobs, int total_blocks, void* stream) {
+    KG_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "kg_pack_weight_batch: empty batch");
+    hipLaunchKernelGGL(pack_weight_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs, njobs);
+    KG_CHECK_LAUNCH("pack_weight_batch");
     return KG_OK;
 }

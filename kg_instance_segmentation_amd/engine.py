@@ -64,6 +64,7 @@ class ConvSpec:
         self.pwT = None      # dgrad packed weights
         self.bias_cat = None
         self.versions = None
+        self.used, self.need_T_last = False, False
 
 
 class Engine:
@@ -74,6 +75,7 @@ class Engine:
         self.param_grads = None
         self.fusedT = {}
         self.head_slots = []
+        self.heads2_seen = {}
         self.grad_hook = None      # parallel.GradReducer.attach: called with [(key, grad)] as backward produces them
 
     # ---- parameters ---------------------------------------------------------------------------
@@ -89,8 +91,22 @@ class Engine:
             self.specs[key] = s
         return s
 
+    def prepare_all(self, train):
+        """Queues the (re)packs of every conv seen in earlier steps so that the first conv launch of this step packs them
+        all with one kernel (ops.PackQueue); specs / levels not seen yet are packed lazily as before."""
+        ops.PACKQ.defer = True
+        try:
+            for s in self.specs.values():
+                if s.used:
+                    self.prepare(s, need_T=train and s.need_T_last)
+            for lvl, (C, dev) in self.heads2_seen.items():
+                self.prepare_heads2(lvl, C, dev, train)
+        finally:
+            ops.PACKQ.defer = False
+
     def prepare(self, s, need_T):
         """(Re)pack weights when the fp32 master parameters changed (tracked by tensor versions)."""
+        s.used, s.need_T_last = True, need_T
         ws = [self.P(n + ".weight") for n in s.names]
         ver = tuple(w._version for w in ws) + tuple(w.data_ptr() for w in ws)
         dev = ws[0].device
@@ -268,6 +284,7 @@ class Engine:
         dev = img.device
         self.tape = [] if record else None
         self.param_grads = {}
+        self.prepare_all(record)
         x8 = Var(ops.img_pack(img), 8, relu=False, req=False)
         dims = [(H, W)]
         # c0 branch (KGnet.py:276): both convs at full resolution; c0 lands in cat0[:, 64:128]
@@ -335,14 +352,10 @@ class Engine:
             self._heads2 = t
         return t
 
-    def heads_second(self, hid, lvl, C, N, H, W):
-        """The three second 7x7 head convs (KGnet.py:161-209, `.2` layers) on the slices of the fused hidden tensor
-        hid [rows, 3C].  Forward: ONE grouped launch (kg_conv2d_halo_heads2) exporting the three fp32 NCHW maps.  Backward: per-head weight/bias gradients, and ONE
-        fused input-gradient conv: the three map gradients are packed side by side into a [rows, 64] buffer
-        (8 | 16 | 40 channels) and multiplied by a block-structured transposed weight matrix [3C][49][64], which
-        runs on the fast LDS-halo kernel instead of three tiny-K gather convs."""
-        dev = hid.t.device
-        train = self.tape is not None
+    def prepare_heads2(self, lvl, C, dev, train):
+        """Packed weights of the second-layer head convs of level lvl: forward (virtual-cout layout, + bias64) and, when
+        training, the block-structured transposed matrix of the fused input gradient."""
+        self.heads2_seen[lvl] = (C, dev)
         specs = [self.spec(f"{h}_head_c{lvl}.2", C, co, 7, 1, 3) for h, co in arch.HEADS]
         ws = [self.P(s.names[0] + ".weight") for s in specs]
         bs = [self.P(s.names[0] + ".bias") for s in specs]
@@ -357,14 +370,10 @@ class Engine:
             bias64 = torch.cat([b.detach() for b in bs] + [lay["zero1"]])[lay["bias_idx"]]
             self.fusedT[key] = (ver, pwF, bias64)
         _, pwF, bias64 = self.fusedT[key]
-        outs = [torch.empty(N, co, H, W, dtype=torch.float32, device=dev) for _, co in arch.HEADS]
-        ops.conv_halo_heads2(hid.t, pwF, bias64, self.heads2_tables(dev)["vmap"], outs[0], outs[1], outs[2], N, H, W, C)
-        slot = {"grad": None}
-        self.head_slots.append((slot, lvl, N, H, W))
+        pwT = None
         if train:
             key = f"heads_c{lvl}.2T"
             ent = self.fusedT.get(key)
-            ws = [self.P(s.names[0] + ".weight") for s in specs]
             ver = tuple(w._version for w in ws) + tuple(w.data_ptr() for w in ws)
             if ent is None or ent[0] != ver or ent[1].buf.device != dev:
                 pwT = ent[1] if ent is not None and ent[1].buf.device == dev else PackedWeight(3 * C, 49, 64, dev)
@@ -372,6 +381,23 @@ class Engine:
                     pwT.pack(w.detach(), row0=k * C, c0=self.HEAD_OFF[k], transposed=True)
                 self.fusedT[key] = (ver, pwT)
             pwT = self.fusedT[key][1]
+        return pwF, bias64, pwT
+
+    def heads_second(self, hid, lvl, C, N, H, W):
+        """The three second 7x7 head convs (KGnet.py:161-209, `.2` layers) on the slices of the fused hidden tensor
+        hid [rows, 3C].  Forward: ONE grouped launch (kg_conv2d_halo_heads2) exporting the three fp32 NCHW maps.  Backward: per-head weight/bias gradients, and ONE
+        fused input-gradient conv: the three map gradients are packed side by side into a [rows, 64] buffer
+        (8 | 16 | 40 channels) and multiplied by a block-structured transposed weight matrix [3C][49][64], which
+        runs on the fast LDS-halo kernel instead of three tiny-K gather convs."""
+        dev = hid.t.device
+        train = self.tape is not None
+        specs = [self.spec(f"{h}_head_c{lvl}.2", C, co, 7, 1, 3) for h, co in arch.HEADS]
+        pwF, bias64, pwT = self.prepare_heads2(lvl, C, dev, train)
+        outs = [torch.empty(N, co, H, W, dtype=torch.float32, device=dev) for _, co in arch.HEADS]
+        ops.conv_halo_heads2(hid.t, pwF, bias64, self.heads2_tables(dev)["vmap"], outs[0], outs[1], outs[2], N, H, W, C)
+        slot = {"grad": None}
+        self.head_slots.append((slot, lvl, N, H, W))
+        if train:
             geom = (N * H * W, H, W, H, W, 7, 7, 1, 3)
 
             def bwd():

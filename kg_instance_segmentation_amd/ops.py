@@ -48,6 +48,47 @@ def round_up(a, b):
     return (a + b - 1) // b * b
 
 
+class PackQueue:
+    """Deferred weight (re)packs: while `defer` is set, PackedWeight.pack / pack_rows only record a job; flush() (called by
+    every conv wrapper) packs all recorded tensors with ONE kg_pack_weight_batch launch.  The job table is uploaded only
+    when it differs from the previous step's (same tensors -> same pointers)."""
+
+    def __init__(self):
+        self.defer = False
+        self.jobs, self.keep = [], []
+        self.sig, self.table = None, None
+
+    def add(self, w, pw, row0, c0, transposed, rowmap):
+        Cout, Cin, KH, KW = w.shape
+        gx = (Cout + 63) // 64 if transposed else Cout
+        gy = Cin if transposed else (Cin + 63) // 64
+        self.jobs.append((w.data_ptr(), pw.buf.data_ptr(), rowmap.data_ptr() if rowmap is not None else 0, Cout, Cin, KH * KW,
+                          pw.K, pw.cin_pad, row0, c0, 1 if transposed else 0, gx, gx * gy))
+        self.keep.append((w, pw, rowmap))
+
+    def flush(self):
+        if not self.jobs:
+            return
+        import numpy as np
+        dt = np.dtype([("w", "<u8"), ("dst", "<u8"), ("rowmap", "<u8")] + [(n, "<i4") for n in
+                      ("Cout", "Cin", "taps", "K", "cin_pad", "row0", "c0", "transposed", "gx", "blk0")])
+        arr = np.zeros(len(self.jobs), dt)
+        blk = 0
+        for i, j in enumerate(self.jobs):
+            arr[i] = j[:12] + (blk,)
+            blk += j[12]
+        dev = self.keep[0][0].device
+        sig = arr.tobytes()
+        if sig != self.sig or self.table is None or self.table.device != dev:
+            self.table = h2d(arr.view(np.uint8).reshape(-1), dev)
+            self.sig = sig
+        _lib.call("kg_pack_weight_batch", ptr(self.table), len(self.jobs), blk, stream_ptr())
+        self.jobs, self.keep = [], []
+
+
+PACKQ = PackQueue()
+
+
 class PackedWeight:
     """bf16 [rows_pad][K] matrix for kg_conv2d_igemm: K = taps * cin_pad (padded to 64)."""
 
@@ -60,6 +101,9 @@ class PackedWeight:
         """w: fp32 OIHW parameter.  forward: rows=Cout, channels=Cin; transposed (dgrad): rows=Cin, channels=Cout."""
         Cout, Cin, KH, KW = w.shape
         assert w.dtype == torch.float32 and w.is_contiguous()
+        if PACKQ.defer:
+            PACKQ.add(w, self, row0, c0, transposed, None)
+            return
         _lib.call("kg_pack_weight", ptr(w), ptr(self.buf), Cout, Cin, KH, KW, self.K, self.cin_pad, row0, c0,
                   1 if transposed else 0, stream_ptr())
 
@@ -74,6 +118,9 @@ class PackedWeight:
         """forward packing of w (fp32 OIHW) with output channel co going to packed row rowmap[co] (device int32)."""
         Cout, Cin, KH, KW = w.shape
         assert w.dtype == torch.float32 and w.is_contiguous() and rowmap.dtype == torch.int32 and rowmap.numel() == Cout
+        if PACKQ.defer:
+            PACKQ.add(w, self, 0, c0, False, rowmap)
+            return
         _lib.call("kg_pack_weight_rows", ptr(w), ptr(self.buf), Cout, Cin, KH, KW, self.K, self.cin_pad, ptr(rowmap), c0,
                   stream_ptr())
 
@@ -94,6 +141,8 @@ def heads2_layout():
 
 def conv_halo_heads2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C):
     """kg_conv2d_halo_heads2: x = fused hidden rows [N*H*W, >=3C]; kp/sh/md fp32 NCHW outputs (kp gets the sigmoid)."""
+    if PACKQ.jobs:
+        PACKQ.flush()
     _rows(x)
     assert kp.is_contiguous() and sh.is_contiguous() and md.is_contiguous() and vmap.dtype == torch.int32
     _lib.call("kg_conv2d_halo_heads2", ptr(x), ptr(pw.buf), ptr(bias64), ptr(vmap), ptr(kp), ptr(sh), ptr(md), N, H, W, C,
@@ -103,6 +152,8 @@ def conv_halo_heads2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C):
 def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, mode=0,
                rowdesc=None, tile=0):
     """geom = (M, H, W, OH, OW, KH, KW, stride, pad): H, W = gathered tensor's dims, OH, OW = output dims."""
+    if PACKQ.jobs:
+        PACKQ.flush()
     M, H, W, OH, OW, KH, KW, stride, pad = geom
     _rows(x)
     f32_C = 0
@@ -127,6 +178,8 @@ def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None,
     tiletab (int32 [ntiles,4] device tensor): ragged boxes instead of N images of HxW.
     k1skip (7x7 only): the packed weights are zero for channels 32..63 of every 64-channel chunk.
     algo_cin: number of input channels that carry data (FLOP accounting of bench.py's timer; unused here)."""
+    if PACKQ.jobs:
+        PACKQ.flush()
     wc = wc or HALO_WC
     if k1skip:
         assert KS == 7 and wc in (0, 1)
@@ -145,6 +198,8 @@ USE_1X1 = True
 
 def conv1x1(x, pw, cout, y, bias=None, res=None, mask=None, relu=False):
     """1x1 stride-1 conv / input gradient as a streaming GEMM over the rows of x (kg_conv1x1)."""
+    if PACKQ.jobs:
+        PACKQ.flush()
     _lib.call("kg_conv1x1", ptr(_rows(x)), ptr(pw.buf), ptr(bias), ptr(_rows(y)), ptr(res), ptr(mask), c_long(x.shape[0]),
               pw.cin_pad, pw.K, ld(x), cout, ld(y), ld(res) if res is not None else 0, ld(mask) if mask is not None else 0,
               1 if relu else 0, stream_ptr())

@@ -111,6 +111,15 @@ class SegBranch:
     def P(self, k):
         return self.m.get_tensor(k)
 
+    def prepare_all(self, train):
+        """Queues the (re)packs of all weights seen in earlier steps for one batched launch (ops.PackQueue)."""
+        ops.PACKQ.defer = True
+        try:
+            for key, e in list(self.packed.items()):
+                self.packw(key, need_T=train and e.get("need_T", False))
+        finally:
+            ops.PACKQ.defer = False
+
     def packw(self, key, need_T):
         """key -> (PackedWeight fwd, PackedWeight dgrad, bias) repacked when the parameter version changes."""
         w = self.P(key + ".weight")
@@ -127,6 +136,7 @@ class SegBranch:
                 e["pwT"] = PackedWeight(cin, k * k, ops.round_up(cout, 8), w.device)
             e["pwT"].pack(w.detach(), transposed=True)
             e["T_ok"] = True
+        e["need_T"] = bool(need_T) or e.get("need_T", False)
         return e["pw"], e["pwT"], self.P(key + ".bias").detach()
 
     # ---- planning (host) ----------------------------------------------------------------------------
@@ -262,6 +272,7 @@ class SegBranch:
         dev = feats[0].device
         if plan.nb[0] == 0:
             return torch.zeros(0, dtype=torch.float32, device=dev), None
+        self.prepare_all(record)
         fr = [self.feat_rows(f) for f in feats]
         CH = arch.FEAT_CH
         pre = [None] * 5
