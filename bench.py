@@ -144,6 +144,73 @@ def pmc_traffic():
     return None
 
 
+def eval_inputs(S, n, seed):
+    """Config 5 of BASELINE.json: GT-derived head maps of n instances (+ N(0, 0.05) on kp clipped to [0,1], N(0, 0.5 px) on
+    the offsets) at the four scales of an SxS image.  Returns [[kp, short, mid] x 4] as numpy fp32 [1,C,H,W] and the boxes."""
+    from oracle import synth
+    f = S / 512.0
+    boxes = synth.random_boxes(S, S, n, seed, max(4, int(14 * f)), max(8, int(40 * f)))
+    dec = []
+    for l, sc in enumerate((1, 2, 4, 8)):
+        H = S // sc
+        gt = synth.gt_maps(np.floor(boxes / sc), H, H)
+        rng = np.random.default_rng(seed * 10 + l)
+        kp = np.clip(gt[0:5] + rng.normal(0, 0.05, (5, H, H)), 0, 1).astype(np.float32)
+        sh = (gt[5:15] + rng.normal(0, 0.5, (10, H, H))).astype(np.float32)
+        md = (gt[15:55] + rng.normal(0, 0.5, (40, H, H))).astype(np.float32)
+        dec.append([kp[None], sh[None], md[None]])
+    return dec, boxes
+
+
+def eval_bench(args, dev):
+    """--mode eval: the test.py:97-123 inference path per image -- forward_dec (eval BN), post-processing of the 4 scales +
+    NMS (bit-exact fp64 on the GPU), forward_seg on the detected boxes -- at 256 / 512 / 1024 with ~300 instances."""
+    from kg_instance_segmentation_amd import KGnet, postprocessing as kpp
+    torch.manual_seed(1234)
+    model = KGnet.resnet50(pretrained=False).to(dev).eval()
+    per = {}
+    for S in (256, 512, 1024):
+        dec_np, boxes = eval_inputs(S, 300, 5)
+        dec = [[torch.from_numpy(a).to(dev) for a in d] for d in dec_np]
+        x = (torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(S)) - 0.5).to(dev)
+
+        def timed(fn, reps):
+            for _ in range(2):
+                r = fn()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps, r
+        with torch.no_grad():
+            t_pp, det = timed(lambda: kpp.detect(dec), args.steps)
+            t_fd, out = timed(lambda: model.forward_dec(x), args.steps)
+            bb = (det if det is not None else np.zeros((0, 5))).astype(np.float32)   # [y1,x1,y2,x2,score] in pixels (test.py:119-123)
+            t_fs, _ = timed(lambda: model.forward_seg(out[4], [bb]), args.steps)
+        per[S] = {"postproc_nms_ms": 1e3 * t_pp, "forward_dec_ms": 1e3 * t_fd, "forward_seg_ms": 1e3 * t_fs, "detections": 0 if det is None else len(det),
+                  "imgs_per_s_postproc": 1.0 / t_pp, "imgs_per_s_end_to_end": 1.0 / (t_pp + t_fd + t_fs), "_det": det, "_dec": dec_np}
+    out = {"metric": "imgs/s (eval: forward_dec + post-proc x4 + NMS + forward_seg) at 512x512, ~300 instances", "value": per[512]["imgs_per_s_end_to_end"],
+           "unit": "imgs/s", "n_gpus": 1, "steps": args.steps, "warmup": 2, "ms_per_step": 1e3 / per[512]["imgs_per_s_end_to_end"],
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (network) / f64 (post-processing)", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[4]: multi-scale eval 256/512/1024, GT-derived head maps of 300 instances + noise for post-processing/NMS, "
+                                  "random-init network for forward_dec / forward_seg on the detected boxes, batch 1"}}
+    if not args.no_cpu_baseline:      # checker + baseline leg: the C oracle on the same head maps
+        from oracle import postproc as op
+        cb = {}
+        for S in (256, 512, 1024):
+            t0 = time.perf_counter(); ref = op.detect(per[S]["_dec"]); dtc = time.perf_counter() - t0
+            det = per[S]["_det"]
+            same = 0 if (ref is None or det is None) else int(sum(1 for a in ref if any(np.array_equal(a, b) for b in det)))
+            nref = 0 if ref is None else len(ref)
+            cb[S] = {"oracle_ms": 1e3 * dtc, "ref_boxes": nref, "identical_boxes": same, "grouping_match_rate": same / max(nref, 1)}
+        out["cpu_baseline"] = {"value": 1e3 / cb[512]["oracle_ms"], "unit": "imgs/s (post-proc + NMS only)", "cores": 1, "kind": "port",
+                               "sample": "one image per size, oracle/kg_oracle.c via oracle/postproc.py", "per_size": cb}
+    for S in per:
+        per[S].pop("_det"); per[S].pop("_dec")
+    out["per_size"] = per
+    print(json.dumps(out))
+
+
 def cpu_baseline(S, nboxes, seed=0):
     """The oracle's torch-CPU restatement of ONE train step at batch 1 (bounded sample), all host cores."""
     from oracle import net as onet, synth, weightgen
@@ -184,6 +251,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--boxes", type=int, default=300)
+    ap.add_argument("--mode", choices=["train", "eval"], default="train", help="eval: inference path (BASELINE configs[4]), 1 GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -199,6 +267,10 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    if args.mode == "eval":
+        if rank == 0:
+            eval_bench(args, dev)
+        return
     torch.manual_seed(1234)
     model = KGnet.resnet50(pretrained=False).to(dev).train()
     parallel.broadcast_parameters(model)
