@@ -27,22 +27,35 @@ import torch
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
 
 
+def random_boxes(H, W, n, seed, smin=14, smax=40):
+    """n axis-aligned boxes (y1,x1,y2,x2) with integer corners, sides U[smin,smax)."""
+    rng = np.random.default_rng(seed)
+    hs = np.minimum(rng.integers(smin, smax, n), H - 2); ws = np.minimum(rng.integers(smin, smax, n), W - 2)
+    y1 = (rng.random(n) * (H - 1 - hs)).astype(np.int64) + 1
+    x1 = (rng.random(n) * (W - 1 - ws)).astype(np.int64) + 1
+    return np.stack([y1, x1, y1 + hs, x1 + ws], 1).astype(np.float64)
+
+
 def make_batch(N, S, nboxes, seed, dev):
-    """Synthetic batch in the collater's layout (collater.py:4-25).  GT maps come from the build's synthesizer
-    (oracle/synth.py is data generation here, not a checker)."""
-    from oracle import synth
+    """Synthetic batch in the collater's layout (collater.py:4-25).  The 55-channel GT maps of the four scales are built
+    by the product's GPU ground-truth generator (preprocessing.get_ground_truth semantics, csrc/preproc.hip) from the
+    boxes scaled as dataset_base.masks_to_bboxes does (floor(box / scale); keypoints tl, tr, bl, br, centre)."""
+    from kg_instance_segmentation_amd import preprocessing as kprep
     x = torch.rand(N, 3, S, S, generator=torch.Generator().manual_seed(seed)) - 0.5
     gt_boxes, gt_masks, lv = [], [], [[] for _ in range(4)]
     for i in range(N):
-        bx = synth.random_boxes(S, S, nboxes, seed * 1000 + i)
+        bx = random_boxes(S, S, nboxes, seed * 1000 + i)
         gt_boxes.append(np.concatenate([bx, np.ones((len(bx), 1))], 1).astype(np.float32))
         m = np.zeros((len(bx), S, S), np.float32)
         for k, b in enumerate(bx.astype(int)):
             m[k, b[0]:b[2] + 1, b[1]:b[3] + 1] = 1.0
         gt_masks.append(m)
         for l, sc in enumerate((1, 2, 4, 8)):
-            lv[l].append(synth.gt_maps(np.floor(bx / sc), S // sc, S // sc))
-    gt = [torch.from_numpy(np.stack(v)).to(dev) for v in lv]
+            y1, x1, y2, x2 = np.floor(bx / sc).T
+            kps = np.stack([np.stack([x1, y1], 1), np.stack([x2, y1], 1), np.stack([x1, y2], 1), np.stack([x2, y2], 1),
+                            np.stack([(x1 + x2) / 2, (y1 + y2) / 2], 1)], 1).astype(np.float32)
+            lv[l].append(kprep.get_ground_truth_device(kps, S // sc, S // sc, dev))
+    gt = [torch.stack(v) for v in lv]
     return x.to(dev), gt, gt_masks, gt_boxes
 
 
@@ -147,13 +160,16 @@ def pmc_traffic():
 def eval_inputs(S, n, seed):
     """Config 5 of BASELINE.json: GT-derived head maps of n instances (+ N(0, 0.05) on kp clipped to [0,1], N(0, 0.5 px) on
     the offsets) at the four scales of an SxS image.  Returns [[kp, short, mid] x 4] as numpy fp32 [1,C,H,W] and the boxes."""
-    from oracle import synth
+    from kg_instance_segmentation_amd import preprocessing as kprep
     f = S / 512.0
-    boxes = synth.random_boxes(S, S, n, seed, max(4, int(14 * f)), max(8, int(40 * f)))
+    boxes = random_boxes(S, S, n, seed, max(4, int(14 * f)), max(8, int(40 * f)))
     dec = []
     for l, sc in enumerate((1, 2, 4, 8)):
         H = S // sc
-        gt = synth.gt_maps(np.floor(boxes / sc), H, H)
+        y1, x1, y2, x2 = np.floor(boxes / sc).T
+        kps = np.stack([np.stack([x1, y1], 1), np.stack([x2, y1], 1), np.stack([x1, y2], 1), np.stack([x2, y2], 1),
+                        np.stack([(x1 + x2) / 2, (y1 + y2) / 2], 1)], 1).astype(np.float32)
+        gt = kprep.get_ground_truth_device(kps, H, H).cpu().numpy()
         rng = np.random.default_rng(seed * 10 + l)
         kp = np.clip(gt[0:5] + rng.normal(0, 0.05, (5, H, H)), 0, 1).astype(np.float32)
         sh = (gt[5:15] + rng.normal(0, 0.5, (10, H, H))).astype(np.float32)

@@ -119,6 +119,11 @@ int kg_skeleton_boxes(const double* skel, const int* nskel, int skel_cap, double
 int kg_nms(const double* boxes, const int* nbox, int box_cap, double thresh, void* ws, long ws_bytes, double* out,
            int* nkeep, void* stream);
 
+/* ---- ground-truth maps of one pyramid scale (preprocessing.get_ground_truth, preprocessing.py:107-118, assembled and cast
+ * as dataset_base.py:99-109): kps = device float32 [n][5][2] (x,y) keypoints tl,tr,bl,br,centre; out = device float32
+ * [55][H][W] (kp 5 | short 10 | mid 40), bit-identical to the reference's float32 tensors ---- */
+int kg_gt_maps(const float* kps, int n, int H, int W, float* out, void* stream);
+
 /* ---- per-box segmentation branch (KGnet.py:246-267, 321-350): ragged row bookkeeping ---- */
 int kg_seg_build_rows(const int* boxtab8, int nb, int* rowdesc, int* row2box, int* srcrow, void* stream);
 int kg_rows_gather(const void* src, int ldsrc, const int* srcrow, void* dst, int lddst, long nrows, int C, void* stream);

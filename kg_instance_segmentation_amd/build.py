@@ -24,6 +24,7 @@ SOURCES = {
     "norm_pool.hip": [],
     "loss.hip": [],
     "postproc.hip": ["-ffp-contract=off"],
+    "preproc.hip": ["-ffp-contract=off"],
     "seg.hip": [],
 }
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -258,6 +258,45 @@ def gen_loss():
     print("loss.npz", out["loss"], out["loss_empty"], out["seg.loss"])
 
 
+def kp_boxes(x1, y1, x2, y2):
+    """[n,5,2] float32 keypoints (tl, tr, bl, br, centre) as dataset_base.py:58-79 builds them."""
+    return np.asarray([[(a, b), (c, b), (a, d), (c, d), (float(a + c) / 2, float(b + d) / 2)] for a, b, c, d in zip(x1, y1, x2, y2)],
+                      np.float32).reshape(-1, 5, 2)
+
+
+def gen_preproc():
+    """Ground-truth map generation (preprocessing.get_ground_truth) -- reference outputs in the layout of
+    dataset_base.py:99-109 ([55,H,W], cast to float32 as torch.FloatTensor does)."""
+    np.int = int                      # preprocessing.py:61 uses the removed alias
+    import preprocessing as rprep
+    from oracle import preproc as opre
+    out = {}
+    rng = np.random.default_rng(11)
+    cases = {}
+    for name, (H, W, n, smin, smax) in {"r48x64": (48, 64, 12, 12, 20), "dense96": (96, 96, 40, 12, 30), "odd33x70": (33, 70, 7, 12, 16)}.items():
+        x1 = rng.integers(0, W - smax, n); y1 = rng.integers(0, H - smax, n)
+        x2 = x1 + rng.integers(smin, smax, n); y2 = y1 + rng.integers(smin, smax, n)
+        cases[name] = (H, W, kp_boxes(x1, y1, x2, y2))
+    # adversarial: identical instances (argmin tie -> first), windows overwriting each other's corners, keypoints on the
+    # image border and in the corners, half-integer centres
+    H, W = 40, 44
+    x1 = np.array([0, 0, 10, 13, 30, 20, 20]); y1 = np.array([0, 0, 10, 12, 26, 5, 5])
+    x2 = np.array([13, 13, 23, 27, 43, 33, 34]); y2 = np.array([12, 12, 24, 25, 39, 18, 18])
+    cases["adv"] = (H, W, kp_boxes(x1, y1, x2, y2))
+    cases["empty"] = (24, 24, np.zeros((0, 5, 2), np.float32))
+    for name, (H, W, bb) in cases.items():
+        kp, sh, md = rprep.get_ground_truth(bb, H, W, 5)
+        ref = np.concatenate((kp, np.transpose(sh, (2, 0, 1)), np.transpose(md, (2, 0, 1))), 0)
+        ref32 = ref.astype(np.float32)
+        assert np.array_equal(ref32.astype(np.float64), ref)            # every value is exactly representable
+        assert np.array_equal(opre.ground_truth(bb, H, W), ref), name    # the oracle restatement is pinned here too
+        out[f"{name}.bboxes"] = bb
+        out[f"{name}.hw"] = np.array([H, W])
+        out[f"{name}.gt"] = ref32
+    np.savez_compressed(os.path.join(GOLD, "preproc.npz"), **out)
+    print("preproc.npz:", {k: v.shape for k, v in out.items() if k.endswith(".gt")})
+
+
 def check_norm():
     import ctypes, math
     libm = ctypes.CDLL("libm.so.6"); libm.fma.restype = ctypes.c_double; libm.fma.argtypes = [ctypes.c_double] * 3
@@ -272,8 +311,12 @@ def check_norm():
 if __name__ == "__main__":
     if "--check-norm" in sys.argv:
         check_norm()
+    if "--only-preproc" in sys.argv:
+        gen_preproc()
+        sys.exit(0)
     torch.manual_seed(0)
     gen_postproc()
     gen_loss()
     gen_net()
+    gen_preproc()
     os.system(f"ls -la {GOLD}")
