@@ -29,7 +29,6 @@ struct HaloArgs {
     int cin_pad, ldx, Cout, ldy, ldres, ldmask, K, flip, relu, f32_C, f32_hw;
     // grouped second-layer heads (GM = 1): per-head channel chunks, virtual-cout -> map-channel table, the 3 fp32 outputs
     int grp_chunks; const int* vmap; float* f32_b; float* f32_c;
-    int dbg;
     int head_split;   // GM: 1 = blockIdx.y is the head (small images: 3x the workgroups), 0 = one workgroup walks all heads
 };
 
@@ -359,7 +358,6 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
     constexpr int TW = 4 * WPX, HWD = TW + KS - 1, TC = WC * 64;
     constexpr int smem = (16 + KS - 1) * HWD * 128 + 3 * TC * 128;
     a.tiles_x = kg_cdiv(a.W, TW);
-    { const char* d = getenv("KG_HALO_DBG"); a.dbg = d ? atoi(d) : 0; }
     static bool attr_done = false;
     if (!attr_done) {
         KG_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<KS, WC, WPX, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
