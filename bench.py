@@ -178,6 +178,53 @@ def eval_inputs(S, n, seed):
     return dec, boxes
 
 
+def gt_bench(args, dev):
+    """--mode gt: ground-truth maps (4 scales) of a batch of 8 images with 300 instances each at 512^2 on the GPU
+    (kg_gt_maps) vs the NumPy oracle on one image (the reference's own NumPy code takes ~58 s per image)."""
+    from kg_instance_segmentation_amd import preprocessing as kprep
+    S, N, n = args.size, args.batch, args.boxes
+    kps = []
+    for i in range(N):
+        bx = random_boxes(S, S, n, 1000 + i)
+        per = []
+        for sc in (1, 2, 4, 8):
+            y1, x1, y2, x2 = np.floor(bx / sc).T
+            per.append(np.stack([np.stack([x1, y1], 1), np.stack([x2, y1], 1), np.stack([x1, y2], 1), np.stack([x2, y2], 1),
+                                 np.stack([(x1 + x2) / 2, (y1 + y2) / 2], 1)], 1).astype(np.float32))
+        kps.append(per)
+    dk = [[torch.from_numpy(k).to(dev) for k in per] for per in kps]
+    outs = [[torch.empty(55, S // sc, S // sc, device=dev) for sc in (1, 2, 4, 8)] for _ in range(N)]
+
+    def run():
+        for i in range(N):
+            for l, sc in enumerate((1, 2, 4, 8)):
+                kprep.get_ground_truth_device(dk[i][l], S // sc, S // sc, dev, out=outs[i][l])
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
+    hbm = N * sum(55 * (S // sc) ** 2 * 4 for sc in (1, 2, 4, 8))
+    out = {"metric": f"imgs/s (ground-truth maps, 4 scales, {n} instances) at {S}x{S}", "value": N / dt, "unit": "imgs/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": 2, "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64 (distances) -> f32 maps", "data": "synthetic",
+           "config": {"workload": f"preprocessing.get_ground_truth x 4 scales, batch {N}, {n} instances/img, keypoints resident in HBM"},
+           "roofline": {"bound": "hbm", "achieved": hbm / dt / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": hbm / dt / 1e9 / 8000.0, "traffic": None,
+                        "note": "algorithmic bytes = the 55-channel fp32 maps written once; the kernel is latency/ALU bound (instance loop per pixel)"}}
+    if not args.no_cpu_baseline:
+        from oracle import preproc
+        t0 = time.perf_counter()
+        ok = True
+        for l, sc in enumerate((1, 2, 4, 8)):
+            ref = preproc.ground_truth(kps[0][l], S // sc, S // sc)
+            ok = ok and bool(np.array_equal(outs[0][l].cpu().numpy().astype(np.float64), ref))
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / dtc, "unit": "imgs/s", "cores": 1, "kind": "port", "sample": "1 image, 4 scales, oracle/preproc.py (vectorised NumPy)",
+                               "bit_identical": ok}
+    print(json.dumps(out))
+
+
 def eval_bench(args, dev):
     """--mode eval: the test.py:97-123 inference path per image -- forward_dec (eval BN), post-processing of the 4 scales +
     NMS (bit-exact fp64 on the GPU), forward_seg on the detected boxes -- at 256 / 512 / 1024 with ~300 instances."""
@@ -267,7 +314,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--boxes", type=int, default=300)
-    ap.add_argument("--mode", choices=["train", "eval"], default="train", help="eval: inference path (BASELINE configs[4]), 1 GPU")
+    ap.add_argument("--mode", choices=["train", "eval", "gt"], default="train",
+                    help="eval: inference path (BASELINE configs[4]); gt: ground-truth map generation (SURVEY 8f N1); 1 GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -283,9 +331,15 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    # host threads: 8 ranks x all-cores OpenMP pools would oversubscribe the node during the host-side glue
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // max(world, 1))))
     if args.mode == "eval":
         if rank == 0:
             eval_bench(args, dev)
+        return
+    if args.mode == "gt":
+        if rank == 0:
+            gt_bench(args, dev)
         return
     torch.manual_seed(1234)
     model = KGnet.resnet50(pretrained=False).to(dev).train()

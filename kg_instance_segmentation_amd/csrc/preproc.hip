@@ -20,31 +20,45 @@
 
 __global__ __launch_bounds__(256) void gt_maps_kernel(const float* __restrict__ kps, int n, int H, int W, float* __restrict__ out) {
     __shared__ float sk[KG_GT_CHUNK * 2];
+    __shared__ int cand[KG_GT_CHUNK];
+    __shared__ int ncand;
     const int i = blockIdx.y;                               // keypoint type
     const long hw = (long)H * W;
-    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    const long p0 = (long)blockIdx.x * 256, p = p0 + threadIdx.x;
     const bool live = p < hw;
     const int y = live ? (int)(p / W) : 0, x = live ? (int)(p - (long)y * W) : 0;
+    // bounding box of the workgroup's 256 consecutive pixels: instances farther than the radius (+1 for int() truncation)
+    // from it can neither own nor overwrite any of them and are culled once per workgroup
+    const long pl = p0 + 255 < hw ? p0 + 255 : hw - 1;
+    const int by0 = (int)(p0 / W), by1 = (int)(pl / W);
+    const int bx0 = by0 == by1 ? (int)(p0 - (long)by0 * W) : 0, bx1 = by0 == by1 ? (int)(pl - (long)by1 * W) : W - 1;
     int owner = -1, last = -1;
     double best = 0.0;
     for (int j0 = 0; j0 < n; j0 += KG_GT_CHUNK) {
         const int m = n - j0 < KG_GT_CHUNK ? n - j0 : KG_GT_CHUNK;
         __syncthreads();
+        if (threadIdx.x == 0) ncand = 0;
+        __syncthreads();
         for (int t = threadIdx.x; t < m; t += 256) {
-            sk[2 * t] = kps[((long)(j0 + t) * 5 + i) * 2];
-            sk[2 * t + 1] = kps[((long)(j0 + t) * 5 + i) * 2 + 1];
+            const float kx = kps[((long)(j0 + t) * 5 + i) * 2], ky = kps[((long)(j0 + t) * 5 + i) * 2 + 1];
+            sk[2 * t] = kx; sk[2 * t + 1] = ky;
+            if (ky >= (float)(by0 - KG_GT_R - 1) && ky <= (float)(by1 + KG_GT_R + 1) && kx >= (float)(bx0 - KG_GT_R - 1) &&
+                kx <= (float)(bx1 + KG_GT_R + 1))
+                cand[atomicAdd(&ncand, 1)] = t;             // unordered: the per-pixel rules below do not depend on the order
         }
         __syncthreads();
         if (!live) continue;
-        for (int t = 0; t < m; ++t) {
+        const int nc = ncand;
+        for (int q = 0; q < nc; ++q) {
+            const int t = cand[q], j = j0 + t;
             const float kx = sk[2 * t], ky = sk[2 * t + 1];
             const int cx = (int)kx, cy = (int)ky;            // int(center) of copy_with_border_check
             const int wx = x - cx, wy = y - cy;
-            if (wx >= -KG_GT_R && wx <= KG_GT_R && wy >= -KG_GT_R && wy <= KG_GT_R) last = j0 + t;
+            if (wx >= -KG_GT_R && wx <= KG_GT_R && wy >= -KG_GT_R && wy <= KG_GT_R && j > last) last = j;   // last writer
             const double dx = (double)kx - (double)x, dy = (double)ky - (double)y;
             if (dx > KG_GT_R || dx < -KG_GT_R || dy > KG_GT_R || dy < -KG_GT_R) continue;
             const double d = sqrt(dx * dx + dy * dy);
-            if (d <= (double)KG_GT_R && (owner < 0 || d < best)) { owner = j0 + t; best = d; }
+            if (d <= (double)KG_GT_R && (owner < 0 || d < best || (d == best && j < owner))) { owner = j; best = d; }   // first argmin
         }
     }
     if (!live) return;
