@@ -17,6 +17,7 @@ LIB = os.path.join(HERE, "libkgnet_hip.so")
 SOURCES = {
     "api.hip": [],
     "conv_igemm.hip": [],
+    "conv_gather.hip": [],
     "conv_halo.hip": [],
     "conv1x1.hip": [],
     "conv_wgrad.hip": [],

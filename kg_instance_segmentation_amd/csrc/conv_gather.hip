@@ -1,0 +1,226 @@
+// conv_gather.hip -- gather implicit-GEMM convolution with an asynchronous LDS ring (cin_pad % 64 == 0, Cout > 64).
+//
+// Serves the convs that cannot use the LDS-halo kernels: strided 3x3 / 1x1 convs of the ResNet trunk and their input
+// gradients (KGnet.py:64-99), and the ragged deep levels of the per-box seg branch (KGnet.py:258-267, crops of a few
+// pixels).  conv_igemm.hip recomputes the gather address of every 16-byte load (6 VALU per MFMA) and keeps only one
+// K-step of global loads in flight (60 % of its wave cycles are waits).  Here:
+//   * the K loop runs tap-outer / channel-chunk-inner: the source row of a pixel is resolved ONCE per tap (9 times for a
+//     3x3, not K/64 times) and the 64-channel chunks of that tap are plain pointer increments;
+//   * tiles go global -> LDS with LDS-direct loads (global_load_lds_dwordx4: no staging registers, no ds_write) into a
+//     3-stage ring; two stages are in flight while one is multiplied, and the per-stage barrier waits with a COUNTED
+//     s_waitcnt vmcnt(6) -- the 6 loads of the newest stage stay outstanding across the barrier (a __syncthreads() would
+//     drain them).  The destination of an LDS-direct load is lane-linear, so the XOR swizzle of the 16-byte slots is
+//     applied to the source chunk; padding / out-of-image taps read a zero line;
+//   * workgroup = 8 waves = 256 pixels x 128 couts, wave tile 64 x 64 (16 MFMA per k-step), same fragment layouts and
+//     epilogue as the other conv kernels (weights = MFMA A, each lane ends with 16 consecutive couts of one pixel).
+#include "conv_args.h"
+
+__device__ uint4 kg_gather_zero_line[8];
+
+#define KG_GLDS(src, dst) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+__global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, const int ncc) {
+    constexpr int TP = 256, TC = 128, NS = 3, XB = TP * 128, WB = TC * 128, STAGE = XB + WB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave & 3, wcw = wave >> 2;
+    const int lm = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * TP, c0 = blockIdx.y * TC;
+    const int cin_pad = ncc * 64;
+
+    // ---- staging assignment: thread -> 16-byte slot cs of rows rr + 64 q ------------------------------------------------
+    const int cs = tid & 7, rr = tid >> 3;
+    const int xchunk = cs ^ ((rr >> 1) & 7);                               // source chunk of the X rows (key of row rr + 64 q)
+    const int wchunk = cs ^ (2 * ((rr >> 4) & 3) + ((rr >> 1) & 1));       // source chunk of the W rows
+    int py[4], px[4], ph[4], pw[4];
+    long pbase[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = m0 + q * 64 + rr;
+        py[q] = px[q] = 0; ph[q] = pw[q] = 0; pbase[q] = -1;
+        if (m < a.M) {
+            if (a.mode >= 2) {
+                const int2 d = a.rowdesc[m];
+                py[q] = d.x >> 16; px[q] = d.x & 0xffff; ph[q] = d.y >> 16; pw[q] = d.y & 0xffff; pbase[q] = m;
+            } else {
+                const int ohw = a.OH * a.OW;
+                const int n = m / ohw, rem = m - n * ohw;
+                py[q] = rem / a.OW; px[q] = rem - py[q] * a.OW; pbase[q] = (long)n * a.H * a.W; ph[q] = a.H; pw[q] = a.W;
+            }
+        }
+    }
+    const bf16_t* wrow[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) wrow[q] = a.w + (long)(c0 + q * 64 + rr) * a.K + wchunk * 8;   // packed rows are padded past Cout
+    const bf16_t* zline = reinterpret_cast<const bf16_t*>(kg_gather_zero_line) + cs * 8;
+    const int smask = (1 << a.stride_log2) - 1;
+
+    const bf16_t* xsrc[4];
+    int i_tap = 0, i_cc = 0, i_slot = 0;
+    auto issue = [&]() {   // global -> LDS loads of the next (tap, 64-channel chunk) stage into ring slot i_slot
+        if (i_cc == 0) {   // new tap: resolve the source row of the thread's 4 pixels
+            const int dy = i_tap / a.KW, dx = i_tap - dy * a.KW;
+            const int dyo = dy - a.pad, dxo = dx - a.pad;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bool ok = pbase[q] >= 0;
+                long row = 0;
+                if (a.mode == 0) {
+                    const int iy = (py[q] << a.stride_log2) + dyo, ix = (px[q] << a.stride_log2) + dxo;
+                    ok = ok && (unsigned)iy < (unsigned)ph[q] && (unsigned)ix < (unsigned)pw[q];
+                    row = pbase[q] + (long)iy * pw[q] + ix;
+                } else if (a.mode == 1) {
+                    const int ty = py[q] - dyo, tx = px[q] - dxo;
+                    ok = ok && ty >= 0 && tx >= 0 && ((ty | tx) & smask) == 0;
+                    const int iy = ty >> a.stride_log2, ix = tx >> a.stride_log2;
+                    ok = ok && iy < ph[q] && ix < pw[q];
+                    row = pbase[q] + (long)iy * pw[q] + ix;
+                } else {
+                    const int sy = a.mode == 2 ? dyo : -dyo, sx = a.mode == 2 ? dxo : -dxo;
+                    const int iy = py[q] + sy, ix = px[q] + sx;
+                    ok = ok && (unsigned)iy < (unsigned)ph[q] && (unsigned)ix < (unsigned)pw[q];
+                    row = pbase[q] + (long)sy * pw[q] + sx;
+                }
+                xsrc[q] = ok ? a.x + row * a.ldx + xchunk * 8 : nullptr;
+            }
+        }
+        unsigned char* st = smem + i_slot * STAGE + wave * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bf16_t* src = xsrc[q] ? xsrc[q] + i_cc * 64 : zline;
+            KG_GLDS(src, st + q * 8192);
+        }
+        const long woff = (long)i_tap * cin_pad + i_cc * 64;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) KG_GLDS(wrow[q] + woff, st + XB + q * 8192);
+        if (++i_cc == ncc) { i_cc = 0; ++i_tap; }
+        i_slot = i_slot == NS - 1 ? 0 : i_slot + 1;
+    };
+
+    // ---- fragment addresses ------------------------------------------------------------------------------------------------
+    int a_off[4][2], b_off[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = wcw * 64 + (lm >> 2) * 16 + i * 4 + (lm & 3);
+        const int key = 2 * ((r >> 4) & 3) + ((r >> 1) & 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) a_off[i][s] = XB + r * 128 + (((4 * s + g) ^ key) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = wp * 64 + j * 16 + lm;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) b_off[j][s] = r * 128 + (((4 * s + g) ^ ((r >> 1) & 7)) * 16);
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nstage = a.ntaps * ncc;
+    issue();
+    if (nstage > 1) issue();
+    int c_slot = 0;
+    for (int s = 0; s < nstage; ++s) {
+        // stage s has landed once at most the 6 loads of stage s+1 are outstanding (loads complete in order)
+        if (s + 1 < nstage) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 2 < nstage) issue();          // into the slot of stage s-1, which every wave has finished reading
+        const unsigned char* st = smem + c_slot * STAGE;
+        bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[k][i] = *reinterpret_cast<const bf16x8*>(st + a_off[i][k]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[k][j] = *reinterpret_cast<const bf16x8*>(st + b_off[j][k]);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k][i], bfr[k][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        c_slot = c_slot == NS - 1 ? 0 : c_slot + 1;
+    }
+
+    // ---- epilogue: lane owns pixel row m and couts cb .. cb+15 --------------------------------------------------------------
+    const int cb = c0 + wcw * 64 + g * 16;
+    if (cb >= a.Cout) return;
+    const bool full = cb + 16 <= a.Cout;
+    float bv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long m = (long)m0 + wp * 64 + j * 16 + lm;
+        if (m >= a.M) continue;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bv[i * 4 + r];
+        if (a.res) {
+            const bf16_t* rq = a.res + m * a.ldres + cb;
+            if (full && ((reinterpret_cast<uintptr_t>(rq) & 15) == 0)) {
+                uint4 r0 = *reinterpret_cast<const uint4*>(rq), r1 = *reinterpret_cast<const uint4*>(rq + 8);
+                const bf16_t* rs0 = reinterpret_cast<const bf16_t*>(&r0);
+                const bf16_t* rs1 = reinterpret_cast<const bf16_t*>(&r1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[e] += bf2f(rs0[e]); v[8 + e] += bf2f(rs1[e]); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (full || cb + e < a.Cout) v[e] += bf2f(rq[e]);
+            }
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if (a.mask) {
+            const bf16_t* mp = a.mask + m * a.ldmask + cb;
+            if (full && ((reinterpret_cast<uintptr_t>(mp) & 15) == 0)) {
+                uint4 q0 = *reinterpret_cast<const uint4*>(mp), q1 = *reinterpret_cast<const uint4*>(mp + 8);
+                const bf16_t* ms0 = reinterpret_cast<const bf16_t*>(&q0);
+                const bf16_t* ms1 = reinterpret_cast<const bf16_t*>(&q1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[e] = bf2f(ms0[e]) > 0.f ? v[e] : 0.f; v[8 + e] = bf2f(ms1[e]) > 0.f ? v[8 + e] : 0.f; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (full || cb + e < a.Cout) v[e] = bf2f(mp[e]) > 0.f ? v[e] : 0.f;
+            }
+        }
+        bf16_t* yp = a.y + m * a.ldy + cb;
+        if (full && ((reinterpret_cast<uintptr_t>(yp) & 15) == 0)) {
+            *reinterpret_cast<uint4*>(yp) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+            *reinterpret_cast<uint4*>(yp + 8) = make_uint4(pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15]));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (cb + e < a.Cout) yp[e] = f2bf(v[e]);
+        }
+    }
+}
+
+int kg_launch_conv_gather(const ConvArgs& a, int cin_pad, hipStream_t st) {
+    constexpr int smem = 3 * (256 * 128 + 128 * 128);
+    static bool attr_done = false;
+    if (!attr_done) {
+        KG_HIP(hipFuncSetAttribute((const void*)conv_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    dim3 grid(kg_cdiv(a.M, 256), kg_cdiv(a.Cout, 128));
+    hipLaunchKernelGGL(conv_gather_kernel, grid, dim3(512), smem, st, a, cin_pad / 64);
+    KG_CHECK_LAUNCH("conv_gather");
+    return KG_OK;
+}

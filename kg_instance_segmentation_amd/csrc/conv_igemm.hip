@@ -11,16 +11,9 @@
 //   * LDS: [sub-step][row][32 k] tiles, XOR-swizzled 16-byte slots -> conflict-free ds_read_b128
 //   * epilogue: bias, residual add, ReLU, ReLU-mask (for dgrad), bf16 NHWC and/or fp32 NCHW store
 #include "kg_common.h"
+#include <stdlib.h>
 
-struct ConvArgs {
-    const bf16_t* x; const bf16_t* w; const float* bias;
-    bf16_t* y; float* y_f32; const bf16_t* res; const bf16_t* mask; const int2* rowdesc;
-    int M, H, W, OH, OW;
-    int ldx, ldy, ldres, ldmask;
-    int Cout, K, cpt, cpt_magic, ntaps, KW, stride_log2, pad, dil;
-    int mode;  // 0 dense forward, 1 dense transposed (dgrad), 2 ragged (+), 3 ragged transposed (-)
-    int relu, f32_C;
-};
+#include "conv_args.h"
 
 __device__ __forceinline__ int fperm(int q) { return (4 - q) & 3; }
 
@@ -280,6 +273,9 @@ extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, 
     a.stride_log2 = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil; a.mode = mode; a.relu = relu; a.f32_C = f32_C;
     KG_CHECK_ARG(magic_for(a.cpt, K / 8, &a.cpt_magic), "kg_conv2d_igemm: no exact magic divisor for cpt=%d", a.cpt);
     hipStream_t st = (hipStream_t)stream;
+    static const int use_gather2 = getenv("KG_GATHER2") ? atoi(getenv("KG_GATHER2")) : 1;
+    if (use_gather2 && tile == 0 && cin_pad % 64 == 0 && y && !y_f32 && Cout > 64 && dil == 1)
+        return kg_launch_conv_gather(a, cin_pad, st);   // deep-prefetch LDS-ring variant (conv_gather.hip)
     // tile: 0 auto; 1 = 16 couts x 256 px; 2 = 32 x 256; 3 = 64 x 256; 4 = 128 x 128; 5 = 64 x 128
     if (tile == 0) tile = Cout <= 16 ? 1 : (Cout <= 32 ? 2 : (Cout <= 64 ? 3 : 4));
     switch (tile) {
