@@ -194,6 +194,7 @@ def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None,
 
 
 USE_1X1 = True
+GATHER_1X1 = __import__("os").environ.get("KG_GATHER_1X1", "1") == "1"
 
 
 def conv1x1(x, pw, cout, y, bias=None, res=None, mask=None, relu=False):
@@ -206,6 +207,8 @@ def conv1x1(x, pw, cout, y, bias=None, res=None, mask=None, relu=False):
 
 
 def can_1x1(x, pw, KH, stride, pad, y, y_f32):
+    if GATHER_1X1 and pw.cin_pad >= 192 and pw.rows > 64:
+        return False      # compute-heavy 1x1 (K >= 192, Cout > 64): the LDS-ring gather kernel (conv_gather.hip) is faster
     return (USE_1X1 and KH == 1 and stride == 1 and pad == 0 and y is not None and y_f32 is None and pw.cin_pad % 64 == 0
             and 64 <= pw.cin_pad <= 1024 and x.shape[1] >= pw.cin_pad and y.shape[0] == x.shape[0])
 
