@@ -378,10 +378,11 @@ def main():
     timer.only_dominant = True
     t0 = time.perf_counter()
     last = None
-    marks = []
+    marks, losses = [], []
     for _ in range(args.steps):
         last = step()
         marks.append(time.perf_counter())
+        losses.append(last)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -403,6 +404,7 @@ def main():
         return
     if os.environ.get("KG_BENCH_VERBOSE"):
         print("per-step host ms:", [round(1e3 * (b - a), 1) for a, b in zip([t0] + marks[:-1], marks)], file=sys.stderr)
+        print("losses:", [round(l, 2) for l in losses], file=sys.stderr)
     imgs = args.batch * world * args.steps
     out = {"metric": "imgs/s (train fwd+bwd) at 512x512", "value": imgs / dt, "unit": "imgs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,

@@ -76,6 +76,7 @@ class Engine:
         self.fusedT = {}
         self.head_slots = []
         self.heads2_seen = {}
+        self.train_steps, self.stamp = 0, ("e", 0)
         self.grad_hook = None      # parallel.GradReducer.attach: called with [(key, grad)] as backward produces them
 
     # ---- parameters ---------------------------------------------------------------------------
@@ -105,10 +106,12 @@ class Engine:
             ops.PACKQ.defer = False
 
     def prepare(self, s, need_T):
-        """(Re)pack weights when the fp32 master parameters changed (tracked by tensor versions)."""
+        """(Re)pack weights: every recorded (training) forward repacks -- optimizers that write through `.data` or fused
+        multi-tensor kernels do not bump tensor versions, so versions alone would leave stale bf16 copies -- and inference
+        repacks when a tensor version / pointer changed or when it follows a training step (self.stamp)."""
         s.used, s.need_T_last = True, need_T
         ws = [self.P(n + ".weight") for n in s.names]
-        ver = tuple(w._version for w in ws) + tuple(w.data_ptr() for w in ws)
+        ver = self.stamp + tuple(w._version for w in ws) + tuple(w.data_ptr() for w in ws)
         dev = ws[0].device
         taps = s.k * s.k
         if s.pw is None or s.versions != ver or s.pw.buf.device != dev:
@@ -284,6 +287,9 @@ class Engine:
         dev = img.device
         self.tape = [] if record else None
         self.param_grads = {}
+        if record:
+            self.train_steps += 1
+        self.stamp = ("t" if record else "e", self.train_steps)
         self.prepare_all(record)
         x8 = Var(ops.img_pack(img), 8, relu=False, req=False)
         dims = [(H, W)]
@@ -359,7 +365,7 @@ class Engine:
         specs = [self.spec(f"{h}_head_c{lvl}.2", C, co, 7, 1, 3) for h, co in arch.HEADS]
         ws = [self.P(s.names[0] + ".weight") for s in specs]
         bs = [self.P(s.names[0] + ".bias") for s in specs]
-        ver = tuple(t._version for t in ws + bs) + tuple(t.data_ptr() for t in ws + bs)
+        ver = self.stamp + tuple(t._version for t in ws + bs) + tuple(t.data_ptr() for t in ws + bs)
         key = f"heads_c{lvl}.2F"
         ent = self.fusedT.get(key)
         if ent is None or ent[0] != ver or ent[1].buf.device != dev:
@@ -374,7 +380,7 @@ class Engine:
         if train:
             key = f"heads_c{lvl}.2T"
             ent = self.fusedT.get(key)
-            ver = tuple(w._version for w in ws) + tuple(w.data_ptr() for w in ws)
+            ver = self.stamp + tuple(w._version for w in ws) + tuple(w.data_ptr() for w in ws)
             if ent is None or ent[0] != ver or ent[1].buf.device != dev:
                 pwT = ent[1] if ent is not None and ent[1].buf.device == dev else PackedWeight(3 * C, 49, 64, dev)
                 for k, w in enumerate(ws):

@@ -107,6 +107,7 @@ class SegBranch:
                 self.param_keys += [f"skip_combine.{i}.{sub}.0.weight", f"skip_combine.{i}.{sub}.0.bias"]
         self.param_keys += ["seg_head.0.weight", "seg_head.0.bias", "seg_head.2.weight", "seg_head.2.bias"]
         self.packed = {}
+        self.train_steps, self.stamp = 0, ("e", 0)     # see Engine.prepare: training forwards always repack
 
     def P(self, k):
         return self.m.get_tensor(k)
@@ -123,7 +124,7 @@ class SegBranch:
     def packw(self, key, need_T):
         """key -> (PackedWeight fwd, PackedWeight dgrad, bias) repacked when the parameter version changes."""
         w = self.P(key + ".weight")
-        ver = (w._version, w.data_ptr())
+        ver = self.stamp + (w._version, w.data_ptr())
         e = self.packed.get(key)
         cout, cin, k, _ = w.shape
         if e is None or e["ver"] != ver or e["pw"].buf.device != w.device:
@@ -272,6 +273,9 @@ class SegBranch:
         dev = feats[0].device
         if plan.nb[0] == 0:
             return torch.zeros(0, dtype=torch.float32, device=dev), None
+        if record:
+            self.train_steps += 1
+        self.stamp = ("t" if record else "e", self.train_steps)
         self.prepare_all(record)
         fr = [self.feat_rows(f) for f in feats]
         CH = arch.FEAT_CH

@@ -198,6 +198,39 @@ def test_optimizer_step_runs(model, state_dict0):
     assert all(np.isfinite(losses))
 
 
+def test_weight_updates_without_version_bump_are_seen(model, state_dict0):
+    """The bf16 packed copies must follow the fp32 master weights even when the optimizer does not bump tensor versions
+    (fused multi-tensor Adam, writes through `.data`): fused and default Adam must give the same loss trajectory, and
+    inference right after training must use the updated weights."""
+    x = torch.rand(2, 3, 64, 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)) - 0.5
+    traj = {}
+    for fused in (False, True):
+        model.load_state_dict(state_dict0)
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=fused)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            d0, d1, d2, d3, _ = model(x, [np.zeros((0, 5), np.float32)] * 2)
+            loss = sum(t.float().pow(2).mean() for d in (d0, d1, d2, d3) for t in d[1:])
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        traj[fused] = losses
+    print("foreach", traj[False], "fused", traj[True])
+    assert abs(traj[False][1] - traj[False][0]) > 1e-4 * abs(traj[False][0])          # the update is visible at all
+    for a, b in zip(traj[False], traj[True]):
+        assert abs(a - b) <= 2e-2 * abs(a)
+    model.eval()
+    with torch.no_grad():
+        a = model.forward_dec(x)[0][1].clone()
+        for p in model.parameters():
+            p.data.mul_(0.5)                       # no version bump
+        model.train(); model(x, [np.zeros((0, 5), np.float32)] * 2); model.eval()   # a training forward in between
+        b = model.forward_dec(x)[0][1]
+    assert float((a - b).abs().max()) > 1e-3 * float(a.abs().max())
+
+
 def test_native_library_is_the_one_loaded():
     import os
     maps = open(f"/proc/{os.getpid()}/maps").read()
