@@ -38,14 +38,14 @@ def _stale(out, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    hdr = os.path.join(CSRC, "kg_common.h")
+    hdrs = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]
     jobs = []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
         if not os.path.exists(s):
             continue
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        if force or _stale(o, [s, hdr, __file__]):
+        if force or _stale(o, [s, __file__] + hdrs):
             jobs.append((s, o, [HIPCC] + FLAGS + extra + ["-c", s, "-o", o]))
 
     def run(job):

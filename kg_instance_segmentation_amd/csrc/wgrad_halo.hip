@@ -53,10 +53,18 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     constexpr int XCH = HPIX * 2 * CIF, XPT = (XCH + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // (a readfirstlane'd wave id schedules 4 % slower)
     const int n_ci_tiles = (a.cin_lim + 16 * CIF - 1) / (16 * CIF);
-    const int ci0 = (blockIdx.x % n_ci_tiles) * 16 * CIF, co0 = (blockIdx.x / n_ci_tiles) * 64;
-    const int split = blockIdx.y;
+    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in linear-id order, and all
+    // (co, ci) blocks of one pixel split read the SAME dY tiles / X halos.  Put the blocks of a split on one XCD so that its
+    // L2 fetches each tile once instead of all 8 L2s fetching it.
+    int blk = blockIdx.x, split = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const int L = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = L & 7, slot = L >> 3;
+        blk = slot % gridDim.x; split = (slot / gridDim.x) * 8 + xcd;
+    }
+    const int ci0 = (blk % n_ci_tiles) * 16 * CIF, co0 = (blk / n_ci_tiles) * 64;
     const int G = lane >> 4, i16 = lane & 15;
 
     f32x4 acc[UPW][NCF];
@@ -93,6 +101,23 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     uint4 dyr[DYPT], xr[XPT];
     const int tiles_total = a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y;
 
+    // per-thread staging coordinates (tile independent): dividing per element and tile cost ~260 VALU per tile and wave,
+    // a third of the tile's MFMA time
+    int dy_ry[DYPT], dy_rx[DYPT];
+#pragma unroll
+    for (int k = 0; k < DYPT; ++k) { const int r = (tid + k * 512) >> 3; dy_ry[k] = r >> 4; dy_rx[k] = r & 15; }
+    const int dy_c = co0 + (tid & 7) * 8;
+    const bool dy_cok = dy_c < a.cout_lim;
+    int x_hy[XPT], x_hx[XPT], x_c[XPT];
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) {
+        const int e = tid + k * 512;
+        const int p = e / (2 * CIF), c = e - p * (2 * CIF);
+        const int hy = p / HWD;
+        x_hy[k] = e < XCH ? hy - PAD : -(1 << 20);      // out-of-range elements fail the bounds test below
+        x_hx[k] = p - hy * HWD - PAD;
+        x_c[k] = ci0 + c * 8;
+    }
     auto load_tile = [&](int t) {
         int oy0, ox0, Hd, Wd; long rowbase;
         if (a.tiletab) {
@@ -104,26 +129,22 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
             const int ty = bt % a.tiles_y; const int n = bt / a.tiles_y;
             oy0 = ty * 16; ox0 = tx * 16; Hd = a.H; Wd = a.W; rowbase = (long)n * a.H * a.W;
         }
+        const long base = rowbase + (long)oy0 * Wd + ox0;
+        const bf16_t* dyb = a.dy + base * a.lddy + dy_c;
+        const bf16_t* xb = a.x + base * a.ldx;
+        const int hrem = Hd - oy0, wrem = Wd - ox0;
 #pragma unroll
         for (int k = 0; k < DYPT; ++k) {
-            const int e = tid + k * 512, r = e >> 3, c8 = e & 7;
-            const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (oy < Hd && ox < Wd && co0 + c8 * 8 < a.cout_lim)
-                v = *reinterpret_cast<const uint4*>(a.dy + (rowbase + (long)oy * Wd + ox) * a.lddy + co0 + c8 * 8);
+            if (dy_ry[k] < hrem && dy_rx[k] < wrem && dy_cok)
+                v = *reinterpret_cast<const uint4*>(dyb + (long)(dy_ry[k] * Wd + dy_rx[k]) * a.lddy);
             dyr[k] = v;
         }
 #pragma unroll
         for (int k = 0; k < XPT; ++k) {
-            const int e = tid + k * 512;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (e < XCH) {
-                const int p = e / (2 * CIF), c = e - p * (2 * CIF);
-                const int hy = p / HWD, hx = p - hy * HWD;
-                const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
-                if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd && ci0 + c * 8 < a.cin_lim)
-                    v = *reinterpret_cast<const uint4*>(a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + ci0 + c * 8);
-            }
+            if ((unsigned)(oy0 + x_hy[k]) < (unsigned)Hd && (unsigned)(ox0 + x_hx[k]) < (unsigned)Wd && x_c[k] < a.cin_lim)
+                v = *reinterpret_cast<const uint4*>(xb + (long)(x_hy[k] * Wd + x_hx[k]) * a.ldx + x_c[k]);
             xr[k] = v;
         }
     };

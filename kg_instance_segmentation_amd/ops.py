@@ -254,6 +254,8 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
         S = max(1, min(512 // nblk if nblk <= 512 else 1, tiles))   # ~2 resident rounds of 1-block-per-CU workgroups
         while S > 1 and S * nelem * 4 > (768 << 20):
             S -= 1
+        if S >= 8:
+            S -= S % 8      # multiples of 8 enable the kernel's XCD-aware block mapping
         part = scratch_f32(S * nelem, x.device, "wgrad")
         wgrad_halo(x, dy, part, N or 0, H, W, cin, cout, cin_lim, cout_lim, KH, S, nelem, tiletab16)
     else:
