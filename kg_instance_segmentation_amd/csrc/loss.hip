@@ -67,10 +67,15 @@ __global__ __launch_bounds__(256) void det_loss_fwd_kernel(const float* __restri
 // global normalisation).
 __global__ void det_loss_final_kernel(const float* __restrict__ part, int nb, double numel,
                                       const float* __restrict__ den_override, float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;       // one wave: lanes stride over the block partials, fixed-order tree combine (reproducible)
     double s[5] = {0, 0, 0, 0, 0};
-    for (int b = 0; b < nb; ++b)
+    for (int b = threadIdx.x; b < nb; b += 64)
         for (int k = 0; k < 5; ++k) s[k] += (double)part[b * 5 + k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_down(s[k], o, 64);
+    if (threadIdx.x != 0) return;
     double m2 = s[2], m4 = s[4], ne = numel;
     if (den_override) { m2 = den_override[0]; m4 = den_override[1]; ne = den_override[2]; }
     float lkp = (float)(s[0] / ne);
