@@ -231,6 +231,35 @@ def test_weight_updates_without_version_bump_are_seen(model, state_dict0):
     assert float((a - b).abs().max()) > 1e-3 * float(a.abs().max())
 
 
+def test_full_size_determinism_and_batch_permutation(model, state_dict0):
+    """BASELINE's full size (512x512): properties that do not need the oracle.  Inference is bit-reproducible and
+    equivariant under a permutation of the batch (no cross-image coupling in eval mode: BN uses running statistics);
+    a training step without boxes (no atomics involved) gives bit-identical parameter gradients twice."""
+    model.load_state_dict(state_dict0)
+    model.eval()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.rand(2, 3, 512, 512, device=DEV, generator=g) - 0.5
+    with torch.no_grad():
+        a = [t.clone() for d in model.forward_dec(x)[:4] for t in d]
+        b = [t.clone() for d in model.forward_dec(x)[:4] for t in d]
+        c = [t.clone() for d in model.forward_dec(x.flip(0))[:4] for t in d]
+    for u, v, w in zip(a, b, c):
+        assert u.shape[-1] in (512, 256, 128, 64) and torch.isfinite(u).all()
+        assert torch.equal(u, v)
+        assert torch.equal(u, w.flip(0))
+    model.train()
+    grads = []
+    for _ in range(2):
+        model.load_state_dict(state_dict0)          # resets the BN running statistics too
+        model.zero_grad()
+        d0, d1, d2, d3, _ = model(x, [np.zeros((0, 5), np.float32)] * 2)
+        sum(t.float().abs().mean() for d in (d0, d1, d2, d3) for t in d).backward()
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 150
+    bad = [n for n in grads[0] if not torch.equal(grads[0][n], grads[1][n])]
+    assert not bad, bad[:5]
+
+
 def test_native_library_is_the_one_loaded():
     import os
     maps = open(f"/proc/{os.getpid()}/maps").read()
