@@ -18,6 +18,7 @@ SOURCES = {
     "api.hip": [],
     "conv_igemm.hip": [],
     "conv_gather.hip": [],
+    "conv_small.hip": [],
     "conv_halo.hip": [],
     "conv1x1.hip": [],
     "conv_wgrad.hip": [],

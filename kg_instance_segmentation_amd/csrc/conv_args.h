@@ -14,3 +14,5 @@ struct ConvArgs {
 
 // conv_gather.hip: the deep-prefetch variant for cin_pad % 64 == 0 and bf16 row outputs
 int kg_launch_conv_gather(const ConvArgs& a, int cin_pad, hipStream_t st);
+// conv_small.hip: direct VALU kernel for cin_pad == 8 (image / single-channel inputs)
+int kg_launch_conv_small(const ConvArgs& a, hipStream_t st);

@@ -1,0 +1,148 @@
+// conv_small.hip -- direct (VALU, fp32-accumulate) convolution for inputs of at most 8 channels.
+//
+// Three convs of KGnet's hot path have a tiny reduction depth per tap: c0_conv.0 (3 -> 64, 3x3 at full resolution,
+// KGnet.py:139-142), the stem conv1 (3 -> 64, 7x7 stride 2, KGnet.py:131) and the input gradient of seg_head.2 (1 -> 64
+// channels, 3x3 over the ragged box pixels, KGnet.py:145-147).  An MFMA implicit GEMM pads the 1..3 channels to a 32-wide
+// k-step (the gather kernel reached 20-60 TFLOP/s there and is latency bound); these layers are bound by their output
+// bytes instead, so: one thread = 4 pixels x 8 consecutive couts, fp32 FMAs, the weights of the workgroup's 64 couts in
+// LDS as fp32 [tap][ci][64] (channels whose weights are all zero -- the padding -- are skipped), one 16-byte load per
+// (pixel, tap), and every output row leaves as 128 contiguous bytes per 8 lanes.
+// Same operands, modes and epilogue as kg_conv2d_igemm (bf16 rows in, packed bf16 weights, bias / residual / ReLU / mask).
+#include "conv_args.h"
+
+__global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* wl = reinterpret_cast<float*>(smem);                 // [ntaps][8 ci][64 co]
+    __shared__ int ci_used;
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.y * 64;
+    if (tid == 0) ci_used = 0;
+    __syncthreads();
+    int used = 0;
+    for (int e = tid; e < a.ntaps * 8 * 64; e += 256) {
+        const int co = e & 63, ci = (e >> 6) & 7, tap = e >> 9;
+        const bf16_t wv = a.w[(long)(c0 + co) * a.K + tap * 8 + ci];      // packed rows are zero past Cout
+        wl[e] = bf2f(wv);
+        if (wv & 0x7fff) used |= 1 << ci;
+    }
+    if (used) atomicOr(&ci_used, used);
+    __syncthreads();
+    const int cmask = ci_used;
+
+    const int cg = tid & 7, pl = tid >> 3;                      // couts c0 + cg*8 .. +7; pixels pl + 32 q
+    const int cb = c0 + cg * 8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+    const int smask = (1 << a.stride_log2) - 1;
+    const int ohw = a.OH * a.OW;
+
+    for (long m0 = (long)blockIdx.x * 128; m0 < a.M; m0 += (long)gridDim.x * 128) {
+        int py[4], px[4], ph[4], pw[4];
+        long pbase[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long m = m0 + pl + 32 * q;
+            py[q] = px[q] = ph[q] = pw[q] = 0; pbase[q] = -1;
+            if (m < a.M) {
+                if (a.mode >= 2) {
+                    const int2 d = a.rowdesc[m];
+                    py[q] = d.x >> 16; px[q] = d.x & 0xffff; ph[q] = d.y >> 16; pw[q] = d.y & 0xffff; pbase[q] = m;
+                } else {
+                    const int n = (int)(m / ohw), rem = (int)(m - (long)n * ohw);
+                    py[q] = rem / a.OW; px[q] = rem - py[q] * a.OW; pbase[q] = (long)n * a.H * a.W; ph[q] = a.H; pw[q] = a.W;
+                }
+            }
+        }
+        float acc[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[q][e] = bv[e];
+        for (int tap = 0; tap < a.ntaps; ++tap) {
+            const int dy = tap / a.KW, dx = tap - dy * a.KW;
+            const int dyo = dy - a.pad, dxo = dx - a.pad;
+            uint4 xv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bool ok = pbase[q] >= 0;
+                long row = 0;
+                if (a.mode == 0) {
+                    const int iy = (py[q] << a.stride_log2) + dyo, ix = (px[q] << a.stride_log2) + dxo;
+                    ok = ok && (unsigned)iy < (unsigned)ph[q] && (unsigned)ix < (unsigned)pw[q];
+                    row = pbase[q] + (long)iy * pw[q] + ix;
+                } else if (a.mode == 1) {
+                    const int ty = py[q] - dyo, tx = px[q] - dxo;
+                    ok = ok && ty >= 0 && tx >= 0 && ((ty | tx) & smask) == 0;
+                    const int iy = ty >> a.stride_log2, ix = tx >> a.stride_log2;
+                    ok = ok && iy < ph[q] && ix < pw[q];
+                    row = pbase[q] + (long)iy * pw[q] + ix;
+                } else {
+                    const int sy = a.mode == 2 ? dyo : -dyo, sx = a.mode == 2 ? dxo : -dxo;
+                    const int iy = py[q] + sy, ix = px[q] + sx;
+                    ok = ok && (unsigned)iy < (unsigned)ph[q] && (unsigned)ix < (unsigned)pw[q];
+                    row = pbase[q] + (long)sy * pw[q] + sx;
+                }
+                xv[q] = ok ? *reinterpret_cast<const uint4*>(a.x + row * a.ldx) : make_uint4(0, 0, 0, 0);
+            }
+            const float* wt = wl + tap * 512 + cg * 8;
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) {
+                if (!((cmask >> ci) & 1)) continue;              // workgroup-uniform
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + ci * 64);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wt + ci * 64 + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf16_t* xs = reinterpret_cast<const bf16_t*>(&xv[q]);
+                    const float xf = bf2f(xs[ci]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[q][e] += w0[e] * xf; acc[q][4 + e] += w1[e] * xf; }
+                }
+            }
+        }
+        if (cb >= a.Cout) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long m = m0 + pl + 32 * q;
+            if (m >= a.M) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[q][e];
+            if (a.res) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(a.res + m * a.ldres + cb);
+                const bf16_t* rs = reinterpret_cast<const bf16_t*>(&rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bf2f(rs[e]);
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            if (a.mask) {
+                const uint4 mv = *reinterpret_cast<const uint4*>(a.mask + m * a.ldmask + cb);
+                const bf16_t* ms = reinterpret_cast<const bf16_t*>(&mv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = bf2f(ms[e]) > 0.f ? v[e] : 0.f;
+            }
+            *reinterpret_cast<uint4*>(a.y + m * a.ldy + cb) =
+                make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        }
+    }
+}
+
+// cin_pad == 8, Cout % 8 == 0, bf16 row output with 16-byte aligned rows (checked by the caller, kg_conv2d_igemm)
+int kg_launch_conv_small(const ConvArgs& a, hipStream_t st) {
+    const int smem = a.ntaps * 8 * 64 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        KG_HIP(hipFuncSetAttribute((const void*)conv_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 49 * 8 * 64 * 4));
+        attr_done = true;
+    }
+    const long groups = (a.M + 127) / 128;
+    const int per_cu = smem <= 32768 ? 4 : 1;
+    long gx = 256L * per_cu * 2;
+    if (gx > groups) gx = groups;
+    hipLaunchKernelGGL(conv_small_kernel, dim3((unsigned)gx, kg_cdiv(a.Cout, 64)), dim3(256), smem, st, a);
+    KG_CHECK_LAUNCH("conv_small");
+    return KG_OK;
+}
