@@ -59,6 +59,10 @@ int kg_pack_weight_rows(const float* w, void* dst, int Cout, int Cin, int KH, in
  * int Cout, Cin, taps, K, cin_pad, row0, c0, transposed, gx, blk0;} (gx = Cout, or ceil(Cout/64) when transposed; blk0 = first
  * workgroup of the job); total_blocks = sum of gx * gy over the jobs */
 int kg_pack_weight_batch(const void* jobs, int njobs, int total_blocks, void* stream);
+/* im2col for <= 8 input channels (weight gradient of the stem conv1, KGnet.py:131, as a 1x1 weight-gradient GEMM):
+ * out[m][tap * cin + ci] = x[src(m, tap)][ci]; out rows of Kpad >= KH*KW*cin bf16 values, padding columns pre-zeroed */
+int kg_im2col_small(const void* x, void* out, int N, int H, int W, int OH, int OW, int KH, int KW, int stride, int pad, int cin,
+                    int ldx, int Kpad, void* stream);
 /* weight gradient (autograd of nn.Conv2d at train.py:153): partial sums [nsplit][Cout][taps][Cin] fp32 */
 int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const int* rowdesc, int M, int H, int W, int OH, int OW,
                     int ldx, int lddy, int Cin, int Cout, int cin_lim, int cout_lim, int KH, int KW, int stride, int pad,

@@ -146,3 +146,36 @@ int kg_launch_conv_small(const ConvArgs& a, hipStream_t st) {
     KG_CHECK_LAUNCH("conv_small");
     return KG_OK;
 }
+
+// ---- im2col for <= 8 input channels: the weight gradient of the stem conv1 (3 -> 64, 7x7 stride 2, KGnet.py:131) as a 1x1
+// weight-gradient GEMM.  The per-tap gather kernel pads the 3 channels to a 64-wide tile for each of the 49 taps (16 TFLOP/s).
+// out[m][tap * cin + ci] = x[src(m, tap)][ci] (zero outside the image), rows of Kpad >= taps * cin bf16 values.
+__global__ __launch_bounds__(256) void im2col_small_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int N, int H, int W,
+                                                           int OH, int OW, int KH, int KW, int stride, int pad, int cin, int ldx, int Kpad) {
+    const long total = (long)N * OH * OW * KH * KW;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int tap = (int)(i % (KH * KW));
+        const long m = i / (KH * KW);
+        const int ox = (int)(m % OW), oy = (int)((m / OW) % OH), n = (int)(m / ((long)OW * OH));
+        const int ky = tap / KW, kx = tap - ky * KW;
+        const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const uint4*>(x + (((long)n * H + iy) * W + ix) * ldx);
+        const bf16_t* vs = reinterpret_cast<const bf16_t*>(&v);
+        bf16_t* o = out + m * Kpad + tap * cin;
+        for (int c = 0; c < cin; ++c) o[c] = vs[c];
+    }
+}
+
+// x: bf16 rows [N*H*W][ldx >= 8]; out: bf16 rows [N*OH*OW][Kpad] (columns >= KH*KW*cin must have been zeroed by the caller)
+extern "C" int kg_im2col_small(const void* x, void* out, int N, int H, int W, int OH, int OW, int KH, int KW, int stride, int pad, int cin,
+                               int ldx, int Kpad, void* stream) {
+    KG_CHECK_ARG(x && out && cin >= 1 && cin <= 8 && ldx % 8 == 0 && Kpad >= KH * KW * cin, "kg_im2col_small: bad arguments");
+    const long total = (long)N * OH * OW * KH * KW;
+    long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(im2col_small_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, N, H, W, OH,
+                       OW, KH, KW, stride, pad, cin, ldx, Kpad);
+    KG_CHECK_LAUNCH("im2col_small");
+    return KG_OK;
+}

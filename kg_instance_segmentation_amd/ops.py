@@ -167,6 +167,7 @@ def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=
 
 
 USE_HALO = True
+IM2COL_WGRAD = __import__("os").environ.get("KG_IM2COL_WGRAD", "1") == "1"
 
 
 HALO_WC = int(__import__("os").environ.get("KG_HALO_WC", "0"))   # tuning override (0 = library default)
@@ -242,6 +243,18 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
     Dense stride-1 "same" 3x3/7x7 convs (N given) use the LDS-halo kernel, everything else the gather kernel."""
     M, H, W, OH, OW, KH, KW, stride, pad = geom
     _rows(x); _rows(dy)
+    if IM2COL_WGRAD and mode == 0 and N is not None and cin <= 4 and KH * KW >= 25 and len(grads) == 1 and not accumulate:
+        # stem conv1 (3 -> 64, 7x7 s2): im2col to [M][taps*cin] and ONE 1x1 weight-gradient GEMM instead of 49 per-tap launches
+        # that pad 3 channels to a 64-wide tile
+        Kc = KH * KW * cin
+        Kpad = round_up(Kc, 8)
+        col = torch.zeros(M, Kpad, dtype=BF16, device=x.device) if Kpad != Kc else torch.empty(M, Kpad, dtype=BF16, device=x.device)
+        _lib.call("kg_im2col_small", ptr(x), ptr(col), N, H, W, OH, OW, KH, KW, stride, pad, cin, ld(x), Kpad, stream_ptr())
+        g, off, cnt = grads[0]
+        tmp = torch.empty(cout, Kc, 1, 1, dtype=torch.float32, device=x.device)
+        conv_wgrad(col, dy, Kc, cout, (M, OH, OW, OH, OW, 1, 1, 1, 0), [(tmp, off, cnt)])
+        g.copy_(tmp.view(cnt, KH * KW, cin).permute(0, 2, 1).reshape(g.shape))     # [co][tap][ci] -> OIHW
+        return "im2col"
     cin_lim = min(round_up(cin, 8), x.shape[1])
     cout_lim = min(round_up(cout, 8), dy.shape[1])
     nelem = cout * KH * KW * cin
