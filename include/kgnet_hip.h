@@ -128,6 +128,11 @@ int kg_nms(const double* boxes, const int* nbox, int box_cap, double thresh, voi
  * [55][H][W] (kp 5 | short 10 | mid 40), bit-identical to the reference's float32 tensors ---- */
 int kg_gt_maps(const float* kps, int n, int H, int W, float* out, void* stream);
 
+/* ---- evaluation metrics (eval_parts.mask_iou inside seg_evaluation, eval_parts.py:4-9,98-150): exact pixel counts.
+ * masks = device bytes [n][ld], ld % 16 == 0, non-zero byte = foreground, padding zero ---- */
+int kg_mask_areas(const void* masks, int n, long ld, int* area, void* stream);
+int kg_mask_inter_pairs(const void* a, const void* b, const int* pairs, int npairs, long ld, int* inter, void* stream);
+
 /* ---- per-box segmentation branch (KGnet.py:246-267, 321-350): ragged row bookkeeping ---- */
 int kg_seg_build_rows(const int* boxtab8, int nb, int* rowdesc, int* row2box, int* srcrow, void* stream);
 int kg_rows_gather(const void* src, int ldsrc, const int* srcrow, void* dst, int lddst, long nrows, int C, void* stream);

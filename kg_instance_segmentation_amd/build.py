@@ -27,6 +27,7 @@ SOURCES = {
     "loss.hip": [],
     "postproc.hip": ["-ffp-contract=off"],
     "preproc.hip": ["-ffp-contract=off"],
+    "evalmetrics.hip": [],
     "seg.hip": [],
 }
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

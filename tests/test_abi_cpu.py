@@ -127,7 +127,8 @@ def test_dropin_shims_expose_the_reference_module_surface():
     want = {"KGnet": ["resnet50", "ResNet"], "loss": ["DetectionLossAll"], "seg_loss": ["SEG_loss"],
             "postprocessing": ["get_skeletons_and_masks", "refine_skeleton", "gather_skeleton"],
             "nms": ["non_maximum_suppression_numpy"], "config": ["EDGES", "NUM_KPS", "KP_RADIUS"],
-            "preprocessing": ["get_ground_truth", "create_position_index"]}
+            "preprocessing": ["get_ground_truth", "create_position_index"],
+            "eval_parts": ["mask_iou", "voc_ap", "bbox_evaluation", "seg_evaluation"]}
     for name, syms in want.items():
         spec = importlib.util.spec_from_file_location(f"_dropin_{name}", os.path.join(root, "dropin", f"{name}.py"))
         mod = importlib.util.module_from_spec(spec)

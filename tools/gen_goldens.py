@@ -297,6 +297,70 @@ def gen_preproc():
     print("preproc.npz:", {k: v.shape for k, v in out.items() if k.endswith(".gt")})
 
 
+def eval_case(rng, H, W, ng, nd):
+    """GT instance masks (rectangles / ellipses) + detections (perturbed copies, duplicates, false positives)."""
+    yy, xx = np.mgrid[0:H, 0:W]
+    gm, gb = [], []
+    for k in range(ng):
+        h, w = rng.integers(10, 24, 2); y1 = rng.integers(0, H - h); x1 = rng.integers(0, W - w)
+        if k % 2:
+            m = (((yy - (y1 + h / 2)) / (h / 2)) ** 2 + ((xx - (x1 + w / 2)) / (w / 2)) ** 2) <= 1.0
+        else:
+            m = (yy >= y1) & (yy < y1 + h) & (xx >= x1) & (xx < x1 + w)
+        r, c = np.where(m)
+        gm.append(m.astype(np.float32)); gb.append([r.min(), c.min(), r.max(), c.max(), 1])
+    gm = np.asarray(gm, np.float32); gb = np.asarray(gb, np.float32)
+    dm, dd = [], []
+    for k in range(nd):
+        j = k % ng
+        if k < ng + 3:                                  # shifted copy of a GT mask (the extra ones are duplicates)
+            sy, sx = rng.integers(-4, 5, 2)
+            m = np.roll(np.roll(gm[j], sy, 0), sx, 1)
+        else:                                           # false positive
+            m = np.zeros((H, W), np.float32); y1 = rng.integers(0, H - 12); x1 = rng.integers(0, W - 12)
+            m[y1:y1 + 12, x1:x1 + 12] = 1
+        r, c = np.where(m > 0)
+        dm.append(m); dd.append([r.min(), c.min(), r.max(), c.max(), 0.99 - 0.031 * k + 0.001 * rng.random()])
+    dm.append(np.zeros((H, W), np.float32)); dd.append([3, 3, 9, 9, 0.2])          # empty mask: union < 1 -> IoU 0
+    return gm, gb[:, :4], np.asarray(dm, np.float32), np.asarray(dd, np.float32)
+
+
+def gen_evalparts():
+    """Evaluation metrics (eval_parts.py) on a stub dataset object."""
+    import eval_parts as rev
+    from oracle import evalparts as oev
+    rng = np.random.default_rng(21)
+    out = {}
+    for name, (H, W, ng, nd) in {"a": (96, 96, 10, 16), "b": (64, 120, 6, 9)}.items():
+        gm, gb, dm, dd = eval_case(rng, H, W, ng, nd)
+
+        class DS:
+            def load_annotation(self, index, type):
+                return gm if type == "mask" else gb
+        for thr in (0.5, 0.75):
+            fp, tp, sc, npos, ovl = rev.seg_evaluation(0, DS(), dm, dd, [], 0, [], thr)
+            ofp, otp, osc, oovl = oev.seg_evaluation(gm, gb, dm, dd, thr)
+            assert np.array_equal(fp, ofp) and np.array_equal(tp, otp) and np.array_equal(np.asarray(sc), osc) and ovl == oovl and npos == len(gm)
+            out[f"{name}.seg{int(thr * 100)}.fp"] = fp; out[f"{name}.seg{int(thr * 100)}.tp"] = tp
+            out[f"{name}.seg{int(thr * 100)}.scores"] = np.asarray(sc, np.float32); out[f"{name}.seg{int(thr * 100)}.overlaps"] = np.asarray(ovl, np.float64)
+            fp, tp, sc, npos = rev.bbox_evaluation(0, DS(), dd, [], 0, thr)
+            ofp, otp, osc = oev.bbox_evaluation(gb, dd, thr)
+            assert np.array_equal(fp, ofp) and np.array_equal(tp, otp) and np.array_equal(np.asarray(sc), osc)
+            out[f"{name}.box{int(thr * 100)}.fp"] = fp; out[f"{name}.box{int(thr * 100)}.tp"] = tp
+        iou = np.array([[rev.mask_iou(a, b) for b in gm] for a in dm], np.float64)
+        assert np.array_equal(iou, np.array([[oev.mask_iou(a, b) for b in gm] for a in dm], np.float64))
+        out[f"{name}.iou"] = iou
+        out[f"{name}.gt_masks"] = gm.astype(np.uint8); out[f"{name}.gt_boxes"] = gb
+        out[f"{name}.det_masks"] = dm.astype(np.uint8); out[f"{name}.det"] = dd
+    tpc = np.cumsum(out["a.seg50.tp"]); fpc = np.cumsum(out["a.seg50.fp"])
+    rec = tpc / 10.0; prec = tpc / np.maximum(tpc + fpc, np.finfo(np.float64).eps)
+    out["ap.rec"] = rec; out["ap.prec"] = prec
+    out["ap.values"] = np.array([rev.voc_ap(rec, prec, True), rev.voc_ap(rec, prec, False)], np.float64)
+    assert out["ap.values"][0] == oev.voc_ap(rec, prec, True) and out["ap.values"][1] == oev.voc_ap(rec, prec, False)
+    np.savez_compressed(os.path.join(GOLD, "evalparts.npz"), **out)
+    print("evalparts.npz:", len(out), "arrays; AP", out["ap.values"])
+
+
 def check_norm():
     import ctypes, math
     libm = ctypes.CDLL("libm.so.6"); libm.fma.restype = ctypes.c_double; libm.fma.argtypes = [ctypes.c_double] * 3
@@ -314,9 +378,13 @@ if __name__ == "__main__":
     if "--only-preproc" in sys.argv:
         gen_preproc()
         sys.exit(0)
+    if "--only-evalparts" in sys.argv:
+        gen_evalparts()
+        sys.exit(0)
     torch.manual_seed(0)
     gen_postproc()
     gen_loss()
     gen_net()
     gen_preproc()
+    gen_evalparts()
     os.system(f"ls -la {GOLD}")
