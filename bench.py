@@ -302,8 +302,24 @@ def cpu_baseline(S, nboxes, seed=0):
     opt.step()
     float(loss)
     dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "imgs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 train step, batch 1, 3x{S}x{S}, {nboxes} GT boxes, torch-CPU oracle (oracle/net.py), {dt:.1f} s"}
+    out = {"value": 1.0 / dt, "unit": "imgs/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"1 train step, batch 1, 3x{S}x{S}, {nboxes} GT boxes, torch-CPU oracle (oracle/net.py), {dt:.1f} s"}
+    out.update(grouping_match_rate(S))
+    return out
+
+
+def grouping_match_rate(S):
+    """Second half of BASELINE's metric: grouping / box assembly / NMS of the HIP path vs the oracle on identical head tensors
+    (GT-derived maps of 300 instances + noise, 4 scales): |identical boxes| / |reference boxes|."""
+    from kg_instance_segmentation_amd import postprocessing as kpp
+    from oracle import postproc as op
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dec_np, _ = eval_inputs(S, 300, 5)
+    det = kpp.detect([[torch.from_numpy(a).to(dev) for a in d] for d in dec_np])
+    t0 = time.time(); ref = op.detect(dec_np); dtc = time.time() - t0
+    nref = 0 if ref is None else len(ref)
+    same = 0 if (ref is None or det is None) else int(sum(1 for a in ref if any(np.array_equal(a, b) for b in det)))
+    return {"grouping_match_rate": same / max(nref, 1), "grouping_ref_boxes": nref, "postproc_oracle_ms": 1e3 * dtc}
 
 
 def main():
@@ -430,6 +446,7 @@ def main():
                                   "launches_per_step": v["launches"] / prof_steps} for k, v in summ.items()}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, 20)
+        out["config"]["grouping_match_rate"] = out["cpu_baseline"]["grouping_match_rate"]
     print(json.dumps(out))
 
 
