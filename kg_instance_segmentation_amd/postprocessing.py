@@ -10,6 +10,7 @@ from . import _lib
 from ._lib import ptr, stream_ptr, c_double, c_long
 
 PEAK_THRESH = 0.004   # postprocessing.py:145
+_STREAMS = {}
 
 
 class _Workspace:
@@ -115,7 +116,25 @@ def detect(dec, nms_thresh=0.5):
     dec = ([kp,short,mid] x 4).  Returns N x 5 float64 ndarray or None."""
     from . import nms as _nms
     dev = dec[0][0].device
-    sks = [skeletons_device(*d) for d in dec]
+    # the scales are independent and the greedy grouping of a scale is ONE workgroup: run them on separate streams
+    main = torch.cuda.current_stream(dev)
+    pool = _STREAMS.setdefault(str(dev), [torch.cuda.Stream(dev) for _ in range(4)])
+    sks, seen, used = [], set(), []
+    for i, d in enumerate(dec):
+        key = tuple(d[0].shape[-2:])
+        st = pool[i % 4] if key not in seen else None      # equal sizes share one cached workspace: keep those in order
+        seen.add(key)
+        if st is None:
+            sks.append(skeletons_device(*d))
+            continue
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            r = skeletons_device(*d)
+        for t in r:
+            t.record_stream(main)
+        sks.append(r); used.append(st)
+    for st in used:
+        main.wait_stream(st)
     cap = sum(s[0].shape[0] for s in sks)
     cap = min(cap, 1 << 15)
     boxes = torch.empty(cap, 5, dtype=torch.float64, device=dev)
