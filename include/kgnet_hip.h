@@ -128,6 +128,10 @@ int kg_nms(const double* boxes, const int* nbox, int box_cap, double thresh, voi
  * [55][H][W] (kp 5 | short 10 | mid 40), bit-identical to the reference's float32 tensors ---- */
 int kg_gt_maps(const float* kps, int n, int H, int W, float* out, void* stream);
 
+/* ---- host glue of SEG_loss (seg_loss.py:57-80), pure host code: crops of the matched ground-truth masks (float32 [n][H][W] per
+ * image), nearest-resized to the patch size, as bytes.  work = int32 [nwork][9]: (img, gt, y1, y2, x1, x2, h1, w1, out offset) ---- */
+int kg_host_crop_masks(const float* const* masks, const int* work, int nwork, int H, int W, unsigned char* out);
+
 /* ---- evaluation metrics (eval_parts.mask_iou inside seg_evaluation, eval_parts.py:4-9,98-150): exact pixel counts.
  * masks = device bytes [n][ld], ld % 16 == 0, non-zero byte = foreground, padding zero ---- */
 int kg_mask_areas(const void* masks, int n, long ld, int* area, void* stream);

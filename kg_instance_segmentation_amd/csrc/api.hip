@@ -39,3 +39,36 @@ extern "C" int kg_tr_probe(void* out, void* stream) {
     KG_CHECK_LAUNCH("tr_probe");
     return KG_OK;
 }
+
+// ---- host glue of SEG_loss (seg_loss.py:57-80): crops of the matched ground-truth masks, nearest-resized to the patch size,
+// written as bytes into one (pinned) staging buffer.  Pure host code: 2400 crops per step cost 7 ms as a Python loop.
+// masks[i] = float32 [n_i][H][W] (C order); work = int32 [nwork][9] rows (img, gt index, y1, y2, x1, x2, h1, w1, out offset):
+// out[off + y*w1 + x] = (uint8) masks[img][g][y1 + sy][x1 + sx] with sy = min(floor(y * (y2-y1)/h1), y2-y1-1) (cv2 INTER_NEAREST rule
+// as stated in seg_loss.nearest_resize), identity when the crop already has the patch size.
+#include <math.h>
+extern "C" int kg_host_crop_masks(const float* const* masks, const int* work, int nwork, int H, int W, unsigned char* out) {
+    KG_CHECK_ARG(masks && work && out && nwork >= 0 && H > 0 && W > 0, "kg_host_crop_masks: bad arguments");
+    for (int k = 0; k < nwork; ++k) {
+        const int* w = work + 9 * k;
+        const float* m = masks[w[0]] + (long)w[1] * H * W;
+        int ya = w[2], yb = w[3], xa = w[4], xb = w[5];
+        const int h1 = w[6], w1 = w[7];
+        unsigned char* o = out + w[8];
+        if (yb > H) yb = H;
+        if (xb > W) xb = W;
+        const int h0 = yb - ya, w0 = xb - xa;
+        if (h0 <= 0 || w0 <= 0) { kg_set_error("kg_host_crop_masks: empty ground-truth crop (work item %d)", k); return KG_ERR_ARG; }
+        const double fy = (double)h0 / h1, fx = (double)w0 / w1;
+        for (int y = 0; y < h1; ++y) {
+            int sy = y;
+            if (h0 != h1 || w0 != w1) { sy = (int)floor(y * fy); if (sy > h0 - 1) sy = h0 - 1; }
+            const float* row = m + (long)(ya + sy) * W + xa;
+            for (int x = 0; x < w1; ++x) {
+                int sx = x;
+                if (h0 != h1 || w0 != w1) { sx = (int)floor(x * fx); if (sx > w0 - 1) sx = w0 - 1; }
+                o[y * w1 + x] = (unsigned char)row[sx];
+            }
+        }
+    }
+    return KG_OK;
+}

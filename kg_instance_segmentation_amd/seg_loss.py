@@ -89,55 +89,67 @@ class SEG_loss(nn.Module):
                     continue
                 pb = np.stack([np.asarray(d[:4].detach().cpu().numpy() if hasattr(d, "detach") else d[:4], np.float32) for d in mask_dets[i]])
                 per_img.append((pb, np.array([p.shape[0] for p in pl]), np.array([p.shape[1] for p in pl]), None, pl))
-        # pass 1: match (vectorised); pass 2: crop the GT masks straight into ONE pinned uint8 staging buffer
-        recs, pairs, work, toff = [], [], [], 0   # recs: (img, patch index in image, npix, first pair, npairs)
+        # pass 1 (vectorised per image): matches, pair weights, crop rectangles; pass 2: one native host call crops the matched
+        # GT masks straight into ONE pinned uint8 staging buffer (kg_host_crop_masks)
+        rec_img, rec_j, rec_npx, rec_p0, rec_cnt = [], [], [], [], []
+        pair_off, pair_w, work = [], [], []
+        toff, npairs = 0, 0
         for i, (pb, hs, ws, offs, pl) in enumerate(per_img):
             gb = np.asarray(gt_boxes[i], np.float32).reshape(-1, 5) if len(gt_boxes[i]) else np.zeros((0, 5), np.float32)
             if len(pb) == 0 or len(gb) == 0:
                 continue
             match = jaccard_matrix(pb, gb[:, :4]) >= 0.5                       # seg_loss.py:55-56
-            nobj = int(match.sum())
+            js, gs = np.nonzero(match)                                          # row-major: patch asc, gt asc
+            nobj = len(js)
             if nobj == 0:
                 continue
             y1 = np.maximum(0, np.round(pb[:, 0]).astype(np.int32)); x1 = np.maximum(0, np.round(pb[:, 1]).astype(np.int32))
             y2 = np.minimum(np.round(pb[:, 2]).astype(np.int32), self.height - 1)
             x2 = np.minimum(np.round(pb[:, 3]).astype(np.int32), self.width - 1)
-            js, gs_all = np.nonzero(match)                                      # row-major: patch asc, gt asc
-            first = np.searchsorted(js, np.unique(js))
-            ujs = js[first]
-            counts = np.diff(np.append(first, len(js)))
-            w_img = 1.0 / nobj / nimg
-            for j, f0, cnt in zip(ujs.tolist(), first.tolist(), counts.tolist()):
-                h1, w1 = int(hs[j]), int(ws[j])
-                npx = h1 * w1
-                recs.append((i, j, npx, len(pairs), cnt))
-                for g in gs_all[f0:f0 + cnt].tolist():
-                    pairs.append((toff, w_img / npx))
-                    work.append((i, g, int(y1[j]), int(y2[j]), int(x1[j]), int(x2[j]), h1, w1, toff))
-                    toff += npx
-        if not recs:
+            hj = np.asarray(hs, np.int64)[js]; wj = np.asarray(ws, np.int64)[js]
+            npx = hj * wj
+            off_k = toff + np.cumsum(npx) - npx
+            toff += int(npx.sum())
+            pair_off.append(off_k); pair_w.append((1.0 / nobj / nimg) / npx)
+            work.append(np.stack([np.full(nobj, i), gs, y1[js], y2[js], x1[js], x2[js], hj, wj, off_k], 1))
+            ujs, first = np.unique(js, return_index=True)
+            cnt = np.diff(np.append(first, nobj))
+            rec_img.append(np.full(len(ujs), i)); rec_j.append(ujs); rec_npx.append(npx[first]); rec_p0.append(npairs + first); rec_cnt.append(cnt)
+            npairs += nobj
+        if not rec_img:
             return None                      # seg_loss.py:93-96
+        rec_img, rec_j, rec_npx, rec_p0, rec_cnt = (np.concatenate(v) for v in (rec_img, rec_j, rec_npx, rec_p0, rec_cnt))
+        work = np.ascontiguousarray(np.concatenate(work), np.int32)
         tgt_host = torch.empty(toff, dtype=torch.uint8, pin_memory=True)
-        tnp = tgt_host.numpy()
-        for (i, g, ya, yb, xa, xb_, h1, w1, off) in work:
-            crop = gt_masks[i][g][ya:yb, xa:xb_]                               # seg_loss.py:64
-            if crop.shape != (h1, w1):
-                crop = nearest_resize(np.asarray(crop), h1, w1)                 # seg_loss.py:77
-                assert crop.shape == (h1, w1), "[loss.py] mask size does not match!"
-            tnp[off:off + h1 * w1].reshape(h1, w1)[...] = crop
+        marr = [np.asarray(m) for m in gt_masks]
+        if all(m.dtype == np.float32 and m.flags.c_contiguous and m.ndim == 3 and m.shape[1:] == marr[0].shape[1:] for m in marr if m.size):
+            import ctypes
+            H0, W0 = next(m.shape[1:] for m in marr if m.size)
+            ptrs = (ctypes.c_void_p * len(marr))(*[m.ctypes.data for m in marr])
+            _lib.call("kg_host_crop_masks", ctypes.cast(ptrs, ctypes.c_void_p), ctypes.c_void_p(work.ctypes.data), len(work), int(H0), int(W0),
+                      ctypes.c_void_p(tgt_host.data_ptr()))
+        else:                                # other mask containers: per-pair NumPy crops
+            tnp = tgt_host.numpy()
+            for (i, g, ya, yb, xa, xb_, h1, w1, off) in work.tolist():
+                crop = marr[i][g][ya:yb, xa:xb_]                               # seg_loss.py:64
+                if crop.shape != (h1, w1):
+                    crop = nearest_resize(np.asarray(crop), h1, w1)             # seg_loss.py:77
+                    assert crop.shape == (h1, w1), "[loss.py] mask size does not match!"
+                tnp[off:off + h1 * w1].reshape(h1, w1)[...] = crop
         if meta is not None:
             flat = meta["flat"]
-            offs = [int(per_img[i][3][j]) for i, j, _, _, _ in recs]
+            offs = np.concatenate([np.asarray(per_img[i][3])[rec_j[rec_img == i]] for i in np.unique(rec_img).tolist()])
         else:                                # patches from elsewhere: concatenate (autograd-tracked)
-            flat = torch.cat([per_img[i][4][j].reshape(-1) for i, j, _, _, _ in recs]).float()
-            offs = list(np.cumsum([0] + [r[2] for r in recs[:-1]]))
+            flat = torch.cat([per_img[i][4][j].reshape(-1) for i, j in zip(rec_img.tolist(), rec_j.tolist())]).float()
+            offs = np.cumsum(rec_npx) - rec_npx
         if not flat.is_cuda:
             raise _lib.KGLibraryError("SEG_loss (MI355X build) needs GPU tensors")
         dev = flat.device
-        ptab = np.array([[o, r[2], r[3], r[4]] for o, r in zip(offs, recs)], np.int32)
-        pair_t = np.zeros(len(pairs), dtype=[("off", np.int32), ("w", np.float32)])
-        pair_t["off"] = [p[0] for p in pairs]; pair_t["w"] = [p[1] for p in pairs]
+        ptab = np.ascontiguousarray(np.stack([offs, rec_npx, rec_p0, rec_cnt], 1), np.int32)
+        pair_t = np.zeros(npairs, dtype=[("off", np.int32), ("w", np.float32)])
+        pair_t["off"] = np.concatenate(pair_off); pair_t["w"] = np.concatenate(pair_w)
+        nrec = len(rec_img)
         tgt = tgt_host.to(dev, non_blocking=True)
         ptab_d = ops.h2d(ptab, dev)
         pairs_d = ops.h2d(pair_t.view(np.uint8), dev)
-        return _SegLossFn.apply(flat, tgt, ptab_d, pairs_d, len(recs))
+        return _SegLossFn.apply(flat, tgt, ptab_d, pairs_d, nrec)

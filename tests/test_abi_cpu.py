@@ -141,3 +141,25 @@ def test_preprocessing_position_index_matches_reference_layout():
     from kg_instance_segmentation_amd import preprocessing as kprep
     p = kprep.create_position_index(3, 5)
     assert p.shape == (3, 5, 2) and tuple(p[2, 4]) == (4, 2)      # (x, y) per pixel, preprocessing.py:4-11
+
+
+def test_host_crop_masks_matches_numpy_rule(lib):
+    """kg_host_crop_masks (host glue of SEG_loss, seg_loss.py:57-80) == NumPy slicing + the nearest-resize rule, incl. crops
+    whose size differs from the patch (clamped boxes)."""
+    import ctypes
+    import numpy as np
+    from kg_instance_segmentation_amd import _lib
+    from kg_instance_segmentation_amd.seg_loss import nearest_resize
+    rng = np.random.default_rng(0)
+    H, W = 40, 56
+    masks = [(rng.random((3, H, W)) > 0.5).astype(np.float32), (rng.random((2, H, W)) > 0.5).astype(np.float32)]
+    work, off = [], 0
+    for (i, g, ya, yb, xa, xb, h1, w1) in [(0, 2, 3, 20, 5, 30, 17, 25), (1, 0, 0, 39, 10, 55, 40, 46), (0, 0, 7, 9, 7, 12, 5, 9), (1, 1, 30, 39, 0, 8, 9, 8)]:
+        work.append([i, g, ya, yb, xa, xb, h1, w1, off]); off += h1 * w1
+    work = np.asarray(work, np.int32)
+    out = np.full(off, 255, np.uint8)
+    ptrs = (ctypes.c_void_p * 2)(*[m.ctypes.data for m in masks])
+    _lib.call("kg_host_crop_masks", ctypes.cast(ptrs, ctypes.c_void_p), ctypes.c_void_p(work.ctypes.data), len(work), H, W, ctypes.c_void_p(out.ctypes.data))
+    for (i, g, ya, yb, xa, xb, h1, w1, o) in work.tolist():
+        ref = nearest_resize(masks[i][g][ya:yb, xa:xb], h1, w1)
+        assert np.array_equal(out[o:o + h1 * w1].reshape(h1, w1), ref.astype(np.uint8))
