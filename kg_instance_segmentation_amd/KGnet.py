@@ -68,11 +68,14 @@ class ResNet(nn.Module):
 
     def __init__(self, block=None, layers=(3, 4, 6, 3), num_classes=1000, zero_init_residual=False):
         super().__init__()
-        if tuple(layers[:3]) != (3, 4, 6):
-            raise NotImplementedError("only the Bottleneck [3,4,6,*] trunk used by the reference drivers is built "
-                                      "(KGnet.py:135-137 uses layers[0..2] only)")
+        if block is not None and getattr(block, "expansion", 4) != 4:
+            raise NotImplementedError("BasicBlock trunks (resnet18/34) cannot run forward_dec in the reference either "
+                                      "(channel plan of KGnet.py:116-119,150-158 assumes expansion 4)")
+        if len(layers) < 3 or any(int(b) < 1 for b in layers[:3]):
+            raise ValueError("layers must give the block counts of layer1..layer3")
+        self.layers_tab = arch.layers_table(layers)          # KGnet.py:135-137 builds layers[0..2] only
         self._param_keys = []
-        for key, shape, kind in arch.state_spec():
+        for key, shape, kind in arch.state_spec(layers):
             parts = key.split(".")
             node = self
             for p in parts[:-1]:
@@ -102,7 +105,7 @@ class ResNet(nn.Module):
             if kind in ("conv_w", "conv_b", "bn_w", "bn_b"):
                 self._param_keys.append(key)
         if zero_init_residual:
-            for name, _, _, blocks, _ in arch.LAYERS:
+            for name, _, _, blocks, _ in self.layers_tab:
                 for b in range(blocks):
                     nn.init.constant_(self.get_tensor(f"{name}.{b}.bn3.weight"), 0)
         self._engine = Engine(self)
@@ -162,7 +165,10 @@ def resnet50(pretrained=False, **kwargs):
 
 
 def resnet101(pretrained=False, **kwargs):
-    raise NotImplementedError("the reference drivers hard-code resnet50 (train.py:35, test.py:53, eval.py:30)")
+    """KGnet.py:388-397 (Bottleneck [3,4,23,3]; pretrained weights are only wired for resnet50, KG_RESNET50_PTH)."""
+    return ResNet(None, [3, 4, 23, 3], **kwargs)
 
 
-resnet152 = resnet101
+def resnet152(pretrained=False, **kwargs):
+    """KGnet.py:400-409 (Bottleneck [3,8,36,3])."""
+    return ResNet(None, [3, 8, 36, 3], **kwargs)

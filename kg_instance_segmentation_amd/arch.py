@@ -2,6 +2,12 @@
 (KGnet.py:125-227; 346 entries) and the layer wiring of forward_dec (KGnet.py:275-318)."""
 
 LAYERS = [("layer1", 64, 64, 3, 1), ("layer2", 256, 128, 4, 2), ("layer3", 512, 256, 6, 2)]  # name, inplanes, planes, blocks, stride
+
+
+def layers_table(layers=(3, 4, 6, 3)):
+    """KGnet.py:135-137: only layers[0..2] are built (Bottleneck, expansion 4); the block counts come from the constructor
+    (resnet50 [3,4,6,3], resnet101 [3,4,23,3], resnet152 [3,8,36,3], KGnet.py:377-410)."""
+    return [(n, i, p, int(b), st) for (n, i, p, _, st), b in zip(LAYERS, layers[:3])]
 FEAT_CH = [64, 64, 256, 512, 1024]          # c0..c4 channels
 SKIP = [(64, 64, 128), (256, 64, 128), (512, 256, 512), (1024, 512, 1024)]  # skip_combine[i]: (in, out, cat)
 HEADS = [("kp", 5), ("short_offset", 10), ("mid_offset", 40)]
@@ -21,10 +27,10 @@ def _conv(p, cout, cin, k, bias=True):
     return s
 
 
-def state_spec():
-    """Ordered [(key, shape, kind)] == reference ResNet(Bottleneck,[3,4,6,3]).state_dict() order."""
+def state_spec(layers=(3, 4, 6, 3)):
+    """Ordered [(key, shape, kind)] == reference ResNet(Bottleneck, layers).state_dict() order."""
     s = _conv("conv1", 64, 3, 7, bias=False) + _bn("bn1", 64)
-    for name, inplanes, planes, blocks, _ in LAYERS:
+    for name, inplanes, planes, blocks, _ in layers_table(layers):
         for b in range(blocks):
             p = f"{name}.{b}"
             cin = inplanes if b == 0 else planes * 4

@@ -305,7 +305,7 @@ class Engine:
         dims.append((H1, W1))
         feats = [c0, c1]
         cats = [cat0, cat1]
-        for li, (name, inplanes, planes, blocks, stride) in enumerate(arch.LAYERS):
+        for li, (name, inplanes, planes, blocks, stride) in enumerate(self.m.layers_tab):
             for b in range(blocks):
                 st = stride if b == 0 else 1
                 Ho, Wo = (Hc - 1) // st + 1, (Wc - 1) // st + 1

@@ -20,9 +20,10 @@ LAYERS = [("layer1", 64, 3, 1), ("layer2", 128, 4, 2), ("layer3", 256, 6, 2)]
 class Net:
     """Functional KGnet over a dict of tensors (leaf tensors may require grad)."""
 
-    def __init__(self, sd, training=False):
+    def __init__(self, sd, training=False, layers=(3, 4, 6, 3)):
         self.sd = sd
         self.training = training
+        self.layers = [(n, p, int(b), st) for (n, p, _, st), b in zip(LAYERS, layers[:3])]   # KGnet.py:135-137
 
     # -- primitives ---------------------------------------------------------
     @staticmethod
@@ -58,7 +59,7 @@ class Net:
         c1 = self.act(self.bn(self.conv(x, "conv1", 2, 3), "bn1", True))
         f = F.max_pool2d(c1, 3, 2, 1)
         feats = [c0, c1]
-        for name, planes, blocks, stride in LAYERS:
+        for name, planes, blocks, stride in self.layers:
             for b in range(blocks):
                 f = self.bottleneck(f, f"{name}.{b}", stride if b == 0 else 1, b == 0)
             feats.append(f)

@@ -33,12 +33,12 @@ def _conv(p, cout, cin, k):
     return [(f"{p}.weight", (cout, cin, k, k)), (f"{p}.bias", (cout,))]
 
 
-def param_specs():
-    """Ordered (key, shape) list == reference state_dict() order (346 entries)."""
+def param_specs(layers=(3, 4, 6, 3)):
+    """Ordered (key, shape) list == reference state_dict() order (346 entries for resnet50's [3,4,6,3])."""
     s = [("conv1.weight", (64, 3, 7, 7))] + _bn("bn1", 64)
-    _bottleneck_layer("layer1", 64, 64, 3, s)
-    _bottleneck_layer("layer2", 256, 128, 4, s)
-    _bottleneck_layer("layer3", 512, 256, 6, s)
+    _bottleneck_layer("layer1", 64, 64, int(layers[0]), s)
+    _bottleneck_layer("layer2", 256, 128, int(layers[1]), s)
+    _bottleneck_layer("layer3", 512, 256, int(layers[2]), s)
     s += _conv("c0_conv.0", 64, 3, 3) + _conv("c0_conv.2", 64, 64, 3)
     for i, (cin, cout, ccat) in enumerate([(64, 64, 128), (256, 64, 128), (512, 256, 512), (1024, 512, 1024)]):
         s += _conv(f"skip_combine.{i}.up.0", cout, cin, 3) + _conv(f"skip_combine.{i}.cat_conv.0", cout, ccat, 1)
@@ -53,12 +53,12 @@ def param_specs():
     return s
 
 
-def gen_state_dict(seed=0, as_torch=True, head_bias=None):
+def gen_state_dict(seed=0, as_torch=True, head_bias=None, layers=(3, 4, 6, 3)):
     """Seeded state_dict.  conv weights ~ kaiming-normal(fan_out) (KGnet.py:212-214),
     biases/BN affine/running stats non-trivial so that every term is exercised.
     head_bias: optional float added to the kp heads' last-layer biases."""
     out = {}
-    for key, shape in param_specs():
+    for key, shape in param_specs(layers):
         rng = np.random.default_rng([seed, zlib.crc32(key.encode())])
         if key.endswith("num_batches_tracked"):
             a = np.zeros((), np.int64)

@@ -260,6 +260,31 @@ def test_full_size_determinism_and_batch_permutation(model, state_dict0):
     assert not bad, bad[:5]
 
 
+def test_other_block_counts(golden):
+    """Bottleneck trunks with other block counts (resnet101 / resnet152 constructors, KGnet.py:388-409): state_dict keys and the
+    eval forward of ResNet(Bottleneck, [1,2,2,1]) against the reference fixture."""
+    from oracle import weightgen
+    g = golden("net_layers.npz")
+    layers = [int(v) for v in g["layers"]]
+    sd = weightgen.gen_state_dict(int(g["seed"]), layers=layers)
+    m = KGnet.ResNet(None, layers)
+    assert list(m.state_dict().keys()) == list(sd.keys()) and len(sd) == int(g["nkeys"])
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x = (torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(77)) - 0.5).to(DEV)
+    with torch.no_grad():
+        d0, d1, d2, d3, feats = m.forward_dec(x)
+    for l, d in enumerate((d0, d1, d2, d3)):
+        for nm, t in zip(("short", "mid"), d[1:]):
+            e = rel_l2(sub(t), g[f"c{l}.{nm}"])
+            print(f"[layers{layers} c{l}.{nm}] rel_l2={e:.4f}")
+            assert e <= 3e-2
+    for l, f in enumerate(feats):
+        assert rel_l2(sub(f, 5)[:, ::7], g[f"feat{l}"]) <= 3e-2
+    assert len(KGnet.resnet101(pretrained=False).state_dict()) == 346 + 17 * 18      # 17 more bottlenecks in layer3
+    assert len(KGnet.resnet152(pretrained=False).state_dict()) == 346 + (4 + 30) * 18
+
+
 def test_native_library_is_the_one_loaded():
     import os
     maps = open(f"/proc/{os.getpid()}/maps").read()

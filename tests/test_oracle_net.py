@@ -102,3 +102,21 @@ def test_train_step(golden, state_dict0):
               "layer2.0.downsample.1.running_var"):
         np.testing.assert_allclose(sd[k].detach().numpy(), g[f"train.stat.{k}"], rtol=1e-4, atol=1e-6)
     assert int(sd["bn1.num_batches_tracked"]) == int(g["train.stat.bn1.num_batches_tracked"])
+
+
+def test_other_block_counts_match_reference(golden):
+    """ResNet(Bottleneck, [1,2,2,1]) (the constructors of KGnet.py:377-410 differ only in the block counts): the oracle with
+    `layers` reproduces the reference's eval forward."""
+    import torch
+    from oracle import net as onet, weightgen
+    g = golden("net_layers.npz")
+    layers = tuple(int(v) for v in g["layers"])
+    sd = weightgen.gen_state_dict(int(g["seed"]), layers=layers)
+    assert len(sd) == int(g["nkeys"])
+    x = torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(77)) - 0.5
+    with torch.no_grad():
+        outs = onet.Net(sd, training=False, layers=layers).forward_dec(x)
+    for l in range(4):
+        for nm, t in zip(("kp", "short", "mid"), outs[l]):
+            a = t.numpy(); a = a[..., ::3, ::3] if a.shape[-1] > 32 else a
+            np.testing.assert_allclose(a, g[f"c{l}.{nm}"], rtol=1e-4, atol=1e-5)

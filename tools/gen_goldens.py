@@ -220,6 +220,29 @@ def gen_net(seed=0):
     print("net.npz written; losses", out["train.loss_dec"], out["train.loss_seg"], "patches", out["train.npatch"])
 
 
+def gen_net_layers(seed=3, layers=(1, 2, 2, 1)):
+    """A Bottleneck trunk with other block counts than resnet50's (the constructors of KGnet.py:377-410 only differ in them):
+    eval forward of ResNet(Bottleneck, [1,2,2,1]) -> tests/golden/net_layers.npz."""
+    sd = weightgen.gen_state_dict(seed, layers=layers)
+    model = rKGnet.ResNet(rKGnet.Bottleneck, list(layers))
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model.load_state_dict(sd)
+    model.eval()
+    x = torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(77)) - 0.5
+    out = {"layers": np.array(layers), "seed": np.array(seed), "x_sha": sha(x.numpy()), "nkeys": np.array(len(sd))}
+    with torch.no_grad():
+        d0, d1, d2, d3, feats = model.forward_dec(x)
+        onet_out = onet.Net({k: v.clone() for k, v in sd.items()}, training=False, layers=layers).forward_dec(x)
+        for l, d in enumerate((d0, d1, d2, d3)):
+            for nm, t, o in zip(("kp", "short", "mid"), d, onet_out[l]):
+                assert torch.allclose(t, o, rtol=1e-4, atol=1e-5), (l, nm)          # the oracle restatement is pinned here too
+                out[f"c{l}.{nm}"] = sub(t)
+        for l, f in enumerate(feats):
+            out[f"feat{l}"] = sub(f, 5)[:, ::7].copy()
+    np.savez_compressed(os.path.join(GOLD, "net_layers.npz"), **out)
+    print("net_layers.npz written:", len(sd), "keys")
+
+
 def gen_loss():
     out = {}
     rng = np.random.default_rng(9)
@@ -378,6 +401,9 @@ if __name__ == "__main__":
     if "--only-preproc" in sys.argv:
         gen_preproc()
         sys.exit(0)
+    if "--only-net-layers" in sys.argv:
+        gen_net_layers()
+        sys.exit(0)
     if "--only-evalparts" in sys.argv:
         gen_evalparts()
         sys.exit(0)
@@ -387,4 +413,5 @@ if __name__ == "__main__":
     gen_net()
     gen_preproc()
     gen_evalparts()
+    gen_net_layers()
     os.system(f"ls -la {GOLD}")
