@@ -260,6 +260,36 @@ def test_full_size_determinism_and_batch_permutation(model, state_dict0):
     assert not bad, bad[:5]
 
 
+@pytest.mark.parametrize("shape", [(1, 200, 136), (3, 72, 264)])
+def test_odd_sizes_vs_oracle(model, state_dict0, shape):
+    """Image sizes that are multiples of 8 but of none of the kernels' tile sizes (16 / 32 / 64 pixels), batch sizes 1 and 3: eval
+    forward + seg branch against the (reference-pinned) oracle network."""
+    from oracle import net as onet
+    N, H, W = shape
+    model.load_state_dict(state_dict0)
+    model.eval()
+    x = torch.rand(N, 3, H, W, generator=torch.Generator().manual_seed(H + W)) - 0.5
+    boxes = [np.array([[4.4, 6.6, 0.55 * H, 0.6 * W, 1.0], [0.3 * H, 0.2 * W, H - 1.0, W - 1.0, 0.9]], np.float32) for _ in range(N)]
+    with torch.no_grad():
+        d0, d1, d2, d3, feats = model.forward_dec(x.to(DEV))
+        patches, dets = model.forward_seg(feats, boxes)
+        net = onet.Net({k: v.clone() for k, v in state_dict0.items()}, training=False)
+        o0, o1, o2, o3, ofe = net.forward_dec(x)
+        opatches, odets = net.forward_seg(ofe, boxes)
+    for l, (d, o) in enumerate(zip((d0, d1, d2, d3), (o0, o1, o2, o3))):
+        for nm, t, r in zip(("short", "mid"), d[1:], o[1:]):
+            e = rel_l2(t.cpu().numpy(), r.numpy())
+            print(f"[{shape} c{l}.{nm}] rel_l2={e:.4f}")
+            assert tuple(t.shape) == tuple(r.shape) and e <= 3e-2
+    for i in range(N):
+        assert len(patches[i]) == len(opatches[i]) == 2
+        for p, r in zip(patches[i], opatches[i]):
+            diff = (p.cpu() - r).abs()
+            print(f"[{shape} seg img {i} {tuple(p.shape)}] max_abs={float(diff.max()):.4f} mean_abs={float(diff.mean()):.5f} frac>0.05={float((diff > 0.05).float().mean()):.5f}")
+            # (random-init logits are saturated: a probability only moves where a logit changes sign, cf. the kp criterion above)
+            assert tuple(p.shape) == tuple(r.shape) and float((diff > 0.05).float().mean()) <= 5e-3 and float(diff.mean()) <= 2e-3
+
+
 def test_other_block_counts(golden):
     """Bottleneck trunks with other block counts (resnet101 / resnet152 constructors, KGnet.py:388-409): state_dict keys and the
     eval forward of ResNet(Bottleneck, [1,2,2,1]) against the reference fixture."""
