@@ -70,7 +70,9 @@ int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const int* rowdes
 /* weight gradient of a dense stride-1 "same" 3x3 / 7x7 conv with dY tile + X halo resident in LDS (all taps per staging pass) */
 int kg_conv2d_wgrad_halo(const void* x, const void* dy, float* dwp, int N, int H, int W, int ldx, int lddy, int Cin, int Cout,
                          int cin_lim, int cout_lim, int KS, int nsplit, long split_stride, const int* tiletab16, int ntiles,
-                         void* stream);   /* tiletab16 != NULL: ragged boxes, one entry per 16x16 tile */
+                         float* dbp, void* stream);   /* tiletab16 != NULL: ragged boxes, one entry per 16x16 tile;
+                         dbp != NULL: also writes the bias-gradient partials [nsplit][Cout] (sum over pixels of dy) */
+int kg_bias_grad_final(const float* part, float* db, int nsplit, int C, int accumulate, void* stream);
 int kg_wgrad_reduce(const float* part, float* grad_oihw, int Cout, int Cin, int KH, int KW, int nsplit, long split_stride,
                     int accumulate, void* stream);
 int kg_bias_grad(const void* dy, float* db, float* scratch, int scratch_floats, int M, int C, int ld, int accumulate,

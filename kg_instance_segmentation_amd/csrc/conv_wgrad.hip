@@ -309,6 +309,14 @@ __global__ __launch_bounds__(256) void bias_grad_vec_kernel(const bf16_t* __rest
     }
 }
 
+// Sums nsplit partial bias gradients [nsplit][C] (written by kg_conv2d_wgrad_halo's bias unit) in fixed order.
+extern "C" int kg_bias_grad_final(const float* part, float* db, int nsplit, int C, int accumulate, void* stream) {
+    KG_CHECK_ARG(part && db && nsplit >= 1 && C >= 1, "kg_bias_grad_final: bad arguments");
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, part, db, nsplit, C, accumulate);
+    KG_CHECK_LAUNCH("bias_grad_final");
+    return KG_OK;
+}
+
 extern "C" int kg_bias_grad(const void* dy, float* db, float* scratch, int scratch_floats, int M, int C, int ld,
                             int accumulate, void* stream) {
     KG_CHECK_ARG(dy && db && scratch, "kg_bias_grad: null pointer");

@@ -27,6 +27,7 @@ struct WgHaloArgs {
     int N, H, W, tiles_x, tiles_y, ldx, lddy;
     int Cin, Cout, cin_lim, cout_lim, nsplit;
     long split_stride;
+    float* dbp;       // optional bias-gradient partials [nsplit][Cout]: db[co] = sum over pixels of dY (KGnet's convs with bias)
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -44,7 +45,7 @@ struct WgGeom {
 
 // NCF = 16-wide output-channel fragments that are computed (4 = all 64; 1 / 3 for the 5-, 10- and 40-channel second
 // head convs, whose dY tile is mostly padding: KGnet.py:161-209 `.2` layers)
-template <int KS, int CIF, int NCF = 4>
+template <int KS, int CIF, int NCF = 4, bool BIAS = false>
 __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     using GE = WgGeom<KS, CIF>;
     constexpr int PAD = GE::PAD, HWD = GE::HWD, HPIX = HWD * HWD, T = GE::T, XB = GE::XB, PITCH = GE::PITCH;
@@ -72,6 +73,20 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     for (int q = 0; q < UPW; ++q)
 #pragma unroll
         for (int c = 0; c < NCF; ++c) acc[q][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Bias gradient for free: db[co] = sum_px dY[px][co] is the weight gradient of a constant-1 input channel, i.e. one more
+    // (tap, ci-fragment) unit with an all-ones B fragment.  49 (7x7) and 36 (3x3) units leave a wave with a free unit slot
+    // (BW, slot BQ < UPW), so the extra NCF MFMAs per k-step do not lengthen the workgroup's critical path.
+    constexpr int BW = UNITS % 8, BQ = UNITS / 8;
+    static_assert(BQ < UPW, "no free unit slot for the bias-gradient unit");
+    const bool do_bias = BIAS && ci0 == 0 && wave == BW;   // (a separate instantiation: the extra accumulators cost the 3x3
+                                                           // variant 23 spilled registers, so only the 7x7 kernels carry the unit)
+    f32x4 accb[BIAS ? NCF : 1];
+#pragma unroll
+    for (int c = 0; c < (BIAS ? NCF : 1); ++c) accb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
     // ---- lane-constant fragment addresses (k-step 0); k-step s adds an immediate ------------------------------------
     // dY^T fragment c (co block), half h: tile row r = (G&1)*16 + (G>>1)*8 + h*4 + (i16>>2)   (+ s*32)
@@ -187,6 +202,10 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
                     bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sy + ay[c][h] + s * 32 * 128));
                     af[c][h * 4 + 0] = v[0]; af[c][h * 4 + 1] = v[1]; af[c][h * 4 + 2] = v[2]; af[c][h * 4 + 3] = v[3];
                 }
+            if (BIAS && do_bias) {                     // wave-uniform
+#pragma unroll
+                for (int c = 0; c < (BIAS ? NCF : 1); ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], ones, accb[c], 0, 0, 0);
+            }
 #pragma unroll
             for (int q = 0; q < UPW; ++q) {
                 if (wave + 8 * q < UNITS) {            // wave-uniform
@@ -206,6 +225,15 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
         cur ^= 1;
     }
 
+    if (BIAS && do_bias && i16 == 0) {     // every column of the unit's result holds the same sum
+#pragma unroll
+        for (int c = 0; c < (BIAS ? NCF : 1); ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + c * 16 + G * 4 + r;
+                if (co < a.Cout) a.dbp[(long)split * a.Cout + co] = accb[c][r];
+            }
+    }
     float* out = a.dwp + (long)split * a.split_stride;
 #pragma unroll
     for (int q = 0; q < UPW; ++q) {
@@ -223,16 +251,16 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     }
 }
 
-template <int KS, int CIF, int NCF = 4>
+template <int KS, int CIF, int NCF = 4, bool BIAS = false>
 static int launch_wg(const WgHaloArgs& a, hipStream_t st) {
     constexpr int smem = 2 * WgGeom<KS, CIF>::BUF;
     static bool attr_done = false;
     if (!attr_done) {
-        KG_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<KS, CIF, NCF>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        KG_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<KS, CIF, NCF, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
     const int n_ci = (a.cin_lim + 16 * CIF - 1) / (16 * CIF), n_co = (a.cout_lim + 63) / 64;
-    hipLaunchKernelGGL((wgrad_halo_kernel<KS, CIF, NCF>), dim3(n_ci * n_co, a.nsplit), dim3(512), smem, st, a);
+    hipLaunchKernelGGL((wgrad_halo_kernel<KS, CIF, NCF, BIAS>), dim3(n_ci * n_co, a.nsplit), dim3(512), smem, st, a);
     KG_CHECK_LAUNCH("wgrad_halo");
     return KG_OK;
 }
@@ -241,7 +269,7 @@ static int launch_wg(const WgHaloArgs& a, hipStream_t st) {
 // dwp receives nsplit partial tensors [Cout][KS*KS][Cin] (fp32), split_stride elements apart.
 extern "C" int kg_conv2d_wgrad_halo(const void* x, const void* dy, float* dwp, int N, int H, int W, int ldx, int lddy,
                                     int Cin, int Cout, int cin_lim, int cout_lim, int KS, int nsplit, long split_stride,
-                                    const int* tiletab, int ntiles, void* stream) {
+                                    const int* tiletab, int ntiles, float* dbp, void* stream) {
     WgHaloArgs a;
     memset(&a, 0, sizeof(a));
     KG_CHECK_ARG(x && dy && dwp, "kg_conv2d_wgrad_halo: null pointer");
@@ -251,9 +279,15 @@ extern "C" int kg_conv2d_wgrad_halo(const void* x, const void* dy, float* dwp, i
     a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dwp = dwp; a.N = N; a.H = H; a.W = W;
     a.tiles_x = kg_cdiv(W, 16); a.tiles_y = kg_cdiv(H, 16); a.ldx = ldx; a.lddy = lddy; a.Cin = Cin; a.Cout = Cout;
     a.cin_lim = cin_lim; a.cout_lim = cout_lim; a.nsplit = nsplit; a.split_stride = split_stride;
-    a.tiletab = (const int4*)tiletab; a.ntiles = ntiles;
+    a.tiletab = (const int4*)tiletab; a.ntiles = ntiles; a.dbp = dbp;
     hipStream_t st = (hipStream_t)stream;
+    KG_CHECK_ARG(!dbp || KS == 7, "kg_conv2d_wgrad_halo: the fused bias gradient is only built for 7x7");
     if (KS == 7) {
+        if (dbp) {
+            if (cout_lim <= 16) return launch_wg<7, 1, 1, true>(a, st);
+            if (cout_lim <= 48) return launch_wg<7, 1, 3, true>(a, st);
+            return launch_wg<7, 1, 4, true>(a, st);
+        }
         if (cout_lim <= 16) return launch_wg<7, 1, 1>(a, st);
         if (cout_lim <= 48) return launch_wg<7, 1, 3>(a, st);
         return launch_wg<7, 1>(a, st);

@@ -163,10 +163,9 @@ class Engine:
                     self.param_grads[n + ".weight"] = gw
                     grads.append((gw, off, co))
                     off += co
-                ops.conv_wgrad(xv.t, g, s.cin, s.cout, geom, grads, N=N)
+                db = torch.empty(s.cout, dtype=torch.float32, device=dev) if s.has_bias else None
+                ops.conv_wgrad(xv.t, g, s.cin, s.cout, geom, grads, N=N, bias_out=db)
                 if s.has_bias:
-                    db = torch.empty(s.cout, dtype=torch.float32, device=dev)
-                    ops.bias_grad(g, s.cout, db)
                     off = 0
                     for n, co in zip(s.names, s.couts):
                         self.param_grads[n + ".bias"] = db[off:off + co]
@@ -410,15 +409,14 @@ class Engine:
                 g = slot["grad"]      # [rows, 64] packed map gradients (set by backward_dec)
                 if g is None:
                     return
-                db64 = torch.empty(64, dtype=torch.float32, device=dev)
-                ops.bias_grad(g, 64, db64)           # one pass over the packed buffer for the three bias gradients
                 for k, ((h, co), s) in enumerate(zip(arch.HEADS, specs)):
                     gk = g[:, self.HEAD_OFF[k]:self.HEAD_OFF[k] + self.HEAD_PAD[k]]
                     w = self.P(s.names[0] + ".weight")
                     gw = torch.empty_like(w)
-                    ops.conv_wgrad(hid.t[:, k * C:(k + 1) * C], gk, C, co, geom, [(gw, 0, co)], N=N)
+                    db = torch.empty(co, dtype=torch.float32, device=dev)      # bias gradient: a free unit of the wgrad kernel
+                    ops.conv_wgrad(hid.t[:, k * C:(k + 1) * C], gk, C, co, geom, [(gw, 0, co)], N=N, bias_out=db)
                     self.param_grads[s.names[0] + ".weight"] = gw
-                    self.param_grads[s.names[0] + ".bias"] = db64[self.HEAD_OFF[k]:self.HEAD_OFF[k] + co]
+                    self.param_grads[s.names[0] + ".bias"] = db
                 dh = torch.empty(hid.rows, 3 * C, dtype=BF16, device=dev)
                 # kp / short cout blocks only see dY channels 0..23 (k-step 1 of the chunk skipped); mid sees 24..63
                 ops.conv_halo(g, pwT, 2 * C, N, H, W, 7, y=dh[:, :2 * C], mask=hid.t[:, :2 * C], flip=True, k1skip=True, algo_cin=7.5)

@@ -238,9 +238,11 @@ def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):
     return s
 
 
-def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=False, N=None, tiletab16=None):
+def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=False, N=None, tiletab16=None, bias_out=None):
     """grads: list of (fp32 OIHW grad tensor, cout_offset, cout_count) sharing x (fused heads) or one entry.
-    Dense stride-1 "same" 3x3/7x7 convs (N given) use the LDS-halo kernel, everything else the gather kernel."""
+    Dense stride-1 "same" 3x3/7x7 convs (N given) use the LDS-halo kernel, everything else the gather kernel.
+    bias_out (fp32 [cout], optional): receives the bias gradient (sum of dy over rows) -- for free inside the halo kernel
+    (one more all-ones unit on a wave with an idle unit slot), with kg_bias_grad otherwise."""
     M, H, W, OH, OW, KH, KW, stride, pad = geom
     _rows(x); _rows(dy)
     if IM2COL_WGRAD and mode == 0 and N is not None and cin <= 4 and KH * KW >= 25 and len(grads) == 1 and not accumulate:
@@ -254,6 +256,8 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
         tmp = torch.empty(cout, Kc, 1, 1, dtype=torch.float32, device=x.device)
         conv_wgrad(col, dy, Kc, cout, (M, OH, OW, OH, OW, 1, 1, 1, 0), [(tmp, off, cnt)])
         g.copy_(tmp.view(cnt, KH * KW, cin).permute(0, 2, 1).reshape(g.shape))     # [co][tap][ci] -> OIHW
+        if bias_out is not None:
+            bias_grad(dy, cout, bias_out)
         return "im2col"
     cin_lim = min(round_up(cin, 8), x.shape[1])
     cout_lim = min(round_up(cout, 8), dy.shape[1])
@@ -270,21 +274,28 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
         if S >= 8:
             S -= S % 8      # multiples of 8 enable the kernel's XCD-aware block mapping
         part = scratch_f32(S * nelem, x.device, "wgrad")
-        wgrad_halo(x, dy, part, N or 0, H, W, cin, cout, cin_lim, cout_lim, KH, S, nelem, tiletab16)
+        dbp = scratch_f32(S * cout, x.device, "wgrad_bias") if (bias_out is not None and KH == 7) else None
+        wgrad_halo(x, dy, part, N or 0, H, W, cin, cout, cin_lim, cout_lim, KH, S, nelem, tiletab16, dbp)
+        if dbp is not None:
+            _lib.call("kg_bias_grad_final", ptr(dbp), ptr(bias_out), S, cout, 1 if accumulate else 0, stream_ptr())
+        elif bias_out is not None:       # 3x3: the extra accumulators would spill in that kernel variant
+            bias_grad(dy, cout, bias_out, accumulate=accumulate)
     else:
         S = wgrad_splits(M, cin_lim, cout_lim, KH * KW, nelem)
         part = scratch_f32(S * nelem, x.device, "wgrad")
         _lib.call("kg_conv2d_wgrad", ptr(x), ptr(dy), ptr(part), ptr(rowdesc), M, H, W, OH, OW, ld(x), ld(dy), cin, cout,
                   cin_lim, cout_lim, KH, KW, stride, pad, 1, mode, S, c_long(nelem), stream_ptr())
+        if bias_out is not None:
+            bias_grad(dy, cout, bias_out, accumulate=accumulate)
     for g, off, cnt in grads:
         _lib.call("kg_wgrad_reduce", ctypes_offset(part, off * KH * KW * cin), ptr(g), cnt, cin, KH, KW, S, c_long(nelem),
                   1 if accumulate else 0, stream_ptr())
     return "halo" if halo else "gather"
 
 
-def wgrad_halo(x, dy, part, N, H, W, cin, cout, cin_lim, cout_lim, KS, S, nelem, tiletab16=None):
+def wgrad_halo(x, dy, part, N, H, W, cin, cout, cin_lim, cout_lim, KS, S, nelem, tiletab16=None, dbp=None):
     _lib.call("kg_conv2d_wgrad_halo", ptr(x), ptr(dy), ptr(part), N, H, W, ld(x), ld(dy), cin, cout, cin_lim, cout_lim, KS, S,
-              c_long(nelem), ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, stream_ptr())
+              c_long(nelem), ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, ptr(dbp), stream_ptr())
 
 
 def ctypes_offset(t, elem_off):

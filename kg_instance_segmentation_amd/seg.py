@@ -320,9 +320,8 @@ class SegBranch:
         geom = (M, 0, 0, M, 1, k, k, 1, (k - 1) // 2)
         gw = torch.empty_like(w)
         use16 = t16 if (k == 3 and t16 is not None and M >= 0.35 * t16.shape[0] * 256) else None
-        ops.conv_wgrad(x, g, cin, cout, geom, [(gw, 0, cout)], mode=2, rowdesc=rowdesc, tiletab16=use16)
         db = torch.empty(cout, dtype=torch.float32, device=w.device)
-        ops.bias_grad(g, cout, db)
+        ops.conv_wgrad(x, g, cin, cout, geom, [(gw, 0, cout)], mode=2, rowdesc=rowdesc, tiletab16=use16, bias_out=db)
         pgrads[key + ".weight"], pgrads[key + ".bias"] = gw, db
         if dx is not None:
             _, pwT, _ = self.packw(key, True)

@@ -397,11 +397,13 @@ def test_conv_wgrad_halo(case):
     xr = torch.zeros(N * H * W, cin_pad, dtype=BF16); xr[:, :cin] = rows_of(x)
     dyr = torch.zeros(N * H * W, cpad, dtype=BF16); dyr[:, :cout] = rows_of(dy)
     gw = torch.full((cout, cin, k, k), float("nan"), dtype=torch.float32, device=DEV)
-    kind = ops.conv_wgrad(xr.to(DEV), dyr.to(DEV), cin, cout, (N * H * W, H, W, H, W, k, k, 1, k // 2), [(gw, 0, cout)], N=N)
+    db = torch.full((cout,), float("nan"), dtype=torch.float32, device=DEV)
+    kind = ops.conv_wgrad(xr.to(DEV), dyr.to(DEV), cin, cout, (N * H * W, H, W, H, W, k, k, 1, k // 2), [(gw, 0, cout)], N=N, bias_out=db)
     assert kind == "halo"
     torch.cuda.synchronize()
     scale = float(w.grad.abs().max())
     report(f"wgrad_halo{case}", gw.cpu(), w.grad, atol=2e-4 * scale, rtol=1e-4)
+    report(f"wgrad_halo{case}.bias", db.cpu(), dy.double().sum((0, 2, 3)), atol=1e-3, rtol=1e-4)     # the fused all-ones unit
 
 
 @pytest.mark.parametrize("case", [(128, 64, 5000, True, True), (64, 128, 4096, False, False), (1024, 512, 777, True, True),
