@@ -130,6 +130,12 @@ int kg_nms(const double* boxes, const int* nbox, int box_cap, double thresh, voi
  * [55][H][W] (kp 5 | short 10 | mid 40), bit-identical to the reference's float32 tensors ---- */
 int kg_gt_maps(const float* kps, int n, int H, int W, float* out, void* stream);
 
+/* ---- fused multi-tensor Adam step (train.py:71,154), fp32, torch.optim.Adam's operation order.  jobs = device array of 48-byte
+ * records {float* p; const float* g; float* m; float* v; long n; int blk0; int pad;}, blk0 = first workgroup of the job (4096
+ * elements per workgroup); step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) ---- */
+int kg_adam_step(const void* jobs, int njobs, int total_blocks, float beta1, float beta2, float eps, float step_size, float bc2_sqrt,
+                 float weight_decay, void* stream);
+
 /* ---- host glue of SEG_loss (seg_loss.py:57-80), pure host code: crops of the matched ground-truth masks (float32 [n][H][W] per
  * image), nearest-resized to the patch size, as bytes.  work = int32 [nwork][9]: (img, gt, y1, y2, x1, x2, h1, w1, out offset) ---- */
 int kg_host_crop_masks(const float* const* masks, const int* work, int nwork, int H, int W, unsigned char* out);

@@ -28,6 +28,7 @@ SOURCES = {
     "postproc.hip": ["-ffp-contract=off"],
     "preproc.hip": ["-ffp-contract=off"],
     "evalmetrics.hip": [],
+    "optim.hip": ["-ffp-contract=off"],
     "seg.hip": [],
 }
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

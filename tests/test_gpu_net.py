@@ -319,3 +319,31 @@ def test_native_library_is_the_one_loaded():
     import os
     maps = open(f"/proc/{os.getpid()}/maps").read()
     assert "libkgnet_hip.so" in maps
+
+
+def test_fused_hip_adam_matches_torch_adam():
+    """kg_adam_step (one launch for all tensors) vs torch.optim.Adam over 3 steps incl. odd sizes, unaligned views and a changed lr."""
+    from kg_instance_segmentation_amd.optim import Adam
+    torch.manual_seed(5)
+    shapes = [(64, 3, 7, 7), (5,), (1023,), (256, 64, 3, 3), (1,), (4097,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = Adam(pa, lr=1e-3), torch.optim.Adam(pb, lr=1e-3)
+    sched_a = torch.optim.lr_scheduler.ExponentialLR(oa, gamma=0.96)          # train.py:72
+    sched_b = torch.optim.lr_scheduler.ExponentialLR(ob, gamma=0.96)
+    big = torch.randn(8192, device=DEV)
+    for it in range(3):
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            g = torch.randn_like(a) * (10.0 ** (k - 2))
+            if a.numel() == 1023:
+                g = big[1:1024].clone().view_as(a)
+                a.grad = big[1:1024].view_as(a)          # a gradient that is an unaligned view of a larger buffer
+                b.grad = g
+                continue
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step(); ob.step(); sched_a.step(); sched_b.step()
+    for a, b in zip(pa, pb):
+        err = float((a - b).abs().max()), float(b.abs().max())
+        assert err[0] <= 2e-6 * max(err[1], 1.0), err
+    sa, sb = oa.state[pa[0]], ob.state[pb[0]]
+    assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-8) and torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-10)
