@@ -177,10 +177,12 @@ __global__ __launch_bounds__(256) void seg_loss_kernel(const float* __restrict__
     if (threadIdx.x == 0 && part) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 __global__ void sum_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;      // one wave, lanes stride over the partials, fixed-order tree combine (reproducible)
     double s = 0.;
-    for (int i = 0; i < n; ++i) s += (double)part[i];
-    out[0] = (float)s;
+    for (int i = threadIdx.x; i < n; i += 64) s += (double)part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (threadIdx.x == 0) out[0] = (float)s;
 }
 extern "C" int kg_seg_loss(const float* prob, const void* tgt, const int* patches, const void* pairs, int npatches,
                            float* part, float* out1, const float* grad_out, float* gprob, void* stream) {
