@@ -163,3 +163,19 @@ def test_host_crop_masks_matches_numpy_rule(lib):
     for (i, g, ya, yb, xa, xb, h1, w1, o) in work.tolist():
         ref = nearest_resize(masks[i][g][ya:yb, xa:xb], h1, w1)
         assert np.array_equal(out[o:o + h1 * w1].reshape(h1, w1), ref.astype(np.uint8))
+
+
+def test_dropin_launcher_shadows_the_scripts_own_modules(tmp_path):
+    """dropin/run.py: a driver started through it imports the shims even though a same-named module sits next to the script
+    (the situation of train.py / test.py inside the reference checkout)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "config.py").write_text("WHO = 'decoy next to the script'\n")
+    (tmp_path / "collater.py").write_text("WHO = 'module that is not replaced'\n")
+    (tmp_path / "driver.py").write_text("import sys, config, collater\nprint(config.__file__); print(collater.WHO); print(sys.argv[1:])\n")
+    r = subprocess.run([sys.executable, os.path.join(root, "dropin", "run.py"), "driver.py", "--flag", "7"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == os.path.join(root, "dropin", "config.py") and lines[1] == "module that is not replaced" and lines[2] == "['--flag', '7']"
