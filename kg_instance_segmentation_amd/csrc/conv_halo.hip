@@ -42,6 +42,11 @@ template <int KS, int WC, int WPX, int GM = 0>
 __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs a) {
     constexpr int PAD = KS / 2, TW = 4 * WPX, HWD = TW + KS - 1, HPIX = (16 + KS - 1) * HWD, TC = WC * 64, NT = WC * WPX * 64, T = KS * KS;
     constexpr int HALO_BYTES = HPIX * 128, WBUF_BYTES = TC * 128;
+    // 7x7, 64-cout workgroups: the weight slices go global -> LDS with LDS-direct loads through a 4-slot ring (no staging registers,
+    // no ds_write); the per-tap barrier is a raw s_barrier behind a COUNTED s_waitcnt vmcnt(1), so the slice of tap t+3 stays in
+    // flight across it (a __syncthreads() would drain it).
+    constexpr bool GLW = KS == 7 && WC == 1;
+    constexpr int NSL = GLW ? 4 : 3;
     constexpr int WPT = TC * 8 / NT;  // weight chunks per thread per tap (= 2)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo = smem;
@@ -93,9 +98,9 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     }
     // weights: ab[slot][s] = ring slot base + row/chunk offset of fragment 0 (fragment i adds the immediate i*512: the
     // swizzle key of row r = (lm>>2)*16 + i*4 + (lm&3) does not depend on i)
-    int ab[3][2];
+    int ab[NSL][2];
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < NSL; ++q)
 #pragma unroll
         for (int s = 0; s < 2; ++s) ab[q][s] = q * WBUF_BYTES + a_off[0][s];
 
@@ -185,19 +190,34 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
             for (int i = 0; i < WPT; ++i) *reinterpret_cast<uint4*>(wbuf + slot_bytes + w_lds[i]) = wreg[i];
         };
         // Weight ring of 3 slots: at the start of tap t slots t%3 and (t+1)%3 are visible, W(t+2) is in registers.
-        wload(0); wstore(0);
-        if (T > 1) { wload(1); wstore(1); }
-        if (T > 2) wload(2);
-        __syncthreads();
+        const bf16_t* wsrc = nullptr;      // GLW: this thread's 16-byte piece of the tap's [64 couts][64 ch] slice
+        auto wglds = [&](int slot_bytes) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
+                                             (__attribute__((address_space(3))) void*)(wbuf + slot_bytes + __builtin_amdgcn_readfirstlane(wave) * 1024), 16, 0, 0);
+            wsrc += a.cin_pad;
+        };
+        if constexpr (GLW) {
+            const int r = tid >> 3, cs = tid & 7;
+            wsrc = a.w + (long)(c0 + r) * a.K + cc * 64 + (cs ^ (2 * ((r >> 4) & 3) + ((r >> 1) & 1))) * 8;
+            wglds(0); wglds(WBUF_BYTES); wglds(2 * WBUF_BYTES);
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // halo + taps 0, 1 have landed; tap 2 may still be in flight
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            wload(0); wstore(0);
+            if (T > 1) { wload(1); wstore(1); }
+            if (T > 2) wload(2);
+            __syncthreads();
+        }
         // Software pipeline over (tap, k-step): the fragments of the NEXT k-step are fetched from LDS while the 16
         // MFMAs of the current one run, so no wave waits on LDS right after the per-tap barrier.  The tap loop is
         // ky (rolled) x kx (unrolled): every lane-dependent address term is a precomputed register (kb / ab), the tap
         // offset is a scalar, fragment j / i offsets are instruction immediates -> ~4 VALU per tap.
         bf16x8 a0[4], b0[4], a1[4], b1[4];
-        int abr[3][2];                 // ab rotated so that index kx%3 is the ring slot of tap (ky,kx)
-        int sbr[3] = {0, WBUF_BYTES, 2 * WBUF_BYTES};
+        int abr[NSL][2];               // ab rotated so that index kx % NSL is the ring slot of tap (ky,kx)
+        int sbr[NSL];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { abr[q][0] = ab[q][0]; abr[q][1] = ab[q][1]; }
+        for (int q = 0; q < NSL; ++q) { abr[q][0] = ab[q][0]; abr[q][1] = ab[q][1]; sbr[q] = q * WBUF_BYTES; }
         int tapb = a.flip ? ((KS - 1) * HWD + (KS - 1)) * 128 : 0;   // halo byte offset of tap (ky, kx = 0)
         const int sx = a.flip ? -128 : 128, sy = a.flip ? -HWD * 128 : HWD * 128;
         auto ldA = [&](auto mk, bf16x8 (&af)[4], int base) {
@@ -219,7 +239,10 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx, ++t) {
                 constexpr int dummy = 0; (void)dummy;
-                const int cur = kx % 3, nxt = (kx + 1) % 3, st = (kx + 2) % 3;
+                const int cur = kx % NSL, nxt = (kx + 1) % NSL, st = (kx + (GLW ? 3 : 2)) % NSL;
+                if constexpr (GLW) {
+                    if (t + 3 < T) wglds(sbr[st]);      // tap t+3 into the slot of tap t-1, which every wave left at the last barrier
+                }
                 const int nkx = (kx + 1 == KS) ? 0 : kx + 1;
                 const int tb = tapb + kx * sx;
                 const int ntb = (kx + 1 == KS) ? tapb + sy : tapb + (kx + 1) * sx;
@@ -240,17 +263,29 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                         mma(mk, a1, b1);
                     }
                 }
-                if (t + 2 < T) {
-                    wstore_at(sbr[st]);
-                    if (t + 3 < T) wload(t + 3);
+                if constexpr (GLW) {
+                    if (t + 1 < T) {       // taps t+1 and t+2 must be visible after the barrier; tap t+3 may stay in flight
+                        if (t + 3 < T) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                    }
+                } else {
+                    if (t + 2 < T) {
+                        wstore_at(sbr[st]);
+                        if (t + 3 < T) wload(t + 3);
+                    }
+                    __syncthreads();
                 }
-                __syncthreads();
             }
             tapb += sy;
-            if (KS % 3 == 1) {   // 7 taps per row: the ring slot of (ky+1, 0) is one further
-                const int s0 = sbr[0]; sbr[0] = sbr[1]; sbr[1] = sbr[2]; sbr[2] = s0;
+            {   // KS taps per row: the ring slot of (ky+1, 0) is KS % NSL further -> rotate the slot tables
+                constexpr int SH = KS % NSL;
+                int sb2[NSL], ab2[NSL][2];
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) { const int v0 = abr[0][s2]; abr[0][s2] = abr[1][s2]; abr[1][s2] = abr[2][s2]; abr[2][s2] = v0; }
+                for (int q = 0; q < NSL; ++q) { sb2[q] = sbr[(q + SH) % NSL]; ab2[q][0] = abr[(q + SH) % NSL][0]; ab2[q][1] = abr[(q + SH) % NSL][1]; }
+#pragma unroll
+                for (int q = 0; q < NSL; ++q) { sbr[q] = sb2[q]; abr[q][0] = ab2[q][0]; abr[q][1] = ab2[q][1]; }
             }
         }
         };
@@ -356,7 +391,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 template <int KS, int WC, int WPX, int GM = 0>
 static int launch_halo(HaloArgs a, hipStream_t st) {
     constexpr int TW = 4 * WPX, HWD = TW + KS - 1, TC = WC * 64;
-    constexpr int smem = (16 + KS - 1) * HWD * 128 + 3 * TC * 128;
+    constexpr int smem = (16 + KS - 1) * HWD * 128 + ((KS == 7 && WC == 1) ? 4 : 3) * TC * 128;
     a.tiles_x = kg_cdiv(a.W, TW);
     static bool attr_done = false;
     if (!attr_done) {
