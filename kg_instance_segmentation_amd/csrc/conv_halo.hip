@@ -42,11 +42,11 @@ template <int KS, int WC, int WPX, int GM = 0>
 __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs a) {
     constexpr int PAD = KS / 2, TW = 4 * WPX, HWD = TW + KS - 1, HPIX = (16 + KS - 1) * HWD, TC = WC * 64, NT = WC * WPX * 64, T = KS * KS;
     constexpr int HALO_BYTES = HPIX * 128, WBUF_BYTES = TC * 128;
-    // 7x7, 64-cout workgroups: the weight slices go global -> LDS with LDS-direct loads through a 4-slot ring (no staging registers,
-    // no ds_write); the per-tap barrier is a raw s_barrier behind a COUNTED s_waitcnt vmcnt(1), so the slice of tap t+3 stays in
-    // flight across it (a __syncthreads() would drain it).
+    // 7x7, 64-cout workgroups: the weight slices go global -> LDS with LDS-direct loads through a 6-slot ring (no staging registers,
+    // no ds_write), two taps per barrier; the barrier is a raw s_barrier behind a COUNTED s_waitcnt vmcnt(1), so the newest slice
+    // stays in flight across it (a __syncthreads() would drain it).
     constexpr bool GLW = KS == 7 && WC == 1;
-    constexpr int NSL = GLW ? 4 : 3;
+    constexpr int NSL = GLW ? 6 : 3;
     constexpr int WPT = TC * 8 / NT;  // weight chunks per thread per tap (= 2)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo = smem;
@@ -199,8 +199,8 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
         if constexpr (GLW) {
             const int r = tid >> 3, cs = tid & 7;
             wsrc = a.w + (long)(c0 + r) * a.K + cc * 64 + (cs ^ (2 * ((r >> 4) & 3) + ((r >> 1) & 1))) * 8;
-            wglds(0); wglds(WBUF_BYTES); wglds(2 * WBUF_BYTES);
-            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // halo + taps 0, 1 have landed; tap 2 may still be in flight
+            wglds(0); wglds(WBUF_BYTES); wglds(2 * WBUF_BYTES); wglds(3 * WBUF_BYTES);
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // halo + taps 0..2 have landed; tap 3 may still be in flight
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         } else {
@@ -239,9 +239,12 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx, ++t) {
                 constexpr int dummy = 0; (void)dummy;
-                const int cur = kx % NSL, nxt = (kx + 1) % NSL, st = (kx + (GLW ? 3 : 2)) % NSL;
-                if constexpr (GLW) {
-                    if (t + 3 < T) wglds(sbr[st]);      // tap t+3 into the slot of tap t-1, which every wave left at the last barrier
+                const int cur = kx % NSL, nxt = (kx + 1) % NSL, st = (kx + 2) % NSL;
+                if constexpr (GLW) {   // pair start (even t): taps t+4, t+5 into the slots of taps t-2, t-1, which every wave has left
+                    if (!(t & 1)) {
+                        if (t + 4 < T) wglds(sbr[(kx + 4) % NSL]);
+                        if (t + 5 < T) wglds(sbr[(kx + 5) % NSL]);
+                    }
                 }
                 const int nkx = (kx + 1 == KS) ? 0 : kx + 1;
                 const int tb = tapb + kx * sx;
@@ -264,8 +267,8 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                     }
                 }
                 if constexpr (GLW) {
-                    if (t + 1 < T) {       // taps t+1 and t+2 must be visible after the barrier; tap t+3 may stay in flight
-                        if (t + 3 < T) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    if ((t & 1) && t + 1 < T) {   // pair end: taps t+1 .. t+3 must be visible after the barrier; tap t+4 may stay in flight
+                        if (t + 4 < T) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 template <int KS, int WC, int WPX, int GM = 0>
 static int launch_halo(HaloArgs a, hipStream_t st) {
     constexpr int TW = 4 * WPX, HWD = TW + KS - 1, TC = WC * 64;
-    constexpr int smem = (16 + KS - 1) * HWD * 128 + ((KS == 7 && WC == 1) ? 4 : 3) * TC * 128;
+    constexpr int smem = (16 + KS - 1) * HWD * 128 + ((KS == 7 && WC == 1) ? 6 : 3) * TC * 128;
     a.tiles_x = kg_cdiv(a.W, TW);
     static bool attr_done = false;
     if (!attr_done) {
