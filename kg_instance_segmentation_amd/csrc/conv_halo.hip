@@ -2,14 +2,15 @@
 //
 // KGnet's FLOPs are 86 % 7x7 stride-1 head convolutions (KGnet.py:161-209) and most of the rest 3x3 stride-1
 // (KGnet.py:139-158); in an im2col-style implicit GEMM every tap re-stages the pixel tile.  Here one workgroup
-// owns a 16x16 output tile and TC = 64*WC output channels:
-//   * the (16+KS-1)^2 x 64-channel input halo is staged into LDS ONCE per 64-channel chunk and re-read by all
-//     KS*KS taps (49x reuse for 7x7) with shifted ds_read_b128 fragment addresses;
-//   * only the [TC][64] weight slice of the current tap streams through a 3-slot LDS ring (register prefetch
-//     three taps ahead), one barrier per tap; MFMA fragments of the next k-step are fetched while the current
-//     16 MFMAs run (register double buffering), so nobody waits on LDS right after a barrier;
+// (default: 8 waves) owns a 16x32-pixel output tile and 64 output channels:
+//   * the (16+KS-1) x (32+KS-1) x 64-channel input halo is staged into LDS ONCE per 64-channel chunk (7x7: by LDS-direct
+//     loads, no staging registers) and re-read by all KS*KS taps (49x reuse for 7x7) with shifted ds_read_b128 addresses;
+//   * only the [64][64] weight slice of a tap streams through an LDS ring.  7x7: 6 slots filled by LDS-direct loads, ONE raw
+//     s_barrier per TWO taps behind a counted s_waitcnt vmcnt(1) (the newest slice stays in flight across the barrier);
+//     3x3 and the wide variants: 3 slots, register prefetch three taps ahead, one __syncthreads() per tap.  MFMA fragments
+//     of the next k-step are fetched while the current 16 MFMAs run (register double buffering);
 //   * both tiles use XOR-swizzled 16-byte slots so the 16-lane ds_read_b128 groups hit 16 distinct slots.
-// Cout <= 64 uses a 16x32 tile with 8 pixel-waves instead (same LDS budget, 2 waves/SIMD).
+// WC = 2, 3 (tuning variants): 16x16-pixel tile with 128 / 192 couts per workgroup.
 // The same kernel computes the input gradient of such a conv (flip = 1, transposed-packed weights).
 // Wave tile = 64 couts x 64 pixels (4 rows of the 16x16 tile), 16 v_mfma_f32_16x16x32_bf16 per 32-wide k-step.
 #include "kg_common.h"
