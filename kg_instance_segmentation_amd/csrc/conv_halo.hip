@@ -46,7 +46,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     // 7x7, 64-cout workgroups: the weight slices go global -> LDS with LDS-direct loads through a 6-slot ring (no staging registers,
     // no ds_write), two taps per barrier; the barrier is a raw s_barrier behind a COUNTED s_waitcnt vmcnt(1), so the newest slice
     // stays in flight across it (a __syncthreads() would drain it).
-    constexpr bool GLW = KS == 7 && WC == 1;
+    constexpr bool GLW = KS == 7 && WC <= 2;
     constexpr int NSL = GLW ? 6 : 3;
     constexpr int WPT = TC * 8 / NT;  // weight chunks per thread per tap (= 2)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -191,17 +191,28 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
             for (int i = 0; i < WPT; ++i) *reinterpret_cast<uint4*>(wbuf + slot_bytes + w_lds[i]) = wreg[i];
         };
         // Weight ring of 3 slots: at the start of tap t slots t%3 and (t+1)%3 are visible, W(t+2) is in registers.
-        const bf16_t* wsrc = nullptr;      // GLW: this thread's 16-byte piece of the tap's [64 couts][64 ch] slice
+        const bf16_t* wsrc[WPT];           // GLW: this thread's 16-byte pieces of the tap's [TC couts][64 ch] slice
         auto wglds = [&](int slot_bytes) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
-                                             (__attribute__((address_space(3))) void*)(wbuf + slot_bytes + __builtin_amdgcn_readfirstlane(wave) * 1024), 16, 0, 0);
-            wsrc += a.cin_pad;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc[i],
+                                                 (__attribute__((address_space(3))) void*)(wbuf + slot_bytes + (i * NT + __builtin_amdgcn_readfirstlane(wave) * 64) * 16), 16, 0, 0);
+                wsrc[i] += a.cin_pad;
+            }
         };
+        auto wait_newest = [&]() {         // all but the WPT loads of the newest slice have landed
+            if constexpr (WPT == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        };
+        static_assert(!GLW || WPT <= 2, "counted waits are written for 1 or 2 loads per slice");
         if constexpr (GLW) {
-            const int r = tid >> 3, cs = tid & 7;
-            wsrc = a.w + (long)(c0 + r) * a.K + cc * 64 + (cs ^ (2 * ((r >> 4) & 3) + ((r >> 1) & 1))) * 8;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const int e = tid + i * NT, r = e >> 3, cs = e & 7;
+                wsrc[i] = a.w + (long)(c0 + r) * a.K + cc * 64 + (cs ^ (2 * ((r >> 4) & 3) + ((r >> 1) & 1))) * 8;
+            }
             wglds(0); wglds(WBUF_BYTES); wglds(2 * WBUF_BYTES); wglds(3 * WBUF_BYTES);
-            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // halo + taps 0..2 have landed; tap 3 may still be in flight
+            wait_newest();                                         // halo + taps 0..2 have landed; tap 3 may still be in flight
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         } else {
@@ -269,7 +280,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                 }
                 if constexpr (GLW) {
                     if ((t & 1) && t + 1 < T) {   // pair end: taps t+1 .. t+3 must be visible after the barrier; tap t+4 may stay in flight
-                        if (t + 4 < T) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                        if (t + 4 < T) wait_newest();
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 template <int KS, int WC, int WPX, int GM = 0>
 static int launch_halo(HaloArgs a, hipStream_t st) {
     constexpr int TW = 4 * WPX, HWD = TW + KS - 1, TC = WC * 64;
-    constexpr int smem = (16 + KS - 1) * HWD * 128 + ((KS == 7 && WC == 1) ? 6 : 3) * TC * 128;
+    constexpr int smem = (16 + KS - 1) * HWD * 128 + ((KS == 7 && WC <= 2) ? 6 : 3) * TC * 128;
     a.tiles_x = kg_cdiv(a.W, TW);
     static bool attr_done = false;
     if (!attr_done) {
