@@ -45,6 +45,11 @@ int kg_conv2d_halo(const void* x, const void* w, const float* bias, void* y, flo
  * indexed by virtual cout (vmap: channel of kp 0-4 | short 5-14 | mid 15-54, or -1); fp32 NCHW outputs */
 int kg_conv2d_halo_heads2(const void* x, const void* w, const float* bias64, const int* vmap, float* kp, float* sh, float* md,
                           int N, int H, int W, int C, int ldx, int K, void* stream);
+/* 3x3 stride-1 "same" conv / input gradient (flip) for cin_pad == 64 and Cout <= 64 (c0_conv.2, layer1 conv2, seg level 0): persistent
+ * workgroups, all 9 taps' weights resident in LDS, the next 16x16 tile's halo fetched by LDS-direct loads during the current tile */
+int kg_conv3x3_c64(const void* x, const void* w, const float* bias, void* y, const void* res, const void* mask, int N, int H, int W,
+                   int ldx, int Cout, int ldy, int ldres, int ldmask, int K, int flip, int relu, const int* tiletab16, int ntiles,
+                   void* stream);
 /* 1x1 stride-1 convolution / its input gradient as a streaming GEMM over rows (dense or ragged): weight slab resident in
  * LDS, pixel fragments straight from global memory, persistent workgroups (KGnet.py:64-99,101-111,155-158) */
 int kg_conv1x1(const void* x, const void* w, const float* bias, void* y, const void* res, const void* mask, long M, int K,

@@ -20,6 +20,7 @@ SOURCES = {
     "conv_gather.hip": [],
     "conv_small.hip": [],
     "conv_halo.hip": [],
+    "conv3_c64.hip": [],
     "conv1x1.hip": [],
     "conv_wgrad.hip": [],
     "wgrad_halo.hip": [],

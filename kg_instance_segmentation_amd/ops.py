@@ -167,6 +167,7 @@ def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=
 
 
 USE_HALO = True
+USE_C3 = __import__("os").environ.get("KG_CONV3_C64", "1") == "1"
 IM2COL_WGRAD = __import__("os").environ.get("KG_IM2COL_WGRAD", "1") == "1"
 
 
@@ -174,13 +175,22 @@ HALO_WC = int(__import__("os").environ.get("KG_HALO_WC", "0"))   # tuning overri
 
 
 def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, flip=False, wc=0,
-              tiletab=None, total_rows=0, k1skip=False, algo_cin=None):
+              tiletab=None, total_rows=0, k1skip=False, algo_cin=None, tiletab16=None):
     """Stride-1 "same" KSxKS conv (or its input gradient when flip) with the input halo resident in LDS.
     tiletab (int32 [ntiles,4] device tensor): ragged boxes instead of N images of HxW.
     k1skip (7x7 only): the packed weights are zero for channels 32..63 of every 64-channel chunk.
     algo_cin: number of input channels that carry data (FLOP accounting of bench.py's timer; unused here)."""
     if PACKQ.jobs:
         PACKQ.flush()
+    if (USE_C3 and KS == 3 and pw.cin_pad == 64 and y is not None and y_f32 is None and wc == 0 and HALO_WC == 0
+            and (tiletab is None or tiletab16 is not None)):
+        # 64 input channels: persistent kernel with resident weights and double-buffered halos (conv3_c64.hip)
+        if PACKQ.jobs:
+            PACKQ.flush()
+        _lib.call("kg_conv3x3_c64", ptr(_rows(x)), ptr(pw.buf), ptr(bias), ptr(y), ptr(res), ptr(mask), N, H, W, ld(x), cout, ld(y),
+                  ld(res) if res is not None else 0, ld(mask) if mask is not None else 0, pw.K, 1 if flip else 0, 1 if relu else 0,
+                  ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, stream_ptr())
+        return
     wc = wc or HALO_WC
     if k1skip:
         assert KS == 7 and wc in (0, 1)

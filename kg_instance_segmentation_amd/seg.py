@@ -246,14 +246,14 @@ class SegBranch:
             _lib.call("kg_rows_gather", ptr(frows), ops.ld(frows), _lib.c_void_p(srcrow.data_ptr() + 4 * row_off),
                       ptr(dst), ops.ld(dst), c_long(nrows), C, stream_ptr())
 
-    def rconv(self, x, pw, cout, rowdesc, M, k, y=None, y_f32=None, bias=None, relu=False, mask=None, mode=2, tiles=None):
+    def rconv(self, x, pw, cout, rowdesc, M, k, y=None, y_f32=None, bias=None, relu=False, mask=None, mode=2, tiles=None, tiles16=None):
         """Ragged conv (mode 2) or its input gradient (mode 3).  3x3 convs over 64-channel-aligned inputs run on the
         LDS-halo kernel with one (box, 16x32 tile) entry per workgroup; the rest on the gather implicit GEMM.
         `tiles` = (tile table of the first `M` rows' boxes); boxes are a prefix, so a prefix of the table is used."""
         if (ops.USE_HALO and k == 3 and tiles is not None and tiles.shape[0] > 0 and pw.cin_pad % 64 == 0 and x.shape[1] >= pw.cin_pad
                 and M >= 0.35 * tiles.shape[0] * 512):     # tiles mostly full: tiny deep-level crops stay on the gather kernel
             ops.conv_halo(x, pw, cout, 0, 0, 0, 3, y=y, y_f32=y_f32, bias=bias, relu=relu, mask=mask, flip=(mode == 3),
-                          tiletab=tiles, total_rows=M)
+                          tiletab=tiles, total_rows=M, tiletab16=tiles16)
             return
         if k == 1 and y is not None and ops.can_1x1(x[:M], pw, 1, 1, 0, y[:M], y_f32):
             ops.conv1x1(x[:M], pw, cout, y[:M], bias=bias, mask=mask[:M] if mask is not None else None, relu=relu)
@@ -296,7 +296,7 @@ class SegBranch:
                 cat = torch.empty(rowsC, ccat, dtype=BF16, device=dev)
                 pw, _, b = self.packw(f"skip_combine.{l}.up.0", record)
                 self.rconv(uin, pw, cout, plan.rowdesc[l], rowsC, 3, y=cat[:, CH[l]:CH[l] + cout], bias=b, relu=True,
-                           tiles=self.T32(plan, l, nc))
+                           tiles=self.T32(plan, l, nc), tiles16=self.T16(plan, l, nc))
                 self.gather(fr[l], plan.srcrow[l], cat[:, 0:CH[l]], rowsC, CH[l])
                 pw, _, b = self.packw(f"skip_combine.{l}.cat_conv.0", record)
                 self.rconv(cat, pw, cout, plan.rowdesc[l], rowsC, 1, y=pre[l][:rowsC], bias=b, relu=True)
@@ -305,7 +305,8 @@ class SegBranch:
         rows0 = plan.rows[0]
         hid = torch.empty(rows0, 64, dtype=BF16, device=dev)
         pw, _, b = self.packw("seg_head.0", record)
-        self.rconv(pre[0], pw, 64, plan.rowdesc[0], rows0, 3, y=hid, bias=b, relu=True, tiles=self.T32(plan, 0, plan.nb[0]))
+        self.rconv(pre[0], pw, 64, plan.rowdesc[0], rows0, 3, y=hid, bias=b, relu=True, tiles=self.T32(plan, 0, plan.nb[0]),
+                   tiles16=self.T16(plan, 0, plan.nb[0]))
         flat = torch.empty(rows0, dtype=torch.float32, device=dev)
         pw, _, b = self.packw("seg_head.2", record)
         self.rconv(hid, pw, 1, plan.rowdesc[0], rows0, 3, y_f32=flat, bias=b, tiles=self.T32(plan, 0, plan.nb[0]))
@@ -325,7 +326,7 @@ class SegBranch:
         pgrads[key + ".weight"], pgrads[key + ".bias"] = gw, db
         if dx is not None:
             _, pwT, _ = self.packw(key, True)
-            self.rconv(g, pwT, cin, rowdesc, M, k, y=dx, mask=mask, mode=3, tiles=t32)
+            self.rconv(g, pwT, cin, rowdesc, M, k, y=dx, mask=mask, mode=3, tiles=t32, tiles16=t16)
 
     def run_backward(self, plan, saved, gflat, feat_shapes):
         pre, cats, uins, hid, flat, top = saved

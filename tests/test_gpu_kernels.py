@@ -337,6 +337,8 @@ def test_seg_loss_matches_golden(golden):
 HALO_CASES = [
     # cin, cout, k, N, H, W, relu, bias
     (64, 64, 3, 2, 20, 28, True, True),
+    (64, 200, 3, 3, 37, 50, False, True),     # conv3_c64.hip: several cout blocks, tiles crossing the image border, many tiles per workgroup
+    (64, 40, 3, 9, 80, 96, True, False),
     (64, 64, 7, 1, 24, 40, True, True),
     (64, 192, 7, 1, 32, 32, True, True),
     (128, 128, 3, 1, 16, 16, False, True),
