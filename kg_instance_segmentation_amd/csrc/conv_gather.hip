@@ -1,4 +1,4 @@
-// conv_gather.hip -- gather implicit-GEMM convolution with an asynchronous LDS ring (cin_pad % 64 == 0, Cout > 64).
+// conv_gather.hip -- gather implicit-GEMM convolution with an asynchronous LDS ring (cin_pad % 64 == 0, Cout >= 64).
 //
 // Serves the convs that cannot use the LDS-halo kernels: strided 3x3 / 1x1 convs of the ResNet trunk and their input
 // gradients (KGnet.py:64-99), and the ragged deep levels of the per-box seg branch (KGnet.py:258-267, crops of a few

@@ -273,8 +273,8 @@ extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, 
     a.stride_log2 = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil; a.mode = mode; a.relu = relu; a.f32_C = f32_C;
     KG_CHECK_ARG(magic_for(a.cpt, K / 8, &a.cpt_magic), "kg_conv2d_igemm: no exact magic divisor for cpt=%d", a.cpt);
     hipStream_t st = (hipStream_t)stream;
-    static const int use_gather2 = getenv("KG_GATHER2") ? atoi(getenv("KG_GATHER2")) : 1;
-    if (use_gather2 && tile == 0 && cin_pad % 64 == 0 && y && !y_f32 && Cout > 64 && dil == 1)
+    static const int use_gather2 = getenv("KG_GATHER2") ? atoi(getenv("KG_GATHER2")) : 2;   // 2: also 64-cout 3x3 convs (half the cout tile idle, still 2x the 64 x 256 tile)
+    if (use_gather2 && tile == 0 && cin_pad % 64 == 0 && y && !y_f32 && (Cout > 64 || (use_gather2 >= 2 && Cout == 64 && KH * KW > 1)) && dil == 1)
         return kg_launch_conv_gather(a, cin_pad, st);   // deep-prefetch LDS-ring variant (conv_gather.hip)
     static const int use_small = getenv("KG_CONV_SMALL") ? atoi(getenv("KG_CONV_SMALL")) : 1;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };

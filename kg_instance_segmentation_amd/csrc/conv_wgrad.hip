@@ -9,6 +9,7 @@
 // One block = (64 co) x (64 ci) x one tap x one pixel split; partial sums go to a
 // [split][co][tap][ci] fp32 buffer reduced (deterministically) by kg_wgrad_reduce.
 #include "kg_common.h"
+#include <stdlib.h>
 
 struct WgradArgs {
     const bf16_t* x; const bf16_t* dy; float* dwp; const int2* rowdesc;
@@ -158,6 +159,124 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         }
 }
 
+// ---- 128 x 128 output tile variant (cin, cout >= 128: the ragged deep seg levels, the wide 1x1 convs).  With 64 x 64 tiles a
+// 256 x 512 x 9-tap gradient re-reads dY and X 288 times through L2 (7.6 GB per launch, L2-bandwidth bound at 0.25 PFLOP/s);
+// 128 x 128 tiles quarter that traffic and quadruple the MFMAs per barrier (32 per wave and 64-pixel chunk).
+// LDS rows are 256 B (128 channels) = 8 units of 32 B; unit XOR f8(r) = (r & 3) | (((r >> 3) & 1) << 2) keeps the 4 rows of a
+// 16-lane transpose-read group and the two groups of a 32-lane LDS cycle on distinct units.
+__device__ __forceinline__ int tr_f8(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+__device__ __forceinline__ bf16x8 load_tr_frag128(const unsigned char* tile, int p0, int cf, int lane) {
+    const int i = lane & 15, G = lane >> 4;
+    bf16x8 out;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = p0 + G * 8 + h * 4 + (i >> 2);
+        const int off = r * 256 + ((cf ^ tr_f8(r)) * 32) + (i & 3) * 8;
+        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + off));
+        out[h * 4 + 0] = v[0]; out[h * 4 + 1] = v[1]; out[h * 4 + 2] = v[2]; out[h * 4 + 3] = v[3];
+    }
+    return out;
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad128_kernel(const WgradArgs a) {
+    constexpr int TB = 64 * 256;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TB];   // [buf][dy | x][64 px][256 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wco = wave >> 1, wci = wave & 1;
+    const int n_ci_tiles = (a.cin_lim + 127) / 128;
+    const int ci0 = (blockIdx.x % n_ci_tiles) * 128, co0 = (blockIdx.x / n_ci_tiles) * 128;
+    const int tap = blockIdx.y, split = blockIdx.z;
+    const int tdy = tap / a.KW, tdx = tap - tdy * a.KW;
+    const int d_y = tdy * a.dil - a.pad, d_x = tdx * a.dil - a.pad;
+    const int c16 = tid & 15, prow = tid >> 4;      // 16-byte chunk within the 128-channel tile; row prow + 16 i
+    const bool x_c_ok = ci0 + c16 * 8 < a.cin_lim, y_c_ok = co0 + c16 * 8 < a.cout_lim;
+    const int ohw = a.OH * a.OW;
+
+    uint4 xr[4], yr[4];
+    auto load_chunk = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = chunk * 64 + prow + 16 * i;
+            uint4 xv = make_uint4(0, 0, 0, 0), yv = make_uint4(0, 0, 0, 0);
+            if (m < a.M) {
+                if (y_c_ok) yv = *reinterpret_cast<const uint4*>(a.dy + (long)m * a.lddy + co0 + c16 * 8);
+                if (x_c_ok) {
+                    long row; bool ok;
+                    if (a.mode >= 2) {
+                        const int2 d = a.rowdesc[m];
+                        const int y = (d.x >> 16) + d_y, x = (d.x & 0xffff) + d_x, h = d.y >> 16, w = d.y & 0xffff;
+                        ok = (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
+                        row = (long)m + (long)d_y * w + d_x;
+                    } else {
+                        const int n = m / ohw, rem = m - n * ohw;
+                        const int oy = rem / a.OW, ox = rem - oy * a.OW;
+                        const int iy = (oy << a.stride_log2) + d_y, ix = (ox << a.stride_log2) + d_x;
+                        ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                        row = ((long)n * a.H + iy) * a.W + ix;
+                    }
+                    if (ok) xv = *reinterpret_cast<const uint4*>(a.x + row * a.ldx + ci0 + c16 * 8);
+                }
+            }
+            xr[i] = xv; yr[i] = yv;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        unsigned char* sy = smem + buf * 2 * TB;
+        unsigned char* sx = sy + TB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = prow + 16 * i;
+            const int off = r * 256 + (((c16 >> 1) ^ tr_f8(r)) * 32) + (c16 & 1) * 16;
+            *reinterpret_cast<uint4*>(sy + off) = yr[i];
+            *reinterpret_cast<uint4*>(sx + off) = xr[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int total_chunks = (a.M + 63) / 64;
+    const int cbeg = split * a.chunks_per_split;
+    int cend = cbeg + a.chunks_per_split;
+    if (cend > total_chunks) cend = total_chunks;
+    if (cbeg < cend) load_chunk(cbeg);
+    for (int ch = cbeg; ch < cend; ++ch) {
+        const int buf = (ch - cbeg) & 1;
+        store_chunk(buf);
+        __syncthreads();
+        if (ch + 1 < cend) load_chunk(ch + 1);
+        const unsigned char* sy = smem + buf * 2 * TB;
+        const unsigned char* sx = sy + TB;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = load_tr_frag128(sy, s * 32, wco * 4 + i, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = load_tr_frag128(sx, s * 32, wci * 4 + j, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* out = a.dwp + (long)split * a.split_stride;
+    const int lm = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ci = ci0 + (wci * 4 + j) * 16 + lm;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + (wco * 4 + i) * 16 + g * 4 + r;
+                if (co < a.Cout && ci < a.Cin) out[((long)co * a.ntaps + tap) * a.Cin + ci] = acc[i][j][r];
+            }
+        }
+}
+
 static int g_wgrad_use_tr = 1;
 extern "C" int kg_set_wgrad_tr(int use_tr) { g_wgrad_use_tr = use_tr; return KG_OK; }
 
@@ -179,6 +298,13 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
     int total_chunks = (M + 63) / 64;        // chunks of the kernel's PX = 64 pixels
     a.chunks_per_split = (total_chunks + nsplit - 1) / nsplit;
     a.split_stride = split_stride;
+    static const int use128 = getenv("KG_WGRAD128") ? atoi(getenv("KG_WGRAD128")) : 1;
+    if (use128 && g_wgrad_use_tr && cin_lim >= 128 && cout_lim >= 128) {
+        dim3 grid128(((cin_lim + 127) / 128) * ((cout_lim + 127) / 128), KH * KW, nsplit);
+        hipLaunchKernelGGL(conv_wgrad128_kernel, grid128, dim3(256), 0, (hipStream_t)stream, a);
+        KG_CHECK_LAUNCH("conv_wgrad128");
+        return KG_OK;
+    }
     dim3 grid(((cin_lim + 63) / 64) * ((cout_lim + 63) / 64), KH * KW, nsplit);
     if (g_wgrad_use_tr)
         hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);

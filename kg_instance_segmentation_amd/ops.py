@@ -167,6 +167,7 @@ def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=
 
 
 USE_HALO = True
+WGRAD128 = __import__("os").environ.get("KG_WGRAD128", "1") == "1"
 USE_C3 = __import__("os").environ.get("KG_CONV3_C64", "1") == "1"
 IM2COL_WGRAD = __import__("os").environ.get("KG_IM2COL_WGRAD", "1") == "1"
 
@@ -240,7 +241,8 @@ def conv_auto(x, pw, cout, geom, N, y=None, y_f32=None, bias=None, res=None, mas
 
 
 def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):
-    base = math.ceil(cin_lim / 64) * math.ceil(cout_lim / 64) * taps
+    t = 128 if (WGRAD128 and cin_lim >= 128 and cout_lim >= 128) else 64      # output tile of kg_conv2d_wgrad
+    base = math.ceil(cin_lim / t) * math.ceil(cout_lim / t) * taps
     chunks = math.ceil(M / 64)
     s = max(1, min(math.ceil(2048 / base), max(1, chunks // 4)))
     while s > 1 and s * nelem * 4 > (768 << 20):
