@@ -15,6 +15,7 @@
 // Wave tile = 64 couts x 64 pixels (4 rows of the 16x16 tile), 16 v_mfma_f32_16x16x32_bf16 per 32-wide k-step.
 #include "kg_common.h"
 #include <type_traits>
+#include <stdlib.h>
 #ifndef KG_HALO_SETPRIO
 #define KG_HALO_SETPRIO 1
 #endif
@@ -30,6 +31,7 @@ struct HaloArgs {
     int cin_pad, ldx, Cout, ldy, ldres, ldmask, K, flip, relu, f32_C, f32_hw;
     // grouped second-layer heads (GM = 1): per-head channel chunks, virtual-cout -> map-channel table, the 3 fp32 outputs
     int grp_chunks; const int* vmap; float* f32_b; float* f32_c;
+    int xcd_map;      // 1: remap (blockIdx.x, blockIdx.y) so that the cout blocks of a pixel tile share an XCD (gridDim.x % 8 == 0)
     int head_split;   // GM: 1 = blockIdx.y is the head (small images: 3x the workgroups), 0 = one workgroup walks all heads
 };
 
@@ -58,16 +60,26 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     const int lm = lane & 15, g = lane >> 4;
     int oy0, ox0, Hd, Wd;
     long rowbase;   // row index of pixel (0,0) of this tile's image / box
+    // XCD-aware mapping: workgroups are dealt to the 8 XCDs (one L2 each) round-robin in linear-id order.  Give every XCD a
+    // contiguous range of pixel tiles and let the cout blocks of a tile follow each other on it, so the halo of a tile (and
+    // the columns it shares with its x neighbour) is fetched into that L2 once instead of once per cout block.
+    int bix = blockIdx.x, biy = blockIdx.y;
+    if (a.xcd_map) {
+        const int L = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = L & 7, slot = L >> 3;
+        biy = slot % gridDim.y;
+        bix = xcd * (gridDim.x >> 3) + slot / gridDim.y;
+    }
     if (a.tiletab) {
-        const int4 tt = a.tiletab[blockIdx.x];
+        const int4 tt = a.tiletab[bix];
         rowbase = tt.x; Hd = tt.y >> 16; Wd = tt.y & 0xffff; oy0 = tt.z >> 16; ox0 = tt.z & 0xffff;
     } else {
-        int bt = blockIdx.x;
+        int bt = bix;
         const int tx = bt % a.tiles_x; bt /= a.tiles_x;
         const int ty = bt % a.tiles_y; const int n = bt / a.tiles_y;
         oy0 = ty * 16; ox0 = tx * TW; Hd = a.H; Wd = a.W; rowbase = (long)n * a.H * a.W;
     }
-    const int c0 = GM == 1 ? 0 : blockIdx.y * TC;   // GM: blockIdx.y = head (kp / short / mid), all on the one 64-row weight tile
+    const int c0 = GM == 1 ? 0 : biy * TC;   // GM: blockIdx.y = head (kp / short / mid), all on the one 64-row weight tile
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -129,8 +141,8 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
         if (KG_HALO_SETPRIO) __builtin_amdgcn_s_setprio(0);
     };
 
-    const int nchunks = (GM == 1 && a.head_split) ? (blockIdx.y + 1) * a.grp_chunks : a.cin_pad / 64;
-    for (int cc = (GM == 1 && a.head_split) ? blockIdx.y * a.grp_chunks : 0; cc < nchunks; ++cc) {
+    const int nchunks = (GM == 1 && a.head_split) ? (biy + 1) * a.grp_chunks : a.cin_pad / 64;
+    for (int cc = (GM == 1 && a.head_split) ? biy * a.grp_chunks : 0; cc < nchunks; ++cc) {
         __syncthreads();
         // ---- stage the halo of this 64-channel chunk ------------------------------------------------
         if (KS == 3) {   // 3x3 (9 taps per staging): all global loads of the halo are issued before the first LDS store
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ch = vm[e];
-                if (ch < 0 || (a.head_split && (ch < 5 ? 0 : ch < 15 ? 1 : 2) != (int)blockIdx.y)) continue;
+                if (ch < 0 || (a.head_split && (ch < 5 ? 0 : ch < 15 ? 1 : 2) != biy)) continue;
                 if (ch < 5) a.y_f32[(nimg * 5 + ch) * hw + pix] = 1.f / (1.f + expf(-v[e]));
                 else if (ch < 15) a.f32_b[(nimg * 10 + ch - 5) * hw + pix] = v[e];
                 else a.f32_c[(nimg * 40 + ch - 15) * hw + pix] = v[e];
@@ -414,6 +426,9 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y, GM == 1 ? (a.head_split ? 3 : 1) : kg_cdiv(a.Cout, TC));
+    static const int use_xcd = getenv("KG_HALO_XCD") ? atoi(getenv("KG_HALO_XCD")) : 1;
+    // (not for the widest heads: 24 cout blocks of one tile stream 24 different 3 MB weight slices through the XCD's 4 MB L2: -2 %)
+    a.xcd_map = use_xcd && !a.tiletab && grid.x % 8 == 0 && (grid.y > 1 || use_xcd > 1) && (long)a.Cout * a.K * 2 <= (24L << 20);
     hipLaunchKernelGGL((conv_halo_kernel<KS, WC, WPX, GM>), grid, dim3(WC * WPX * 64), smem, st, a);
     KG_CHECK_LAUNCH("conv_halo");
     return KG_OK;
