@@ -62,7 +62,7 @@ __global__ __launch_bounds__(512) void conv3_c64_kernel(const C3Args a) {
             if (e < HPIX * 8) {
                 const int p = e >> 3, cs = e & 7;
                 const int hy = p / HWD, hx = p - hy * HWD;
-                const int c = cs ^ ((hx >> 1) & 7);
+                const int c = cs ^ (hx & 6);
                 const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
                 const bf16_t* src = reinterpret_cast<const bf16_t*>(kg_c3_zero_line) + c * 8;
                 if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd) src = a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + c * 8;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512) void conv3_c64_kernel(const C3Args a) {
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int fx = a.flip ? 2 - kx : kx;
-        const int key = ((lm + fx) >> 1) & 7;
+        const int key = (lm + fx) & 6;
 #pragma unroll
         for (int s = 0; s < 2; ++s) kb[kx][s] = ((wave * 2) * HWD + lm + fx) * 128 + (((4 * s + g) ^ key) * 16);
     }

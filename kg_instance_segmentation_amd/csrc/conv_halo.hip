@@ -22,6 +22,20 @@
 
 __device__ uint4 kg_halo_zero_line[8];   // 128 zero bytes: source of the padding pixels of a halo
 
+// hipcc models global_load_lds (LDS-DMA) as a FLAT access that may return out of order: once one is pending, EVERY LDS wait it
+// inserts is s_waitcnt lgkmcnt(0), which also waits for the fragment reads just issued for the NEXT k-step and exposes one LDS
+// latency per tap (tools/micro/mfma_peak.hip: 1.80 -> 1.94 PFLOP/s on the bare loop skeleton).  The 7x7 tap loop therefore issues
+// its fragment reads from inline asm (invisible to that pass) and counts lgkmcnt by hand; the wait is tied to the fragment
+// registers it guards ("+v"), so the MFMAs that consume them cannot be scheduled above it.
+template <int OFF>
+__device__ __forceinline__ void lds_rd128(bf16x8& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N>   // returns once at most N LDS reads of this wave are outstanding (they return in order)
+__device__ __forceinline__ void lgkm_wait(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+}
+
 struct HaloArgs {
     const bf16_t* x; const bf16_t* w; const float* bias;
     bf16_t* y; float* y_f32; const bf16_t* res; const bf16_t* mask;
@@ -50,6 +64,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     // stays in flight across it (a __syncthreads() would drain it).
     constexpr bool GLW = KS == 7 && WC <= 2;
     constexpr int NSL = GLW ? 6 : 3;
+    constexpr bool ASMRD = GLW && GM != 1;   // fragment reads from inline asm with hand-counted lgkmcnt (see lds_rd128); the grouped-heads variant spills with it
     constexpr int WPT = TC * 8 / NT;  // weight chunks per thread per tap (= 2)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo = smem;
@@ -105,7 +120,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) {
         const int fx = a.flip ? KS - 1 - kx : kx;
-        const int key = ((xb + fx) >> 1) & 7;
+        const int key = (xb + fx) & 6;   // conflict-free for every tap shift under the ds_read_b128 lane groups {0-3,12-15,20-27} ...; ((x >> 1) & 7 was 2-way for 3 of 4 shifts)
 #pragma unroll
         for (int s = 0; s < 2; ++s) kb[kx][s] = (((wp & 3) * 4) * HWD + xb) * 128 + (((4 * s + g) ^ key) * 16);
     }
@@ -164,7 +179,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                 const int e = tid + q * NT;
                 const int p = e >> 3, c = e & 7;
                 const int hx = p % HWD;
-                if (e < HPIX * 8) *reinterpret_cast<uint4*>(halo + p * 128 + ((c ^ ((hx >> 1) & 7)) * 16)) = hreg[q];
+                if (e < HPIX * 8) *reinterpret_cast<uint4*>(halo + p * 128 + ((c ^ (hx & 6)) * 16)) = hreg[q];
             }
         } else
         {   // 7x7: LDS-direct loads (global_load_lds_dwordx4): the whole halo is in flight at once and needs no staging
@@ -179,7 +194,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                 if (e < HPIX * 8) {
                     const int p = e >> 3, cs = e & 7;
                     const int hy = p / HWD, hx = p - hy * HWD;
-                    const int c = cs ^ ((hx >> 1) & 7);
+                    const int c = cs ^ (hx & 6);
                     const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
                     const bf16_t* src = reinterpret_cast<const bf16_t*>(kg_halo_zero_line) + c * 8;
                     if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd)
@@ -238,6 +253,11 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
         // ky (rolled) x kx (unrolled): every lane-dependent address term is a precomputed register (kb / ab), the tap
         // offset is a scalar, fragment j / i offsets are instruction immediates -> ~4 VALU per tap.
         bf16x8 a0[4], b0[4], a1[4], b1[4];
+        if constexpr (ASMRD) {         // fragments a masked variant never loads still pass through lgkm_wait
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a0[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; a1[i] = a0[i]; }
+        }
+        const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
         int abr[NSL][2];               // ab rotated so that index kx % NSL is the ring slot of tap (ky,kx)
         int sbr[NSL];
 #pragma unroll
@@ -246,19 +266,41 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
         const int sx = a.flip ? -128 : 128, sy = a.flip ? -HWD * 128 : HWD * 128;
         auto ldA = [&](auto mk, bf16x8 (&af)[4], int base) {
             constexpr int MK = decltype(mk)::value;
+            if constexpr (ASMRD) {
+                const unsigned ad = lds0 + HALO_BYTES + base;
+                if (MK & 1) lds_rd128<0>(af[0], ad);
+                if (MK & 2) lds_rd128<512>(af[1], ad);
+                if (MK & 4) lds_rd128<1024>(af[2], ad);
+                if (MK & 8) lds_rd128<1536>(af[3], ad);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if ((MK >> i) & 1) af[i] = *reinterpret_cast<const bf16x8*>(wbuf + base + i * 512);
+                for (int i = 0; i < 4; ++i)
+                    if ((MK >> i) & 1) af[i] = *reinterpret_cast<const bf16x8*>(wbuf + base + i * 512);
+            }
         };
         auto ldB = [&](bf16x8 (&bfr)[4], int tb, int kbv) {
-            const unsigned char* hb = halo + tb + kbv;
+            if constexpr (ASMRD) {
+                const unsigned ad = lds0 + tb + kbv;
+                lds_rd128<0>(bfr[0], ad); lds_rd128<HWD * 128>(bfr[1], ad); lds_rd128<2 * HWD * 128>(bfr[2], ad); lds_rd128<3 * HWD * 128>(bfr[3], ad);
+            } else {
+                const unsigned char* hb = halo + tb + kbv;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(hb + j * (HWD * 128));
+                for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(hb + j * (HWD * 128));
+            }
+        };
+        // GLW: wait until the fragments (af, bfr) have landed; `newer` = a later k-step's NRD reads were issued after them
+        auto lwait = [&](auto mk, bf16x8 (&af)[4], bf16x8 (&bfr)[4], bool newer) {
+            if constexpr (ASMRD) {
+                constexpr int MK = decltype(mk)::value;
+                constexpr int NRD = 4 + (MK & 1) + ((MK >> 1) & 1) + ((MK >> 2) & 1) + ((MK >> 3) & 1);
+                if (newer) lgkm_wait<NRD>(af, bfr);
+                else lgkm_wait<0>(af, bfr);
+            }
         };
         auto run_taps = [&](auto mk) {
         ldA(mk, a0, abr[0][0]); ldB(b0, tapb, kb[0][0]);
         int t = 0;
-#pragma unroll 1
+#pragma unroll (ASMRD ? KS : 1)   // 7x7: fully unrolled -> tap parity, ring slots and tails are compile-time, no branch merges (the waitcnt pass then counts lgkmcnt precisely)
         for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx, ++t) {
@@ -275,18 +317,23 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                 const int ntb = (kx + 1 == KS) ? tapb + sy : tapb + (kx + 1) * sx;
                 if constexpr ((decltype(mk)::value & 16) == 0) {
                     ldA(mk, a1, abr[cur][1]); ldB(b1, tb, kb[kx][1]);
+                    lwait(mk, a0, b0, true);
                     mma(mk, a0, b0);
                     if (t + 1 < T) { ldA(mk, a0, abr[nxt][0]); ldB(b0, ntb, kb[nkx][0]); }
+                    lwait(mk, a1, b1, t + 1 < T);
                     mma(mk, a1, b1);
                 } else {   // only k-step 0 of the chunk is non-zero: taps alternate between the two fragment buffers
                     if (kx + 1 == KS) {
+                        lwait(mk, a0, b0, false);
                         mma(mk, a0, b0);
                         if (t + 1 < T) { ldA(mk, a0, abr[nxt][0]); ldB(b0, ntb, kb[nkx][0]); }
                     } else if (kx % 2 == 0) {
                         ldA(mk, a1, abr[nxt][0]); ldB(b1, ntb, kb[nkx][0]);
+                        lwait(mk, a0, b0, true);
                         mma(mk, a0, b0);
                     } else {
                         ldA(mk, a0, abr[nxt][0]); ldB(b0, ntb, kb[nkx][0]);
+                        lwait(mk, a1, b1, true);
                         mma(mk, a1, b1);
                     }
                 }
