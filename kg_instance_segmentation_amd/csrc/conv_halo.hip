@@ -22,20 +22,6 @@
 
 __device__ uint4 kg_halo_zero_line[8];   // 128 zero bytes: source of the padding pixels of a halo
 
-// hipcc models global_load_lds (LDS-DMA) as a FLAT access that may return out of order: once one is pending, EVERY LDS wait it
-// inserts is s_waitcnt lgkmcnt(0), which also waits for the fragment reads just issued for the NEXT k-step and exposes one LDS
-// latency per tap (tools/micro/mfma_peak.hip: 1.80 -> 1.94 PFLOP/s on the bare loop skeleton).  The 7x7 tap loop therefore issues
-// its fragment reads from inline asm (invisible to that pass) and counts lgkmcnt by hand; the wait is tied to the fragment
-// registers it guards ("+v"), so the MFMAs that consume them cannot be scheduled above it.
-template <int OFF>
-__device__ __forceinline__ void lds_rd128(bf16x8& d, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
-template <int N>   // returns once at most N LDS reads of this wave are outstanding (they return in order)
-__device__ __forceinline__ void lgkm_wait(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
-}
-
 struct HaloArgs {
     const bf16_t* x; const bf16_t* w; const float* bias;
     bf16_t* y; float* y_f32; const bf16_t* res; const bf16_t* mask;
@@ -257,7 +243,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 #pragma unroll
             for (int i = 0; i < 4; ++i) { a0[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; a1[i] = a0[i]; }
         }
-        const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+        const unsigned lds0 = lds_addr(smem);
         int abr[NSL][2];               // ab rotated so that index kx % NSL is the ring slot of tap (ky,kx)
         int sbr[NSL];
 #pragma unroll

@@ -54,4 +54,22 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
+// hipcc models global_load_lds (LDS-DMA) as a FLAT access that may return out of order: once one is pending, EVERY LDS wait it
+// inserts is s_waitcnt lgkmcnt(0), which also waits for the fragment reads just issued for the NEXT k-step and exposes one LDS
+// latency per tap (tools/micro/mfma_peak.hip: 1.80 -> 1.94 PFLOP/s on the bare loop skeleton).  The 7x7 tap loop therefore issues
+// its fragment reads from inline asm (invisible to that pass) and counts lgkmcnt by hand; the wait is tied to the fragment
+// registers it guards ("+v"), so the MFMAs that consume them cannot be scheduled above it.
+template <int OFF>
+__device__ __forceinline__ void lds_rd128(bf16x8& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N>   // returns once at most N LDS reads of this wave are outstanding (they return in order)
+__device__ __forceinline__ void lgkm_wait(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {   // LDS byte address of a pointer into __shared__ memory
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+
 static inline int kg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
