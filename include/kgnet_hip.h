@@ -80,6 +80,10 @@ int kg_conv2d_wgrad_halo(const void* x, const void* dy, float* dwp, int N, int H
 int kg_bias_grad_final(const float* part, float* db, int nsplit, int C, int accumulate, void* stream);
 int kg_wgrad_reduce(const float* part, float* grad_oihw, int Cout, int Cin, int KH, int KW, int nsplit, long split_stride,
                     int accumulate, void* stream);
+/* the same for a conv fused along Cout (heads sharing their input): tensor k receives the next counts[k] rows; ngrads <= 4;
+   grads / counts are HOST arrays */
+int kg_wgrad_reduce_multi(const float* part, float* const* grads_oihw, const int* counts, int ngrads, int Cin, int KH, int KW,
+                          int nsplit, long split_stride, int accumulate, void* stream);
 int kg_bias_grad(const void* dy, float* db, float* scratch, int scratch_floats, int M, int C, int ld, int accumulate,
                  void* stream);
 int kg_set_wgrad_tr(int use_transpose_read);   /* test switch: LDS transpose-read vs scalar fragment loads */

@@ -317,12 +317,16 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
 // Sum the split partials [S][Cout][taps][Cin] and write the OIHW fp32 gradient [Cout][Cin][taps]
 // (accumulate != 0: grad += sum).  Fixed summation order => bitwise reproducible gradients.  One block per
 // (co, 64-channel ci chunk): coalesced reads along ci, transpose through LDS, coalesced writes along (ci,tap).
+struct ReduceDst { float* g[4]; int end[4]; };   // output tensor k holds the rows [end[k-1], end[k]) of the fused conv (heads sharing an input)
 template <int CH>   // ci chunk per block: 64 for big layers, 16 to get enough blocks on small ones
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad,
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const ReduceDst dst4,
                                                            int Cout, int Cin, int taps, int S, long split_stride,
                                                            int accumulate) {
     __shared__ float tile[49 * (CH + 1)];
     const int co = blockIdx.x, ci0 = blockIdx.y * CH;
+    int k = 0, row0 = 0;
+    while (k < 3 && co >= dst4.end[k]) { row0 = dst4.end[k]; ++k; }
+    float* __restrict__ grad = dst4.g[k] - (long)row0 * Cin * taps;   // so that row `co` of the fused conv lands in row co - row0
     const int nci = Cin - ci0 < CH ? Cin - ci0 : CH;
     for (int e = threadIdx.x; e < taps * CH; e += 256) {
         const int tap = e / CH, ci = e - tap * CH;
@@ -350,18 +354,41 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+static int launch_reduce(const float* part, const ReduceDst& d, int Cout, int Cin, int taps, int nsplit, long split_stride, int accumulate,
+                         hipStream_t st) {
+    if ((long)Cout * ((Cin + 63) / 64) >= 2048)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(Cout, (Cin + 63) / 64), dim3(256), 0, st, part, d, Cout, Cin, taps, nsplit,
+                           split_stride, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(Cout, (Cin + 15) / 16), dim3(256), 0, st, part, d, Cout, Cin, taps, nsplit,
+                           split_stride, accumulate);
+    KG_CHECK_LAUNCH("wgrad_reduce");
+    return KG_OK;
+}
+
 extern "C" int kg_wgrad_reduce(const float* part, float* grad, int Cout, int Cin, int KH, int KW, int nsplit,
                                long split_stride, int accumulate, void* stream) {
     KG_CHECK_ARG(part && grad, "kg_wgrad_reduce: null pointer");
     KG_CHECK_ARG(KH * KW <= 49, "kg_wgrad_reduce: at most 49 taps");
-    if ((long)Cout * ((Cin + 63) / 64) >= 2048)
-        hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(Cout, (Cin + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, grad, Cout,
-                           Cin, KH * KW, nsplit, split_stride, accumulate);
-    else
-        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(Cout, (Cin + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, grad, Cout,
-                           Cin, KH * KW, nsplit, split_stride, accumulate);
-    KG_CHECK_LAUNCH("wgrad_reduce");
-    return KG_OK;
+    ReduceDst d;
+    for (int k = 0; k < 4; ++k) { d.g[k] = grad; d.end[k] = Cout; }
+    d.end[0] = Cout;
+    return launch_reduce(part, d, Cout, Cin, KH * KW, nsplit, split_stride, accumulate, (hipStream_t)stream);
+}
+
+// Same for a conv fused along Cout (heads that share their input, KGnet.py:161-209): ngrads <= 4 gradient tensors, tensor k = the
+// next counts[k] output rows of the fused conv.  One launch instead of one per head.
+extern "C" int kg_wgrad_reduce_multi(const float* part, float* const* grads, const int* counts, int ngrads, int Cin, int KH, int KW,
+                                     int nsplit, long split_stride, int accumulate, void* stream) {
+    KG_CHECK_ARG(part && grads && counts && ngrads >= 1 && ngrads <= 4, "kg_wgrad_reduce_multi: 1..4 gradient tensors");
+    KG_CHECK_ARG(KH * KW <= 49, "kg_wgrad_reduce_multi: at most 49 taps");
+    ReduceDst d;
+    int end = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (k < ngrads) { KG_CHECK_ARG(grads[k] && counts[k] > 0, "kg_wgrad_reduce_multi: bad tensor %d", k); end += counts[k]; }
+        d.g[k] = grads[k < ngrads ? k : ngrads - 1]; d.end[k] = end;
+    }
+    return launch_reduce(part, d, end, Cin, KH * KW, nsplit, split_stride, accumulate, (hipStream_t)stream);
 }
 
 // Bias gradient: db[c] = sum over rows of dy[row][c] (bf16 rows, fp32 sum), fixed-order two-stage.

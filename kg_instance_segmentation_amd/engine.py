@@ -72,6 +72,7 @@ class Engine:
         self.m = module
         self.specs = {}
         self.tape = None
+        self.nbt = []
         self.param_grads = None
         self.fusedT = {}
         self.head_slots = []
@@ -191,7 +192,7 @@ class Engine:
             out = torch.empty(xv.rows, C, dtype=BF16, device=dev)
         if self.m.training:
             mean, invstd, scale, shift = ops.bn_stats_train(xv.t, C, gamma.detach(), beta.detach(), rm, rv)
-            self.P(p + ".num_batches_tracked").add_(1)
+            self.nbt.append(self.P(p + ".num_batches_tracked"))      # += 1 for all 43 layers in one launch at the end of forward_dec
         else:
             scale, shift = ops.bn_scale_shift_eval(C, gamma.detach(), beta.detach(), rm, rv)
             mean = invstd = None
@@ -286,6 +287,7 @@ class Engine:
         dev = img.device
         self.tape = [] if record else None
         self.param_grads = {}
+        self.nbt = []
         if record:
             self.train_steps += 1
         self.stamp = ("t" if record else "e", self.train_steps)
@@ -339,6 +341,9 @@ class Engine:
             hid, _, _ = self.conv(catv[lvl], self.spec(f"heads_c{lvl}.0", C, C, 7, 1, 3, fused=fused), N, Hh, Wh, True)
             outs = self.heads_second(hid, lvl, C, N, Hh, Wh)
             maps.extend(outs)
+        if self.nbt:
+            torch._foreach_add_(self.nbt, 1)
+            self.nbt = []
         self.feats, self.dims, self.N, self.maps = feats, dims, N, maps
         return maps, feats, dims
 

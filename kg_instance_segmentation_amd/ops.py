@@ -299,9 +299,17 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
                   cin_lim, cout_lim, KH, KW, stride, pad, 1, mode, S, c_long(nelem), stream_ptr())
         if bias_out is not None:
             bias_grad(dy, cout, bias_out, accumulate=accumulate)
-    for g, off, cnt in grads:
-        _lib.call("kg_wgrad_reduce", ctypes_offset(part, off * KH * KW * cin), ptr(g), cnt, cin, KH, KW, S, c_long(nelem),
-                  1 if accumulate else 0, stream_ptr())
+    contiguous = all(grads[i][1] + grads[i][2] == grads[i + 1][1] for i in range(len(grads) - 1))
+    if 1 < len(grads) <= 4 and contiguous:      # heads fused along Cout: one reduction launch for all of them
+        import ctypes
+        gp = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g, _, _ in grads])
+        cn = (ctypes.c_int * len(grads))(*[cnt for _, _, cnt in grads])
+        _lib.call("kg_wgrad_reduce_multi", ctypes_offset(part, grads[0][1] * KH * KW * cin), gp, cn, len(grads), cin, KH, KW, S,
+                  c_long(nelem), 1 if accumulate else 0, stream_ptr())
+    else:
+        for g, off, cnt in grads:
+            _lib.call("kg_wgrad_reduce", ctypes_offset(part, off * KH * KW * cin), ptr(g), cnt, cin, KH, KW, S, c_long(nelem),
+                      1 if accumulate else 0, stream_ptr())
     return "halo" if halo else "gather"
 
 
