@@ -17,7 +17,7 @@
 #include <type_traits>
 #include <stdlib.h>
 #ifndef KG_HALO_SETPRIO
-#define KG_HALO_SETPRIO 1
+#define KG_HALO_SETPRIO 0
 #endif
 
 __device__ uint4 kg_halo_zero_line[8];   // 128 zero bytes: source of the padding pixels of a halo
