@@ -250,6 +250,24 @@ def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):
     return s
 
 
+def halo_wgrad_splits(nblk, tiles, cit, taps, nelem, cus=256):
+    """Pixel splits of kg_conv2d_wgrad_halo: one workgroup per CU is resident (2 x 47..78 KB of LDS + ~250 VGPRs x 8 waves), so
+    the launch runs in ceil(nblk * S / 256) rounds; pick S by a small cost model (round count x tiles per workgroup + per-workgroup
+    prologue / partial write + the reduction's bytes) instead of a fixed 2 rounds -- 192 x 2 = 384 workgroups is 1.5 rounds."""
+    tile_us = 256 * 64 * cit * taps * 2 / 5.3e6          # one 16x16 tile at ~1.35 PFLOP/s / 256 CUs
+    best, best_t = 1, None
+    for S in range(1, max(1, min(tiles, 2048 // nblk if nblk <= 2048 else 1)) + 1):
+        if S > 1 and S * nelem * 4 > (768 << 20):
+            break
+        rounds = math.ceil(nblk * S / cus)
+        t = rounds * (math.ceil(tiles / S) * tile_us + 10.0) + S * nelem * 8 / 3e6
+        if S >= 8 and S % 8 == 0:
+            t *= 0.97                                    # multiples of 8 enable the kernel's XCD-aware block mapping
+        if best_t is None or t < best_t:
+            best, best_t = S, t
+    return best
+
+
 def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=False, N=None, tiletab16=None, bias_out=None):
     """grads: list of (fp32 OIHW grad tensor, cout_offset, cout_count) sharing x (fused heads) or one entry.
     Dense stride-1 "same" 3x3/7x7 convs (N given) use the LDS-halo kernel, everything else the gather kernel.
@@ -280,11 +298,7 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
         cit = 16 if KH == 7 else 64
         nblk = math.ceil(cin_lim / cit) * math.ceil(cout_lim / 64)
         tiles = tiletab16.shape[0] if tiletab16 is not None else N * math.ceil(H / 16) * math.ceil(W / 16)
-        S = max(1, min(512 // nblk if nblk <= 512 else 1, tiles))   # ~2 resident rounds of 1-block-per-CU workgroups
-        while S > 1 and S * nelem * 4 > (768 << 20):
-            S -= 1
-        if S >= 8:
-            S -= S % 8      # multiples of 8 enable the kernel's XCD-aware block mapping
+        S = halo_wgrad_splits(nblk, tiles, cit, KH * KW, nelem)
         part = scratch_f32(S * nelem, x.device, "wgrad")
         dbp = scratch_f32(S * cout, x.device, "wgrad_bias") if (bias_out is not None and KH == 7) else None
         wgrad_halo(x, dy, part, N or 0, H, W, cin, cout, cin_lim, cout_lim, KH, S, nelem, tiletab16, dbp)

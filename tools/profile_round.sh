@@ -18,3 +18,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${tag}_pmc_w
 python $R/tools/pmc_summary.py $O/${tag}_pmc_hbm.json $(find $O/${tag}_pmc_rd $O/${tag}_pmc_wr -name "*counter_collection.csv") >> $O/${tag}_prof.log 2>&1
 rm -rf $O/${tag}_pmc_rd $O/${tag}_pmc_wr   # raw per-dispatch CSVs are large
 tail -3 $O/${tag}_prof.log; cat $O/${tag}_bench_n1.json | cut -c1-600
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $O/${tag}_shp -o p -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timer > $O/${tag}_shp.log 2>&1
+python $R/tools/rocprof_shapes.py $(find $O/${tag}_shp -name "*kernel_trace.csv" | head -1) $O/${tag}_bench_launch_shapes.csv 5 >> $O/${tag}_prof.log 2>&1
+rm -rf $O/${tag}_shp
