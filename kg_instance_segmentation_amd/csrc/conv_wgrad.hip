@@ -318,36 +318,61 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
 // (accumulate != 0: grad += sum).  Fixed summation order => bitwise reproducible gradients.  One block per
 // (co, 64-channel ci chunk): coalesced reads along ci, transpose through LDS, coalesced writes along (ci,tap).
 struct ReduceDst { float* g[4]; int end[4]; };   // output tensor k holds the rows [end[k-1], end[k]) of the fused conv (heads sharing an input)
+// G = blockDim.x / (taps * CH) >= 2 (small layers with many splits, e.g. 3x3 64 -> 64 with 256 splits): G thread groups each sum a
+// contiguous range of the splits in order, then group 0 adds the G partial sums in group order -- still one fixed summation order.
 template <int CH>   // ci chunk per block: 64 for big layers, 16 to get enough blocks on small ones
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const ReduceDst dst4,
-                                                           int Cout, int Cin, int taps, int S, long split_stride,
-                                                           int accumulate) {
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, const ReduceDst dst4,
+                                                            int Cout, int Cin, int taps, int S, long split_stride,
+                                                            int accumulate) {
     __shared__ float tile[49 * (CH + 1)];
+    __shared__ float red[1024];
     const int co = blockIdx.x, ci0 = blockIdx.y * CH;
     int k = 0, row0 = 0;
     while (k < 3 && co >= dst4.end[k]) { row0 = dst4.end[k]; ++k; }
     float* __restrict__ grad = dst4.g[k] - (long)row0 * Cin * taps;   // so that row `co` of the fused conv lands in row co - row0
     const int nci = Cin - ci0 < CH ? Cin - ci0 : CH;
-    for (int e = threadIdx.x; e < taps * CH; e += 256) {
-        const int tap = e / CH, ci = e - tap * CH;
+    const int E = taps * CH, NT = blockDim.x;
+    const int G = NT >= 2 * E ? NT / E : 1;
+    auto sum_range = [&](const float* src, int k0, int k1) {
         float s = 0.f;
-        if (ci < nci) {
-            const float* src = part + ((long)co * taps + tap) * Cin + ci0 + ci;
-            int k = 0;
-            for (; k + 8 <= S; k += 8) {   // 8 independent loads in flight; the adds keep the fixed k order
-                float v[8];
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {   // 8 independent loads in flight; the adds keep the fixed k order
+            float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = src[(long)(k + u) * split_stride];
+            for (int u = 0; u < 8; ++u) v[u] = src[(long)(k + u) * split_stride];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s += v[u];
-            }
-            for (; k < S; ++k) s += src[(long)k * split_stride];
+            for (int u = 0; u < 8; ++u) s += v[u];
         }
-        tile[tap * (CH + 1) + ci] = s;
+        for (; k < k1; ++k) s += src[(long)k * split_stride];
+        return s;
+    };
+    if (G > 1) {
+        const int g = threadIdx.x / E, e = threadIdx.x - g * E;
+        const int tap = e / CH, ci = e - tap * CH;
+        const int Sg = (S + G - 1) / G;
+        if (g < G) {
+            float s = 0.f;
+            const int k0 = g * Sg, k1 = k0 + Sg < S ? k0 + Sg : S;
+            if (ci < nci && k0 < k1) s = sum_range(part + ((long)co * taps + tap) * Cin + ci0 + ci, k0, k1);
+            red[g * E + e] = s;
+        }
+        __syncthreads();
+        if (g == 0) {
+            float s = red[e];
+            for (int q = 1; q < G; ++q) s += red[q * E + e];
+            tile[tap * (CH + 1) + ci] = s;
+        }
+    } else {
+        for (int e = threadIdx.x; e < E; e += NT) {
+            const int tap = e / CH, ci = e - tap * CH;
+            float s = 0.f;
+            if (ci < nci) s = sum_range(part + ((long)co * taps + tap) * Cin + ci0 + ci, 0, S);
+            tile[tap * (CH + 1) + ci] = s;
+        }
     }
     __syncthreads();
     float* dst = grad + ((long)co * Cin + ci0) * taps;
-    for (int j = threadIdx.x; j < nci * taps; j += 256) {
+    for (int j = threadIdx.x; j < nci * taps; j += NT) {
         const int ci = j / taps, tap = j - ci * taps;
         const float v = tile[tap * (CH + 1) + ci];
         dst[j] = accumulate ? dst[j] + v : v;
@@ -359,9 +384,17 @@ static int launch_reduce(const float* part, const ReduceDst& d, int Cout, int Ci
     if ((long)Cout * ((Cin + 63) / 64) >= 2048)
         hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(Cout, (Cin + 63) / 64), dim3(256), 0, st, part, d, Cout, Cin, taps, nsplit,
                            split_stride, accumulate);
-    else
-        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(Cout, (Cin + 15) / 16), dim3(256), 0, st, part, d, Cout, Cin, taps, nsplit,
+    else {
+        int nt = 256;
+        const int E = taps * 16;
+        if (2 * E <= 1024 && nsplit >= 16) {       // few elements, many splits: several thread groups share the splits
+            int G = 1024 / E;
+            if (G > nsplit / 8) G = nsplit / 8;
+            if (G >= 2) nt = E * G;
+        }
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(Cout, (Cin + 15) / 16), dim3(nt), 0, st, part, d, Cout, Cin, taps, nsplit,
                            split_stride, accumulate);
+    }
     KG_CHECK_LAUNCH("wgrad_reduce");
     return KG_OK;
 }
