@@ -10,6 +10,7 @@
 //   * lane layout and epilogue (bias / residual / ReLU / ReLU-mask, bf16 rows) are those of conv_igemm.hip.
 // Rows are just rows: the same kernel serves dense images and the ragged seg-branch pixel lists.
 #include "kg_common.h"
+#include <stdlib.h>
 
 struct C1Args {
     const bf16_t* x; const bf16_t* w; const float* bias;
@@ -185,22 +186,25 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
 //   * the fp32 accumulators (+bias) go through an LDS transpose tile [128][64] (aliasing the X tile), and the epilogue
 //     (residual add, ReLU, ReLU-mask, bf16 rounding: one rounding, as in the other kernels) runs on 8-cout pieces with
 //     coalesced 16-byte residual / mask loads and stores.
-template <int KC>
+// NB > 1 (K = 64 only): the workgroup computes NB 64-cout blocks from ONE staged X tile (a 64 -> 128 input gradient at 512^2 read
+// its 268 MB of X once per cout block: 1.07 GB instead of 0.8 GB); the fp32 output tile then has its own LDS region.
+template <int KC, int NB = 1>
 __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const C1Args a) {
     constexpr int TM = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* wl = smem;                       // [KC][64 couts][128 B]
-    unsigned char* xl = smem + KC * 8192;           // [KC][TM][128 B]  (X tile)  /  [TM][256 B] fp32 (output tile)
+    unsigned char* wl = smem;                       // [NB][KC][64 couts][128 B]
+    unsigned char* xl = smem + NB * KC * 8192;      // [KC][TM][128 B]  (X tile)
+    unsigned char* ol = NB == 1 ? xl : xl + KC * TM * 128;   // [TM][256 B] fp32 output tile (NB == 1: aliases the X tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lm = lane & 15, g = lane >> 4;
-    const int c0 = blockIdx.y * 64;
+    const int c0 = blockIdx.y * 64 * NB;
 
-    for (int e = tid; e < KC * 64 * 8; e += 256) {
-        const int c = e & 7, r = (e >> 3) & 63, kc = e >> 9;
+    for (int e = tid; e < NB * KC * 64 * 8; e += 256) {
+        const int c = e & 7, r = (e >> 3) & 63, kc = (e >> 9) % KC, nb = e / (KC * 512);
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (c0 + r < a.wrows) v = *reinterpret_cast<const uint4*>(a.w + (long)(c0 + r) * a.wK + kc * 64 + c * 8);
+        if (c0 + nb * 64 + r < a.wrows) v = *reinterpret_cast<const uint4*>(a.w + (long)(c0 + nb * 64 + r) * a.wK + kc * 64 + c * 8);
         const int key = 2 * ((r >> 4) & 3) + ((r >> 1) & 1);
-        *reinterpret_cast<uint4*>(wl + kc * 8192 + r * 128 + ((c ^ key) * 16)) = v;
+        *reinterpret_cast<uint4*>(wl + (nb * KC + kc) * 8192 + r * 128 + ((c ^ key) * 16)) = v;
     }
     int a_off[4][2];
 #pragma unroll
@@ -210,9 +214,11 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const C1Args a) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) a_off[i][s] = r * 128 + (((4 * s + g) ^ key) * 16);
     }
-    float bv[16];
+    float bv[NB][16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) bv[e] = (a.bias && c0 + g * 16 + e < a.Cout) ? a.bias[c0 + g * 16 + e] : 0.f;
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bv[nb][e] = (a.bias && c0 + nb * 64 + g * 16 + e < a.Cout) ? a.bias[c0 + nb * 64 + g * 16 + e] : 0.f;
 
     // X staging: thread -> (row, 16-byte chunk) pairs, 8 (KC=1) or 16 (KC=2) consecutive lanes per row
     constexpr int XPT = TM * KC * 8 / 256;
@@ -243,69 +249,71 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const C1Args a) {
     }
     // epilogue pieces: thread -> (row, 8-cout piece)
     const int e_c8 = tid & 7, e_r0 = tid >> 3;   // rows e_r0 + 32*q
-    const int cpiece = c0 + e_c8 * 8;
-    const bool piece_ok = cpiece < a.Cout;       // Cout % 8 == 0 on this path
 
     long tile = blockIdx.x;
     if (tile < ntiles) xload(tile);
     for (; tile < ntiles; tile += gridDim.x) {
-        __syncthreads();                          // previous tile's output reads are done (xl is reused)
+        __syncthreads();                          // previous tile's output reads are done (NB == 1: xl is reused)
 #pragma unroll
         for (int q = 0; q < XPT; ++q) *reinterpret_cast<uint4*>(xl + x_lds[q]) = xr[q];
         __syncthreads();
         if (tile + gridDim.x < ntiles) xload(tile + gridDim.x);
-        f32x4 acc[4][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{bv[i * 4 + 0], bv[i * 4 + 1], bv[i * 4 + 2], bv[i * 4 + 3]};
-#pragma unroll
-        for (int ks = 0; ks < 2 * KC; ++ks) {
-            bf16x8 af[4], bf[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wl + (ks >> 1) * 8192 + a_off[i][ks & 1]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(xl + (ks >> 1) * (TM * 128) + b_off[j][ks & 1]);
+        for (int nb = 0; nb < NB; ++nb) {
+            f32x4 acc[4][2];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();                          // all B fragments read: xl becomes the fp32 output tile
+                for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{bv[nb][i * 4 + 0], bv[nb][i * 4 + 1], bv[nb][i * 4 + 2], bv[nb][i * 4 + 3]};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = wave * 32 + j * 16 + lm;
+            for (int ks = 0; ks < 2 * KC; ++ks) {
+                bf16x8 af[4], bf[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(xl + r * 256 + (((g * 4 + i) ^ (r & 15)) * 16)) = acc[i][j];
-        }
-        __syncthreads();
-        if (piece_ok) {
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wl + (nb * KC + (ks >> 1)) * 8192 + a_off[i][ks & 1]);
 #pragma unroll
-            for (int q = 0; q < TM / 32; ++q) {
-                const int r = e_r0 + 32 * q;
-                const long m = tile * TM + r;
-                if (m >= a.M) continue;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(xl + r * 256 + (((2 * e_c8) ^ (r & 15)) * 16));
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(xl + r * 256 + (((2 * e_c8 + 1) ^ (r & 15)) * 16));
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                if (a.res) {
-                    const uint4 rv = *reinterpret_cast<const uint4*>(a.res + m * a.ldres + cpiece);
-                    const bf16_t* rs = reinterpret_cast<const bf16_t*>(&rv);
+                for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(xl + (ks >> 1) * (TM * 128) + b_off[j][ks & 1]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += bf2f(rs[e]);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            if (NB == 1 || nb > 0) __syncthreads();   // NB == 1: all B fragments read, xl becomes the output tile; else: the previous block's output reads are done
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = wave * 32 + j * 16 + lm;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(ol + r * 256 + (((g * 4 + i) ^ (r & 15)) * 16)) = acc[i][j];
+            }
+            __syncthreads();
+            const int cpiece = c0 + nb * 64 + e_c8 * 8;
+            if (cpiece < a.Cout) {               // Cout % 8 == 0 on this path
+#pragma unroll
+                for (int q = 0; q < TM / 32; ++q) {
+                    const int r = e_r0 + 32 * q;
+                    const long m = tile * TM + r;
+                    if (m >= a.M) continue;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(ol + r * 256 + (((2 * e_c8) ^ (r & 15)) * 16));
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(ol + r * 256 + (((2 * e_c8 + 1) ^ (r & 15)) * 16));
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if (a.res) {
+                        const uint4 rv = *reinterpret_cast<const uint4*>(a.res + m * a.ldres + cpiece);
+                        const bf16_t* rs = reinterpret_cast<const bf16_t*>(&rv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bf2f(rs[e]);
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    }
+                    if (a.mask) {
+                        const uint4 mv = *reinterpret_cast<const uint4*>(a.mask + m * a.ldmask + cpiece);
+                        const bf16_t* ms = reinterpret_cast<const bf16_t*>(&mv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = bf2f(ms[e]) > 0.f ? v[e] : 0.f;
+                    }
+                    *reinterpret_cast<uint4*>(a.y + m * a.ldy + cpiece) =
+                        make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
                 }
-                if (a.relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-                }
-                if (a.mask) {
-                    const uint4 mv = *reinterpret_cast<const uint4*>(a.mask + m * a.ldmask + cpiece);
-                    const bf16_t* ms = reinterpret_cast<const bf16_t*>(&mv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = bf2f(ms[e]) > 0.f ? v[e] : 0.f;
-                }
-                *reinterpret_cast<uint4*>(a.y + m * a.ldy + cpiece) =
-                    make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
             }
         }
     }
@@ -327,13 +335,24 @@ extern "C" int kg_conv1x1(const void* x, const void* w, const float* bias, void*
     if (K <= 128 && Cout % 8 == 0 && ldy % 8 == 0 && al16(y) && al16(x) && (!res || (ldres % 8 == 0 && al16(res))) &&
         (!mask || (ldmask % 8 == 0 && al16(mask)))) {
         const int kc = K / 64;
-        const int smem_s = kc * 8192 + (kc == 1 ? 32768 : 32768);   // X tile (16/32 KB) aliased with the 32 KB fp32 output tile
+        static const int use_nb = getenv("KG_C1_NB") ? atoi(getenv("KG_C1_NB")) : 1;
+        const int nb = (use_nb && kc == 1 && Cout > 64) ? (Cout > 128 ? 4 : 2) : 1;   // cout blocks per workgroup (K = 64: X is the big operand)
+        // weights + X tile (16 / 32 KB) aliased with the 32 KB fp32 output tile; nb > 1: separate X and output tiles
+        const int smem_s = nb == 1 ? kc * 8192 + 32768 : nb * 8192 + 16384 + 32768;
+        static bool attr_done_s = false;
+        if (!attr_done_s) {
+            KG_HIP(hipFuncSetAttribute((const void*)conv1x1_stream_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8192 + 49152));
+            KG_HIP(hipFuncSetAttribute((const void*)conv1x1_stream_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8192 + 49152));
+            attr_done_s = true;
+        }
         const long nt = (M + 127) / 128;
-        const int nyb = kg_cdiv(Cout, 64);
-        long gxs = (long)256 * (kc == 1 ? 4 : 3) / nyb;
+        const int nyb = kg_cdiv(Cout, 64 * nb);
+        long gxs = (long)256 * (nb == 1 ? (kc == 1 ? 4 : 3) : 2) / nyb;
         if (gxs < 64) gxs = 64;
         if (gxs > nt) gxs = nt;
-        if (kc == 1) hipLaunchKernelGGL(conv1x1_stream_kernel<1>, dim3((unsigned)gxs, nyb), dim3(256), smem_s, (hipStream_t)stream, a);
+        if (nb == 4) hipLaunchKernelGGL((conv1x1_stream_kernel<1, 4>), dim3((unsigned)gxs, nyb), dim3(256), smem_s, (hipStream_t)stream, a);
+        else if (nb == 2) hipLaunchKernelGGL((conv1x1_stream_kernel<1, 2>), dim3((unsigned)gxs, nyb), dim3(256), smem_s, (hipStream_t)stream, a);
+        else if (kc == 1) hipLaunchKernelGGL(conv1x1_stream_kernel<1>, dim3((unsigned)gxs, nyb), dim3(256), smem_s, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(conv1x1_stream_kernel<2>, dim3((unsigned)gxs, nyb), dim3(256), smem_s, (hipStream_t)stream, a);
         KG_CHECK_LAUNCH("conv1x1_stream");
         return KG_OK;
