@@ -158,6 +158,23 @@ def pmc_traffic():
     return None
 
 
+def pmc_mfma():
+    """MFMA-pipe utilisation and effective shader clock of the dominant kernel from the committed PMC pass
+    (profiles/*_pmc_mfma_lds.json: SQ_VALU_MFMA_BUSY_CYCLES summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_mfma_lds.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if k.replace(" ", "") == "conv_halo_kernel<7,1,8,0>" and v.get("GRBM_GUI_ACTIVE"):
+                return {"mfma_busy_frac": (v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (v["GRBM_GUI_ACTIVE"] / 8.0),
+                        "active_cycles_per_launch": v["GRBM_GUI_ACTIVE"] / 8.0,
+                        "lds_bank_conflict_cycles": v.get("SQ_LDS_BANK_CONFLICT")}
+    return None
+
+
 def eval_inputs(S, n, seed):
     """Config 5 of BASELINE.json: GT-derived head maps of n instances (+ N(0, 0.05) on kp clipped to [0,1], N(0, 0.5 px) on
     the offsets) at the four scales of an SxS image.  Returns [[kp, short, mid] x 4] as numpy fp32 [1,C,H,W] and the boxes."""
