@@ -456,10 +456,14 @@ def main():
         dom = timer.summary(dom_rec).get(KernelTimer.DOMINANT)
         if dom:
             ach = dom["flops"] / dom["seconds"] / 1e12
+            pm = pmc_mfma()
             out["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel<7,1,8,0> (7x7 head convs, forward + input gradient)",
                                "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
                                "traffic": pmc_traffic(), "avg_launch_ms": 1e3 * dom["seconds"] / dom["launches"],
                                "launches": dom["launches"], "share_of_step": dom["seconds"] / dt,
+                               "pmc": pm and dict(pm, effective_clock_ghz=pm["active_cycles_per_launch"] / (1e9 * dom["seconds"] / dom["launches"]),
+                                                  note="committed rocprofv3 PMC pass: MFMA-pipe busy / active cycles of this kernel; clock = profiled "
+                                                       "active cycles per launch / this run's launch time (DVFS: below 2.4 GHz under MFMA load)"),
                                "note": "achieved = algorithmic conv FLOPs (2*N*H*W*Cout*49*Cin) of the launches / their HIP-event time, "
                                        "measured inside the timed region; traffic = HBM bytes per launch from the committed PMC pass"}
         summ = timer.summary()

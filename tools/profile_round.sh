@@ -19,6 +19,11 @@ python $R/tools/pmc_summary.py $O/${tag}_pmc_hbm.json $(find $O/${tag}_pmc_rd $O
 rm -rf $O/${tag}_pmc_rd $O/${tag}_pmc_wr   # raw per-dispatch CSVs are large
 tail -3 $O/${tag}_prof.log; cat $O/${tag}_bench_n1.json | cut -c1-600
 cd /tmp
+# MFMA-pipe utilisation / LDS conflicts: two more counter passes (SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs)
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/${tag}_pmc_a -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer > $O/${tag}_pmc_a.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $O/${tag}_pmc_b -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer > $O/${tag}_pmc_b.log 2>&1
+python $R/tools/pmc_summary.py $O/${tag}_pmc_mfma_lds.json $(find $O/${tag}_pmc_a $O/${tag}_pmc_b -name "*counter_collection.csv") > /dev/null 2>&1
+rm -rf $O/${tag}_pmc_a $O/${tag}_pmc_b
 rocprofv3 --kernel-trace --output-format csv -d $O/${tag}_shp -o p -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timer > $O/${tag}_shp.log 2>&1
 python $R/tools/rocprof_shapes.py $(find $O/${tag}_shp -name "*kernel_trace.csv" | head -1) $O/${tag}_bench_launch_shapes.csv 5 >> $O/${tag}_prof.log 2>&1
 rm -rf $O/${tag}_shp
