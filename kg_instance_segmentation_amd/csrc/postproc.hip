@@ -70,6 +70,62 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ coun
     int run = threadIdx.x ? tot[threadIdx.x - 1] : 0;
     for (int i = b0; i < b0 + per && i < n; ++i) { int v = in[i]; out[i] = run; run += v; }
 }
+// Multi-block exclusive scan of `rows` independent arrays of n ints (the single-workgroup kernel above reads 4 KB-strided runs:
+// 1.8 ms for the 5 x 1024^2 Hough cell counts).  SCAN_NB chunks per row: chunk sums, then every chunk scans itself behind the
+// prefix of the chunk sums before it (int4 accesses, 1024 elements per round of the workgroup).
+#define SCAN_NB 256
+__global__ __launch_bounds__(256) void scan_sums_kernel(const int* __restrict__ count, int* __restrict__ part, int n, int chunk) {
+    const int* in = count + (long)blockIdx.y * n;
+    const int b0 = blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
+    int s = 0;
+    for (int i = b0 + threadIdx.x * 4; i < b1; i += 1024) {       // chunk % 4 == 0, n % 4 == 0
+        const int4 v = *reinterpret_cast<const int4*>(in + i);
+        s += v.x + v.y + v.z + v.w;
+    }
+    __shared__ int red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.y * SCAN_NB + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void scan_chunks_kernel(const int* __restrict__ count, const int* __restrict__ part,
+                                                          int* __restrict__ offs, int n, int chunk) {
+    const int* in = count + (long)blockIdx.y * n;
+    int* out = offs + (long)blockIdx.y * n;
+    __shared__ int wsum[4];
+    __shared__ int s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {   // prefix of the chunk sums before this chunk
+        int s = 0;
+        for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) s += part[blockIdx.y * SCAN_NB + b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) wsum[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    const int b0 = blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
+    for (int r0 = b0; r0 < b1; r0 += 1024) {
+        const int i = r0 + threadIdx.x * 4;
+        int4 v = make_int4(0, 0, 0, 0);
+        if (i < b1) v = *reinterpret_cast<const int4*>(in + i);
+        const int tsum = v.x + v.y + v.z + v.w;
+        int inc = tsum;                                          // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int base = s_carry;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        const int ex = base + inc - tsum;
+        if (i < b1) *reinterpret_cast<int4*>(out + i) = make_int4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = base + inc;
+        __syncthreads();
+    }
+}
 __global__ void hough_fill_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W,
                                   const int* __restrict__ offs, int* __restrict__ cursor,
                                   unsigned* __restrict__ keys, double* __restrict__ vals) {
@@ -246,6 +302,145 @@ __global__ void kp_rank_kernel(const int* __restrict__ npk, int cap, const int* 
         sid[rank] = ids[i]; sx[rank] = xs[i]; sy[rank] = ys[i]; sconf[rank] = ci;
     }
 }
+// Fast path of the greedy grouping (n <= GK_NL keypoints, image <= 1024 x 1024).  The sequential dependence over the seeds stays, but
+// one seed costs ONE workgroup barrier (none if it is dropped) and a few LDS list steps instead of two scans over all remaining
+// keypoints in global memory:
+//   * keypoint coordinates (int16), a state byte (bit 0 alive, bit 1 member of a skeleton, bits 2..4 type) and per (type, 32 x 32-px
+//     cell) linked lists live in LDS (radius 6 and 10 < 32: a 3 x 3 cell neighbourhood covers every candidate; list order is
+//     irrelevant: the minimum distance with ties to the lower index is order independent);
+//   * the "<= 10 px from slot `id` of ANY existing skeleton" test (postprocessing.py:100) == some keypoint of type id that is a MEMBER
+//     of a skeleton lies within 10 px, or the seed lies within 10 px of the origin and some skeleton lacks type id (missing slot = (0,0));
+//     every wave evaluates it for itself (lanes 16..25), so a dropped seed needs no barrier;
+//   * wave w finds the match of the w-th target type (lanes 0..8 walk the 3 x 3 cells around the proposal); the four matches are
+//     exchanged through a parity-double-buffered LDS slot behind the one barrier, after which EVERY wave applies the (identical) state
+//     updates itself and keeps the skeleton / missing-type counters in registers;
+//   * the seeds' four mid offsets (random global reads) are fetched 256 seeds at a time; skeletons are recorded as keypoint indices and
+//     expanded to [x, y, conf] rows by all threads at the end.
+#define GK_NL 8192
+#define GK_CELLS 1024      // (1024 / 32)^2
+struct GroupLds {
+    short kx[GK_NL], ky[GK_NL];
+    unsigned short nxt[GK_NL];
+    unsigned char st[GK_NL];
+    int head[5 * GK_CELLS];
+    float pre[256][4][2];
+    int match[2][4];
+};
+__device__ void group_fast(GroupLds& L, int n, const int* __restrict__ sid, const int* __restrict__ sx, const int* __restrict__ sy,
+                           const double* __restrict__ sconf, const float* __restrict__ mid, int H, int W, int skcap,
+                           int* __restrict__ skidx, double* __restrict__ skel, int* __restrict__ nskel) {
+    const long HW = (long)H * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int CW = (W + 31) >> 5, CH = (H + 31) >> 5;
+    for (int c = tid; c < 5 * GK_CELLS; c += 256) L.head[c] = -1;
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) {
+        const int t = sid[j], x = sx[j], y = sy[j];
+        L.kx[j] = (short)x; L.ky[j] = (short)y; L.st[j] = (unsigned char)(1 | (t << 2));
+        const int old = atomicExch(&L.head[t * GK_CELLS + (y >> 5) * CW + (x >> 5)], j);
+        L.nxt[j] = (unsigned short)(old < 0 ? 0xffff : old);
+    }
+    int ns = 0, par = 0, miss0 = 0, miss1 = 0, miss2 = 0, miss3 = 0, miss4 = 0;     // wave-uniform, identical in every wave
+    const bool roleB = lane < 9, roleA = lane >= 16 && lane < 25;
+    const int rl = roleB ? lane : lane - 16;
+    const int dcx = rl % 3 - 1, dcy = rl / 3 - 1;                                   // the lane's cell of the 3 x 3 neighbourhood
+    for (int i = 0; i < n; ++i) {
+        if ((i & 255) == 0) {              // mid offsets of the next 256 seeds (uniform branch)
+            __syncthreads();
+            const int q = i + tid;
+            if (q < n) {
+                const int id = sid[q];
+                const long pix = (long)sy[q] * W + sx[q];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int m = KG_MID_IDX[id][w + (w >= id ? 1 : 0)];
+                    L.pre[tid][w][0] = mid[(long)(2 * m) * HW + pix];
+                    L.pre[tid][w][1] = mid[(long)(2 * m + 1) * HW + pix];
+                }
+            }
+            __syncthreads();
+        }
+        const int sti = L.st[i];
+        if (!(sti & 1)) continue;          // uniform within a wave; every wave sees its own (identical) state updates
+        const int id = sti >> 2, kx = L.kx[i], ky = L.ky[i];
+        const int t = wave + (wave >= id ? 1 : 0);
+        const double px = (double)kx + (double)L.pre[i & 255][wave][0];
+        const double py = (double)ky + (double)L.pre[i & 255][wave][1];
+        // lanes 0..8: candidates of type t around the proposal; lanes 16..24: skeleton members of type id around the seed
+        int j = -1;
+        if (roleB) {
+            if (px > -64. && py > -64. && px < 2048. && py < 2048.) {               // (further out: nothing within 6 px)
+                const int cx = ((int)floor(px) >> 5) + dcx, cy = ((int)floor(py) >> 5) + dcy;
+                if (cx >= 0 && cy >= 0 && cx < CW && cy < CH) j = L.head[t * GK_CELLS + cy * CW + cx];
+            }
+        } else if (roleA) {
+            const int cx = (kx >> 5) + dcx, cy = (ky >> 5) + dcy;
+            if (cx >= 0 && cy >= 0 && cx < CW && cy < CH) j = L.head[id * GK_CELLS + cy * CW + cx];
+        }
+        double bd = 1e300; int bj = 0x7fffffff, hit = 0;
+        while (j >= 0) {
+            const int stj = L.st[j], xj = L.kx[j], yj = L.ky[j];
+            if (roleB) {
+                if (stj & 1) {             // alive => not yet popped => later in the sorted list than the seed
+                    const double d = norm2(px - (double)xj, py - (double)yj);
+                    if (d <= 6. && (d < bd || (d == bd && j < bj))) { bd = d; bj = j; }
+                }
+            } else if (stj & 2) {
+                const int dx = kx - xj, dy = ky - yj;
+                hit |= (dx * dx + dy * dy) <= 100;   // integer coordinates: sqrt(dx^2+dy^2) <= 10 <=> dx^2+dy^2 <= 100 exactly
+            }
+            const int nj = L.nxt[j];
+            j = nj == 0xffff ? -1 : nj;
+        }
+        if (lane == 25) {
+            const int mi = id == 0 ? miss0 : id == 1 ? miss1 : id == 2 ? miss2 : id == 3 ? miss3 : miss4;
+            hit = (kx * kx + ky * ky <= 100) && mi > 0;
+        }
+        if (__ballot(hit) != 0) {          // dropped: no barrier, every wave clears the alive bit itself
+            if (lane == 0) L.st[i] = (unsigned char)(sti & ~1);
+            continue;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const double od = __shfl_xor(bd, o, 64); const int oj = __shfl_xor(bj, o, 64);
+            if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+        }
+        if (lane == 0) L.match[par][wave] = bj;
+        __syncthreads();
+        int mj[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mj[w] = L.match[par][w];
+        if (lane == 0) {
+            L.st[i] = (unsigned char)((sti & ~1) | 2);
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                if (mj[w] != 0x7fffffff) L.st[mj[w]] = (unsigned char)((L.st[mj[w]] & ~1) | 2);
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (mj[w] != 0x7fffffff) continue;
+            const int tt = w + (w >= id ? 1 : 0);
+            miss0 += tt == 0; miss1 += tt == 1; miss2 += tt == 2; miss3 += tt == 3; miss4 += tt == 4;
+        }
+        if (tid == 0 && ns < skcap) {
+            int* rec = skidx + (long)ns * 5;
+            rec[id] = i;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) rec[w + (w >= id ? 1 : 0)] = mj[w] == 0x7fffffff ? -1 : mj[w];
+        }
+        ++ns; par ^= 1;
+    }
+    __syncthreads();
+    if (tid == 0) *nskel = ns;
+    const int nrec = ns < skcap ? ns : skcap;
+    for (int e = tid; e < nrec * 5; e += 256) {
+        const int jj = skidx[e];
+        double* o = skel + (long)e * 3;
+        if (jj >= 0) { o[0] = (double)sx[jj]; o[1] = (double)sy[jj]; o[2] = sconf[jj]; }
+        else { o[0] = 0.; o[1] = 0.; o[2] = 0.; }
+    }
+}
+
 __global__ __launch_bounds__(256) void group_kernel(const int* __restrict__ npk, int cap, const int* __restrict__ sid,
                                                     const int* __restrict__ sx, const int* __restrict__ sy,
                                                     const double* __restrict__ sconf, const float* __restrict__ mid,
@@ -254,6 +449,11 @@ __global__ __launch_bounds__(256) void group_kernel(const int* __restrict__ npk,
                                                     int* __restrict__ nskel) {
     // skxy[s][5][2]: integer slot coordinates of skeleton s (missing slot = (0,0)) for the <=10 test
     int n = *npk; if (n > cap) n = cap;
+    extern __shared__ __attribute__((aligned(16))) unsigned char group_smem[];
+    if (n <= GK_NL && H <= 1024 && W <= 1024) {      // (the general path below serves larger inputs)
+        group_fast(*reinterpret_cast<GroupLds*>(group_smem), n, sid, sx, sy, sconf, mid, H, W, skcap, skxy, skel, nskel);
+        return;
+    }
     const long HW = (long)H * W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < n; i += 256) alive[i] = 1;
@@ -444,6 +644,7 @@ extern "C" long kg_postproc_workspace_bytes(int H, int W, int peak_cap, int skel
     b += (al256((size_t)peak_cap * 4) * 3 + al256((size_t)peak_cap * 8)) * 2;  // peaks + sorted peaks
     b += al256(peak_cap);                  // alive
     b += al256((size_t)skel_cap * 10 * 4);  // skxy
+    b += al256(5 * SCAN_NB * 4);           // chunk sums of the multi-block scan
     return (long)b + 4096;
 }
 
@@ -451,7 +652,7 @@ struct PPWs {
     int *count, *offs, *cursor; unsigned* keys; double *vals, *sorted, *heat, *tmp, *blur;
     int *heavy_list, *heavy_n, *blkcount, *blkbase, *npk;
     int *ids, *xs, *ys; double* conf; int *sid, *sx, *sy; double* sconf;
-    unsigned char* alive; int* skxy; int nblk;
+    unsigned char* alive; int* skxy; int nblk; int* scanpart;
 };
 static void carve(void* ws, int H, int W, int peak_cap, int skel_cap, PPWs* p) {
     size_t HW = (size_t)H * W;
@@ -469,6 +670,7 @@ static void carve(void* ws, int H, int W, int peak_cap, int skel_cap, PPWs* p) {
     p->sid = (int*)take((size_t)peak_cap * 4); p->sx = (int*)take((size_t)peak_cap * 4); p->sy = (int*)take((size_t)peak_cap * 4);
     p->sconf = (double*)take((size_t)peak_cap * 8);
     p->alive = (unsigned char*)take(peak_cap); p->skxy = (int*)take((size_t)skel_cap * 10 * 4);
+    p->scanpart = (int*)take(5 * SCAN_NB * 4);
 }
 
 // P1..P4 for one scale (batch element 0 of the maps).  kp [5][H][W], soff [10][H][W], mid [40][H][W] fp32
@@ -491,7 +693,13 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
     KG_HIP(hipMemsetAsync(p.heavy_n, 0, 4, st));
     int gx = (4 * HW + 255) / 256; if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(hough_count_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.count);
-    hipLaunchKernelGGL(scan_kernel, dim3(5), dim3(1024), 0, st, p.count, p.offs, HW);
+    if (HW >= 65536 && HW % 4 == 0) {
+        const int chunk = (int)(((HW + SCAN_NB - 1) / SCAN_NB + 3) / 4 * 4);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(SCAN_NB, 5), dim3(256), 0, st, p.count, p.scanpart, HW, chunk);
+        hipLaunchKernelGGL(scan_chunks_kernel, dim3(SCAN_NB, 5), dim3(256), 0, st, p.count, p.scanpart, p.offs, HW, chunk);
+    } else {
+        hipLaunchKernelGGL(scan_kernel, dim3(5), dim3(1024), 0, st, p.count, p.offs, HW);
+    }
     hipLaunchKernelGGL(hough_fill_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.offs, p.cursor, p.keys, p.vals);
     int gc = (HW + 255) / 256; if (gc > 4096) gc = 4096;
     hipLaunchKernelGGL(hough_sum_light_kernel, dim3(gc, 5), dim3(256), 0, st, HW, p.count, p.offs, p.keys, p.vals, norm, p.heat,
@@ -509,7 +717,12 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
                        p.ids, p.xs, p.ys, p.conf);
     hipLaunchKernelGGL(kp_rank_kernel, dim3(256), dim3(256), 0, st, p.npk, peak_cap, p.ids, p.xs, p.ys, p.conf, p.sid, p.sx, p.sy,
                        p.sconf);
-    hipLaunchKernelGGL(group_kernel, dim3(1), dim3(256), 0, st, p.npk, peak_cap, p.sid, p.sx, p.sy, p.sconf, mid, H, W, p.alive,
+    static bool group_attr = false;
+    if (!group_attr) {
+        KG_HIP(hipFuncSetAttribute((const void*)group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GroupLds)));
+        group_attr = true;
+    }
+    hipLaunchKernelGGL(group_kernel, dim3(1), dim3(256), sizeof(GroupLds), st, p.npk, peak_cap, p.sid, p.sx, p.sy, p.sconf, mid, H, W, p.alive,
                        skel_cap, p.skxy, skel, nskel);
     if (heat_out) KG_HIP(hipMemcpyAsync(heat_out, p.heat, (size_t)5 * HW * 8, hipMemcpyDeviceToDevice, st));
     if (blur_out) KG_HIP(hipMemcpyAsync(blur_out, p.blur, (size_t)5 * HW * 8, hipMemcpyDeviceToDevice, st));

@@ -116,23 +116,29 @@ def detect(dec, nms_thresh=0.5):
     dec = ([kp,short,mid] x 4).  Returns N x 5 float64 ndarray or None."""
     from . import nms as _nms
     dev = dec[0][0].device
-    # the scales are independent and the greedy grouping of a scale is ONE workgroup: run them on separate streams
+    # the scales are independent and the greedy grouping of a scale is ONE workgroup: run them on separate streams -- the caller's
+    # stream for the first (largest) scale + 3 side streams = 4, the number of hardware queues a process gets by default (a fifth
+    # stream shares a queue with another one and its scale runs after that one's grouping instead of beside it)
     main = torch.cuda.current_stream(dev)
-    pool = _STREAMS.setdefault(str(dev), [torch.cuda.Stream(dev) for _ in range(4)])
-    sks, seen, used = [], set(), []
+    pool = _STREAMS.setdefault(str(dev), [torch.cuda.Stream(dev) for _ in range(3)])
+    ready = main.record_event()            # the head maps are complete here; the side streams start from this point
+    sks, by_key, used = [], {}, []
     for i, d in enumerate(dec):
         key = tuple(d[0].shape[-2:])
-        st = pool[i % 4] if key not in seen else None      # equal sizes share one cached workspace: keep those in order
-        seen.add(key)
+        if key not in by_key:              # equal sizes share one cached workspace: they stay on one stream, in order
+            by_key[key] = None if not by_key else pool[(len(by_key) - 1) % 3]
+        st = by_key[key]
         if st is None:
             sks.append(skeletons_device(*d))
             continue
-        st.wait_stream(main)
+        if st not in used:
+            st.wait_event(ready)
+            used.append(st)
         with torch.cuda.stream(st):
             r = skeletons_device(*d)
         for t in r:
             t.record_stream(main)
-        sks.append(r); used.append(st)
+        sks.append(r)
     for st in used:
         main.wait_stream(st)
     cap = sum(s[0].shape[0] for s in sks)
