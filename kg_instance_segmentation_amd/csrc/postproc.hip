@@ -305,12 +305,12 @@ __global__ void kp_rank_kernel(const int* __restrict__ npk, int cap, const int* 
 // Fast path of the greedy grouping (n <= GK_NL keypoints, image <= 1024 x 1024).  The sequential dependence over the seeds stays, but
 // one seed costs ONE workgroup barrier (none if it is dropped) and a few LDS list steps instead of two scans over all remaining
 // keypoints in global memory:
-//   * keypoint coordinates (int16), a state byte (bit 0 alive, bit 1 member of a skeleton, bits 2..4 type) and per (type, 32 x 32-px
-//     cell) linked lists live in LDS (radius 6 and 10 < 32: a 3 x 3 cell neighbourhood covers every candidate; list order is
+//   * keypoint coordinates (int16), a state byte (bit 0 alive, bit 1 member of a skeleton, bits 2..4 type) and per (type, cell)
+//     linked lists live in LDS (cells of 8 / 16 / 32 px; a 3 x 3 or 5 x 5 cell neighbourhood covers the radius-6 / radius-10 tests; list order is
 //     irrelevant: the minimum distance with ties to the lower index is order independent);
 //   * the "<= 10 px from slot `id` of ANY existing skeleton" test (postprocessing.py:100) == some keypoint of type id that is a MEMBER
 //     of a skeleton lies within 10 px, or the seed lies within 10 px of the origin and some skeleton lacks type id (missing slot = (0,0));
-//     every wave evaluates it for itself (lanes 16..25), so a dropped seed needs no barrier;
+//     every wave evaluates it for itself (lanes 16.. and 48), so a dropped seed needs no barrier;
 //   * wave w finds the match of the w-th target type (lanes 0..8 walk the 3 x 3 cells around the proposal); the four matches are
 //     exchanged through a parity-double-buffered LDS slot behind the one barrier, after which EVERY wave applies the (identical) state
 //     updates itself and keeps the skeleton / missing-type counters in registers;
@@ -331,19 +331,23 @@ __device__ void group_fast(GroupLds& L, int n, const int* __restrict__ sid, cons
                            int* __restrict__ skidx, double* __restrict__ skel, int* __restrict__ nskel) {
     const long HW = (long)H * W;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int CW = (W + 31) >> 5, CH = (H + 31) >> 5;
+    // cell size 8 / 16 / 32 px by image size (<= 32 x 32 cells): dense small scales get short lists.  Radius 6 < 8: 3 x 3 cells for the
+    // candidate search; radius 10: 5 x 5 cells of 8 px, 3 x 3 otherwise, for the skeleton-member test.
+    const int CS = (H <= 256 && W <= 256) ? 3 : (H <= 512 && W <= 512) ? 4 : 5;
+    const int CW = (W + (1 << CS) - 1) >> CS, CH = (H + (1 << CS) - 1) >> CS;
+    const int RA = CS == 3 ? 2 : 1, NA = (2 * RA + 1) * (2 * RA + 1);
     for (int c = tid; c < 5 * GK_CELLS; c += 256) L.head[c] = -1;
     __syncthreads();
     for (int j = tid; j < n; j += 256) {
         const int t = sid[j], x = sx[j], y = sy[j];
         L.kx[j] = (short)x; L.ky[j] = (short)y; L.st[j] = (unsigned char)(1 | (t << 2));
-        const int old = atomicExch(&L.head[t * GK_CELLS + (y >> 5) * CW + (x >> 5)], j);
+        const int old = atomicExch(&L.head[t * GK_CELLS + (y >> CS) * CW + (x >> CS)], j);
         L.nxt[j] = (unsigned short)(old < 0 ? 0xffff : old);
     }
     int ns = 0, par = 0, miss0 = 0, miss1 = 0, miss2 = 0, miss3 = 0, miss4 = 0;     // wave-uniform, identical in every wave
-    const bool roleB = lane < 9, roleA = lane >= 16 && lane < 25;
-    const int rl = roleB ? lane : lane - 16;
-    const int dcx = rl % 3 - 1, dcy = rl / 3 - 1;                                   // the lane's cell of the 3 x 3 neighbourhood
+    const bool roleB = lane < 9, roleA = lane >= 16 && lane < 16 + NA;
+    const int rl = roleB ? lane : lane - 16, rw = roleB ? 3 : 2 * RA + 1;
+    const int dcx = rl % rw - (rw >> 1), dcy = rl / rw - (rw >> 1);                 // the lane's cell of the neighbourhood
     for (int i = 0; i < n; ++i) {
         if ((i & 255) == 0) {              // mid offsets of the next 256 seeds (uniform branch)
             __syncthreads();
@@ -366,15 +370,15 @@ __device__ void group_fast(GroupLds& L, int n, const int* __restrict__ sid, cons
         const int t = wave + (wave >= id ? 1 : 0);
         const double px = (double)kx + (double)L.pre[i & 255][wave][0];
         const double py = (double)ky + (double)L.pre[i & 255][wave][1];
-        // lanes 0..8: candidates of type t around the proposal; lanes 16..24: skeleton members of type id around the seed
+        // lanes 0..8: candidates of type t around the proposal; lanes 16..16+NA-1: skeleton members of type id around the seed
         int j = -1;
         if (roleB) {
             if (px > -64. && py > -64. && px < 2048. && py < 2048.) {               // (further out: nothing within 6 px)
-                const int cx = ((int)floor(px) >> 5) + dcx, cy = ((int)floor(py) >> 5) + dcy;
+                const int cx = ((int)floor(px) >> CS) + dcx, cy = ((int)floor(py) >> CS) + dcy;
                 if (cx >= 0 && cy >= 0 && cx < CW && cy < CH) j = L.head[t * GK_CELLS + cy * CW + cx];
             }
         } else if (roleA) {
-            const int cx = (kx >> 5) + dcx, cy = (ky >> 5) + dcy;
+            const int cx = (kx >> CS) + dcx, cy = (ky >> CS) + dcy;
             if (cx >= 0 && cy >= 0 && cx < CW && cy < CH) j = L.head[id * GK_CELLS + cy * CW + cx];
         }
         double bd = 1e300; int bj = 0x7fffffff, hit = 0;
@@ -392,7 +396,7 @@ __device__ void group_fast(GroupLds& L, int n, const int* __restrict__ sid, cons
             const int nj = L.nxt[j];
             j = nj == 0xffff ? -1 : nj;
         }
-        if (lane == 25) {
+        if (lane == 48) {
             const int mi = id == 0 ? miss0 : id == 1 ? miss1 : id == 2 ? miss2 : id == 3 ? miss3 : miss4;
             hit = (kx * kx + ky * ky <= 100) && mi > 0;
         }
@@ -582,6 +586,7 @@ __global__ __launch_bounds__(1024) void boxes_kernel(const int* __restrict__ nsk
 }
 
 // ---- P9 ---------------------------------------------------------------------------------------
+#define NMS_NL 2048
 // one block.  order[] = indices sorted by confidence ascending (ties: index ascending).
 __global__ __launch_bounds__(1024) void nms_kernel(const int* __restrict__ nbox, int boxcap,
                                                    const double* __restrict__ boxes, double thresh,
@@ -595,6 +600,42 @@ __global__ __launch_bounds__(1024) void nms_kernel(const int* __restrict__ nbox,
         order[rank] = i; dead[i] = 0;
     }
     __syncthreads();
+    extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
+    if (n <= NMS_NL) {   // boxes (in rank order), areas and the suppressed flags in LDS: one barrier and no global access per kept box
+        double* sb = reinterpret_cast<double*>(nms_smem);            // [n][4]
+        double* sarea = sb + 4 * NMS_NL;
+        unsigned char* sdead = reinterpret_cast<unsigned char*>(sarea + NMS_NL);
+        for (int q = threadIdx.x; q < n; q += 1024) {
+            const double* b = boxes + (long)order[q] * 5;
+            sb[q * 4] = b[0]; sb[q * 4 + 1] = b[1]; sb[q * 4 + 2] = b[2]; sb[q * 4 + 3] = b[3];
+            sarea[q] = (b[3] - b[1]) * (b[2] - b[0]);
+            sdead[q] = 0;
+        }
+        __syncthreads();
+        int nk = 0;
+        for (int p = n - 1; p >= 0; --p) {
+            if (sdead[p]) continue;  // uniform
+            if (threadIdx.x == 0) keep[nk] = order[p];
+            ++nk;
+            const double cy1 = sb[p * 4], cx1 = sb[p * 4 + 1], cy2 = sb[p * 4 + 2], cx2 = sb[p * 4 + 3];
+            const double carea = (cx2 - cx1) * (cy2 - cy1);
+            for (int q = threadIdx.x; q < p; q += 1024) {
+                if (sdead[q]) continue;
+                const double* b = sb + q * 4;
+                double yy1 = b[0] > cy1 ? b[0] : cy1, xx1 = b[1] > cx1 ? b[1] : cx1;
+                double yy2 = b[2] < cy2 ? b[2] : cy2, xx2 = b[3] < cx2 ? b[3] : cx2;
+                double w = xx2 - xx1, h = yy2 - yy1;
+                w = w > 0. ? w : 0.; h = h > 0. ? h : 0.;
+                double inter = w * h;
+                double uni = (sarea[q] - inter) + carea;
+                double iou = inter / uni;
+                if (!(iou <= thresh)) sdead[q] = 1;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *nkeep = nk;
+        return;
+    }
     int nk = 0;
     for (int p = n - 1; p >= 0; --p) {
         const int cur = order[p];
@@ -756,7 +797,13 @@ extern "C" int kg_nms(const double* boxes, const int* nbox, int box_cap, double 
     int* keep = (int*)q; q += al256((size_t)box_cap * 4);
     unsigned char* dead = q;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), 0, st, nbox, box_cap, boxes, thresh, order, dead, keep, nkeep);
+    constexpr int nms_lds = NMS_NL * (5 * 8 + 1);
+    static bool nms_attr = false;
+    if (!nms_attr) {
+        KG_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, nms_lds));
+        nms_attr = true;
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), nms_lds, st, nbox, box_cap, boxes, thresh, order, dead, keep, nkeep);
     hipLaunchKernelGGL(gather_rows5_kernel, dim3(64), dim3(256), 0, st, boxes, keep, nkeep, out);
     KG_CHECK_LAUNCH("nms");
     return KG_OK;
