@@ -284,6 +284,8 @@ extern "C" int kg_conv2d_wgrad_halo(const void* x, const void* dy, float* dwp, i
     KG_CHECK_ARG(!dbp || KS == 7, "kg_conv2d_wgrad_halo: the fused bias gradient is only built for 7x7");
     if (KS == 7) {
         if (dbp) {
+            // 5- / 10-cout second head layers: 32 input channels per workgroup (the dY tile is staged once per 32 instead of 16)
+            if (cout_lim <= 16 && cin_lim >= 32) return launch_wg<7, 2, 1, true>(a, st);
             if (cout_lim <= 16) return launch_wg<7, 1, 1, true>(a, st);
             if (cout_lim <= 48) return launch_wg<7, 1, 3, true>(a, st);
             return launch_wg<7, 1, 4, true>(a, st);

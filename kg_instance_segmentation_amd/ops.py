@@ -295,7 +295,7 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
     halo = (USE_HALO and stride == 1 and KH == KW and KH in (3, 7) and pad == KH // 2
             and ((mode == 0 and N is not None) or (mode == 2 and tiletab16 is not None)))
     if halo:
-        cit = 16 if KH == 7 else 64
+        cit = (32 if (cout_lim <= 16 and cin_lim >= 32 and bias_out is not None) else 16) if KH == 7 else 64   # input channels per workgroup (wgrad_halo.hip)
         nblk = math.ceil(cin_lim / cit) * math.ceil(cout_lim / 64)
         tiles = tiletab16.shape[0] if tiletab16 is not None else N * math.ceil(H / 16) * math.ceil(W / 16)
         S = halo_wgrad_splits(nblk, tiles, cit, KH * KW, nelem)
