@@ -14,11 +14,12 @@ from .ops import BF16, PackedWeight
 
 class Var:
     """Activation (bf16 rows view) + its gradient slot."""
-    __slots__ = ("t", "C", "relu", "grad", "masked", "req", "parent", "c0")
+    __slots__ = ("t", "C", "relu", "grad", "masked", "pending", "pmasked", "req", "parent", "c0")
 
     def __init__(self, t, C, relu=False, req=True, parent=None, c0=0):
         self.t, self.C, self.relu, self.req = t, C, relu, req
         self.grad, self.masked = None, True
+        self.pending, self.pmasked = None, True     # one more contribution whose addition is deferred to take_grad (fused with the mask)
         self.parent, self.c0 = parent, c0
 
     @property
@@ -41,14 +42,24 @@ class Var:
             return
         if self.grad is None:
             self.grad, self.masked = g, masked
+        elif self.pending is None:
+            self.pending, self.pmasked = g, masked
         else:
-            ops.add_rows(self.grad, g, self.grad, self.C)
-            self.masked = self.masked and masked
+            ops.add_rows(self.grad, self.pending, self.grad, self.C)
+            self.masked = self.masked and self.pmasked
+            self.pending, self.pmasked = g, masked
 
     def take_grad(self):
         g = self.grad
-        if g is not None and self.relu and not self.masked:
+        if g is None:
+            return None
+        need_mask = self.relu and not (self.masked and self.pmasked)
+        if self.pending is not None:       # sum of the two contributions and the ReLU mask in ONE pass (same bf16 rounding as two)
+            ops.add_rows(g, self.pending, g, self.C, mask=self.t if need_mask else None)
+            self.pending, self.pmasked = None, True
+        elif need_mask:
             ops.add_rows(g, None, g, self.C, mask=self.t)
+        if need_mask:
             self.masked = True
         return g
 
