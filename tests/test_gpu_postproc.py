@@ -128,6 +128,21 @@ def test_random_maps_many_peaks():
     assert ok
 
 
+def test_random_maps_general_grouping_path():
+    """> 8192 peaks: the grouping kernel leaves its LDS fast path (GK_NL in postproc.hip) for the general global-memory one."""
+    rng = np.random.default_rng(13)
+    H, W = 384, 512
+    kp = (rng.random((1, 5, H, W)) ** 2).astype(np.float32)
+    short = (rng.normal(size=(1, 10, H, W)) * 2).astype(np.float32)
+    mid = (rng.normal(size=(1, 40, H, W)) * 6).astype(np.float32)
+    r = run_stages(kp, short, mid)
+    heat = op.hough(kp, short); blur = op.gauss(heat); ids, xs, ys, conf = op.peaks(blur); skel = op.group(ids, xs, ys, conf, mid)
+    print("peaks", len(ids), "skeletons", len(skel))
+    assert len(ids) > 8192
+    ok = diff_report("peaks", r["peaks"], np.stack([ids, xs, ys], 1).reshape(-1, 3)) & diff_report("skel", r["skel"], skel)
+    assert ok
+
+
 def test_detect_fused_matches_oracle():
     decs = []
     for sc, (H, W, n, seed) in zip((1, 2, 4, 8), [(256, 256, 60, 21), (128, 128, 30, 22), (64, 64, 10, 23), (32, 32, 3, 24)]):
