@@ -462,3 +462,24 @@ def test_conv_halo_heads2(case):
     ops.conv_halo_heads2(rows_of(hid).to(DEV), pw, bias64, vm, outs[0], outs[1], outs[2], N, H, W, C)
     for name, o, r in zip(("kp", "short", "mid"), outs, refs):
         report(f"heads2{case}.{name}", o.cpu(), r, atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("cin,taps,S,counts", [(64, 9, 256, [64]), (64, 49, 40, [64, 64, 64]), (512, 49, 1, [5, 10, 40]), (24, 1, 64, [16, 8])])
+def test_wgrad_reduce_multi(cin, taps, S, counts):
+    """kg_wgrad_reduce_multi: split partials [S][cout][tap][ci] -> one OIHW gradient per fused head, vs a float64 sum
+    (covers the thread-group path for small layers with many splits and the accumulate flag)."""
+    import ctypes
+    k = int(round(taps ** 0.5))
+    cout = sum(counts)
+    g = torch.Generator().manual_seed(cin + taps + S)
+    part = torch.randn(S, cout, taps, cin, generator=g).to(DEV)
+    ref = part.double().sum(0).permute(0, 2, 1).reshape(cout, cin, k, k)
+    outs = [torch.full((c, cin, k, k), 0.5, dtype=torch.float32, device=DEV) for c in counts]
+    gp = (ctypes.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+    cn = (ctypes.c_int * len(outs))(*counts)
+    for acc in (0, 1):
+        _lib.call("kg_wgrad_reduce_multi", _lib.ptr(part), gp, cn, len(outs), cin, k, k, S, ctypes.c_long(cout * taps * cin), acc, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        got = torch.cat(outs, 0).double()
+        want = ref * (acc + 1)
+        assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
