@@ -102,8 +102,18 @@ def call(name, *args):
         raise KGLibraryError(f"{name} failed ({rc}): {lib.kg_last_error().decode()}")
 
 
+_RAW_STREAM = None
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device (honours `with torch.cuda.stream(...)`).
+    ~1000 launches per training step go through here: the raw-stream query is 5x cheaper than building a torch.cuda.Stream object."""
+    global _RAW_STREAM
     import torch
+    if _RAW_STREAM is None:
+        _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _RAW_STREAM:
+        return c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
