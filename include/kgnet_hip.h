@@ -107,7 +107,8 @@ int kg_maxpool3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx
 int kg_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int IH, int IW, int OH, int OW, int C,
                     const int* boxdesc, const int* row2box, long total_out_rows, void* stream);
 int kg_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int IH, int IW, int OH, int OW, int C,
-                    const int* boxdesc, const int* row2box, long total_in_rows, void* stream);
+                    const int* boxdesc, const int* row2box, long total_in_rows, const void* mask, int ldmask, void* stream);
+                    /* mask != NULL: dx is zeroed where mask <= 0 (ReLU backward of the upsampled tensor, KGnet.py:110) */
 int kg_add_rows(const void* a, int lda, const void* b, int ldb, const void* mask, int ldm, void* y, int ldy, long M,
                 int C, void* stream);
 int kg_sigmoid_inplace(float* x, long n, void* stream);                              /* torch.sigmoid, KGnet.py:300,345 */

@@ -402,7 +402,7 @@ __device__ __forceinline__ void bil_cand(int i, float scale, int out, int* lo, i
 }
 __global__ void bilinear_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dx, int lddx, int IH,
                                     int IW, int OH, int OW, int C8, long total_rows, const BilBox* __restrict__ desc,
-                                    const int* __restrict__ row2box) {
+                                    const int* __restrict__ row2box, const bf16_t* __restrict__ mask, int ldmask) {
     long total = total_rows * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int c = (int)(i % C8) * 8; long p = i / C8;
@@ -438,6 +438,12 @@ __global__ void bilinear_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, bf1
                 for (int e = 0; e < 8; ++e) g[e] += w * bf2f(ds[e]);
             }
         }
+        if (mask) {                      // ReLU backward of the tensor that was upsampled (zero where its forward value was <= 0)
+            const uint4 mv = *reinterpret_cast<const uint4*>(mask + p * ldmask + c);
+            const bf16_t* ms = reinterpret_cast<const bf16_t*>(&mv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = bf2f(ms[e]) > 0.f ? g[e] : 0.f;
+        }
         uint4 o = make_uint4(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]), pack2bf(g[4], g[5]), pack2bf(g[6], g[7]));
         *reinterpret_cast<uint4*>(dx + p * lddx + c) = o;
     }
@@ -455,14 +461,14 @@ extern "C" int kg_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, 
     return KG_OK;
 }
 extern "C" int kg_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int IH, int IW, int OH, int OW, int C,
-                               const int* boxdesc, const int* row2box, long total_in_rows, void* stream) {
-    KG_CHECK_ARG(dy && dx && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "kg_bilinear_bwd: bad args");
+                               const int* boxdesc, const int* row2box, long total_in_rows, const void* mask, int ldmask, void* stream) {
+    KG_CHECK_ARG(dy && dx && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && (!mask || ldmask % 8 == 0), "kg_bilinear_bwd: bad args");
     long rows = boxdesc ? total_in_rows : (long)N * IH * IW;
     if (rows == 0) return KG_OK;
     long total = rows * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy,
-                       (bf16_t*)dx, lddx, IH, IW, OH, OW, C / 8, rows, (const BilBox*)boxdesc, row2box);
+                       (bf16_t*)dx, lddx, IH, IW, OH, OW, C / 8, rows, (const BilBox*)boxdesc, row2box, (const bf16_t*)mask, ldmask);
     KG_CHECK_LAUNCH("bilinear_bwd");
     return KG_OK;
 }

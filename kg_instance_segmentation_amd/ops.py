@@ -394,10 +394,10 @@ def bilinear_fwd(x, y, N, IH, IW, OH, OW, C, boxdesc=None, row2box=None):
               c_long(rows), stream_ptr())
 
 
-def bilinear_bwd(dy, dx, N, IH, IW, OH, OW, C, boxdesc=None, row2box=None):
+def bilinear_bwd(dy, dx, N, IH, IW, OH, OW, C, boxdesc=None, row2box=None, mask=None):
     rows = dx.shape[0] if boxdesc is not None else 0
     _lib.call("kg_bilinear_bwd", ptr(_rows(dy)), ld(dy), ptr(_rows(dx)), ld(dx), N, IH, IW, OH, OW, C, ptr(boxdesc), ptr(row2box),
-              c_long(rows), stream_ptr())
+              c_long(rows), ptr(mask), ld(mask) if mask is not None else 0, stream_ptr())
 
 
 def add_rows(a, b, y, C, mask=None):

@@ -367,8 +367,7 @@ class SegBranch:
                 self.conv_bwd(f"skip_combine.{l}.up.0", uin, dcat[:, CH[l]:CH[l] + cout], plan.rowdesc[l], rowsC, 3, pgrads, dx=duin,
                               t32=self.T32(plan, l, nc), t16=self.T16(plan, l, nc))
                 nxt = torch.empty(plan.rows[l + 1], CH[l + 1], dtype=BF16, device=dev)
-                ops.bilinear_bwd(duin, nxt, 0, 0, 0, 0, 0, CH[l + 1], boxdesc=plan.bil_d[l], row2box=plan.row2box[l + 1])
-                ops.add_rows(nxt, None, nxt, CH[l + 1], mask=pre[l + 1])
+                ops.bilinear_bwd(duin, nxt, 0, 0, 0, 0, 0, CH[l + 1], boxdesc=plan.bil_d[l], row2box=plan.row2box[l + 1], mask=pre[l + 1])
             dpre = nxt
         if dpre is not None:
             scatter(dpre, top, plan.rows[top])
