@@ -351,12 +351,12 @@ def test_fused_hip_adam_matches_torch_adam():
 
 def test_training_trajectory_vs_oracle(state_dict0):
     """Four Adam steps (lr 1e-4, the reference's optimizer, train.py:71) on one seeded 64 x 64 batch against the oracle network
-    trained on the CPU in fp32 with torch.optim.Adam.  Step 0 (identical weights) is within the stated 5 % loss tolerance; the
-    later steps follow the same curve within 12 % (measured: 104.8 / 104.9 / 78.2 / 54.7 vs 103.8 / 109.6 / 84.8 / 59.9) -- the
-    random-init fixture's gradients are chaotic under bf16 storage, so the trajectories separate slowly."""
-    from oracle import net as onet, synth
-    from kg_instance_segmentation_amd.loss import DetectionLossAll
-    from kg_instance_segmentation_amd.seg_loss import SEG_loss
+    trained on the CPU with torch.optim.Adam, in fp32 and as bf16-STORAGE emulation (oracle/net_bf16.py: same fp32 arithmetic,
+    tensors rounded where the HIP path stores bf16).  Step 0 (identical weights) is within the stated 5 % of fp32; afterwards the
+    three curves fall together (HIP 104.8 / 104.9 / 78.2 / 54.7, fp32 103.8 / 109.6 / 84.8 / 59.9, emulation 105.2 / 109.0 / 80.1 /
+    59.2 on one host and 105.1 / 108.0 / 79.3 / 55.9 on another: the random-init fixture is chaotic under perturbations of the size
+    of a bf16 rounding or a different CPU reduction order), so the bound on the later steps is 12 %."""
+    from oracle import net as onet, net_bf16, synth
     from kg_instance_segmentation_amd.optim import Adam
     x, gt_boxes, gt_masks, gt_lv = synth.train_batch(1, 64, 64, 5, n_boxes=3)
     model = KGnet.resnet50(pretrained=False)
@@ -364,11 +364,7 @@ def test_training_trajectory_vs_oracle(state_dict0):
     model = model.to(DEV).train()
     opt = Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
     ldec, lseg = DetectionLossAll(5), SEG_loss(64, 64)
-    osd = {k: v.clone() for k, v in state_dict0.items()}
-    oparams = [v.requires_grad_(True) for k, v in osd.items() if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))]
-    oopt = torch.optim.Adam(oparams, lr=1e-4)
-    net = onet.Net(osd, training=True)
-    got, ref = [], []
+    got = []
     for it in range(4):
         opt.zero_grad()
         d0, d1, d2, d3, pred = model(x.to(DEV), gt_boxes)
@@ -378,17 +374,28 @@ def test_training_trajectory_vs_oracle(state_dict0):
         loss.backward()
         opt.step()
         got.append(float(loss.detach()))
-        oopt.zero_grad()
-        o0, o1, o2, o3, opred = net.forward(x, gt_boxes)
-        oloss = sum(onet.detection_loss(p, t) for p, t in zip((o0, o1, o2, o3), gt_lv))
-        ol2 = onet.seg_loss(opred, gt_masks, gt_boxes, 64, 64)
-        oloss = oloss if ol2 is None else oloss + ol2
-        oloss.backward()
-        oopt.step()
-        ref.append(float(oloss.detach()))
-    print("loss per step: hip", [round(v, 3) for v in got], "oracle", [round(v, 3) for v in ref])
-    assert ref[-1] < ref[0] and got[-1] < got[0]
-    assert abs(got[0] - ref[0]) <= 5e-2 * abs(ref[0]), (got, ref)
-    for a, b in zip(got, ref):
-        assert abs(a - b) <= 0.12 * abs(b), (got, ref)
-    assert got[-1] < 0.7 * got[0] and ref[-1] < 0.7 * ref[0]
+
+    def oracle_run(cls):
+        osd = {k: v.clone() for k, v in state_dict0.items()}
+        oparams = [v.requires_grad_(True) for k, v in osd.items() if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))]
+        oopt = torch.optim.Adam(oparams, lr=1e-4)
+        net = cls(osd, training=True)
+        out = []
+        for it in range(4):
+            oopt.zero_grad()
+            o0, o1, o2, o3, opred = net.forward(x, gt_boxes)
+            oloss = sum(onet.detection_loss(p, t) for p, t in zip((o0, o1, o2, o3), gt_lv))
+            ol2 = onet.seg_loss(opred, gt_masks, gt_boxes, 64, 64)
+            oloss = oloss if ol2 is None else oloss + ol2
+            oloss.backward()
+            oopt.step()
+            out.append(float(oloss.detach()))
+        return out
+
+    ref32, ref16 = oracle_run(onet.Net), oracle_run(net_bf16.NetBF16)
+    print("loss per step: hip", [round(v, 3) for v in got], "oracle fp32", [round(v, 3) for v in ref32], "oracle bf16-storage", [round(v, 3) for v in ref16])
+    assert abs(got[0] - ref32[0]) <= 5e-2 * abs(ref32[0]), (got, ref32)
+    for a, b, c in zip(got, ref32, ref16):
+        assert abs(a - c) <= 0.12 * abs(c), (got, ref16)
+        assert abs(a - b) <= 0.12 * abs(b), (got, ref32)
+    assert got[-1] < 0.7 * got[0] and ref32[-1] < 0.7 * ref32[0]
