@@ -276,7 +276,7 @@ extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, 
     static const int use_gather2 = getenv("KG_GATHER2") ? atoi(getenv("KG_GATHER2")) : 2;   // 2: also 64-cout 3x3 convs (half the cout tile idle, still 2x the 64 x 256 tile)
     if (use_gather2 && tile == 0 && cin_pad % 64 == 0 && y && !y_f32 && (Cout > 64 || (use_gather2 >= 2 && Cout == 64 && KH * KW > 1)) && dil == 1)
         return kg_launch_conv_gather(a, cin_pad, st);   // deep-prefetch LDS-ring variant (conv_gather.hip)
-    static const int use_small = getenv("KG_CONV_SMALL") ? atoi(getenv("KG_CONV_SMALL")) : 1;
+    static const int use_small = getenv("KG_CONV_SMALL") ? atoi(getenv("KG_CONV_SMALL")) : 6;   // (6: the stride-2 7x7 stem too)
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (use_small && tile == 0 && cin_pad == 8 && KH * KW <= use_small * 9 && y && !y_f32 && Cout % 8 == 0 && ldy % 8 == 0 && al16(y) &&
         (!res || (ldres % 8 == 0 && al16(res))) && (!mask || (ldmask % 8 == 0 && al16(mask))) && dil == 1)

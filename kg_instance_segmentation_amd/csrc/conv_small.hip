@@ -9,6 +9,7 @@
 // (pixel, tap), and every output row leaves as 128 contiguous bytes per 8 lanes.
 // Same operands, modes and epilogue as kg_conv2d_igemm (bf16 rows in, packed bf16 weights, bias / residual / ReLU / mask).
 #include "conv_args.h"
+#include <stdlib.h>
 
 __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -130,8 +131,125 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
     }
 }
 
+// ---- MFMA variant: FOUR taps per 32-wide k-step.  With cin_pad == 8 the 8 channels of one (pixel, tap) are exactly one lane's
+// 16-byte share of a v_mfma_f32_16x16x32_bf16 B fragment (lane group g = tap 4s + g), and the packed weight row [tap][8] is laid
+// out the same way, so both operands are plain 16-byte global loads -- no LDS, no barrier, no per-tap padding to 32 channels (the
+// gather kernel's 20-60 TFLOP/s on these layers) and no fp32 FMAs (the VALU kernel above is latency bound at 0.29 ms for 3 -> 64 at
+// 8 x 512^2).  A wave owns 64 pixels x 64 couts; 3x3: 3 k-steps, 7x7: 13.  Bound by the output bytes.
+__global__ __launch_bounds__(256) void conv_small_mfma_kernel(const ConvArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 15, g = lane >> 4;
+    const long m0 = (long)blockIdx.x * 256 + wave * 64;
+    const int c0 = blockIdx.y * 64;
+    const int smask = (1 << a.stride_log2) - 1;
+    const int ohw = a.OH * a.OW;
+    int py[4], px[4], ph[4], pw[4];
+    long pbase[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long m = m0 + j * 16 + lm;
+        py[j] = px[j] = ph[j] = pw[j] = 0; pbase[j] = -1;
+        if (m < a.M) {
+            if (a.mode >= 2) {
+                const int2 d = a.rowdesc[m];
+                py[j] = d.x >> 16; px[j] = d.x & 0xffff; ph[j] = d.y >> 16; pw[j] = d.y & 0xffff; pbase[j] = m;
+            } else {
+                const int n = (int)(m / ohw), rem = (int)(m - (long)n * ohw);
+                py[j] = rem / a.OW; px[j] = rem - py[j] * a.OW; pbase[j] = (long)n * a.H * a.W; ph[j] = a.H; pw[j] = a.W;
+            }
+        }
+    }
+    const bf16_t* wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wrow[i] = a.w + (long)(c0 + (lm >> 2) * 16 + i * 4 + (lm & 3)) * a.K + 8 * g;   // rows / columns past the tensor are zero
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nks = (a.ntaps + 3) >> 2;
+    for (int s = 0; s < nks; ++s) {
+        const int tap = 4 * s + g;
+        const int dy = tap / a.KW, dx = tap - dy * a.KW;
+        const int dyo = dy - a.pad, dxo = dx - a.pad;
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wrow[i] + 32 * s);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool ok = pbase[j] >= 0 && tap < a.ntaps;
+            long row = 0;
+            if (a.mode == 0) {
+                const int iy = (py[j] << a.stride_log2) + dyo, ix = (px[j] << a.stride_log2) + dxo;
+                ok = ok && (unsigned)iy < (unsigned)ph[j] && (unsigned)ix < (unsigned)pw[j];
+                row = pbase[j] + (long)iy * pw[j] + ix;
+            } else if (a.mode == 1) {
+                const int ty = py[j] - dyo, tx = px[j] - dxo;
+                ok = ok && ty >= 0 && tx >= 0 && ((ty | tx) & smask) == 0;
+                const int iy = ty >> a.stride_log2, ix = tx >> a.stride_log2;
+                ok = ok && iy < ph[j] && ix < pw[j];
+                row = pbase[j] + (long)iy * pw[j] + ix;
+            } else {
+                const int sy = a.mode == 2 ? dyo : -dyo, sx = a.mode == 2 ? dxo : -dxo;
+                const int iy = py[j] + sy, ix = px[j] + sx;
+                ok = ok && (unsigned)iy < (unsigned)ph[j] && (unsigned)ix < (unsigned)pw[j];
+                row = pbase[j] + (long)sy * pw[j] + sx;
+            }
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) v = *reinterpret_cast<const uint4*>(a.x + row * a.ldx);
+            bfr[j] = *reinterpret_cast<const bf16x8*>(&v);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    // ---- epilogue: lane owns pixel row m and couts cb .. cb+15 (Cout % 8 == 0, 16-byte aligned rows: checked by the caller) ----
+    const int cb = c0 + g * 16;
+    if (cb >= a.Cout) return;
+    float bv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long m = m0 + j * 16 + lm;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {            // two 8-cout halves
+            if (cb + h * 8 >= a.Cout) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[h * 2 + (e >> 2)][j][e & 3] + bv[h * 8 + e];
+            if (a.res) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(a.res + m * a.ldres + cb + h * 8);
+                const bf16_t* rs = reinterpret_cast<const bf16_t*>(&rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bf2f(rs[e]);
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
+            if (a.mask) {
+                const uint4 mv = *reinterpret_cast<const uint4*>(a.mask + m * a.ldmask + cb + h * 8);
+                const bf16_t* ms = reinterpret_cast<const bf16_t*>(&mv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = bf2f(ms[e]) > 0.f ? v[e] : 0.f;
+            }
+            *reinterpret_cast<uint4*>(a.y + m * a.ldy + cb + h * 8) =
+                make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        }
+    }
+}
+
 // cin_pad == 8, Cout % 8 == 0, bf16 row output with 16-byte aligned rows (checked by the caller, kg_conv2d_igemm)
 int kg_launch_conv_small(const ConvArgs& a, hipStream_t st) {
+    static const int use_mfma = getenv("KG_CONV_SMALL_MFMA") ? atoi(getenv("KG_CONV_SMALL_MFMA")) : 1;
+    if (use_mfma && a.K >= 32 * ((a.ntaps + 3) / 4)) {
+        hipLaunchKernelGGL(conv_small_mfma_kernel, dim3((unsigned)((a.M + 255) / 256), kg_cdiv(a.Cout, 64)), dim3(256), 0, st, a);
+        KG_CHECK_LAUNCH("conv_small_mfma");
+        return KG_OK;
+    }
     const int smem = a.ntaps * 8 * 64 * 4;
     static bool attr_done = false;
     if (!attr_done) {
