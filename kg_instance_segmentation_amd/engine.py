@@ -84,6 +84,7 @@ class Engine:
         self.specs = {}
         self.tape = None
         self.nbt = []
+        self.bn_eval = {}
         self.param_grads = None
         self.fusedT = {}
         self.head_slots = []
@@ -205,7 +206,13 @@ class Engine:
             mean, invstd, scale, shift = ops.bn_stats_train(xv.t, C, gamma.detach(), beta.detach(), rm, rv)
             self.nbt.append(self.P(p + ".num_batches_tracked"))      # += 1 for all 43 layers in one launch at the end of forward_dec
         else:
-            scale, shift = ops.bn_scale_shift_eval(C, gamma.detach(), beta.detach(), rm, rv)
+            # inference: scale / shift only change with the parameters -- cached under the same validity key as the packed weights
+            ver = self.stamp + tuple(t._version for t in (gamma, beta, rm, rv)) + tuple(t.data_ptr() for t in (gamma, beta, rm, rv))
+            hit = self.bn_eval.get(p)
+            if hit is None or hit[0] != ver:
+                hit = (ver, ops.bn_scale_shift_eval(C, gamma.detach(), beta.detach(), rm, rv))
+                self.bn_eval[p] = hit
+            scale, shift = hit[1]
             mean = invstd = None
         ops.bn_apply(xv.t, C, scale, shift, out, res=res.t if res is not None else None, relu=relu)
         yv = Var(out, C, relu=relu)
