@@ -24,6 +24,7 @@ class Net:
         self.sd = sd
         self.training = training
         self.layers = [(n, p, int(b), st) for (n, p, _, st), b in zip(LAYERS, layers[:3])]   # KGnet.py:135-137
+        self.kp_logits, self.seg_logits = {}, []      # pre-sigmoid values of the last forward (parity tests compare logits)
 
     # -- primitives ---------------------------------------------------------
     @staticmethod
@@ -77,6 +78,8 @@ class Net:
             for head in ("kp", "short_offset", "mid_offset"):
                 p = f"{head}_head_c{lvl}"
                 y = self.conv(self.conv(h, p + ".0", 1, 3, True), p + ".2", 1, 3)
+                if head == "kp":
+                    self.kp_logits[lvl] = y
                 out.append(torch.sigmoid(y) if head == "kp" else y)
             dec.append(out)
         return dec[0], dec[1], dec[2], dec[3], feats
@@ -102,6 +105,7 @@ class Net:
     def forward_seg(self, feats, bboxes):
         patches = [[] for _ in bboxes]
         dets = [[] for _ in bboxes]
+        self.seg_logits = [[] for _ in bboxes]
         h0, w0 = feats[0].shape[2:]
         for i, bb in enumerate(bboxes):
             if len(bb) == 0:
@@ -121,6 +125,7 @@ class Net:
                     u = self.conv(self.up(pre, crops[lvl]), f"skip_combine.{lvl}.up.0", 1, 1, True)
                     pre = self.conv(torch.cat((crops[lvl], u), 1), f"skip_combine.{lvl}.cat_conv.0", 1, 0, True)
                 y = self.conv(self.conv(pre, "seg_head.0", 1, 1, True), "seg_head.2", 1, 1)
+                self.seg_logits[i].append(y[0, 0])
                 patches[i].append(torch.sigmoid(y)[0, 0])
                 dets[i].append(torch.tensor(np.append(np.asarray(box, np.float32), np.float32(score))))
         return [patches, dets]

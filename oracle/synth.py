@@ -86,3 +86,12 @@ def train_batch(N, H, W, seed, n_boxes=4, smin=14, smax=30):
     gt_lv = [torch.from_numpy(np.stack([gt_maps(np.floor(gt_boxes[i][:, :4] / sc), H // sc, W // sc) for i in range(N)]))
              for sc in (1, 2, 4, 8)]
     return x, gt_boxes, gt_masks, gt_lv
+
+
+def grad_sample_index(name, numel, k=1024):
+    """Seeded subset (sorted flat indices) of a parameter's gradient kept in the golden fixtures (tests/golden/net_cal.npz
+    stores min(numel, k) entries per parameter instead of 296 MB of gradients)."""
+    import zlib
+    if numel <= k:
+        return np.arange(numel)
+    return np.sort(np.random.default_rng([17, zlib.crc32(name.encode())]).choice(numel, k, replace=False))

@@ -53,10 +53,21 @@ def param_specs(layers=(3, 4, 6, 3)):
     return s
 
 
-def gen_state_dict(seed=0, as_torch=True, head_bias=None, layers=(3, 4, 6, 3)):
+# "cal" variant: per-key factors on top of the seeded kaiming weights.  The raw random-init network has kp / seg logits of
+# order +-500 (the 7x7 C -> 5 convs amplify by sqrt(2C/5) per kaiming fan_out) and, in train mode, is chaotic: a perturbation
+# grows ~x1.2 per layer through the 43 batch-statistics BN layers (x3600 end to end, measured with oracle/net_bf16.py).
+# The calibrated fixture scales the last head / seg-head convs so that logits are O(1) (sigmoids unsaturated) and the
+# bottlenecks' last BN gains to 0.25 (near-identity residual blocks, as in a trained / zero_init_residual-style network,
+# KGnet.py:219-227), which makes floating-point parity checks meaningful element by element.
+CAL_SCALE = {"kp": 0.1, "short_offset": 0.35, "mid_offset": 1.0, "seg_head.2.weight": 0.02, "bn3.weight": 0.25}
+
+
+def gen_state_dict(seed=0, as_torch=True, head_bias=None, layers=(3, 4, 6, 3), variant="raw"):
     """Seeded state_dict.  conv weights ~ kaiming-normal(fan_out) (KGnet.py:212-214),
     biases/BN affine/running stats non-trivial so that every term is exercised.
-    head_bias: optional float added to the kp heads' last-layer biases."""
+    head_bias: optional float added to the kp heads' last-layer biases.
+    variant: "raw" (the plain random init) or "cal" (CAL_SCALE applied: unsaturated logits, well-conditioned trunk)."""
+    assert variant in ("raw", "cal")
     out = {}
     for key, shape in param_specs(layers):
         rng = np.random.default_rng([seed, zlib.crc32(key.encode())])
@@ -74,6 +85,14 @@ def gen_state_dict(seed=0, as_torch=True, head_bias=None, layers=(3, 4, 6, 3)):
                  else rng.standard_normal(shape) * 0.05).astype(np.float32)
         else:  # conv bias
             a = rng.uniform(-0.05, 0.05, shape).astype(np.float32)
+        if variant == "cal":
+            f = None
+            if key.endswith(".2.weight") and "_head_c" in key:
+                f = CAL_SCALE[key.split("_head_c")[0]]
+            elif key == "seg_head.2.weight" or key.endswith("bn3.weight"):
+                f = CAL_SCALE["seg_head.2.weight" if key.startswith("seg") else "bn3.weight"]
+            if f is not None:
+                a = (a * np.float32(f)).astype(np.float32)
         out[key] = a
     if as_torch:
         import torch

@@ -120,3 +120,65 @@ def test_other_block_counts_match_reference(golden):
         for nm, t in zip(("kp", "short", "mid"), outs[l]):
             a = t.numpy(); a = a[..., ::3, ::3] if a.shape[-1] > 32 else a
             np.testing.assert_allclose(a, g[f"c{l}.{nm}"], rtol=1e-4, atol=1e-5)
+
+
+def _cal_sd():
+    from oracle import weightgen
+    return weightgen.gen_state_dict(0, variant="cal")
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_cal_fixture_eval_logits(golden, name):
+    """Calibrated fixture (unsaturated logits): the oracle reproduces the reference's PRE-SIGMOID kp / seg logits, offsets and
+    features at the fp32 tolerance SURVEY 8d states (rtol 1e-4, atol 1e-5)."""
+    g = golden("net_cal.npz")
+    x = _x(g, name)
+    net = onet.Net(_cal_sd(), training=False)
+    with torch.no_grad():
+        d0, d1, d2, d3, feats = net.forward_dec(x)
+        for l, d in enumerate((d0, d1, d2, d3)):
+            np.testing.assert_allclose(sub(net.kp_logits[l]), g[f"{name}.eval.c{l}.kp_logit"], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(sub(d[1]), g[f"{name}.eval.c{l}.short"], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(sub(d[2]), g[f"{name}.eval.c{l}.mid"], rtol=1e-4, atol=1e-5)
+            assert 0.2 < float(net.kp_logits[l].pow(2).mean().sqrt()) < 5.0          # the fixture is unsaturated
+        for l, f in enumerate(feats):
+            np.testing.assert_allclose(sub(f, 5)[:, ::7], g[f"{name}.eval.feat{l}"], rtol=1e-4, atol=1e-5)
+        if name == "b":
+            net.forward_seg(feats, [g["b.boxes0"], g["b.boxes1"]])
+            for i in range(2):
+                assert len(net.seg_logits[i]) == int(g[f"b.seg.count{i}"])
+                for j, z in enumerate(net.seg_logits[i]):
+                    np.testing.assert_allclose(z.numpy(), g[f"b.seg_logit.{i}.{j}"], rtol=1e-4, atol=1e-5)
+
+
+def test_cal_fixture_train_step(golden):
+    """One train step of the calibrated fixture at 2 x 128 x 128: losses, train-mode logits and a seeded subset of EVERY parameter
+    gradient against the reference (the fixture is well conditioned, so fp32-vs-fp32 agreement is tight)."""
+    g = golden("net_cal.npz")
+    N, H, W, s, nb = [int(v) for v in g["train.cfg"]]
+    x, gt_boxes, gt_masks, gt_lv = synth.train_batch(N, H, W, s, n_boxes=nb)
+    assert np.array_equal(sha(x.numpy()), g["train.x_sha"])
+    sd = _cal_sd()
+    names = [str(n) for n in g["train.grad_names"]]
+    for n in names:
+        sd[n].requires_grad_(True)
+    net = onet.Net(sd, training=True)
+    d0, d1, d2, d3, pred = net.forward(x, gt_boxes)
+    l1 = [onet.detection_loss(p, t) for p, t in zip((d0, d1, d2, d3), gt_lv)]
+    l2 = onet.seg_loss(pred, gt_masks, gt_boxes, H, W)
+    np.testing.assert_allclose([float(v) for v in l1], g["train.loss_dec"], rtol=2e-5)
+    assert abs(float(l2) - float(g["train.loss_seg"])) <= 2e-5 * abs(float(g["train.loss_seg"]))
+    for l, d in enumerate((d0, d1, d2, d3)):
+        np.testing.assert_allclose(sub(net.kp_logits[l].detach(), 5), g[f"train.c{l}.kp_logit"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(sub(d[2].detach(), 5), g[f"train.c{l}.mid"], rtol=1e-3, atol=1e-4)
+    (sum(l1) + l2).backward()
+    off = 0
+    for n, nrm in zip(names, g["train.grad_norm"]):
+        gr = sd[n].grad.numpy().ravel()
+        idx = synth.grad_sample_index(n, gr.size)
+        ref = g["train.grad_samples"][off:off + idx.size]; off += idx.size
+        got = gr[idx]
+        cos = float(got.astype(np.float64) @ ref.astype(np.float64) / (np.linalg.norm(got.astype(np.float64)) * np.linalg.norm(ref.astype(np.float64)) + 1e-300))
+        assert cos >= 0.9999, (n, cos)
+        assert abs(float(np.linalg.norm(gr.astype(np.float64))) - nrm) <= 2e-3 * nrm + 1e-9, n
+    assert off == g["train.grad_samples"].size

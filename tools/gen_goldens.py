@@ -220,6 +220,74 @@ def gen_net(seed=0):
     print("net.npz written; losses", out["train.loss_dec"], out["train.loss_seg"], "patches", out["train.npatch"])
 
 
+def gen_net_cal(seed=0):
+    """The calibrated fixture (oracle/weightgen.py variant "cal": unsaturated logits, near-identity residual blocks): eval
+    forward incl. the PRE-SIGMOID kp / seg logits (forward hooks on the reference's head modules) and one train step at
+    2 x 128 x 128 with a seeded subset of every parameter gradient -> tests/golden/net_cal.npz."""
+    sd = weightgen.gen_state_dict(seed, variant="cal")
+    model = rKGnet.resnet50(pretrained=False)
+    model.load_state_dict(sd)
+    cap = {"kp": {}, "seg": []}
+    for lvl in range(4):
+        getattr(model, f"kp_head_c{lvl}").register_forward_hook(lambda m, i, o, lvl=lvl: cap["kp"].__setitem__(lvl, o.detach().clone()))
+    model.seg_head.register_forward_hook(lambda m, i, o: cap["seg"].append(o.detach().clone()))
+    out = {"seed": np.array(seed)}
+    boxes_b = [np.array([[10.2, 12.7, 40.5, 50.5, 1.0], [0.0, 0.0, 95.0, 127.0, 0.9], [30.5, 60.5, 37.5, 71.5, 0.8],
+                         [50, 20, 52, 90, 0.7], [64.4, 100.6, 90.2, 126.9, 0.6], [2.5, 3.5, 14.5, 17.5, 0.5]], np.float32),
+               np.array([[20, 30, 60, 80, 1.0], [5, 100, 25, 120, 1.0], [70.5, 8.5, 93.5, 40.5, 1.0]], np.float32)]
+    for name, (N, H, W, s) in {"a": (1, 64, 64, 100), "b": (2, 96, 128, 101)}.items():
+        x = torch.rand(N, 3, H, W, generator=torch.Generator().manual_seed(s)) - 0.5
+        out[f"{name}.x_sha"] = sha(x.numpy()); out[f"{name}.cfg"] = np.array([N, H, W, s])
+        model.eval()
+        with torch.no_grad():
+            d0, d1, d2, d3, feats = model.forward_dec(x)
+            for l, d in enumerate((d0, d1, d2, d3)):
+                out[f"{name}.eval.c{l}.kp_logit"] = sub(cap["kp"][l])
+                assert torch.equal(torch.sigmoid(cap["kp"][l]), d[0])
+                out[f"{name}.eval.c{l}.short"] = sub(d[1]); out[f"{name}.eval.c{l}.mid"] = sub(d[2])
+            for l, f in enumerate(feats):
+                out[f"{name}.eval.feat{l}"] = sub(f, 5)[:, ::7].copy()
+            if name == "b":
+                cap["seg"].clear()
+                patches, dets = model.forward_seg(feats, boxes_b)
+                out["b.boxes0"] = boxes_b[0]; out["b.boxes1"] = boxes_b[1]
+                k = 0
+                for i in range(2):
+                    out[f"b.seg.count{i}"] = np.array(len(patches[i]))
+                    for j, p in enumerate(patches[i]):
+                        z = cap["seg"][k][0, 0]; k += 1
+                        assert torch.equal(torch.sigmoid(z), p)
+                        out[f"b.seg_logit.{i}.{j}"] = z.numpy()
+    model.load_state_dict(sd)
+    model.train()
+    N, H, W, s = 2, 128, 128, 7
+    x, gt_boxes, gt_masks, gt_lv = synth.train_batch(N, H, W, s, n_boxes=6)
+    cap["seg"].clear()
+    pr0, pr1, pr2, pr3, pred = model(x, gt_boxes)
+    ldec = rloss.DetectionLossAll(kp_radius=5); lseg = rseg.SEG_loss(height=H, width=W)
+    l1s = [ldec(p, g_) for p, g_ in zip((pr0, pr1, pr2, pr3), gt_lv)]
+    l2 = lseg(pred, gt_masks, gt_boxes)
+    (sum(l1s) + l2).backward()
+    out["train.cfg"] = np.array([N, H, W, s, 6]); out["train.x_sha"] = sha(x.numpy())
+    out["train.loss_dec"] = np.array([float(v) for v in l1s]); out["train.loss_seg"] = np.array(float(l2))
+    out["train.npatch"] = np.array([len(p) for p in pred[0]])
+    for l, d in enumerate((pr0, pr1, pr2, pr3)):
+        out[f"train.c{l}.kp_logit"] = sub(cap["kp"][l], 5); out[f"train.c{l}.short"] = sub(d[1], 5); out[f"train.c{l}.mid"] = sub(d[2], 5)
+    names, norms, samples = [], [], []
+    for k, p in model.named_parameters():
+        g = p.grad.numpy().ravel()
+        names.append(k); norms.append(float(np.linalg.norm(g.astype(np.float64))))
+        samples.append(g[synth.grad_sample_index(k, g.size)])
+    out["train.grad_names"] = np.array(names); out["train.grad_norm"] = np.array(norms)
+    out["train.grad_samples"] = np.concatenate(samples).astype(np.float32)
+    msd = model.state_dict()
+    for k in ("bn1.running_mean", "bn1.running_var", "layer3.5.bn3.running_mean", "layer3.5.bn3.running_var"):
+        out[f"train.stat.{k}"] = msd[k].numpy()
+    np.savez_compressed(os.path.join(GOLD, "net_cal.npz"), **out)
+    print("net_cal.npz written; losses", out["train.loss_dec"], out["train.loss_seg"], "patches", out["train.npatch"],
+          "grad samples", out["train.grad_samples"].shape)
+
+
 def gen_net_layers(seed=3, layers=(1, 2, 2, 1)):
     """A Bottleneck trunk with other block counts than resnet50's (the constructors of KGnet.py:377-410 only differ in them):
     eval forward of ResNet(Bottleneck, [1,2,2,1]) -> tests/golden/net_layers.npz."""
@@ -404,6 +472,9 @@ if __name__ == "__main__":
     if "--only-net-layers" in sys.argv:
         gen_net_layers()
         sys.exit(0)
+    if "--only-net-cal" in sys.argv:
+        gen_net_cal()
+        sys.exit(0)
     if "--only-evalparts" in sys.argv:
         gen_evalparts()
         sys.exit(0)
@@ -414,4 +485,5 @@ if __name__ == "__main__":
     gen_preproc()
     gen_evalparts()
     gen_net_layers()
+    gen_net_cal()
     os.system(f"ls -la {GOLD}")
