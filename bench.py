@@ -116,11 +116,11 @@ class KernelTimer:
             return r
         orig_h2 = ops.conv_halo_heads2
 
-        def heads2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C):
+        def heads2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C, **k):
             if not timer.on or timer.only_dominant:
-                return orig_h2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C)
+                return orig_h2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record(); r = orig_h2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C); e.record()
+            s.record(); r = orig_h2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C, **k); e.record()
             timer.rec.append(("conv_halo_heads2<7>", 2.0 * N * H * W * 55 * 49 * C, s, e, f"N={N} H={H} cout=5+10+40 C={C}"))
             return r
         # engine/seg call through `ops.<fn>` (and conv_auto resolves these names at call time)

@@ -11,12 +11,26 @@
  *   - return value: 0 = ok, otherwise kg_last_error() (thread-local) describes the failure.
  *   - activations ("rows"): bf16, pixel-major [row][ld] (NHWC), channel counts multiples of 8.
  *   - weights: fp32 OIHW master copies are packed to bf16 [Cout_pad][K] by kg_pack_weight.
+ *   - precision: the reference computes in fp32 (KGnet.py:22-29 -> F.conv2d on fp32 tensors).  The fast matrix path of gfx950
+ *     is bf16 MFMA with fp32 accumulation, so tensors that must carry more than bf16 are stored as P "planes" of bf16 whose
+ *     sum is the value (P = 2: 16 significant bits, P = 3: the fp32 value exactly) and a product of an xP-plane activation
+ *     with a wP-plane weight is the sum of the bf16 MFMA products x_i * w_j with i + j < max(xP, wP).  Entry points that
+ *     take rows operands accept a `const kg_planes_t* planes` (host struct, NULL = single-plane bf16 everywhere); each
+ *     documents which operand uses which slot.
  */
 #ifndef KGNET_HIP_H
 #define KGNET_HIP_H
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+typedef struct kg_planes {
+    int a_planes, a_pstride;   /* first bf16 rows operand: planes, element stride between planes (same row, same ld) */
+    int b_planes, b_pstride;   /* second bf16 rows operand */
+    int c_planes, c_pstride;   /* third bf16 rows operand */
+    int y_planes, y_pstride;   /* output rows */
+    int w_planes;              /* planes of the packed weights (virtual-channel layout, see kg_pack_weight) */
+} kg_planes_t;
 
 const char* kg_last_error(void);
 int kg_version(void);
@@ -33,18 +47,20 @@ int kg_f64_probe(const double* a, const double* b, double* out5n, int n, void* s
 int kg_conv2d_igemm(const void* x, const void* w, const float* bias, void* y, float* y_f32, const void* res,
                     const void* mask, const int* rowdesc, int M, int H, int W, int OH, int OW, int cin_pad, int ldx,
                     int Cout, int ldy, int ldres, int ldmask, int K, int KH, int KW, int stride, int pad, int dil,
-                    int mode, int relu, int f32_C, int tile, void* stream);
+                    int mode, int relu, int f32_C, int tile, const kg_planes_t* planes, void* stream);
+                    /* planes: a = x, b = res, y = y; cin_pad = channels of ONE x plane */
 /* the same convolution for stride 1, "same" padding, KS in {3,7}, cin_pad % 64 == 0: input halo resident in LDS
  * (the 7x7 head convolutions of KGnet.py:161-209 are 86 % of the network's FLOPs).  flip = 1: input gradient. */
 int kg_conv2d_halo(const void* x, const void* w, const float* bias, void* y, float* y_f32, const void* res,
                    const void* mask, int N, int H, int W, int cin_pad, int ldx, int Cout, int ldy, int ldres, int ldmask,
                    int K, int KS, int flip, int relu, int f32_C, int wc, const int* tiletab, int ntiles, int total_rows,
-                   void* stream);   /* tiletab != NULL: ragged boxes, one {row0,(h<<16)|w,(oy0<<16)|ox0,0} entry per workgroup */
+                   const kg_planes_t* planes, void* stream);   /* planes: a = x, b = res, y = y.  tiletab != NULL: ragged boxes, one {row0,(h<<16)|w,(oy0<<16)|ox0,0} entry per workgroup */
 /* the three second-layer 7x7 head convolutions of one scale (KGnet.py:161-209 `.2` layers, sigmoid on kp :300) in one launch
  * over the fused hidden rows [N*H*W][>=3C]: w = packed [64 virtual couts][49][3C] (kg_pack_weight_rows), bias64 / vmap[64]
  * indexed by virtual cout (vmap: channel of kp 0-4 | short 5-14 | mid 15-54, or -1); fp32 NCHW outputs */
 int kg_conv2d_halo_heads2(const void* x, const void* w, const float* bias64, const int* vmap, float* kp, float* sh, float* md,
-                          int N, int H, int W, int C, int ldx, int K, void* stream);
+                          int N, int H, int W, int C, int ldx, int K, int kp_sigmoid, const kg_planes_t* planes, void* stream);   /* kp_sigmoid: 1 = torch.sigmoid on kp as KGnet.py:300, 0 = raw logits.  planes: a = x;
+                          w holds [head][virtual planes][C] channels per tap (kg_pack_weight_rows with tap_stride) */
 /* 3x3 stride-1 "same" conv / input gradient (flip) for cin_pad == 64 and Cout <= 64 (c0_conv.2, layer1 conv2, seg level 0): persistent
  * workgroups, all 9 taps' weights resident in LDS, the next 16x16 tile's halo fetched by LDS-direct loads during the current tile */
 int kg_conv3x3_c64(const void* x, const void* w, const float* bias, void* y, const void* res, const void* mask, int N, int H, int W,
@@ -54,15 +70,20 @@ int kg_conv3x3_c64(const void* x, const void* w, const float* bias, void* y, con
  * LDS, pixel fragments straight from global memory, persistent workgroups (KGnet.py:64-99,101-111,155-158) */
 int kg_conv1x1(const void* x, const void* w, const float* bias, void* y, const void* res, const void* mask, long M, int K,
                int wK, int ldx, int Cout, int ldy, int ldres, int ldmask, int relu, void* stream);
-/* fp32 OIHW parameter -> packed bf16 matrix rows (forward) or its transpose (data gradient). */
+/* fp32 OIHW parameter -> packed bf16 matrix rows (forward) or its transpose (data gradient).  x_planes / w_planes: split-bf16
+ * layout; per tap the row holds one cin_pad-channel copy of weight plane j for every kept product x_i * w_j
+ * (i + j < max(x_planes, w_planes)), ordered by descending i + j, then descending j (smallest products first, hi * hi last,
+ * so that the fp32 accumulator rounds like the reference's); a conv kernel walks these "virtual channels" like a single-plane
+ * conv with more input channels and only remaps the activation side to plane i.  (1, 1) = the plain bf16 matrix. */
 int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad, int row0, int c0,
-                   int transposed, void* stream);
-/* forward packing with a row table: packed row of output channel co = rowmap[co] (device int array) */
+                   int transposed, int x_planes, int w_planes, void* stream);
+/* forward packing with a row table: packed row of output channel co = rowmap[co] (device int array); tap_stride: channels per
+ * tap row when several plane groups share the matrix (0 = vplanes * cin_pad) */
 int kg_pack_weight_rows(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad, const int* rowmap,
-                        int c0, void* stream);
-/* all (re)packs of a step in one launch: jobs = device array of 64-byte records {const float* w; void* dst; const int* rowmap;
- * int Cout, Cin, taps, K, cin_pad, row0, c0, transposed, gx, blk0;} (gx = Cout, or ceil(Cout/64) when transposed; blk0 = first
- * workgroup of the job); total_blocks = sum of gx * gy over the jobs */
+                        int c0, int x_planes, int w_planes, int tap_stride, void* stream);
+/* all (re)packs of a step in one launch: jobs = device array of 80-byte records {const float* w; void* dst; const int* rowmap;
+ * int Cout, Cin, taps, K, cin_pad, row0, c0, transposed, gx, blk0, x_planes, w_planes, tap_stride, pad;} (gx = Cout, or
+ * ceil(Cout/64) when transposed; blk0 = first workgroup of the job); total_blocks = sum of gx * gy over the jobs */
 int kg_pack_weight_batch(const void* jobs, int njobs, int total_blocks, void* stream);
 /* im2col for <= 8 input channels (weight gradient of the stem conv1, KGnet.py:131, as a 1x1 weight-gradient GEMM):
  * out[m][tap * cin + ci] = x[src(m, tap)][ci]; out rows of Kpad >= KH*KW*cin bf16 values, padding columns pre-zeroed */
@@ -90,30 +111,32 @@ int kg_set_wgrad_tr(int use_transpose_read);   /* test switch: LDS transpose-rea
 
 /* ---- backbone glue: image pack, BatchNorm2d (KGnet.py:82-97,132), MaxPool2d (KGnet.py:134), bilinear
  *      F.interpolate(align_corners=False) (KGnet.py:110,288-297), elementwise joins ---- */
-int kg_img_pack(const float* img_nchw, void* out_rows8, int N, int C, int H, int W, void* stream);
+/* planes slots of this group: a = first input (x / dy of bilinear_bwd), b = second input (res / dy), y = output; masks use plane 0 */
+int kg_img_pack(const float* img_nchw, void* out_rows8, int ldout, int N, int C, int H, int W, const kg_planes_t* planes, void* stream);
 int kg_bn_stats_train(const void* x, int ldx, int M, int C, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float momentum, float eps, float* mean_out, float* invstd_out, float* scale,
-                      float* shift, float* scratch, int scratch_floats, void* stream);
+                      float* shift, float* scratch, int scratch_floats, const kg_planes_t* planes, void* stream);
 int kg_bn_scale_shift_eval(int C, const float* gamma, const float* beta, const float* running_mean,
                            const float* running_var, float eps, float* scale, float* shift, void* stream);
 int kg_bn_apply(const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldres, void* y,
-                int ldy, int M, int C, int relu, void* stream);
+                int ldy, int M, int C, int relu, const kg_planes_t* planes, void* stream);
 int kg_bn_bwd(const void* x, int ldx, const void* dy, int lddy, const float* gamma, const float* mean,
               const float* invstd, float* dgamma, float* dbeta, int accumulate, void* dx, int lddx, int M, int C,
-              float* scratch, int scratch_floats, void* stream);
-int kg_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, void* stream);
+              float* scratch, int scratch_floats, const kg_planes_t* planes, void* stream);
+int kg_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, const kg_planes_t* planes, void* stream);
 int kg_maxpool3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C,
-                      void* stream);
+                      const kg_planes_t* planes, void* stream);
 int kg_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int IH, int IW, int OH, int OW, int C,
-                    const int* boxdesc, const int* row2box, long total_out_rows, void* stream);
+                    const int* boxdesc, const int* row2box, long total_out_rows, const kg_planes_t* planes, void* stream);
 int kg_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int IH, int IW, int OH, int OW, int C,
-                    const int* boxdesc, const int* row2box, long total_in_rows, const void* mask, int ldmask, void* stream);
+                    const int* boxdesc, const int* row2box, long total_in_rows, const void* mask, int ldmask,
+                    const kg_planes_t* planes, void* stream);
                     /* mask != NULL: dx is zeroed where mask <= 0 (ReLU backward of the upsampled tensor, KGnet.py:110) */
 int kg_add_rows(const void* a, int lda, const void* b, int ldb, const void* mask, int ldm, void* y, int ldy, long M,
-                int C, void* stream);
+                int C, const kg_planes_t* planes, void* stream);
 int kg_sigmoid_inplace(float* x, long n, void* stream);                              /* torch.sigmoid, KGnet.py:300,345 */
 int kg_grad_pack(const float* g_nchw, const float* prob, void* out_rows, int N, int C, int H, int W, int ld, int cpad,
-                 void* stream);
+                 const kg_planes_t* planes, void* stream);   /* planes: y = out_rows */
 
 /* ---- losses: DetectionLossAll (loss.py:12-49) and the per-pair mask BCE of SEG_loss (seg_loss.py:86-94) ---- */
 int kg_detection_loss_fwd(const float* kp, const float* sh, const float* md, const float* gt, int N, int H, int W,
@@ -162,6 +185,22 @@ int kg_rows_scatter_add(const void* g, int ld, const int* srcrow, float* acc, in
 int kg_rows_scatter_add_bf16(const void* g, int ld, const int* srcrow, void* acc_bf16, int C, long nrows, int accld, void* stream);
 int kg_f32_to_bf16_rows(const float* acc, void* out, int C, long rows, int ldout, const void* addto, int ldadd,
                         void* stream);
+/* crops of the fp32 feature maps forward_dec returns (KGnet.py:318 -> get_patches :246-256): dst (planes y) = src_f32[srcrow[r]] */
+int kg_rows_gather_f32(const float* src, int ldsrc, const int* srcrow, void* dst, int lddst, long nrows, int C,
+                       const kg_planes_t* planes, void* stream);
+/* fp32 export of a rows tensor (planes a) -- the feature maps c0..c4 of forward_dec's return value (KGnet.py:318) -- and back
+ * (planes y = acc (+ addto, planes b)): the gradients autograd hands forward_dec for them */
+int kg_planes_to_f32(const void* x, int ldx, float* out, int ldout, long rows, int C, const kg_planes_t* planes, void* stream);
+int kg_f32_to_planes(const float* acc, int ldacc, void* out, int ldout, const void* addto, int ldadd, long rows, int C,
+                     const kg_planes_t* planes, void* stream);
+/* gradient of get_patches' slicing (KGnet.py:246-256) w.r.t. a feature map, deterministic: out[n][y][x][0:C] (fp32, every
+ * element written) = sum over the boxes containing (y, x), in ascending box order, of their crop-gradient row.  Rows
+ * [0, rows_a) of the ragged list are read from ga, the others from gb (row r - rows_a); boxtab = {n,y1,x1,h,w,row0,H,W}
+ * per box; bin_start / bin_boxes = CSR lists of the boxes touching each bin_size x bin_size bin of each image.
+ * planes: a = ga, b = gb */
+int kg_crop_grad_reduce(const void* ga, int lda, const void* gb, int ldb, long rows_a, const int* boxtab, const int* bin_start,
+                        const int* bin_boxes, int bin_size, int N, int H, int W, int C, float* out,
+                        const kg_planes_t* planes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,9 +8,12 @@ Same surface as the reference: `resnet50(pretrained)` returns an `nn
 with autograd (`loss.backward()` fills `.grad` of all parameters).  There is no PyTorch/CPU fallback
 for the arithmetic: a missing libkgnet_hip.so or a non-GPU tensor raises.
 
-Numerics: convolutions run on bf16 MFMA with fp32 accumulation over bf16 activations; head maps are
-exported as fp32 NCHW, feature maps c0..c4 as bf16 NCHW-shaped channels-last views (they are only
-ever fed back into forward_seg).
+Numerics: the reference computes in fp32.  Here convolutions run on bf16 MFMA with fp32 accumulation over split-bf16
+storage (engine.py): `precision="mixed"` (default; env KG_PRECISION) keeps the trunk (stem, layer1-3, decoder) in
+hi + lo bf16 planes (16 significant bits, 3 MFMA products) and the two-layer 7x7 heads / seg branch in bf16;
+"fp32" stores hi + mid + lo (the fp32 value exactly, 6 products) everywhere; "bf16" is single-plane.
+Head maps and the feature maps c0..c4 are returned as fp32 tensors like the reference's (KGnet.py:318;
+the feature maps are NCHW-shaped with channels-last memory).
 """
 import math
 import os
@@ -36,11 +39,8 @@ class _DecFunction(torch.autograd.Function):
     def forward(ctx, model, record, x, *params):
         eng = model._engine   # (grad mode is off inside Function.forward: `record` is decided by the caller)
         maps, feats, dims = eng.forward_dec(x, record)
-        N = x.shape[0]
-        outs = list(maps)
-        for fv, (h, w) in zip(feats, dims):
-            outs.append(fv.t.view(N, h, w, fv.C).permute(0, 3, 1, 2))
-        ctx.model, ctx.recorded = model, record
+        outs = list(maps) + eng.export_feats()
+        ctx.model, ctx.recorded, ctx.generation = model, record, eng.generation
         ctx.keys = model._param_keys
         return tuple(outs)
 
@@ -49,14 +49,18 @@ class _DecFunction(torch.autograd.Function):
         if not ctx.recorded:
             raise RuntimeError("KGnet forward was run without gradient recording")
         eng = ctx.model._engine
+        if ctx.generation != eng.generation or eng.tape is None:
+            raise RuntimeError("KGnet backward: the engine keeps the activations of the LATEST forward_dec only; another "
+                               "forward_dec ran on this model between this loss's forward and its backward")
         fg = []
         for g in grads[12:]:
             if g is None:
                 fg.append(None)
             else:
                 n, c, h, w = g.shape
-                fg.append(g.permute(0, 2, 3, 1).reshape(n * h * w, c).to(torch.bfloat16).contiguous())
-        pg = eng.backward_dec(list(grads[:12]), fg)
+                fg.append(g.float().permute(0, 2, 3, 1).contiguous().view(n * h * w, c))
+        with torch.cuda.device(next(g for g in grads if g is not None).device):
+            pg = eng.backward_dec(list(grads[:12]), fg)
         out = [None, None, None]
         for k in ctx.keys:
             out.append(pg.get(k))
@@ -66,7 +70,7 @@ class _DecFunction(torch.autograd.Function):
 class ResNet(nn.Module):
     """KGnet (ResNet-50[:layer3] + top-down decoder + 12 heads + per-box seg branch)."""
 
-    def __init__(self, block=None, layers=(3, 4, 6, 3), num_classes=1000, zero_init_residual=False):
+    def __init__(self, block=None, layers=(3, 4, 6, 3), num_classes=1000, zero_init_residual=False, precision=None):
         super().__init__()
         if block is not None and getattr(block, "expansion", 4) != 4:
             raise NotImplementedError("BasicBlock trunks (resnet18/34) cannot run forward_dec in the reference either "
@@ -108,8 +112,26 @@ class ResNet(nn.Module):
             for name, _, _, blocks, _ in self.layers_tab:
                 for b in range(blocks):
                     nn.init.constant_(self.get_tensor(f"{name}.{b}.bn3.weight"), 0)
-        self._engine = Engine(self)
+        self._engine = Engine(self, precision)
         self._seg = SegBranch(self)
+
+    # ---- precision / cache control (extensions; the reference has neither) --------------------------
+    @property
+    def precision(self):
+        return self._engine.precision
+
+    def set_precision(self, precision):
+        """"mixed" (default), "fp32" or "bf16" -- see the module docstring."""
+        self._engine.set_precision(precision)
+        self._seg.invalidate_caches()
+        return self
+
+    def invalidate_caches(self):
+        """Drop the packed bf16 weight copies and folded BatchNorm constants: call after writing parameters or running
+        statistics in a way PyTorch's version counters do not see (`p.data.copy_`, third-party fused optimizers) when no
+        training forward follows before the next inference."""
+        self._engine.invalidate_caches()
+        self._seg.invalidate_caches()
 
     # ---- helpers ----------------------------------------------------------------------------------
     def get_tensor(self, key):
@@ -134,12 +156,14 @@ class ResNet(nn.Module):
         self._check_input(x)
         params = [self.get_tensor(k) for k in self._param_keys]
         record = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        outs = _DecFunction.apply(self, record, x, *params)
+        with torch.cuda.device(x.device):      # kernels launch on the stream of the tensors' device, not of the "current" one
+            outs = _DecFunction.apply(self, record, x, *params)
         d = [list(outs[3 * i:3 * i + 3]) for i in range(4)]
         return d[0], d[1], d[2], d[3], list(outs[12:17])
 
     def forward_seg(self, feat_seg, bboxes):
-        return self._seg.forward(feat_seg, bboxes)
+        with torch.cuda.device(feat_seg[0].device):
+            return self._seg.forward(feat_seg, bboxes)
 
     def forward(self, x, bboxes):
         dec0, dec1, dec2, dec3, feat_seg = self.forward_dec(x)

@@ -17,15 +17,15 @@ _SIGS = {
     "kg_version": [],
     "kg_device_arch": [ctypes.c_char_p, c_int],
     "kg_tr_probe": [P, P],
-    "kg_conv2d_igemm": [P, P, P, P, P, P, P, P] + [c_int] * 21 + [P],
-    "kg_conv2d_halo": [P, P, P, P, P, P, P] + [c_int] * 15 + [P, c_int, c_int, P],
+    "kg_conv2d_igemm": [P, P, P, P, P, P, P, P] + [c_int] * 21 + [P, P],
+    "kg_conv2d_halo": [P, P, P, P, P, P, P] + [c_int] * 15 + [P, c_int, c_int, P, P],
     "kg_conv1x1": [P, P, P, P, P, P, c_long] + [c_int] * 8 + [P],
     "kg_conv3x3_c64": [P, P, P, P, P, P] + [c_int] * 11 + [P, c_int, P],
-    "kg_pack_weight": [P, P] + [c_int] * 9 + [P],
-    "kg_pack_weight_rows": [P, P] + [c_int] * 6 + [P, c_int, P],
+    "kg_pack_weight": [P, P] + [c_int] * 11 + [P],
+    "kg_pack_weight_rows": [P, P] + [c_int] * 6 + [P, c_int, c_int, c_int, c_int, P],
     "kg_pack_weight_batch": [P, c_int, c_int, P],
     "kg_im2col_small": [P, P] + [c_int] * 12 + [P],
-    "kg_conv2d_halo_heads2": [P, P, P, P, P, P, P] + [c_int] * 6 + [P],
+    "kg_conv2d_halo_heads2": [P, P, P, P, P, P, P] + [c_int] * 7 + [P, P],
     "kg_set_wgrad_tr": [c_int],
     "kg_conv2d_wgrad": [P, P, P, P] + [c_int] * 18 + [c_long, P],
     "kg_conv2d_wgrad_halo": [P, P, P] + [c_int] * 11 + [c_long, P, c_int, P, P],
@@ -33,21 +33,21 @@ _SIGS = {
     "kg_wgrad_reduce": [P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, P],
     "kg_wgrad_reduce_multi": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, P],
     "kg_bias_grad": [P, P, P, c_int, c_int, c_int, c_int, c_int, P],
-    "kg_img_pack": [P, P, c_int, c_int, c_int, c_int, P],
-    "kg_bn_stats_train": [P, c_int, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P, c_int, P],
+    "kg_img_pack": [P, P, c_int, c_int, c_int, c_int, c_int, P, P],
+    "kg_bn_stats_train": [P, c_int, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P, c_int, P, P],
     "kg_bn_scale_shift_eval": [c_int, P, P, P, P, c_float, P, P, P],
-    "kg_bn_apply": [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P],
-    "kg_bn_bwd": [P, c_int, P, c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_int, P, c_int, P],
-    "kg_maxpool3s2_fwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P],
-    "kg_maxpool3s2_bwd": [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P],
-    "kg_bilinear_fwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_long, P],
-    "kg_bilinear_bwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_long, P, c_int, P],
-    "kg_add_rows": [P, c_int, P, c_int, P, c_int, P, c_int, c_long, c_int, P],
+    "kg_bn_apply": [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P, P],
+    "kg_bn_bwd": [P, c_int, P, c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_int, P, c_int, P, P],
+    "kg_maxpool3s2_fwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P],
+    "kg_maxpool3s2_bwd": [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P],
+    "kg_bilinear_fwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_long, P, P],
+    "kg_bilinear_bwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_long, P, c_int, P, P],
+    "kg_add_rows": [P, c_int, P, c_int, P, c_int, P, c_int, c_long, c_int, P, P],
     "kg_detection_loss_fwd": [P, P, P, P, c_int, c_int, c_int, c_float, P, P, c_int, P, P],
     "kg_detection_loss_bwd": [P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, P, P, P],
     "kg_seg_loss": [P, P, P, P, c_int, P, P, P, P, P],
     "kg_sigmoid_inplace": [P, c_long, P],
-    "kg_grad_pack": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "kg_grad_pack": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "kg_postproc_workspace_bytes": [c_int, c_int, c_int, c_int],
     "kg_postproc_scale": [P, P, P, c_int, c_int, c_double, P, c_long, c_int, c_int, P, P, P, P, P, P, P, P],
     "kg_skeleton_boxes": [P, P, c_int, c_double, c_int, P, P, c_int, P],
@@ -63,6 +63,10 @@ _SIGS = {
     "kg_rows_scatter_add": [P, c_int, P, P, c_int, c_long, c_int, P],
     "kg_rows_scatter_add_bf16": [P, c_int, P, P, c_int, c_long, c_int, P],
     "kg_f32_to_bf16_rows": [P, P, c_int, c_long, c_int, P, c_int, P],
+    "kg_rows_gather_f32": [P, c_int, P, P, c_int, c_long, c_int, P, P],
+    "kg_planes_to_f32": [P, c_int, P, c_int, c_long, c_int, P, P],
+    "kg_f32_to_planes": [P, c_int, P, c_int, P, c_int, c_long, c_int, P, P],
+    "kg_crop_grad_reduce": [P, c_int, P, c_int, c_long, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P],
 }
 _RESTYPE = {"kg_postproc_workspace_bytes": c_long}
 SYMBOLS = tuple(_SIGS) + ("kg_last_error",)

@@ -10,7 +10,71 @@ struct ConvArgs {
     int Cout, K, cpt, cpt_magic, ntaps, KW, stride_log2, pad, dil;
     int mode;  // 0 dense forward, 1 dense transposed (dgrad), 2 ragged (+), 3 ragged transposed (-)
     int relu, f32_C;
+    KMap km;                   // split-bf16 planes of x (kg_common.h): X-side offset of virtual channel unit q
+    int yP, yps, rP, rps;      // planes / plane strides of the output rows and of the residual
 };
+
+// Shared tail of every conv kernel: v[NV] = accumulators + bias of output channels cb .. cb+NV-1 of row m.
+// (+ residual planes) -> ReLU -> ReLU mask (plane 0 of the masking tensor carries its sign) -> split-bf16 store.
+struct EpiArgs {
+    bf16_t* y; const bf16_t* res; const bf16_t* mask;
+    int ldy, ldres, ldmask, Cout, relu, yP, yps, rP, rps;
+};
+template <int NV>
+__device__ __forceinline__ void kg_conv_epilogue(const EpiArgs& e, long m, int cb, float (&v)[NV]) {
+    const bool full = cb + NV <= e.Cout;
+    const int nvalid = full ? NV : e.Cout - cb;
+    if (e.res) {
+        const bf16_t* rq = e.res + m * e.ldres + cb;
+        if (NV % 8 == 0 && full && ((reinterpret_cast<uintptr_t>(rq) & 15) == 0) && (e.rps % 8 == 0)) {
+#pragma unroll
+            for (int q = 0; q < NV / 8; ++q) {
+                float t[8];
+                kg_load_planes8(rq + q * 8, e.rP, e.rps, t);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[q * 8 + k] += t[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                if (k < nvalid) v[k] += kg_load_planes1(rq + k, e.rP, e.rps);
+        }
+    }
+    if (e.relu) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+    }
+    if (e.mask) {
+        const bf16_t* mp = e.mask + m * e.ldmask + cb;
+        if (NV % 8 == 0 && full && ((reinterpret_cast<uintptr_t>(mp) & 15) == 0)) {
+#pragma unroll
+            for (int q = 0; q < NV / 8; ++q) {
+                const uint4 mv = *reinterpret_cast<const uint4*>(mp + q * 8);
+                const bf16_t* ms = reinterpret_cast<const bf16_t*>(&mv);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[q * 8 + k] = bf2f(ms[k]) > 0.f ? v[q * 8 + k] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                if (k < nvalid) v[k] = bf2f(mp[k]) > 0.f ? v[k] : 0.f;
+        }
+    }
+    if (e.y) {
+        bf16_t* yp = e.y + m * e.ldy + cb;
+        if constexpr (NV % 8 == 0) {
+            if (full && ((reinterpret_cast<uintptr_t>(yp) & 15) == 0)) { kg_store_planes<NV>(yp, e.yP, e.yps, v, true); return; }
+        }
+        kg_store_planes_n<NV>(yp, e.yP, e.yps, v, nvalid);
+    }
+}
+static inline void kg_fill_planes(ConvArgs& a, const kg_planes_t& pp, int cin_pad_plane, int unit) {
+    a.km = kg_make_kmap(cin_pad_plane, unit, pp.a_planes, pp.a_pstride, pp.w_planes);
+    a.yP = pp.y_planes; a.yps = pp.y_pstride; a.rP = pp.b_planes; a.rps = pp.b_pstride;
+}
+__device__ __forceinline__ EpiArgs kg_epi(const ConvArgs& a) {
+    return EpiArgs{a.y, a.res, a.mask, a.ldy, a.ldres, a.ldmask, a.Cout, a.relu, a.yP, a.yps, a.rP, a.rps};
+}
 
 // conv_gather.hip: the deep-prefetch variant for cin_pad % 64 == 0 and bf16 row outputs
 int kg_launch_conv_gather(const ConvArgs& a, int cin_pad, hipStream_t st);

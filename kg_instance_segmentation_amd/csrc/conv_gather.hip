@@ -87,9 +87,10 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
             }
         }
         unsigned char* st = smem + i_slot * STAGE + wave * 1024;
+        const int xo = a.km.xoff(i_cc);      // planes: virtual chunk -> (x plane, channel chunk)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const bf16_t* src = xsrc[q] ? xsrc[q] + i_cc * 64 : zline;
+            const bf16_t* src = xsrc[q] ? xsrc[q] + xo : zline;
             KG_GLDS(src, st + q * 8192);
         }
         const long woff = (long)i_tap * cin_pad + i_cc * 64;
@@ -155,10 +156,10 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
     // ---- epilogue: lane owns pixel row m and couts cb .. cb+15 --------------------------------------------------------------
     const int cb = c0 + wcw * 64 + g * 16;
     if (cb >= a.Cout) return;
-    const bool full = cb + 16 <= a.Cout;
     float bv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+    const EpiArgs ep = kg_epi(a);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const long m = (long)m0 + wp * 64 + j * 16 + lm;
@@ -168,47 +169,7 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bv[i * 4 + r];
-        if (a.res) {
-            const bf16_t* rq = a.res + m * a.ldres + cb;
-            if (full && ((reinterpret_cast<uintptr_t>(rq) & 15) == 0)) {
-                uint4 r0 = *reinterpret_cast<const uint4*>(rq), r1 = *reinterpret_cast<const uint4*>(rq + 8);
-                const bf16_t* rs0 = reinterpret_cast<const bf16_t*>(&r0);
-                const bf16_t* rs1 = reinterpret_cast<const bf16_t*>(&r1);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { v[e] += bf2f(rs0[e]); v[8 + e] += bf2f(rs1[e]); }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if (full || cb + e < a.Cout) v[e] += bf2f(rq[e]);
-            }
-        }
-        if (a.relu) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-        }
-        if (a.mask) {
-            const bf16_t* mp = a.mask + m * a.ldmask + cb;
-            if (full && ((reinterpret_cast<uintptr_t>(mp) & 15) == 0)) {
-                uint4 q0 = *reinterpret_cast<const uint4*>(mp), q1 = *reinterpret_cast<const uint4*>(mp + 8);
-                const bf16_t* ms0 = reinterpret_cast<const bf16_t*>(&q0);
-                const bf16_t* ms1 = reinterpret_cast<const bf16_t*>(&q1);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { v[e] = bf2f(ms0[e]) > 0.f ? v[e] : 0.f; v[8 + e] = bf2f(ms1[e]) > 0.f ? v[8 + e] : 0.f; }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if (full || cb + e < a.Cout) v[e] = bf2f(mp[e]) > 0.f ? v[e] : 0.f;
-            }
-        }
-        bf16_t* yp = a.y + m * a.ldy + cb;
-        if (full && ((reinterpret_cast<uintptr_t>(yp) & 15) == 0)) {
-            *reinterpret_cast<uint4*>(yp) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-            *reinterpret_cast<uint4*>(yp + 8) = make_uint4(pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15]));
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if (cb + e < a.Cout) yp[e] = f2bf(v[e]);
-        }
+        kg_conv_epilogue<16>(ep, m, cb, v);
     }
 }
 

@@ -13,7 +13,7 @@
 // WC = 2, 3 (tuning variants): 16x16-pixel tile with 128 / 192 couts per workgroup.
 // The same kernel computes the input gradient of such a conv (flip = 1, transposed-packed weights).
 // Wave tile = 64 couts x 64 pixels (4 rows of the 16x16 tile), 16 v_mfma_f32_16x16x32_bf16 per 32-wide k-step.
-#include "kg_common.h"
+#include "conv_args.h"
 #include <type_traits>
 #include <stdlib.h>
 #ifndef KG_HALO_SETPRIO
@@ -33,6 +33,11 @@ struct HaloArgs {
     int grp_chunks; const int* vmap; float* f32_b; float* f32_c;
     int xcd_map;      // 1: remap (blockIdx.x, blockIdx.y) so that the cout blocks of a pixel tile share an XCD (gridDim.x % 8 == 0)
     int head_split;   // GM: 1 = blockIdx.y is the head (small images: 3x the workgroups), 0 = one workgroup walks all heads
+    // split-bf16 planes (kg_common.h): cin_pad counts the VIRTUAL channels of a tap (what the packed weights hold); km maps a
+    // virtual 64-channel chunk to its (x plane, channel chunk); GM = 1: grp_chunks virtual chunks and grp_C real channels per head
+    KMap km; int grp_C;
+    int kp_raw;       // GM = 1: 1 = export the kp logits without the sigmoid of KGnet.py:300 (parity tests, logit-space consumers)
+    int yP, yps, rP, rps;
 };
 
 // WPX = pixel waves: 4 -> 16x16 output tile, 8 -> 16 rows x 32 columns (two 16x16 halves side by side)
@@ -145,6 +150,9 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     const int nchunks = (GM == 1 && a.head_split) ? (biy + 1) * a.grp_chunks : a.cin_pad / 64;
     for (int cc = (GM == 1 && a.head_split) ? biy * a.grp_chunks : 0; cc < nchunks; ++cc) {
         __syncthreads();
+        int xo;                                    // X-side element offset of this (virtual) chunk
+        if constexpr (GM == 1) { const int hd = cc / a.grp_chunks; xo = hd * a.grp_C + a.km.xoff(cc - hd * a.grp_chunks); }
+        else xo = a.km.xoff(cc);
         // ---- stage the halo of this 64-channel chunk ------------------------------------------------
         if (KS == 3) {   // 3x3 (9 taps per staging): all global loads of the halo are issued before the first LDS store
             constexpr int HPT = (HPIX * 8 + NT - 1) / NT;
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                 const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (e < HPIX * 8 && (unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd)
-                    v = *reinterpret_cast<const uint4*>(a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + cc * 64 + c * 8);
+                    v = *reinterpret_cast<const uint4*>(a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + xo + c * 8);
                 hreg[q] = v;
             }
 #pragma unroll
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                     const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
                     const bf16_t* src = reinterpret_cast<const bf16_t*>(kg_halo_zero_line) + c * 8;
                     if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd)
-                        src = a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + cc * 64 + c * 8;
+                        src = a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + xo + c * 8;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)(halo + (q * NT + wave_u * 64) * 16), 16, 0, 0);
                 }
@@ -367,10 +375,10 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     // ---- epilogue: lane owns pixel (oy0 + wp*4 + j, ox0 + lm) and couts cb .. cb+15 ----------------------
     const int cb = c0 + wc * 64 + g * 16;
     if (cb >= a.Cout) return;
-    const bool full = cb + 16 <= a.Cout;
     float bv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+    const EpiArgs ep{a.y, a.res, a.mask, a.ldy, a.ldres, a.ldmask, a.Cout, a.relu, a.yP, a.yps, a.rP, a.rps};
     const int ox = ox0 + (wp >> 2) * 16 + lm;
     int vm[16];
     if constexpr (GM == 1) {
@@ -394,50 +402,17 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
             for (int e = 0; e < 16; ++e) {
                 const int ch = vm[e];
                 if (ch < 0 || (a.head_split && (ch < 5 ? 0 : ch < 15 ? 1 : 2) != biy)) continue;
-                if (ch < 5) a.y_f32[(nimg * 5 + ch) * hw + pix] = 1.f / (1.f + expf(-v[e]));
+                if (ch < 5) a.y_f32[(nimg * 5 + ch) * hw + pix] = a.kp_raw ? v[e] : 1.f / (1.f + expf(-v[e]));
                 else if (ch < 15) a.f32_b[(nimg * 10 + ch - 5) * hw + pix] = v[e];
                 else a.f32_c[(nimg * 40 + ch - 15) * hw + pix] = v[e];
             }
             continue;
         }
-        if (a.res) {
-            const bf16_t* rp = a.res + m * a.ldres + cb;
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if (full || cb + e < a.Cout) v[e] += bf2f(rp[e]);
-        }
-        if (a.relu) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-        }
-        if (a.mask) {
-            const bf16_t* mp = a.mask + m * a.ldmask + cb;
-            if (full && ((reinterpret_cast<uintptr_t>(mp) & 15) == 0)) {
-                uint4 m0 = *reinterpret_cast<const uint4*>(mp), m1 = *reinterpret_cast<const uint4*>(mp + 8);
-                const bf16_t* ms0 = reinterpret_cast<const bf16_t*>(&m0);
-                const bf16_t* ms1 = reinterpret_cast<const bf16_t*>(&m1);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { v[e] = bf2f(ms0[e]) > 0.f ? v[e] : 0.f; v[8 + e] = bf2f(ms1[e]) > 0.f ? v[8 + e] : 0.f; }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if (full || cb + e < a.Cout) v[e] = bf2f(mp[e]) > 0.f ? v[e] : 0.f;
-            }
-        }
-        if (a.y) {
-            bf16_t* yp = a.y + m * a.ldy + cb;
-            if (full && ((reinterpret_cast<uintptr_t>(yp) & 15) == 0)) {
-                uint4 o0 = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-                uint4 o1 = make_uint4(pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15]));
-                *reinterpret_cast<uint4*>(yp) = o0;
-                *reinterpret_cast<uint4*>(yp + 8) = o1;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    if (cb + e < a.Cout) yp[e] = f2bf(v[e]);
-            }
-        }
         if (a.y_f32) {
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            }
             // dense: NCHW [N][f32_C][H*W]; ragged: [f32_C][total rows] (f32_hw = total rows, image index 0)
             const long hw = a.tiletab ? (long)a.f32_hw : (long)a.H * a.W;
             const long nimg = a.tiletab ? 0 : rowbase / hw, pix = a.tiletab ? m : (long)oy * Wd + ox;
@@ -445,6 +420,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
             for (int e = 0; e < 16; ++e)
                 if (cb + e < a.Cout) a.y_f32[(nimg * a.f32_C + cb + e) * hw + pix] = v[e];
         }
+        if (a.y) kg_conv_epilogue<16>(ep, m, cb, v);      // (last: the split store consumes v)
     }
 }
 
@@ -474,18 +450,26 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
 extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, void* y, float* y_f32, const void* res,
                               const void* mask, int N, int H, int W, int cin_pad, int ldx, int Cout, int ldy, int ldres,
                               int ldmask, int K, int KS, int flip, int relu, int f32_C, int wc, const int* tiletab,
-                              int ntiles, int total_rows, void* stream) {
+                              int ntiles, int total_rows, const kg_planes_t* planes, void* stream) {
+    // planes: a = x (cin_pad = channels of ONE plane; the packed weights hold vplanes * cin_pad virtual channels per tap), b = res, y = y
     HaloArgs a;
     memset(&a, 0, sizeof(a));
+    const kg_planes_t pp = kg_planes_or_default(planes);
+    KG_CHECK_ARG(kg_planes_ok(pp), "kg_conv2d_halo: bad kg_planes_t");
+    int segs_[3];
+    const int vplanes = kg_kmap_segs(pp.a_planes, pp.w_planes, segs_);
+    a.km = kg_make_kmap(cin_pad, 64, pp.a_planes, pp.a_pstride, pp.w_planes);
+    a.yP = pp.y_planes; a.yps = pp.y_pstride; a.rP = pp.b_planes; a.rps = pp.b_pstride;
+    KG_CHECK_ARG(!(y_f32 && (res || mask)), "kg_conv2d_halo: fp32 exports take no residual / mask");
     KG_CHECK_ARG(x && w && (y || y_f32), "kg_conv2d_halo: null pointer");
     KG_CHECK_ARG(KS == 3 || KS == 7, "kg_conv2d_halo: kernel size must be 3 or 7");
     KG_CHECK_ARG(cin_pad % 64 == 0 && ldx % 8 == 0, "kg_conv2d_halo: cin_pad must be a multiple of 64 (got %d)", cin_pad);
-    KG_CHECK_ARG(K >= KS * KS * cin_pad, "kg_conv2d_halo: K too small");
+    KG_CHECK_ARG(K >= KS * KS * cin_pad * vplanes, "kg_conv2d_halo: K too small");
     KG_CHECK_ARG((tiletab && ntiles > 0 && Cout > 0) || (N > 0 && H > 0 && W > 0 && Cout > 0), "kg_conv2d_halo: empty problem");
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.y_f32 = y_f32;
     a.res = (const bf16_t*)res; a.mask = (const bf16_t*)mask;
     a.N = N; a.H = H; a.W = W; a.tiles_x = kg_cdiv(W, 16); a.tiles_y = kg_cdiv(H, 16);
-    a.cin_pad = cin_pad; a.ldx = ldx; a.Cout = Cout; a.ldy = ldy; a.ldres = ldres; a.ldmask = ldmask; a.K = K;
+    a.cin_pad = cin_pad * vplanes; a.ldx = ldx; a.Cout = Cout; a.ldy = ldy; a.ldres = ldres; a.ldmask = ldmask; a.K = K;
     a.flip = flip; a.relu = relu; a.f32_C = f32_C; a.tiletab = (const int4*)tiletab; a.ntiles = ntiles; a.f32_hw = total_rows;
     const int k1skip = wc >> 8; wc &= 255;   // bit 8: the weights are zero for channels 32..63 of every chunk -> k-step 1 is skipped
     if (wc == 0) wc = 1;   // measured on MI355X: the 16x32-pixel x 64-cout tile (8 waves) beats the 16x16 x 128/192-cout tiles at every KGnet shape
@@ -513,15 +497,22 @@ extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, v
 // heads zero); bias64: bias per virtual cout; vmap[64] (device): virtual cout -> channel of (kp 0-4 | short 5-14 |
 // mid 15-54) or -1.  kp / sh / md: fp32 NCHW outputs [N][5|10|40][H][W].
 extern "C" int kg_conv2d_halo_heads2(const void* x, const void* w, const float* bias64, const int* vmap, float* kp, float* sh,
-                                     float* md, int N, int H, int W, int C, int ldx, int K, void* stream) {
+                                     float* md, int N, int H, int W, int C, int ldx, int K, int kp_sigmoid, const kg_planes_t* planes, void* stream) {
+    // planes: a = x (the fused hidden rows; plane stride >= 3C), w: virtual channels [head][w-plane segments][C] per tap
     HaloArgs a;
     memset(&a, 0, sizeof(a));
+    const kg_planes_t pp = kg_planes_or_default(planes);
+    KG_CHECK_ARG(kg_planes_ok(pp), "kg_conv2d_halo_heads2: bad kg_planes_t");
+    int segs_[3];
+    const int vplanes = kg_kmap_segs(pp.a_planes, pp.w_planes, segs_);
+    a.km = kg_make_kmap(C, 64, pp.a_planes, pp.a_pstride, pp.w_planes);
+    a.yP = 1; a.rP = 1; a.grp_C = C; a.kp_raw = kp_sigmoid ? 0 : 1;
     KG_CHECK_ARG(x && w && vmap && kp && sh && md, "kg_conv2d_halo_heads2: null pointer");
     KG_CHECK_ARG(C % 64 == 0 && C > 0 && ldx % 8 == 0 && ldx >= 3 * C, "kg_conv2d_halo_heads2: C must be a multiple of 64 (got %d)", C);
-    KG_CHECK_ARG(K >= 49 * 3 * C && N > 0 && H > 0 && W > 0, "kg_conv2d_halo_heads2: bad sizes");
+    KG_CHECK_ARG(K >= 49 * 3 * C * vplanes && N > 0 && H > 0 && W > 0, "kg_conv2d_halo_heads2: bad sizes");
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias64; a.y_f32 = kp; a.f32_b = sh; a.f32_c = md; a.vmap = vmap;
-    a.N = N; a.H = H; a.W = W; a.tiles_y = kg_cdiv(H, 16); a.cin_pad = 3 * C; a.ldx = ldx; a.Cout = 64; a.K = K;
-    a.grp_chunks = C / 64;
+    a.N = N; a.H = H; a.W = W; a.tiles_y = kg_cdiv(H, 16); a.cin_pad = 3 * C * vplanes; a.ldx = ldx; a.Cout = 64; a.K = K;
+    a.grp_chunks = vplanes * C / 64;
     a.head_split = (long)N * kg_cdiv(H, 16) * kg_cdiv(W, 32) < 256;   // too few pixel tiles to fill 256 CUs
     return launch_halo<7, 1, 8, 1>(a, (hipStream_t)stream);
 }

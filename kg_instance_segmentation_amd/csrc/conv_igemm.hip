@@ -96,7 +96,7 @@ __global__ __launch_bounds__(WC* WP * 64) void conv_igemm_kernel(const ConvArgs 
                         ok = (unsigned)iy < (unsigned)ph[i] && (unsigned)ix < (unsigned)pw[i];
                         row = (long)pbase[i] + (long)sy * pw[i] + sx;
                     }
-                    if (ok) v = *reinterpret_cast<const uint4*>(a.x + row * a.ldx + cc * 8);
+                    if (ok) v = *reinterpret_cast<const uint4*>(a.x + row * a.ldx + a.km.xoff(cc));
                 }
                 xr[s][i] = v;
             }
@@ -173,11 +173,11 @@ __global__ __launch_bounds__(WC* WP * 64) void conv_igemm_kernel(const ConvArgs 
     constexpr int NV = 4 * CF;
     const int cb = c0 + wc * CF * 16 + g * NV;  // first output channel of this lane
     if (cb >= a.Cout) return;
-    const bool full = cb + NV <= a.Cout;
     float bv[NV];
 #pragma unroll
     for (int e = 0; e < NV; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
     const int ohw = a.OH * a.OW;
+    const EpiArgs ep = kg_epi(a);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wp * 64 + j * 16 + lm;
@@ -187,34 +187,10 @@ __global__ __launch_bounds__(WC* WP * 64) void conv_igemm_kernel(const ConvArgs 
         for (int i = 0; i < CF; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bv[i * 4 + r];
-        if (a.res) {
-            const bf16_t* rp = a.res + (long)m * a.ldres + cb;
+        if (a.y_f32) {       // fp32 exports carry no residual / mask in KGnet (head maps)
+            if (a.relu) {
 #pragma unroll
-            for (int e = 0; e < NV; ++e)
-                if (full || cb + e < a.Cout) v[e] += bf2f(rp[e]);
-        }
-        if (a.relu) {
-#pragma unroll
-            for (int e = 0; e < NV; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-        }
-        if (a.mask) {
-            const bf16_t* mp = a.mask + (long)m * a.ldmask + cb;
-#pragma unroll
-            for (int e = 0; e < NV; ++e)
-                if (full || cb + e < a.Cout) v[e] = bf2f(mp[e]) > 0.f ? v[e] : 0.f;
-        }
-        if (a.y) {
-            bf16_t* yp = a.y + (long)m * a.ldy + cb;
-            if (full && ((reinterpret_cast<uintptr_t>(yp) & 7) == 0)) {
-#pragma unroll
-                for (int i = 0; i < CF; ++i) {
-                    uint2 pk = make_uint2(pack2bf(v[i * 4], v[i * 4 + 1]), pack2bf(v[i * 4 + 2], v[i * 4 + 3]));
-                    *reinterpret_cast<uint2*>(yp + i * 4) = pk;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < NV; ++e)
-                    if (cb + e < a.Cout) yp[e] = f2bf(v[e]);
+                for (int e = 0; e < NV; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             }
         }
         if (a.y_f32) {
@@ -223,6 +199,7 @@ __global__ __launch_bounds__(WC* WP * 64) void conv_igemm_kernel(const ConvArgs 
             for (int e = 0; e < NV; ++e)
                 if (cb + e < a.Cout) a.y_f32[((long)n * a.f32_C + cb + e) * ohw + pix] = v[e];
         }
+        if (a.y) kg_conv_epilogue<NV>(ep, m, cb, v);      // (last: the split store consumes v)
     }
 }
 
@@ -254,12 +231,20 @@ extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, 
                                const void* res, const void* mask, const int* rowdesc, int M, int H, int W,
                                int OH, int OW, int cin_pad, int ldx, int Cout, int ldy, int ldres, int ldmask,
                                int K, int KH, int KW, int stride, int pad, int dil, int mode, int relu,
-                               int f32_C, int tile, void* stream) {
+                               int f32_C, int tile, const kg_planes_t* planes, void* stream) {
+    // planes: a = x (cin_pad = channels of ONE plane; the packed weights hold vplanes * cin_pad virtual channels per tap,
+    // see kg_pack_weight), b = res, y = y
     ConvArgs a;
     memset(&a, 0, sizeof(a));
+    const kg_planes_t pp = kg_planes_or_default(planes);
+    KG_CHECK_ARG(kg_planes_ok(pp), "kg_conv2d_igemm: bad kg_planes_t");
+    int segs_[3];
+    const int vplanes = kg_kmap_segs(pp.a_planes, pp.w_planes, segs_);
+    const int cin_virt = vplanes * cin_pad;
+    KG_CHECK_ARG(!(y_f32 && (res || mask)), "kg_conv2d_igemm: fp32 exports take no residual / mask");
     KG_CHECK_ARG(x && w && (y || y_f32), "kg_conv2d_igemm: null pointer");
     KG_CHECK_ARG(cin_pad > 0 && cin_pad % 8 == 0 && ldx % 8 == 0, "kg_conv2d_igemm: cin_pad/ldx must be multiples of 8 (got %d, %d)", cin_pad, ldx);
-    KG_CHECK_ARG(K % 64 == 0 && K >= KH * KW * cin_pad, "kg_conv2d_igemm: K=%d must be a multiple of 64 and >= taps*cin_pad=%d", K, KH * KW * cin_pad);
+    KG_CHECK_ARG(K % 64 == 0 && K >= KH * KW * cin_virt, "kg_conv2d_igemm: K=%d must be a multiple of 64 and >= taps*cin_pad=%d", K, KH * KW * cin_virt);
     KG_CHECK_ARG(KH * KW <= 49 && KH * KW >= 1, "kg_conv2d_igemm: at most 49 taps");
     KG_CHECK_ARG(stride == 1 || stride == 2, "kg_conv2d_igemm: stride must be 1 or 2");
     KG_CHECK_ARG(mode >= 0 && mode <= 3, "kg_conv2d_igemm: bad mode");
@@ -269,16 +254,19 @@ extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, 
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.y_f32 = y_f32;
     a.res = (const bf16_t*)res; a.mask = (const bf16_t*)mask; a.rowdesc = (const int2*)rowdesc;
     a.M = M; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.ldx = ldx; a.ldy = ldy; a.ldres = ldres; a.ldmask = ldmask;
-    a.Cout = Cout; a.K = K; a.cpt = cin_pad / 8; a.ntaps = KH * KW; a.KW = KW;
+    a.Cout = Cout; a.K = K; a.cpt = cin_virt / 8; a.ntaps = KH * KW; a.KW = KW;
+    kg_fill_planes(a, pp, cin_pad, 8);
     a.stride_log2 = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil; a.mode = mode; a.relu = relu; a.f32_C = f32_C;
     KG_CHECK_ARG(magic_for(a.cpt, K / 8, &a.cpt_magic), "kg_conv2d_igemm: no exact magic divisor for cpt=%d", a.cpt);
     hipStream_t st = (hipStream_t)stream;
     static const int use_gather2 = getenv("KG_GATHER2") ? atoi(getenv("KG_GATHER2")) : 2;   // 2: also 64-cout 3x3 convs (half the cout tile idle, still 2x the 64 x 256 tile)
-    if (use_gather2 && tile == 0 && cin_pad % 64 == 0 && y && !y_f32 && (Cout > 64 || (use_gather2 >= 2 && Cout == 64 && KH * KW > 1)) && dil == 1)
-        return kg_launch_conv_gather(a, cin_pad, st);   // deep-prefetch LDS-ring variant (conv_gather.hip)
+    if (use_gather2 && tile == 0 && cin_pad % 64 == 0 && y && !y_f32 && (Cout > 64 || (use_gather2 >= 2 && Cout == 64 && (KH * KW > 1 || vplanes > 1))) && dil == 1) {
+        a.km = kg_make_kmap(cin_pad, 64, pp.a_planes, pp.a_pstride, pp.w_planes);
+        return kg_launch_conv_gather(a, cin_virt, st);   // deep-prefetch LDS-ring variant (conv_gather.hip)
+    }
     static const int use_small = getenv("KG_CONV_SMALL") ? atoi(getenv("KG_CONV_SMALL")) : 6;   // (6: the stride-2 7x7 stem too)
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (use_small && tile == 0 && cin_pad == 8 && KH * KW <= use_small * 9 && y && !y_f32 && Cout % 8 == 0 && ldy % 8 == 0 && al16(y) &&
+    if (use_small && vplanes == 1 && pp.y_planes == 1 && pp.b_planes == 1 && tile == 0 && cin_pad == 8 && KH * KW <= use_small * 9 && y && !y_f32 && Cout % 8 == 0 && ldy % 8 == 0 && al16(y) &&
         (!res || (ldres % 8 == 0 && al16(res))) && (!mask || (ldmask % 8 == 0 && al16(mask))) && dil == 1)
         return kg_launch_conv_small(a, st);   // <= 8 input channels: direct VALU kernel (conv_small.hip)
     // tile: 0 auto; 1 = 16 couts x 256 px; 2 = 32 x 256; 3 = 64 x 256; 4 = 128 x 128; 5 = 64 x 128
@@ -301,9 +289,32 @@ extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, 
 // forward: one block per (co, 64-ci chunk): contiguous fp32 reads [ci][tap], LDS transpose, 128-byte bf16 writes
 // along ci for every tap.  transposed: one block per (64-co chunk, ci): reads `taps` contiguous floats per co,
 // writes 128-byte bf16 runs along co for every tap.
+// Split-bf16 planes (kg_common.h): with xP activation planes and wP weight planes the row of a tap holds nv virtual planes of
+// cin_pad channels each, virtual plane v = a copy of w plane wj(v) (kg_plane_pairs: smallest products first); cin_virt =
+// nv * cin_pad channels per tap; xP = wP = 1 is the plain bf16 layout.
+struct PackPlanes { int wP, nv, cin_virt; unsigned wtab; };
+static inline PackPlanes make_pack_planes(int xP, int wP, int cin_pad) {
+    PackPlanes q;
+    int xi[6], wj[6];
+    q.wP = wP < 1 ? 1 : wP;
+    q.nv = kg_plane_pairs(xP < 1 ? 1 : xP, q.wP, xi, wj);
+    q.wtab = 0;
+    for (int v = 0; v < q.nv; ++v) q.wtab |= (unsigned)wj[v] << (2 * v);
+    q.cin_virt = q.nv * cin_pad;
+    return q;
+}
+__device__ __forceinline__ void pack_store_planes(bf16_t* __restrict__ rowp, float v, const PackPlanes& q, int cin_pad) {
+    // rowp = &dst[row * K + tap * cin_virt + c0 + channel] of virtual plane 0
+    bf16_t pl[3];
+    for (int j = 0; j < 3; ++j) { pl[j] = f2bf(v); v -= bf2f(pl[j]); }
+    for (int k = 0; k < q.nv; ++k) {
+        const int j = (q.wtab >> (2 * k)) & 3;
+        rowp[(long)k * cin_pad] = j == 0 ? pl[0] : (j == 1 ? pl[1] : pl[2]);
+    }
+}
 __device__ __forceinline__ void pack_weight_block(float* tile, const float* __restrict__ w, bf16_t* __restrict__ dst, int Cout, int Cin,
                                                   int taps, int K, int cin_pad, int row0, int c0, int transposed,
-                                                  const int* __restrict__ rowmap, int bx, int by) {
+                                                  const int* __restrict__ rowmap, int bx, int by, const PackPlanes q) {
     if (!transposed) {
         const int co = bx, ci0 = by * 64;
         const int nci = Cin - ci0 < 64 ? Cin - ci0 : 64;
@@ -312,7 +323,7 @@ __device__ __forceinline__ void pack_weight_block(float* tile, const float* __re
         __syncthreads();
         for (int e = threadIdx.x; e < taps * 64; e += 256) {
             const int tap = e >> 6, ci = e & 63;
-            if (ci < nci) dst[(long)(rowmap ? rowmap[co] : row0 + co) * K + (long)tap * cin_pad + c0 + ci0 + ci] = f2bf(tile[ci * 50 + tap]);
+            if (ci < nci) pack_store_planes(dst + (long)(rowmap ? rowmap[co] : row0 + co) * K + (long)tap * q.cin_virt + c0 + ci0 + ci, tile[ci * 50 + tap], q, cin_pad);
         }
     } else {
         const int co0 = bx * 64, ci = by;
@@ -324,22 +335,22 @@ __device__ __forceinline__ void pack_weight_block(float* tile, const float* __re
         __syncthreads();
         for (int e = threadIdx.x; e < taps * 64; e += 256) {
             const int tap = e >> 6, co = e & 63;
-            if (co < nco) dst[(long)(row0 + ci) * K + (long)tap * cin_pad + c0 + co0 + co] = f2bf(tile[co * 50 + tap]);
+            if (co < nco) pack_store_planes(dst + (long)(row0 + ci) * K + (long)tap * q.cin_virt + c0 + co0 + co, tile[co * 50 + tap], q, cin_pad);
         }
     }
 }
 
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int Cout,
                                                           int Cin, int taps, int K, int cin_pad, int row0, int c0,
-                                                          int transposed, const int* __restrict__ rowmap) {
+                                                          int transposed, const int* __restrict__ rowmap, const PackPlanes q) {
     __shared__ float tile[64 * 50];
-    pack_weight_block(tile, w, dst, Cout, Cin, taps, K, cin_pad, row0, c0, transposed, rowmap, blockIdx.x, blockIdx.y);
+    pack_weight_block(tile, w, dst, Cout, Cin, taps, K, cin_pad, row0, c0, transposed, rowmap, blockIdx.x, blockIdx.y, q);
 }
 
 // All weight (re)packs of a training step in ONE launch: the 170+ per-tensor launches were launch-bound (5 us each).
-struct PackJob {   // 64 bytes, mirrored by ops.PackQueue
+struct PackJob {   // 80 bytes, mirrored by ops.PackQueue
     const float* w; bf16_t* dst; const int* rowmap;
-    int Cout, Cin, taps, K, cin_pad, row0, c0, transposed, gx, blk0;
+    int Cout, Cin, taps, K, cin_pad, row0, c0, transposed, gx, blk0, xP, wP, tap_stride, pad_;   // tap_stride: 0 = vplanes * cin_pad
 };
 __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
     __shared__ float tile[64 * 50];
@@ -350,33 +361,55 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackJob* _
     }
     const PackJob j = jobs[lo];
     const int b = blockIdx.x - j.blk0;
-    pack_weight_block(tile, j.w, j.dst, j.Cout, j.Cin, j.taps, j.K, j.cin_pad, j.row0, j.c0, j.transposed, j.rowmap, b % j.gx, b / j.gx);
+    PackPlanes q;
+    q.wP = j.wP < 1 ? 1 : j.wP;
+    {   // kg_plane_pairs on the device: descending i + j, then descending j
+        const int xP = j.xP < 1 ? 1 : j.xP, T = xP > q.wP ? xP : q.wP;
+        q.nv = 0; q.wtab = 0;
+        for (int sum = T - 1; sum >= 0; --sum)
+            for (int jj = q.wP - 1; jj >= 0; --jj) {
+                const int i = sum - jj;
+                if (i >= 0 && i < xP) { q.wtab |= (unsigned)jj << (2 * q.nv); ++q.nv; }
+            }
+        q.cin_virt = j.tap_stride > 0 ? j.tap_stride : q.nv * j.cin_pad;
+    }
+    pack_weight_block(tile, j.w, j.dst, j.Cout, j.Cin, j.taps, j.K, j.cin_pad, j.row0, j.c0, j.transposed, j.rowmap, b % j.gx, b / j.gx, q);
 }
 
+// x_planes / w_planes: split-bf16 layout of the packed matrix (1, 1 = plain bf16); cin_pad = channels of ONE plane, c0 = channel
+// offset inside a plane copy, K >= taps * vplanes * cin_pad.
 extern "C" int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad,
-                              int row0, int c0, int transposed, void* stream) {
+                              int row0, int c0, int transposed, int x_planes, int w_planes, void* stream) {
     KG_CHECK_ARG(w && dst, "kg_pack_weight: null pointer");
     KG_CHECK_ARG(KH * KW <= 49, "kg_pack_weight: at most 49 taps");
+    KG_CHECK_ARG(x_planes <= 3 && w_planes <= 3, "kg_pack_weight: at most 3 planes");
+    const PackPlanes q = make_pack_planes(x_planes, w_planes, cin_pad);
+    KG_CHECK_ARG(K >= KH * KW * q.cin_virt, "kg_pack_weight: K too small for the plane layout");
     dim3 grid = transposed ? dim3((Cout + 63) / 64, Cin) : dim3(Cout, (Cin + 63) / 64);
     hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, Cout,
-                       Cin, KH * KW, K, cin_pad, row0, c0, transposed, (const int*)nullptr);
+                       Cin, KH * KW, K, cin_pad, row0, c0, transposed, (const int*)nullptr, q);
     KG_CHECK_LAUNCH("pack_weight");
     return KG_OK;
 }
 
 // forward packing with a row table: dst row of output channel co = rowmap[co] (device int array)
 extern "C" int kg_pack_weight_rows(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad,
-                                   const int* rowmap, int c0, void* stream) {
+                                   const int* rowmap, int c0, int x_planes, int w_planes, int tap_stride, void* stream) {
+    // tap_stride: channels per tap row of the packed matrix when several plane groups share it (the fused second-layer heads:
+    // [head][virtual planes][C] per tap -> 3 * vplanes * C); 0 = vplanes * cin_pad
     KG_CHECK_ARG(w && dst && rowmap, "kg_pack_weight_rows: null pointer");
     KG_CHECK_ARG(KH * KW <= 49, "kg_pack_weight_rows: at most 49 taps");
+    KG_CHECK_ARG(x_planes <= 3 && w_planes <= 3, "kg_pack_weight_rows: at most 3 planes");
+    PackPlanes q = make_pack_planes(x_planes, w_planes, cin_pad);
+    if (tap_stride > 0) q.cin_virt = tap_stride;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(Cout, (Cin + 63) / 64), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst,
-                       Cout, Cin, KH * KW, K, cin_pad, 0, c0, 0, rowmap);
+                       Cout, Cin, KH * KW, K, cin_pad, 0, c0, 0, rowmap, q);
     KG_CHECK_LAUNCH("pack_weight_rows");
     return KG_OK;
 }
 
 // jobs: device array of njobs PackJob records (see struct PackJob: {w, dst, rowmap, Cout, Cin, taps, K, cin_pad, row0, c0,
-// transposed, gx, blk0}; gx = grid x of the job = Cout (forward) or ceil(Cout/64) (transposed), blk0 = first block of the
+// transposed, gx, blk0, xP, wP, tap_stride}; gx = grid x of the job = Cout (forward) or ceil(Cout/64) (transposed), blk0 = first block of the
 // job in this launch); total_blocks = sum of the jobs' gx * gy.
 extern "C" int kg_pack_weight_batch(const void* jobs, int njobs, int total_blocks, void* stream) {
     KG_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "kg_pack_weight_batch: empty batch");

@@ -73,3 +73,132 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {   // LDS byte addr
 }
 
 static inline int kg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- split-bf16 storage ("planes") -------------------------------------------------------------------------------------
+// The reference computes in fp32 (KGnet.py:22-29 -> F.conv2d on fp32 tensors).  CDNA4's fast matrix path is bf16 MFMA with
+// fp32 accumulation, so wider-than-bf16 tensors are stored as P planes of bf16 whose sum is the value:
+//   P = 1: bf16;  P = 2: hi + lo (16 significant bits);  P = 3: hi + mid + lo == the fp32 value exactly.
+// Plane p of a rows tensor lives `pstride` elements after plane p-1 (same row, same ld).  A product of an (xP)-plane
+// activation with a (wP)-plane weight is evaluated as the bf16 MFMA products x_i * w_j with i + j < max(xP, wP)
+// (3 products for P = 2, 6 for P = 3: every dropped term is below the last kept plane), accumulated in fp32.
+// ABI side: kg_planes_t (include/kgnet_hip.h); a null pointer means single-plane bf16 everywhere.
+struct kg_planes_t {
+    int a_planes, a_pstride;   // first bf16 rows operand (x; dY of an input gradient)
+    int b_planes, b_pstride;   // second bf16 rows operand (dY of a weight gradient / BN backward; residual of a conv)
+    int c_planes, c_pstride;   // third bf16 rows operand
+    int y_planes, y_pstride;   // output rows
+    int w_planes;              // planes of the packed weights (virtual-channel layout of kg_pack_weight*)
+};
+static inline kg_planes_t kg_planes_or_default(const kg_planes_t* p) {
+    kg_planes_t d = {1, 0, 1, 0, 1, 0, 1, 0, 1};
+    if (p) {
+        d = *p;
+        if (d.a_planes < 1) d.a_planes = 1;
+        if (d.b_planes < 1) d.b_planes = 1;
+        if (d.c_planes < 1) d.c_planes = 1;
+        if (d.y_planes < 1) d.y_planes = 1;
+        if (d.w_planes < 1) d.w_planes = 1;
+    }
+    return d;
+}
+static inline bool kg_planes_ok(const kg_planes_t& d) {
+    return d.a_planes <= 3 && d.b_planes <= 3 && d.c_planes <= 3 && d.y_planes <= 3 && d.w_planes <= 3 &&
+           d.a_pstride % 8 == 0 && d.b_pstride % 8 == 0 && d.c_pstride % 8 == 0 && d.y_pstride % 8 == 0;
+}
+
+// K-side map of a convolution over a planed input.  The kept products x_i * w_j (i + j < max(xP, wP)) are ordered SMALLEST FIRST
+// (descending i + j; the hi * hi product last), so that the low-order terms are summed while the fp32 accumulator is still
+// small and the final hi * hi additions round like the reference's own fp32 accumulation.  The packed weights hold, per tap,
+// one cin_pad-channel copy of w plane j(v) for every virtual plane v; a kernel walks the `total` channel units of a tap exactly
+// as for a single-plane conv and only remaps the X-side offset of unit q to plane i(v).
+static inline int kg_plane_pairs(int xP, int wP, int* xi, int* wj) {   // xi / wj [6]; returns the number of virtual planes
+    const int T = xP > wP ? xP : wP;
+    int n = 0;
+    for (int sum = T - 1; sum >= 0; --sum)
+        for (int j = wP - 1; j >= 0; --j) {
+            const int i = sum - j;
+            if (i >= 0 && i < xP) { xi[n] = i; wj[n] = j; ++n; }
+        }
+    return n;
+}
+struct KMap {
+    int n;            // channel units per plane (C / unit)
+    int total;        // units per tap = virtual planes * n
+    int xps;          // element stride between x planes
+    int unit;         // channels per unit (64 for the tile kernels, 8 for conv_igemm)
+    unsigned xtab;    // x plane of virtual plane v: (xtab >> 2v) & 3
+    __device__ __forceinline__ int xoff(int q) const {   // element offset (plane + channel) of virtual unit q
+        if (total == n) return q * unit;
+        const int v = q / n;
+        return (int)((xtab >> (2 * v)) & 3u) * xps + (q - v * n) * unit;
+    }
+};
+static inline int kg_kmap_segs(int xP, int wP, int* s) {   // (kept for callers that only need the count) returns the virtual planes
+    int xi[6], wj[6];
+    (void)s;
+    return kg_plane_pairs(xP, wP, xi, wj);
+}
+static inline KMap kg_make_kmap(int C, int unit, int xP, int xps, int wP) {
+    int xi[6], wj[6];
+    const int nv = kg_plane_pairs(xP, wP, xi, wj);
+    KMap m;
+    m.n = C / unit; m.unit = unit; m.xps = xps; m.total = nv * m.n; m.xtab = 0;
+    for (int v = 0; v < nv; ++v) m.xtab |= (unsigned)xi[v] << (2 * v);
+    return m;
+}
+
+// fp32 -> P planes (round-to-nearest-even at every level: the residual of each plane is exact in fp32)
+template <int NV>
+__device__ __forceinline__ void kg_store_planes(bf16_t* yp, int P, int ps, float (&v)[NV], bool vec) {
+    static_assert(NV % 8 == 0, "stores are 16-byte chunks");
+    for (int p = 0; p < P; ++p) {
+        bf16_t h[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) h[e] = f2bf(v[e]);
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < NV / 8; ++q) {
+                uint4 o;
+                o.x = (uint32_t)h[q * 8 + 0] | ((uint32_t)h[q * 8 + 1] << 16); o.y = (uint32_t)h[q * 8 + 2] | ((uint32_t)h[q * 8 + 3] << 16);
+                o.z = (uint32_t)h[q * 8 + 4] | ((uint32_t)h[q * 8 + 5] << 16); o.w = (uint32_t)h[q * 8 + 6] | ((uint32_t)h[q * 8 + 7] << 16);
+                *reinterpret_cast<uint4*>(yp + (long)p * ps + q * 8) = o;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) yp[(long)p * ps + e] = h[e];
+        }
+        if (p + 1 < P) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) v[e] -= bf2f(h[e]);
+        }
+    }
+}
+// partial variant: only the first nvalid channels exist
+template <int NV>
+__device__ __forceinline__ void kg_store_planes_n(bf16_t* yp, int P, int ps, float (&v)[NV], int nvalid) {
+    for (int p = 0; p < P; ++p) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const bf16_t h = f2bf(v[e]);
+            if (e < nvalid) yp[(long)p * ps + e] = h;
+            v[e] -= bf2f(h);
+        }
+    }
+}
+// sum of the planes of 8 consecutive channels (16-byte aligned), lowest plane first so that the sum is exact
+__device__ __forceinline__ void kg_load_planes8(const bf16_t* xp, int P, int ps, float (&v)[8]) {
+    uint4 q = *reinterpret_cast<const uint4*>(xp + (long)(P - 1) * ps);
+    const bf16_t* s = reinterpret_cast<const bf16_t*>(&q);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bf2f(s[e]);
+    for (int p = P - 2; p >= 0; --p) {
+        q = *reinterpret_cast<const uint4*>(xp + (long)p * ps);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bf2f(s[e]);
+    }
+}
+__device__ __forceinline__ float kg_load_planes1(const bf16_t* xp, int P, int ps) {
+    float v = bf2f(xp[(long)(P - 1) * ps]);
+    for (int p = P - 2; p >= 0; --p) v += bf2f(xp[(long)p * ps]);
+    return v;
+}

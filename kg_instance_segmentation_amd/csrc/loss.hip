@@ -214,7 +214,7 @@ extern "C" int kg_sigmoid_inplace(float* x, long n, void* stream) {
 // Pack an fp32 NCHW gradient [N][C][HW] into bf16 rows [N*HW][ld] (channels >= C zero-filled up to
 // cpad).  If prob != null the gradient is w.r.t. sigmoid output and is multiplied by p*(1-p).
 __global__ void grad_pack_kernel(const float* __restrict__ g, const float* __restrict__ prob, bf16_t* __restrict__ out,
-                                 int N, int C, long HW, int ld, int cpad) {
+                                 int N, int C, long HW, int ld, int cpad, int P, int ps) {
     long total = (long)N * HW;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long n = i / HW, p = i - n * HW;
@@ -231,18 +231,20 @@ __global__ void grad_pack_kernel(const float* __restrict__ g, const float* __res
                 }
                 v[e] = t;
             }
-            uint4 o4 = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-            *reinterpret_cast<uint4*>(out + i * ld + c0) = o4;
+            kg_store_planes<8>(out + i * ld + c0, P, ps, v, true);
         }
     }
 }
+// planes: y = out (split-bf16 planes of the packed gradient rows)
 extern "C" int kg_grad_pack(const float* g, const float* prob, void* out, int N, int C, int H, int W, int ld, int cpad,
-                            void* stream) {
+                            const kg_planes_t* planes, void* stream) {
     KG_CHECK_ARG(g && out && cpad % 8 == 0 && ld % 8 == 0 && cpad >= C, "kg_grad_pack: bad args");
+    const kg_planes_t pp = kg_planes_or_default(planes);
+    KG_CHECK_ARG(kg_planes_ok(pp), "kg_grad_pack: bad kg_planes_t");
     long total = (long)N * H * W;
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(grad_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, prob, (bf16_t*)out, N, C,
-                       (long)H * W, ld, cpad);
+                       (long)H * W, ld, cpad, pp.y_planes, pp.y_pstride);
     KG_CHECK_LAUNCH("grad_pack");
     return KG_OK;
 }

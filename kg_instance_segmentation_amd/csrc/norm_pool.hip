@@ -6,23 +6,33 @@
 // thread moves 16-byte channel chunks (8 bf16) so a wave covers whole 128-byte lines.
 #include "kg_common.h"
 
+// Rows operands with split-bf16 planes (kg_common.h): value = sum of P bf16 planes, `ps` elements apart.
+struct RowsR { const bf16_t* p; int ld, P, ps; };
+struct RowsW { bf16_t* p; int ld, P, ps; };
+__device__ __forceinline__ void rd8(const RowsR& t, long r, int c, float (&v)[8]) { kg_load_planes8(t.p + r * t.ld + c, t.P, t.ps, v); }
+__device__ __forceinline__ void wr8(const RowsW& t, long r, int c, float (&v)[8]) { kg_store_planes<8>(t.p + r * t.ld + c, t.P, t.ps, v, true); }
+#define KG_PLANES(pl)                                                       \
+    const kg_planes_t pp = kg_planes_or_default(pl);                        \
+    KG_CHECK_ARG(kg_planes_ok(pp), "bad kg_planes_t (at most 3 planes, strides multiples of 8)")
+
 // ---------------------------------------------------------------------------------------------
-__global__ void img_pack_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int N, int C, int HW) {
+__global__ void img_pack_kernel(const float* __restrict__ img, RowsW out, int N, int C, int HW) {
     long total = (long)N * HW;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long n = i / HW, p = i - n * HW;
         float v[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = c < C ? img[(n * C + c) * HW + p] : 0.f;
-        uint4 o = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-        *reinterpret_cast<uint4*>(out + i * 8) = o;
+        wr8(out, i, 0, v);
     }
 }
-extern "C" int kg_img_pack(const float* img, void* out, int N, int C, int H, int W, void* stream) {
-    KG_CHECK_ARG(img && out && C <= 8, "kg_img_pack: bad args");
+// planes: y = the packed rows [N*H*W][ldout] (8 channels per plane, plane stride y_pstride)
+extern "C" int kg_img_pack(const float* img, void* out, int ldout, int N, int C, int H, int W, const kg_planes_t* planes, void* stream) {
+    KG_CHECK_ARG(img && out && C <= 8 && ldout >= 8 && ldout % 8 == 0, "kg_img_pack: bad args");
+    KG_PLANES(planes);
     long total = (long)N * H * W;
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(img_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)out, N, C, H * W);
+    hipLaunchKernelGGL(img_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, RowsW{(bf16_t*)out, ldout, pp.y_planes, pp.y_pstride}, N, C, H * W);
     KG_CHECK_LAUNCH("img_pack");
     return KG_OK;
 }
@@ -33,8 +43,7 @@ extern "C" int kg_img_pack(const float* img, void* out, int N, int C, int H, int
 // combined in double by the finalize kernels (fixed order => reproducible).
 // MODE 0: (sum x, sum x^2)      MODE 1: (sum dy, sum dy*xhat) with xhat=(x-mean)*invstd
 template <int MODE>
-__global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict__ x, int ldx,
-                                                        const bf16_t* __restrict__ dy, int lddy,
+__global__ __launch_bounds__(256) void colreduce_kernel(const RowsR x, const RowsR dy,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, float* __restrict__ part,
                                                         int M, int C, int rows_per_block) {
@@ -53,17 +62,17 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const bf16_t* __restrict
         int r0 = blockIdx.x * rows_per_block, r1 = r0 + rows_per_block;
         if (r1 > M) r1 = M;
         for (int r = r0 + rl; r < r1; r += 32) {
-            uint4 xv = *reinterpret_cast<const uint4*>(x + (long)r * ldx + c0);
-            const bf16_t* xs = reinterpret_cast<const bf16_t*>(&xv);
+            float xs[8];
+            rd8(x, r, c0, xs);
             if (MODE == 0) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { float f = bf2f(xs[e]); s0[e] += f; s1[e] += f * f; }
+                for (int e = 0; e < 8; ++e) { float f = xs[e]; s0[e] += f; s1[e] += f * f; }
             } else {
-                uint4 dv = *reinterpret_cast<const uint4*>(dy + (long)r * lddy + c0);
-                const bf16_t* ds = reinterpret_cast<const bf16_t*>(&dv);
+                float ds[8];
+                rd8(dy, r, c0, ds);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float d = bf2f(ds[e]), xh = (bf2f(xs[e]) - mu[e]) * is[e];
+                    float d = ds[e], xh = (xs[e] - mu[e]) * is[e];
                     s0[e] += d; s1[e] += d * xh;
                 }
             }
@@ -153,17 +162,19 @@ static int reduce_geometry(int M, int C, int scratch_floats, int* nb, int* rpb) 
     return 1;
 }
 
+// planes: a = x
 extern "C" int kg_bn_stats_train(const void* x, int ldx, int M, int C, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float momentum, float eps,
                                  float* mean_out, float* invstd_out, float* scale, float* shift, float* scratch,
-                                 int scratch_floats, void* stream) {
+                                 int scratch_floats, const kg_planes_t* planes, void* stream) {
+    KG_PLANES(planes);
     KG_CHECK_ARG(x && gamma && beta && mean_out && invstd_out && scale && shift && scratch, "kg_bn_stats_train: null pointer");
     KG_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0, "kg_bn_stats_train: C/ld must be multiples of 8");
     int nb, rpb;
     KG_CHECK_ARG(reduce_geometry(M, C, scratch_floats, &nb, &rpb), "kg_bn_stats_train: scratch too small");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colreduce_kernel<0>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                       (const bf16_t*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, scratch, M, C, rpb);
+    hipLaunchKernelGGL(colreduce_kernel<0>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, RowsR{(const bf16_t*)x, ldx, pp.a_planes, pp.a_pstride},
+                       RowsR{nullptr, 0, 1, 0}, (const float*)nullptr, (const float*)nullptr, scratch, M, C, rpb);
     hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(64), 0, st, scratch, nb, C, (long)M, gamma,
                        beta, running_mean, running_var, momentum, eps, mean_out, invstd_out, scale, shift);
     KG_CHECK_LAUNCH("bn_stats_train");
@@ -179,82 +190,80 @@ extern "C" int kg_bn_scale_shift_eval(int C, const float* gamma, const float* be
 }
 
 // y = [relu]( x*scale + shift [+ res] )
-__global__ void bn_apply_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ scale,
-                                const float* __restrict__ shift, const bf16_t* __restrict__ res, int ldres,
-                                bf16_t* __restrict__ y, int ldy, long M, int C8, int relu) {
+__global__ void bn_apply_kernel(const RowsR x, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const RowsR res,
+                                const RowsW y, long M, int C8, int relu) {
     long total = M * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i / C8; int c = (int)(i - r * C8) * 8;
-        uint4 xv = *reinterpret_cast<const uint4*>(x + r * ldx + c);
-        const bf16_t* xs = reinterpret_cast<const bf16_t*>(&xv);
         float v[8];
+        rd8(x, r, c, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = bf2f(xs[e]) * scale[c + e] + shift[c + e];
-        if (res) {
-            uint4 rv = *reinterpret_cast<const uint4*>(res + r * ldres + c);
-            const bf16_t* rs = reinterpret_cast<const bf16_t*>(&rv);
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * scale[c + e] + shift[c + e];
+        if (res.p) {
+            float rs[8];
+            rd8(res, r, c, rs);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bf2f(rs[e]);
+            for (int e = 0; e < 8; ++e) v[e] += rs[e];
         }
         if (relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
         }
-        uint4 o = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-        *reinterpret_cast<uint4*>(y + r * ldy + c) = o;
+        wr8(y, r, c, v);
     }
 }
+// planes: a = x, b = res, y = y
 extern "C" int kg_bn_apply(const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldres,
-                           void* y, int ldy, int M, int C, int relu, void* stream) {
+                           void* y, int ldy, int M, int C, int relu, const kg_planes_t* planes, void* stream) {
+    KG_PLANES(planes);
     KG_CHECK_ARG(x && scale && shift && y, "kg_bn_apply: null pointer");
     KG_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (!res || ldres % 8 == 0), "kg_bn_apply: C/ld must be multiples of 8");
     long total = (long)M * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, scale,
-                       shift, (const bf16_t*)res, ldres, (bf16_t*)y, ldy, (long)M, C / 8, relu);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, RowsR{(const bf16_t*)x, ldx, pp.a_planes, pp.a_pstride}, scale,
+                       shift, RowsR{(const bf16_t*)res, ldres, pp.b_planes, pp.b_pstride}, RowsW{(bf16_t*)y, ldy, pp.y_planes, pp.y_pstride}, (long)M, C / 8, relu);
     KG_CHECK_LAUNCH("bn_apply");
     return KG_OK;
 }
 
 // dx = coef_a*dy + coef_b*xhat + coef_c   (train-mode BN backward, second pass)
-__global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dy, int lddy,
+__global__ void bn_bwd_apply_kernel(const RowsR x, const RowsR dy,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ coef, bf16_t* __restrict__ dx, int lddx, long M, int C) {
+                                    const float* __restrict__ coef, const RowsW dx, long M, int C) {
     const int C8 = C / 8;
     long total = M * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i / C8; int c = (int)(i - r * C8) * 8;
-        uint4 xv = *reinterpret_cast<const uint4*>(x + r * ldx + c);
-        uint4 dv = *reinterpret_cast<const uint4*>(dy + r * lddy + c);
-        const bf16_t* xs = reinterpret_cast<const bf16_t*>(&xv);
-        const bf16_t* ds = reinterpret_cast<const bf16_t*>(&dv);
-        float v[8];
+        float xs[8], ds[8], v[8];
+        rd8(x, r, c, xs); rd8(dy, r, c, ds);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float xh = (bf2f(xs[e]) - mean[c + e]) * invstd[c + e];
-            v[e] = coef[c + e] * bf2f(ds[e]) + coef[C + c + e] * xh + coef[2 * C + c + e];
+            float xh = (xs[e] - mean[c + e]) * invstd[c + e];
+            v[e] = coef[c + e] * ds[e] + coef[C + c + e] * xh + coef[2 * C + c + e];
         }
-        uint4 o = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-        *reinterpret_cast<uint4*>(dx + r * lddx + c) = o;
+        wr8(dx, r, c, v);
     }
 }
+// planes: a = x, b = dy, y = dx
 extern "C" int kg_bn_bwd(const void* x, int ldx, const void* dy, int lddy, const float* gamma, const float* mean,
                          const float* invstd, float* dgamma, float* dbeta, int accumulate, void* dx, int lddx, int M,
-                         int C, float* scratch, int scratch_floats, void* stream) {
+                         int C, float* scratch, int scratch_floats, const kg_planes_t* planes, void* stream) {
+    KG_PLANES(planes);
+    const RowsR xr{(const bf16_t*)x, ldx, pp.a_planes, pp.a_pstride}, dyr{(const bf16_t*)dy, lddy, pp.b_planes, pp.b_pstride};
     KG_CHECK_ARG(x && dy && gamma && mean && invstd && dgamma && dbeta && dx && scratch, "kg_bn_bwd: null pointer");
     KG_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "kg_bn_bwd: C/ld must be multiples of 8");
     int nb, rpb;
     KG_CHECK_ARG(reduce_geometry(M, C, scratch_floats - 3 * C, &nb, &rpb), "kg_bn_bwd: scratch too small");
     hipStream_t st = (hipStream_t)stream;
     float* coef = scratch; float* part = scratch + 3 * C;
-    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, (const bf16_t*)x, ldx,
-                       (const bf16_t*)dy, lddy, mean, invstd, part, M, C, rpb);
+    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, xr, dyr, mean, invstd, part, M, C, rpb);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, st, part, nb, C, (long)M, gamma,
                        invstd, dgamma, dbeta, accumulate, coef);
     long total = (long)M * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy,
-                       mean, invstd, coef, (bf16_t*)dx, lddx, (long)M, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, xr, dyr,
+                       mean, invstd, coef, RowsW{(bf16_t*)dx, lddx, pp.y_planes, pp.y_pstride}, (long)M, C);
     KG_CHECK_LAUNCH("bn_bwd");
     return KG_OK;
 }
@@ -262,7 +271,7 @@ extern "C" int kg_bn_bwd(const void* x, int ldx, const void* dy, int lddy, const
 // ---------------------------------------------------------------------------------------------
 // MaxPool2d(3, stride 2, pad 1) (KGnet.py:134).  First maximum in (kh,kw) scan order wins ties,
 // as torch's max_pool2d does.
-__device__ __forceinline__ void pool_window_max(const bf16_t* __restrict__ x, int ldx, long nbase, int H, int W,
+__device__ __forceinline__ void pool_window_max(const RowsR& x, long nbase, int H, int W,
                                                 int oy, int ox, int c, float* best, int* arg) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; arg[e] = -1; }
@@ -272,31 +281,30 @@ __device__ __forceinline__ void pool_window_max(const bf16_t* __restrict__ x, in
         for (int kw = 0; kw < 3; ++kw) {
             int ix = ox * 2 - 1 + kw;
             if ((unsigned)ix >= (unsigned)W) continue;
-            uint4 v = *reinterpret_cast<const uint4*>(x + (nbase + (long)iy * W + ix) * ldx + c);
-            const bf16_t* s = reinterpret_cast<const bf16_t*>(&v);
+            float s[8];
+            rd8(x, nbase + (long)iy * W + ix, c, s);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float f = bf2f(s[e]);
+                float f = s[e];
                 if (f > best[e] || arg[e] < 0) { best[e] = f; arg[e] = kh * 3 + kw; }
             }
         }
     }
 }
-__global__ void maxpool_fwd_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int N, int H,
+__global__ void maxpool_fwd_kernel(const RowsR x, const RowsW y, int N, int H,
                                    int W, int OH, int OW, int C8) {
     long total = (long)N * OH * OW * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int c = (int)(i % C8) * 8; long p = i / C8;
         int ox = (int)(p % OW); long q = p / OW; int oy = (int)(q % OH); long n = q / OH;
         float best[8]; int arg[8];
-        pool_window_max(x, ldx, n * H * W, H, W, oy, ox, c, best, arg);
-        uint4 o = make_uint4(pack2bf(best[0], best[1]), pack2bf(best[2], best[3]), pack2bf(best[4], best[5]), pack2bf(best[6], best[7]));
-        *reinterpret_cast<uint4*>(y + p * ldy + c) = o;
+        pool_window_max(x, n * H * W, H, W, oy, ox, c, best, arg);
+        wr8(y, p, c, best);
     }
 }
 // gather-form backward: each input pixel sums dy of the (<=4) windows whose argmax it is.
-__global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dy, int lddy,
-                                   bf16_t* __restrict__ dx, int lddx, int N, int H, int W, int OH, int OW, int C8) {
+__global__ void maxpool_bwd_kernel(const RowsR x, const RowsR dy,
+                                   const RowsW dx, int N, int H, int W, int OH, int OW, int C8) {
     long total = (long)N * H * W * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int c = (int)(i % C8) * 8; long p = i / C8;
@@ -314,36 +322,39 @@ __global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ x, int ldx, const 
                 int kw = ix - (ox * 2 - 1);
                 if (kw < 0 || kw > 2) continue;
                 float best[8]; int arg[8];
-                pool_window_max(x, ldx, n * H * W, H, W, oy, ox, c, best, arg);
-                uint4 dv = *reinterpret_cast<const uint4*>(dy + ((n * OH + oy) * OW + ox) * lddy + c);
-                const bf16_t* ds = reinterpret_cast<const bf16_t*>(&dv);
+                pool_window_max(x, n * H * W, H, W, oy, ox, c, best, arg);
+                float ds[8];
+                rd8(dy, (n * OH + oy) * OW + ox, c, ds);
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (arg[e] == kh * 3 + kw) g[e] += bf2f(ds[e]);
+                    if (arg[e] == kh * 3 + kw) g[e] += ds[e];
             }
         }
-        uint4 o = make_uint4(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]), pack2bf(g[4], g[5]), pack2bf(g[6], g[7]));
-        *reinterpret_cast<uint4*>(dx + p * lddx + c) = o;
+        wr8(dx, p, c, g);
     }
 }
-extern "C" int kg_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, void* stream) {
+// planes: a = x, y = y
+extern "C" int kg_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, const kg_planes_t* planes, void* stream) {
     KG_CHECK_ARG(x && y && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "kg_maxpool3s2_fwd: bad args");
+    KG_PLANES(planes);
     int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     long total = (long)N * OH * OW * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y,
-                       ldy, N, H, W, OH, OW, C / 8);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, RowsR{(const bf16_t*)x, ldx, pp.a_planes, pp.a_pstride},
+                       RowsW{(bf16_t*)y, ldy, pp.y_planes, pp.y_pstride}, N, H, W, OH, OW, C / 8);
     KG_CHECK_LAUNCH("maxpool_fwd");
     return KG_OK;
 }
+// planes: a = x, b = dy, y = dx
 extern "C" int kg_maxpool3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H,
-                                 int W, int C, void* stream) {
+                                 int W, int C, const kg_planes_t* planes, void* stream) {
     KG_CHECK_ARG(x && dy && dx && C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "kg_maxpool3s2_bwd: bad args");
+    KG_PLANES(planes);
     int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     long total = (long)N * H * W * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                       (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, N, H, W, OH, OW, C / 8);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, RowsR{(const bf16_t*)x, ldx, pp.a_planes, pp.a_pstride},
+                       RowsR{(const bf16_t*)dy, lddy, pp.b_planes, pp.b_pstride}, RowsW{(bf16_t*)dx, lddx, pp.y_planes, pp.y_pstride}, N, H, W, OH, OW, C / 8);
     KG_CHECK_LAUNCH("maxpool_bwd");
     return KG_OK;
 }
@@ -362,7 +373,7 @@ __device__ __forceinline__ void bil_src(int dst, float scale, int in, int* i0, i
 // Ragged mode (desc != null): one box per "image"; desc[b] = {in_row0, ih, iw, out_row0, oh, ow} and
 // rows are box-local raster order (used by the per-box seg branch, KGnet.py:258-267).
 struct BilBox { int in_row0, ih, iw, out_row0, oh, ow; };
-__global__ void bilinear_fwd_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int IH,
+__global__ void bilinear_fwd_kernel(const RowsR x, const RowsW y, int IH,
                                     int IW, int OH, int OW, int C8, long total_rows, const BilBox* __restrict__ desc,
                                     const int* __restrict__ row2box) {
     long total = total_rows * C8;
@@ -381,16 +392,13 @@ __global__ void bilinear_fwd_kernel(const bf16_t* __restrict__ x, int ldx, bf16_
         bil_src(oy, (float)ih / (float)oh, ih, &y0, &y1, &ly);
         bil_src(ox, (float)iw / (float)ow, iw, &x0, &x1, &lx);
         float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
-        uint4 a = *reinterpret_cast<const uint4*>(x + (in0 + (long)y0 * iw + x0) * ldx + c);
-        uint4 b = *reinterpret_cast<const uint4*>(x + (in0 + (long)y0 * iw + x1) * ldx + c);
-        uint4 d = *reinterpret_cast<const uint4*>(x + (in0 + (long)y1 * iw + x0) * ldx + c);
-        uint4 e4 = *reinterpret_cast<const uint4*>(x + (in0 + (long)y1 * iw + x1) * ldx + c);
-        const bf16_t *pa = (const bf16_t*)&a, *pb = (const bf16_t*)&b, *pd = (const bf16_t*)&d, *pe = (const bf16_t*)&e4;
+        float pa[8], pb[8], pd[8], pe[8];
+        rd8(x, in0 + (long)y0 * iw + x0, c, pa); rd8(x, in0 + (long)y0 * iw + x1, c, pb);
+        rd8(x, in0 + (long)y1 * iw + x0, c, pd); rd8(x, in0 + (long)y1 * iw + x1, c, pe);
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = w00 * bf2f(pa[e]) + w01 * bf2f(pb[e]) + w10 * bf2f(pd[e]) + w11 * bf2f(pe[e]);
-        uint4 o = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-        *reinterpret_cast<uint4*>(y + p * ldy + c) = o;
+        for (int e = 0; e < 8; ++e) v[e] = w00 * pa[e] + w01 * pb[e] + w10 * pd[e] + w11 * pe[e];
+        wr8(y, p, c, v);
     }
 }
 // gather-form backward: each input pixel scans the output pixels that can reference it.
@@ -400,7 +408,7 @@ __device__ __forceinline__ void bil_cand(int i, float scale, int out, int* lo, i
     int l = (int)floorf(a) - 1, h = (int)ceilf(b) + 1;
     *lo = l < 0 ? 0 : l; *hi = h > out - 1 ? out - 1 : h;
 }
-__global__ void bilinear_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dx, int lddx, int IH,
+__global__ void bilinear_bwd_kernel(const RowsR dy, const RowsW dx, int IH,
                                     int IW, int OH, int OW, int C8, long total_rows, const BilBox* __restrict__ desc,
                                     const int* __restrict__ row2box, const bf16_t* __restrict__ mask, int ldmask) {
     long total = total_rows * C8;
@@ -432,10 +440,10 @@ __global__ void bilinear_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, bf1
                 if (x0 != ix && x1 != ix) continue;
                 float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
                 float w = wy * wx;
-                uint4 dv = *reinterpret_cast<const uint4*>(dy + (out0 + (long)oy * ow + ox) * lddy + c);
-                const bf16_t* ds = reinterpret_cast<const bf16_t*>(&dv);
+                float ds[8];
+                rd8(dy, out0 + (long)oy * ow + ox, c, ds);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) g[e] += w * bf2f(ds[e]);
+                for (int e = 0; e < 8; ++e) g[e] += w * ds[e];
             }
         }
         if (mask) {                      // ReLU backward of the tensor that was upsampled (zero where its forward value was <= 0)
@@ -444,52 +452,53 @@ __global__ void bilinear_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, bf1
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] = bf2f(ms[e]) > 0.f ? g[e] : 0.f;
         }
-        uint4 o = make_uint4(pack2bf(g[0], g[1]), pack2bf(g[2], g[3]), pack2bf(g[4], g[5]), pack2bf(g[6], g[7]));
-        *reinterpret_cast<uint4*>(dx + p * lddx + c) = o;
+        wr8(dx, p, c, g);
     }
 }
+// planes: a = x, y = y
 extern "C" int kg_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int IH, int IW, int OH, int OW, int C,
-                               const int* boxdesc, const int* row2box, long total_out_rows, void* stream) {
+                               const int* boxdesc, const int* row2box, long total_out_rows, const kg_planes_t* planes, void* stream) {
     KG_CHECK_ARG(x && y && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "kg_bilinear_fwd: bad args");
+    KG_PLANES(planes);
     long rows = boxdesc ? total_out_rows : (long)N * OH * OW;
     if (rows == 0) return KG_OK;
     long total = rows * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                       (bf16_t*)y, ldy, IH, IW, OH, OW, C / 8, rows, (const BilBox*)boxdesc, row2box);
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, RowsR{(const bf16_t*)x, ldx, pp.a_planes, pp.a_pstride},
+                       RowsW{(bf16_t*)y, ldy, pp.y_planes, pp.y_pstride}, IH, IW, OH, OW, C / 8, rows, (const BilBox*)boxdesc, row2box);
     KG_CHECK_LAUNCH("bilinear_fwd");
     return KG_OK;
 }
+// planes: a = dy, y = dx (mask: plane 0 of the forward tensor carries its sign)
 extern "C" int kg_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int IH, int IW, int OH, int OW, int C,
-                               const int* boxdesc, const int* row2box, long total_in_rows, const void* mask, int ldmask, void* stream) {
+                               const int* boxdesc, const int* row2box, long total_in_rows, const void* mask, int ldmask,
+                               const kg_planes_t* planes, void* stream) {
     KG_CHECK_ARG(dy && dx && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && (!mask || ldmask % 8 == 0), "kg_bilinear_bwd: bad args");
+    KG_PLANES(planes);
     long rows = boxdesc ? total_in_rows : (long)N * IH * IW;
     if (rows == 0) return KG_OK;
     long total = rows * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy,
-                       (bf16_t*)dx, lddx, IH, IW, OH, OW, C / 8, rows, (const BilBox*)boxdesc, row2box, (const bf16_t*)mask, ldmask);
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, RowsR{(const bf16_t*)dy, lddy, pp.a_planes, pp.a_pstride},
+                       RowsW{(bf16_t*)dx, lddx, pp.y_planes, pp.y_pstride}, IH, IW, OH, OW, C / 8, rows, (const BilBox*)boxdesc, row2box, (const bf16_t*)mask, ldmask);
     KG_CHECK_LAUNCH("bilinear_bwd");
     return KG_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
 // out[row][c] = a[row][c] + b[row][c] (+ optional ReLU mask by m > 0); used for gradient joins.
-__global__ void add_rows_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb,
-                                const bf16_t* __restrict__ m, int ldm, bf16_t* __restrict__ y, int ldy, long M, int C8) {
+__global__ void add_rows_kernel(const RowsR a, const RowsR b,
+                                const bf16_t* __restrict__ m, int ldm, const RowsW y, long M, int C8) {
     long total = M * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i / C8; int c = (int)(i - r * C8) * 8;
-        uint4 av = *reinterpret_cast<const uint4*>(a + r * lda + c);
-        const bf16_t* as = (const bf16_t*)&av;
         float v[8];
+        rd8(a, r, c, v);
+        if (b.p) {
+            float bs[8];
+            rd8(b, r, c, bs);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = bf2f(as[e]);
-        if (b) {
-            uint4 bv = *reinterpret_cast<const uint4*>(b + r * ldb + c);
-            const bf16_t* bs = (const bf16_t*)&bv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bf2f(bs[e]);
+            for (int e = 0; e < 8; ++e) v[e] += bs[e];
         }
         if (m) {
             uint4 mv = *reinterpret_cast<const uint4*>(m + r * ldm + c);
@@ -497,18 +506,19 @@ __global__ void add_rows_kernel(const bf16_t* __restrict__ a, int lda, const bf1
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = bf2f(ms[e]) > 0.f ? v[e] : 0.f;
         }
-        uint4 o = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-        *reinterpret_cast<uint4*>(y + r * ldy + c) = o;
+        wr8(y, r, c, v);
     }
 }
+// planes: a = a, b = b, y = y (mask: plane 0)
 extern "C" int kg_add_rows(const void* a, int lda, const void* b, int ldb, const void* mask, int ldm, void* y, int ldy,
-                           long M, int C, void* stream) {
+                           long M, int C, const kg_planes_t* planes, void* stream) {
+    KG_PLANES(planes);
     KG_CHECK_ARG(a && y && C % 8 == 0 && lda % 8 == 0 && ldy % 8 == 0 && (!b || ldb % 8 == 0) && (!mask || ldm % 8 == 0), "kg_add_rows: bad args");
     if (M == 0) return KG_OK;
     long total = M * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(add_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda,
-                       (const bf16_t*)b, ldb, (const bf16_t*)mask, ldm, (bf16_t*)y, ldy, M, C / 8);
+    hipLaunchKernelGGL(add_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, RowsR{(const bf16_t*)a, lda, pp.a_planes, pp.a_pstride},
+                       RowsR{(const bf16_t*)b, ldb, pp.b_planes, pp.b_pstride}, (const bf16_t*)mask, ldm, RowsW{(bf16_t*)y, ldy, pp.y_planes, pp.y_pstride}, M, C / 8);
     KG_CHECK_LAUNCH("add_rows");
     return KG_OK;
 }

@@ -133,3 +133,140 @@ extern "C" int kg_f32_to_bf16_rows(const float* acc, void* out, int C, long rows
     KG_CHECK_LAUNCH("f32_to_bf16_rows");
     return KG_OK;
 }
+
+// ---- split-bf16 / fp32 variants (kg_common.h "planes") ---------------------------------------------------------------------
+// dst[r][0:C] (P planes) = src[srcrow[r]][0:C] with src fp32 rows (the fp32 feature maps forward_dec returns, KGnet.py:318)
+__global__ void rows_gather_f32_kernel(const float* __restrict__ src, int ldsrc, const int* __restrict__ srcrow,
+                                       bf16_t* __restrict__ dst, int lddst, int P, int ps, long nrows, int C8) {
+    long total = nrows * C8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / C8; int c = (int)(i - r * C8) * 8;
+        const float4* sp = reinterpret_cast<const float4*>(src + (long)srcrow[r] * ldsrc + c);
+        const float4 a = sp[0], b = sp[1];
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        kg_store_planes<8>(dst + r * lddst + c, P, ps, v, true);
+    }
+}
+// planes: y = dst
+extern "C" int kg_rows_gather_f32(const float* src, int ldsrc, const int* srcrow, void* dst, int lddst, long nrows, int C,
+                                  const kg_planes_t* planes, void* stream) {
+    KG_CHECK_ARG(src && srcrow && dst && C % 8 == 0 && ldsrc % 4 == 0 && lddst % 8 == 0, "kg_rows_gather_f32: bad args");
+    const kg_planes_t pp = kg_planes_or_default(planes);
+    KG_CHECK_ARG(kg_planes_ok(pp) && (reinterpret_cast<uintptr_t>(src) & 15) == 0, "kg_rows_gather_f32: bad planes / alignment");
+    if (nrows == 0) return KG_OK;
+    long total = nrows * (C / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(rows_gather_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ldsrc, srcrow,
+                       (bf16_t*)dst, lddst, pp.y_planes, pp.y_pstride, nrows, C / 8);
+    KG_CHECK_LAUNCH("rows_gather_f32");
+    return KG_OK;
+}
+
+// out[row][0:C] (fp32) = sum of the planes of x[row][0:C]   (exports of c0..c4, KGnet.py:318: the reference returns fp32)
+__global__ void planes_to_f32_kernel(const bf16_t* __restrict__ x, int ldx, int P, int ps, float* __restrict__ out, int ldout,
+                                     long rows, int C8) {
+    long total = rows * C8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / C8; int c = (int)(i - r * C8) * 8;
+        float v[8];
+        kg_load_planes8(x + r * ldx + c, P, ps, v);
+        float4* op = reinterpret_cast<float4*>(out + r * ldout + c);
+        op[0] = make_float4(v[0], v[1], v[2], v[3]); op[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+// planes: a = x
+extern "C" int kg_planes_to_f32(const void* x, int ldx, float* out, int ldout, long rows, int C, const kg_planes_t* planes, void* stream) {
+    KG_CHECK_ARG(x && out && C % 8 == 0 && ldx % 8 == 0 && ldout % 4 == 0, "kg_planes_to_f32: bad args");
+    const kg_planes_t pp = kg_planes_or_default(planes);
+    KG_CHECK_ARG(kg_planes_ok(pp) && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "kg_planes_to_f32: bad planes / alignment");
+    if (rows == 0) return KG_OK;
+    long total = rows * (C / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(planes_to_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, pp.a_planes, pp.a_pstride,
+                       out, ldout, rows, C / 8);
+    KG_CHECK_LAUNCH("planes_to_f32");
+    return KG_OK;
+}
+
+// out[row][0:C] (P planes) = acc[row][0:C] (fp32) (+ addto planes)
+__global__ void f32_to_planes_kernel(const float* __restrict__ acc, int ldacc, bf16_t* __restrict__ out, int ldout, int P, int ps,
+                                     const bf16_t* __restrict__ addto, int ldadd, int aP, int aps, long rows, int C8) {
+    long total = rows * C8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / C8; int c = (int)(i - r * C8) * 8;
+        const float4* sp = reinterpret_cast<const float4*>(acc + r * ldacc + c);
+        const float4 a = sp[0], b = sp[1];
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if (addto) {
+            float t[8];
+            kg_load_planes8(addto + r * ldadd + c, aP, aps, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+        kg_store_planes<8>(out + r * ldout + c, P, ps, v, true);
+    }
+}
+// planes: b = addto, y = out
+extern "C" int kg_f32_to_planes(const float* acc, int ldacc, void* out, int ldout, const void* addto, int ldadd, long rows, int C,
+                                const kg_planes_t* planes, void* stream) {
+    KG_CHECK_ARG(acc && out && C % 8 == 0 && ldout % 8 == 0 && ldacc % 4 == 0 && (!addto || ldadd % 8 == 0), "kg_f32_to_planes: bad args");
+    const kg_planes_t pp = kg_planes_or_default(planes);
+    KG_CHECK_ARG(kg_planes_ok(pp) && (reinterpret_cast<uintptr_t>(acc) & 15) == 0, "kg_f32_to_planes: bad planes / alignment");
+    if (rows == 0) return KG_OK;
+    long total = rows * (C / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(f32_to_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, ldacc, (bf16_t*)out, ldout, pp.y_planes,
+                       pp.y_pstride, (const bf16_t*)addto, ldadd, pp.b_planes, pp.b_pstride, rows, C / 8);
+    KG_CHECK_LAUNCH("f32_to_planes");
+    return KG_OK;
+}
+
+// ---- deterministic crop-gradient reduction ---------------------------------------------------------------------------------
+// Gradient of get_patches' slicing (KGnet.py:246-256): dfeat[n][y][x][c] = sum over the boxes b that contain (y, x) of
+// g[row0_b + (y - y1_b) * w_b + (x - x1_b)][c].  Gather form, one thread per (feature pixel, 8 channels): the candidate boxes
+// of a pixel come from a bin grid (bins of BS x BS pixels, CSR lists in ascending box order, built by the host next to the box
+// table), the sum runs in fp32 in that fixed order -> no atomics, bit-reproducible, every output element written exactly once.
+// Rows [0, rows_a) of the ragged list come from ga (a column slice of the concat gradient), the rest from gb (already offset:
+// gb row r - rows_a); either may be null when its range is empty.
+__global__ void crop_grad_reduce_kernel(const bf16_t* __restrict__ ga, int lda, const bf16_t* __restrict__ gb, int ldb, int gP, int gps_a,
+                                        int gps_b, long rows_a, const int* __restrict__ boxtab, const int* __restrict__ bin_start,
+                                        const int* __restrict__ bin_boxes, int BS, int BY, int BX, int H, int W,
+                                        float* __restrict__ out, long npix, int C8) {
+    long total = npix * C8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long p = i / C8; int c = (int)(i - p * C8) * 8;
+        const int x = (int)(p % W); long q = p / W; const int y = (int)(q % H); const int n = (int)(q / H);
+        const int bin = (n * BY + y / BS) * BX + x / BS;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = bin_start[bin]; k < bin_start[bin + 1]; ++k) {
+            const int* t = boxtab + bin_boxes[k] * 8;   // {n, y1, x1, h, w, row0, H, W}
+            const int dy = y - t[1], dx = x - t[2];
+            if ((unsigned)dy >= (unsigned)t[3] || (unsigned)dx >= (unsigned)t[4]) continue;
+            const long r = (long)t[5] + (long)dy * t[4] + dx;
+            float v[8];
+            if (r < rows_a) kg_load_planes8(ga + r * lda + c, gP, gps_a, v);
+            else kg_load_planes8(gb + (r - rows_a) * ldb + c, gP, gps_b, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+        float4* op = reinterpret_cast<float4*>(out + p * (long)(C8 * 8) + c);
+        op[0] = make_float4(acc[0], acc[1], acc[2], acc[3]); op[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+// planes: a = ga, b = gb (same plane count)
+extern "C" int kg_crop_grad_reduce(const void* ga, int lda, const void* gb, int ldb, long rows_a, const int* boxtab, const int* bin_start,
+                                   const int* bin_boxes, int bin_size, int N, int H, int W, int C, float* out,
+                                   const kg_planes_t* planes, void* stream) {
+    KG_CHECK_ARG(boxtab && bin_start && bin_boxes && out && C % 8 == 0 && bin_size > 0 && N > 0 && H > 0 && W > 0, "kg_crop_grad_reduce: bad args");
+    KG_CHECK_ARG((!ga || lda % 8 == 0) && (!gb || ldb % 8 == 0) && (ga || gb), "kg_crop_grad_reduce: bad gradient operands");
+    const kg_planes_t pp = kg_planes_or_default(planes);
+    KG_CHECK_ARG(kg_planes_ok(pp) && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "kg_crop_grad_reduce: bad planes / alignment");
+    const long npix = (long)N * H * W;
+    long total = npix * (C / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 32768) blocks = 32768;
+    hipLaunchKernelGGL(crop_grad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ga, lda, (const bf16_t*)gb, ldb,
+                       pp.a_planes, pp.a_pstride, pp.b_pstride, ga ? rows_a : 0, boxtab, bin_start, bin_boxes, bin_size, kg_cdiv(H, bin_size),
+                       kg_cdiv(W, bin_size), H, W, out, npix, C / 8);
+    KG_CHECK_LAUNCH("crop_grad_reduce");
+    return KG_OK;
+}

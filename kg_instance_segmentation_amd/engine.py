@@ -5,19 +5,46 @@ and records one closure that launches the matching backward kernels.  Activation
 pixel-major rows; channel concatenations (torch.cat at KGnet.py:289-298) never happen -- producers
 write straight into column slices of the concat buffer.  ReLU backward is folded into the
 data-gradient kernels' epilogue (mask operand) whenever every contribution passes through one.
+
+Precision (ops.PT, csrc/kg_common.h "planes"): the reference is fp32 (KGnet.py:22-29).  A tensor is stored as P planes of
+bf16 whose sum is the value and multiplied with bf16 MFMA products accumulated in fp32:
+  "mixed" (default): trunk = stem, c0_conv, layer1-3 and the top-down decoder (14 % of the FLOPs, 43 BatchNorm layers whose
+           train-mode statistics amplify a storage error ~x1.2 per layer) in P = 2 (hi + lo, 3 products); the two 7x7 head
+           layers (86 % of the FLOPs, two layers deep) and the seg branch in P = 1 (plain bf16);
+  "fp32":  P = 3 everywhere (hi + mid + lo == the fp32 value exactly, 6 products): fp32-faithful results;
+  "bf16":  P = 1 everywhere.
 """
+import os
+
 import torch
 
 from . import arch, ops
-from .ops import BF16, PackedWeight
+from .ops import BF16, PT, PackedWeight
+
+PRECISIONS = {"bf16": (1, 1, 1), "mixed": (2, 1, 1), "fp32": (3, 3, 3)}      # planes of (trunk, heads, seg branch)
+
+
+def default_precision():
+    p = os.environ.get("KG_PRECISION", "mixed")
+    if p not in PRECISIONS:
+        raise ValueError(f"KG_PRECISION must be one of {sorted(PRECISIONS)} (got {p!r})")
+    return p
+
+
+def trunc(t, P):
+    """the first P planes of a rows tensor (plane 0 alone is the bf16 rounding of the value)"""
+    if isinstance(t, PT):
+        return t if t.P <= P else PT(t.t, P, t.ps)
+    return t
 
 
 class Var:
-    """Activation (bf16 rows view) + its gradient slot."""
+    """Activation (split-bf16 rows, ops.PT) + its gradient slot."""
     __slots__ = ("t", "C", "relu", "grad", "masked", "pending", "pmasked", "req", "parent", "c0")
 
     def __init__(self, t, C, relu=False, req=True, parent=None, c0=0):
-        self.t, self.C, self.relu, self.req = t, C, relu, req
+        self.t = t if isinstance(t, PT) else PT(t)
+        self.C, self.relu, self.req = C, relu, req
         self.grad, self.masked = None, True
         self.pending, self.pmasked = None, True     # one more contribution whose addition is deferred to take_grad (fused with the mask)
         self.parent, self.c0 = parent, c0
@@ -26,15 +53,19 @@ class Var:
     def rows(self):
         return self.t.shape[0]
 
+    @property
+    def P(self):
+        return self.t.P
+
     def alloc_grad(self):
         """Buffer the data-gradient kernel should write (a slice of the parent's grad for slice vars)."""
         if self.parent is not None:
             p = self.parent
             if p.grad is None:
-                p.grad = torch.empty(p.t.shape[0], p.C, dtype=BF16, device=p.t.device)
+                p.grad = ops.alloc_pt(p.rows, p.C, p.P, p.t.device)
                 p.masked = True
-            return p.grad[:, self.c0:self.c0 + self.C]
-        return torch.empty(self.t.shape[0], self.C, dtype=BF16, device=self.t.device)
+            return p.grad.cols(self.c0, self.c0 + self.C)
+        return ops.alloc_pt(self.rows, self.C, self.P, self.t.device)
 
     def add_grad(self, g, masked):
         if self.parent is not None:      # written in place into the parent's buffer
@@ -54,21 +85,23 @@ class Var:
         if g is None:
             return None
         need_mask = self.relu and not (self.masked and self.pmasked)
-        if self.pending is not None:       # sum of the two contributions and the ReLU mask in ONE pass (same bf16 rounding as two)
-            ops.add_rows(g, self.pending, g, self.C, mask=self.t if need_mask else None)
+        if self.pending is not None:       # sum of the two contributions and the ReLU mask in ONE pass
+            ops.add_rows(g, self.pending, g, self.C, mask=self.t.hi() if need_mask else None)
             self.pending, self.pmasked = None, True
         elif need_mask:
-            ops.add_rows(g, None, g, self.C, mask=self.t)
+            ops.add_rows(g, None, g, self.C, mask=self.t.hi())
         if need_mask:
             self.masked = True
         return g
 
 
 class ConvSpec:
-    """One convolution (or a group fused along Cout that shares its input)."""
+    """One convolution (or a group fused along Cout that shares its input).  P = planes it multiplies (input and weights),
+    gP = planes of its output's gradient (the dY operand of its input gradient)."""
 
-    def __init__(self, names, cin, couts, k, stride, pad, bias):
+    def __init__(self, names, cin, couts, k, stride, pad, bias, P, gP):
         self.names, self.cin, self.couts, self.k, self.stride, self.pad, self.has_bias = names, cin, couts, k, stride, pad, bias
+        self.P, self.gP = P, gP
         self.cout = sum(couts)
         self.cin_pad = ops.round_up(cin, 8)
         self.pw = None       # forward packed weights
@@ -79,29 +112,41 @@ class ConvSpec:
 
 
 class Engine:
-    def __init__(self, module):
+    def __init__(self, module, precision=None):
         self.m = module
-        self.specs = {}
+        self.set_precision(precision or default_precision())
         self.tape = None
         self.nbt = []
-        self.bn_eval = {}
         self.param_grads = None
-        self.fusedT = {}
         self.head_slots = []
-        self.heads2_seen = {}
-        self.train_steps, self.stamp = 0, ("e", 0)
+        self.train_steps, self.stamp = 0, ("e", 0, 0)
+        self.generation = 0        # bumped by every forward_dec: a backward must belong to the latest recorded forward
+        self.raw_kp_logits = False   # test hook: inference-only export of the kp LOGITS instead of sigmoid(logits) (KGnet.py:300)
         self.grad_hook = None      # parallel.GradReducer.attach: called with [(key, grad)] as backward produces them
+
+    def set_precision(self, precision):
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)} (got {precision!r})")
+        self.precision = precision
+        self.pt, self.ph, self.pseg = PRECISIONS[precision]
+        self.invalidate_caches()
+
+    def invalidate_caches(self):
+        """Forget every packed-weight / folded-BatchNorm copy (call after writing parameters behind PyTorch's back)."""
+        self.specs, self.bn_eval, self.fusedT, self.heads2_seen = {}, {}, {}, {}
+        self._heads2 = None
 
     # ---- parameters ---------------------------------------------------------------------------
     def P(self, key):
         return self.m.get_tensor(key)
 
-    def spec(self, key, cin, cout, k, stride=1, pad=0, bias=True, fused=None):
+    def spec(self, key, cin, cout, k, stride=1, pad=0, bias=True, fused=None, P=None, gP=None):
         s = self.specs.get(key)
         if s is None:
             names = fused if fused else [key]
             couts = [cout] * len(names) if fused else [cout]
-            s = ConvSpec(names, cin, couts, k, stride, pad, bias)
+            P = self.pt if P is None else P
+            s = ConvSpec(names, cin, couts, k, stride, pad, bias, P, P if gP is None else gP)
             self.specs[key] = s
         return s
 
@@ -121,7 +166,8 @@ class Engine:
     def prepare(self, s, need_T):
         """(Re)pack weights: every recorded (training) forward repacks -- optimizers that write through `.data` or fused
         multi-tensor kernels do not bump tensor versions, so versions alone would leave stale bf16 copies -- and inference
-        repacks when a tensor version / pointer changed or when it follows a training step (self.stamp)."""
+        repacks when a tensor version / pointer changed, when it follows a training step, or when the parameter epoch moved
+        (self.stamp; ops.PARAM_EPOCH is bumped by this package's optimizer and by every train-mode BatchNorm update)."""
         s.used, s.need_T_last = True, need_T
         ws = [self.P(n + ".weight") for n in s.names]
         ver = self.stamp + tuple(w._version for w in ws) + tuple(w.data_ptr() for w in ws)
@@ -129,7 +175,7 @@ class Engine:
         taps = s.k * s.k
         if s.pw is None or s.versions != ver or s.pw.buf.device != dev:
             if s.pw is None or s.pw.buf.device != dev:
-                s.pw = PackedWeight(s.cout, taps, s.cin_pad, dev)
+                s.pw = PackedWeight(s.cout, taps, s.cin_pad, dev, xP=s.P, wP=s.P)
                 s.pwT = None
             r = 0
             for w, co in zip(ws, s.couts):
@@ -143,7 +189,7 @@ class Engine:
                 s.pwT.stale = True
         if need_T and (s.pwT is None or getattr(s.pwT, "stale", True)):
             if s.pwT is None:
-                s.pwT = PackedWeight(s.cin, taps, ops.round_up(s.cout, 8), dev)
+                s.pwT = PackedWeight(s.cin, taps, ops.round_up(s.cout, 8), dev, xP=s.gP, wP=s.P)
             r = 0
             for w, co in zip(ws, s.couts):
                 s.pwT.pack(w.detach(), c0=r, transposed=True)
@@ -151,18 +197,22 @@ class Engine:
             s.pwT.stale = False
 
     # ---- ops ------------------------------------------------------------------------------------
-    def conv(self, xv, s, N, H, W, relu, out=None, y_f32=None, tile=0):
-        """xv: Var over [N*H*W, >=cin_pad]; returns Var over [N*OH*OW, cout] (or fp32 NCHW when y_f32)."""
+    def conv(self, xv, s, N, H, W, relu, out=None, y_f32=None, tile=0, oP=None):
+        """xv: Var over [N*H*W, >=cin_pad]; returns Var over [N*OH*OW, cout] (or fp32 NCHW when y_f32).
+        oP: planes of the output (default: the conv's own precision)."""
         train = self.tape is not None
         self.prepare(s, need_T=train and xv.req)
         OH = (H + 2 * s.pad - s.k) // s.stride + 1
         OW = (W + 2 * s.pad - s.k) // s.stride + 1
         M = N * OH * OW
         dev = xv.t.device
+        oP = s.P if oP is None else oP
+        assert oP == s.gP, "the gradient of a conv output carries the output's planes"
         if y_f32 is None and out is None:
-            out = torch.empty(M, s.cout, dtype=BF16, device=dev)
+            out = ops.alloc_pt(M, s.cout, oP, dev)
         geom = (M, H, W, OH, OW, s.k, s.k, s.stride, s.pad)
-        ops.conv_auto(xv.t, s.pw, s.cout, geom, N, y=out, y_f32=y_f32, bias=s.bias_cat if s.has_bias else None, relu=relu, tile=tile)
+        xin = trunc(xv.t, s.P)
+        ops.conv_auto(xin, s.pw, s.cout, geom, N, y=out, y_f32=y_f32, bias=s.bias_cat if s.has_bias else None, relu=relu, tile=tile)
         yv = Var(out, s.cout, relu=relu)
         if train:
             def bwd():
@@ -177,7 +227,7 @@ class Engine:
                     grads.append((gw, off, co))
                     off += co
                 db = torch.empty(s.cout, dtype=torch.float32, device=dev) if s.has_bias else None
-                ops.conv_wgrad(xv.t, g, s.cin, s.cout, geom, grads, N=N, bias_out=db)
+                ops.conv_wgrad(xin, g, s.cin, s.cout, geom, grads, N=N, bias_out=db)
                 if s.has_bias:
                     off = 0
                     for n, co in zip(s.names, s.couts):
@@ -187,7 +237,7 @@ class Engine:
                     existing = xv.grad if xv.parent is None else None
                     dx = existing if existing is not None else xv.alloc_grad()
                     gin = (N * H * W, OH, OW, H, W, s.k, s.k, s.stride, s.pad)
-                    ops.conv_auto(g, s.pwT, s.cin, gin, N, y=dx, res=existing, mask=xv.t if xv.relu else None, transposed=True)
+                    ops.conv_auto(g, s.pwT, s.cin, gin, N, y=dx, res=existing, mask=xv.t.hi() if xv.relu else None, transposed=True)
                     if existing is None:
                         xv.add_grad(dx, masked=xv.relu)
                     else:
@@ -201,10 +251,11 @@ class Engine:
         gamma, beta = self.P(p + ".weight"), self.P(p + ".bias")
         rm, rv = self.P(p + ".running_mean"), self.P(p + ".running_var")
         if out is None:
-            out = torch.empty(xv.rows, C, dtype=BF16, device=dev)
+            out = ops.alloc_pt(xv.rows, C, self.pt, dev)
         if self.m.training:
             mean, invstd, scale, shift = ops.bn_stats_train(xv.t, C, gamma.detach(), beta.detach(), rm, rv)
             self.nbt.append(self.P(p + ".num_batches_tracked"))      # += 1 for all 43 layers in one launch at the end of forward_dec
+            self.stats_written = True
         else:
             # inference: scale / shift only change with the parameters -- cached under the same validity key as the packed weights
             ver = self.stamp + tuple(t._version for t in (gamma, beta, rm, rv)) + tuple(t.data_ptr() for t in (gamma, beta, rm, rv))
@@ -226,7 +277,7 @@ class Engine:
                     return
                 dg = torch.empty(C, dtype=torch.float32, device=dev)
                 db = torch.empty(C, dtype=torch.float32, device=dev)
-                dx = torch.empty(xv.rows, C, dtype=BF16, device=dev)
+                dx = ops.alloc_pt(xv.rows, C, xv.P, dev)
                 ops.bn_bwd(xv.t, g, C, gamma.detach(), mean, invstd, dg, db, dx)
                 self.param_grads[p + ".weight"] = dg
                 self.param_grads[p + ".bias"] = db
@@ -239,7 +290,7 @@ class Engine:
     def maxpool(self, xv, N, H, W):
         C = xv.C
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        out = torch.empty(N * OH * OW, C, dtype=BF16, device=xv.t.device)
+        out = ops.alloc_pt(N * OH * OW, C, xv.P, xv.t.device)
         ops.maxpool_fwd(xv.t, out, N, H, W, C)
         yv = Var(out, C, relu=False)
         if self.tape is not None:
@@ -247,7 +298,7 @@ class Engine:
                 g = yv.take_grad()
                 if g is None:
                     return
-                dx = torch.empty(xv.rows, C, dtype=BF16, device=xv.t.device)
+                dx = ops.alloc_pt(xv.rows, C, xv.P, xv.t.device)
                 ops.maxpool_bwd(xv.t, g, dx, N, H, W, C)
                 xv.add_grad(dx, masked=False)
             self.tape.append(bwd)
@@ -255,7 +306,7 @@ class Engine:
 
     def upsample(self, xv, N, IH, IW, OH, OW):
         C = xv.C
-        out = torch.empty(N * OH * OW, C, dtype=BF16, device=xv.t.device)
+        out = ops.alloc_pt(N * OH * OW, C, xv.P, xv.t.device)
         ops.bilinear_fwd(xv.t, out, N, IH, IW, OH, OW, C)
         yv = Var(out, C, relu=False)
         if self.tape is not None:
@@ -263,14 +314,14 @@ class Engine:
                 g = yv.take_grad()
                 if g is None:
                     return
-                dx = torch.empty(xv.rows, C, dtype=BF16, device=xv.t.device)
+                dx = ops.alloc_pt(xv.rows, C, xv.P, xv.t.device)
                 ops.bilinear_bwd(g, dx, N, IH, IW, OH, OW, C)
                 xv.add_grad(dx, masked=False)
             self.tape.append(bwd)
         return yv
 
     def concat(self, buf, parts):
-        """buf [rows, sum C]; parts = Vars whose .t are the column slices of buf (already written)."""
+        """buf = PT [rows, sum C]; parts = Vars whose .t are the column slices of buf (already written)."""
         cv = Var(buf, buf.shape[1], relu=all(p.relu for p in parts))
         if self.tape is not None:
             def bwd():
@@ -279,7 +330,7 @@ class Engine:
                     return
                 c = 0
                 for p in parts:
-                    p.add_grad(g[:, c:c + p.C], masked=cv.relu)
+                    p.add_grad(g.cols(c, c + p.C), masked=cv.relu)
                     c += p.C
             self.tape.append(bwd)
         return cv
@@ -303,23 +354,28 @@ class Engine:
         """img fp32 [N,3,H,W].  Returns (maps: 12 fp32 NCHW tensors, feats: 5 Vars, dims)."""
         N, _, H, W = img.shape
         dev = img.device
+        if record and self.raw_kp_logits:
+            raise RuntimeError("raw_kp_logits is an inference-only test hook (the losses expect probabilities)")
         self.tape = [] if record else None
+        self.generation += 1
         self.param_grads = {}
         self.nbt = []
+        self.stats_written = False
         if record:
             self.train_steps += 1
-        self.stamp = ("t" if record else "e", self.train_steps)
+        self.stamp = ("t" if record else "e", self.train_steps, ops.PARAM_EPOCH[0])
         self.prepare_all(record)
-        x8 = Var(ops.img_pack(img), 8, relu=False, req=False)
+        pt = self.pt
+        x8 = Var(ops.img_pack(img, pt), 8, relu=False, req=False)
         dims = [(H, W)]
         # c0 branch (KGnet.py:276): both convs at full resolution; c0 lands in cat0[:, 64:128]
-        cat0 = torch.empty(N * H * W, 128, dtype=BF16, device=dev)
+        cat0 = ops.alloc_pt(N * H * W, 128, pt, dev)
         c0a, _, _ = self.conv(x8, self.spec("c0_conv.0", 3, 64, 3, 1, 1), N, H, W, True)
-        c0, _, _ = self.conv(c0a, self.spec("c0_conv.2", 64, 64, 3, 1, 1), N, H, W, True, out=cat0[:, 64:128])
+        c0, _, _ = self.conv(c0a, self.spec("c0_conv.2", 64, 64, 3, 1, 1), N, H, W, True, out=cat0.cols(64, 128))
         # stem (KGnet.py:278-282)
         s1, H1, W1 = self.conv(x8, self.spec("conv1", 3, 64, 7, 2, 3, bias=False), N, H, W, False)
-        cat1 = torch.empty(N * H1 * W1, 128, dtype=BF16, device=dev)
-        c1 = self.bn(s1, "bn1", True, out=cat1[:, 64:128])
+        cat1 = ops.alloc_pt(N * H1 * W1, 128, pt, dev)
+        c1 = self.bn(s1, "bn1", True, out=cat1.cols(64, 128))
         f, Hc, Wc = self.maxpool(c1, N, H1, W1)
         dims.append((H1, W1))
         feats = [c0, c1]
@@ -330,9 +386,9 @@ class Engine:
                 Ho, Wo = (Hc - 1) // st + 1, (Wc - 1) // st + 1
                 out = None
                 if b == blocks - 1 and li < 2:  # c2 / c3 land in their concat buffers
-                    catb = torch.empty(N * Ho * Wo, planes * 8, dtype=BF16, device=dev)
+                    catb = ops.alloc_pt(N * Ho * Wo, planes * 8, pt, dev)
                     cats.append(catb)
-                    out = catb[:, planes * 4:planes * 8]
+                    out = catb.cols(planes * 4, planes * 8)
                 f, Hc, Wc = self.bottleneck(f, f"{name}.{b}", N, Hc, Wc, inplanes if b == 0 else planes * 4, planes, st, b == 0, out=out)
             feats.append(f)
             dims.append((Hc, Wc))
@@ -345,7 +401,7 @@ class Engine:
             cin, cu = up_ch[lvl]
             u_in = self.upsample(cur, N, IH, IW, OH, OW)
             buf = cats[lvl]
-            u, _, _ = self.conv(u_in, self.spec(f"c{lvl + 1}_up_conv.0", cin, cu, 3, 1, 1), N, OH, OW, True, out=buf[:, 0:cu])
+            u, _, _ = self.conv(u_in, self.spec(f"c{lvl + 1}_up_conv.0", cin, cu, 3, 1, 1), N, OH, OW, True, out=buf.cols(0, cu))
             cv = self.concat(buf, [u, feats[lvl]])
             cur, _, _ = self.conv(cv, self.spec(f"c{lvl}_cat_refine.0", buf.shape[1], cu, 1), N, OH, OW, True)
             catv[lvl] = cur
@@ -356,12 +412,14 @@ class Engine:
             C = arch.HEAD_CH[lvl]
             Hh, Wh = dims[lvl]
             fused = [f"{h}_head_c{lvl}.0" for h, _ in arch.HEADS]
-            hid, _, _ = self.conv(catv[lvl], self.spec(f"heads_c{lvl}.0", C, C, 7, 1, 3, fused=fused), N, Hh, Wh, True)
+            hid, _, _ = self.conv(catv[lvl], self.spec(f"heads_c{lvl}.0", C, C, 7, 1, 3, fused=fused, P=self.ph), N, Hh, Wh, True)
             outs = self.heads_second(hid, lvl, C, N, Hh, Wh)
             maps.extend(outs)
         if self.nbt:
             torch._foreach_add_(self.nbt, 1)
             self.nbt = []
+        if self.stats_written:
+            ops.PARAM_EPOCH[0] += 1      # the running statistics moved: folded eval-mode scale / shift copies are stale
         self.feats, self.dims, self.N, self.maps = feats, dims, N, maps
         return maps, feats, dims
 
@@ -384,7 +442,8 @@ class Engine:
         """Packed weights of the second-layer head convs of level lvl: forward (virtual-cout layout, + bias64) and, when
         training, the block-structured transposed matrix of the fused input gradient."""
         self.heads2_seen[lvl] = (C, dev)
-        specs = [self.spec(f"{h}_head_c{lvl}.2", C, co, 7, 1, 3) for h, co in arch.HEADS]
+        ph = self.ph
+        specs = [self.spec(f"{h}_head_c{lvl}.2", C, co, 7, 1, 3, P=ph) for h, co in arch.HEADS]
         ws = [self.P(s.names[0] + ".weight") for s in specs]
         bs = [self.P(s.names[0] + ".bias") for s in specs]
         ver = self.stamp + tuple(t._version for t in ws + bs) + tuple(t.data_ptr() for t in ws + bs)
@@ -392,9 +451,9 @@ class Engine:
         ent = self.fusedT.get(key)
         if ent is None or ent[0] != ver or ent[1].buf.device != dev:
             lay = self.heads2_tables(dev)
-            pwF = ent[1] if ent is not None and ent[1].buf.device == dev else PackedWeight(64, 49, 3 * C, dev)
+            pwF = ent[1] if ent is not None and ent[1].buf.device == dev else PackedWeight(64, 49, C, dev, xP=ph, wP=ph, groups=3)
             for k, w in enumerate(ws):
-                pwF.pack_rows(w.detach(), lay["rows"][k], c0=k * C)
+                pwF.pack_rows(w.detach(), lay["rows"][k], group=k)
             bias64 = torch.cat([b.detach() for b in bs] + [lay["zero1"]])[lay["bias_idx"]]
             self.fusedT[key] = (ver, pwF, bias64)
         _, pwF, bias64 = self.fusedT[key]
@@ -404,7 +463,7 @@ class Engine:
             ent = self.fusedT.get(key)
             ver = self.stamp + tuple(w._version for w in ws) + tuple(w.data_ptr() for w in ws)
             if ent is None or ent[0] != ver or ent[1].buf.device != dev:
-                pwT = ent[1] if ent is not None and ent[1].buf.device == dev else PackedWeight(3 * C, 49, 64, dev)
+                pwT = ent[1] if ent is not None and ent[1].buf.device == dev else PackedWeight(3 * C, 49, 64, dev, xP=ph, wP=ph)
                 for k, w in enumerate(ws):
                     pwT.pack(w.detach(), row0=k * C, c0=self.HEAD_OFF[k], transposed=True)
                 self.fusedT[key] = (ver, pwT)
@@ -419,55 +478,68 @@ class Engine:
         runs on the fast LDS-halo kernel instead of three tiny-K gather convs."""
         dev = hid.t.device
         train = self.tape is not None
-        specs = [self.spec(f"{h}_head_c{lvl}.2", C, co, 7, 1, 3) for h, co in arch.HEADS]
+        specs = [self.spec(f"{h}_head_c{lvl}.2", C, co, 7, 1, 3, P=self.ph) for h, co in arch.HEADS]
         pwF, bias64, pwT = self.prepare_heads2(lvl, C, dev, train)
         outs = [torch.empty(N, co, H, W, dtype=torch.float32, device=dev) for _, co in arch.HEADS]
-        ops.conv_halo_heads2(hid.t, pwF, bias64, self.heads2_tables(dev)["vmap"], outs[0], outs[1], outs[2], N, H, W, C)
+        ops.conv_halo_heads2(hid.t, pwF, bias64, self.heads2_tables(dev)["vmap"], outs[0], outs[1], outs[2], N, H, W, C,
+                             kp_sigmoid=not self.raw_kp_logits)
         slot = {"grad": None}
         self.head_slots.append((slot, lvl, N, H, W))
         if train:
             geom = (N * H * W, H, W, H, W, 7, 7, 1, 3)
 
             def bwd():
-                g = slot["grad"]      # [rows, 64] packed map gradients (set by backward_dec)
+                g = slot["grad"]      # PT [rows, 64] packed map gradients (set by backward_dec)
                 if g is None:
                     return
                 for k, ((h, co), s) in enumerate(zip(arch.HEADS, specs)):
-                    gk = g[:, self.HEAD_OFF[k]:self.HEAD_OFF[k] + self.HEAD_PAD[k]]
+                    gk = g.cols(self.HEAD_OFF[k], self.HEAD_OFF[k] + self.HEAD_PAD[k])
                     w = self.P(s.names[0] + ".weight")
                     gw = torch.empty_like(w)
                     db = torch.empty(co, dtype=torch.float32, device=dev)      # bias gradient: a free unit of the wgrad kernel
-                    ops.conv_wgrad(hid.t[:, k * C:(k + 1) * C], gk, C, co, geom, [(gw, 0, co)], N=N, bias_out=db)
+                    ops.conv_wgrad(hid.t.cols(k * C, (k + 1) * C), gk, C, co, geom, [(gw, 0, co)], N=N, bias_out=db)
                     self.param_grads[s.names[0] + ".weight"] = gw
                     self.param_grads[s.names[0] + ".bias"] = db
-                dh = torch.empty(hid.rows, 3 * C, dtype=BF16, device=dev)
+                dh = ops.alloc_pt(hid.rows, 3 * C, hid.P, dev)
                 # kp / short cout blocks only see dY channels 0..23 (k-step 1 of the chunk skipped); mid sees 24..63
-                ops.conv_halo(g, pwT, 2 * C, N, H, W, 7, y=dh[:, :2 * C], mask=hid.t[:, :2 * C], flip=True, k1skip=True, algo_cin=7.5)
-                ops.conv_halo(g, pwT.rows_from(2 * C), C, N, H, W, 7, y=dh[:, 2 * C:], mask=hid.t[:, 2 * C:], flip=True, algo_cin=40)
+                ops.conv_halo(g, pwT, 2 * C, N, H, W, 7, y=dh.cols(0, 2 * C), mask=hid.t.hi()[:, :2 * C], flip=True, k1skip=True, algo_cin=7.5)
+                ops.conv_halo(g, pwT.rows_from(2 * C), C, N, H, W, 7, y=dh.cols(2 * C, 3 * C), mask=hid.t.hi()[:, 2 * C:], flip=True, algo_cin=40)
                 hid.add_grad(dh, masked=True)
             self.tape.append(bwd)
         return outs
 
+    def export_feats(self):
+        """c0..c4 as the reference returns them (KGnet.py:318): fp32, NCHW-shaped (channels-last memory)."""
+        outs = []
+        for fv, (h, w) in zip(self.feats, self.dims):
+            o = torch.empty(fv.rows, fv.C, dtype=torch.float32, device=fv.t.device)
+            ops.planes_to_f32(fv.t, fv.C, o)
+            outs.append(o.view(self.N, h, w, fv.C).permute(0, 3, 1, 2))
+        return outs
+
     def backward_dec(self, map_grads, feat_grads):
-        """map_grads: 12 fp32 NCHW (or None); feat_grads: 5 bf16 rows tensors (or None)."""
+        """map_grads: 12 fp32 NCHW (or None); feat_grads: 5 fp32 [rows, C] tensors (or None)."""
         for (slot, lvl, N, Hh, Wh) in self.head_slots:
             gs = map_grads[3 * lvl:3 * lvl + 3]
             if all(g is None for g in gs):
                 continue
             dev = self.maps[3 * lvl].device
-            packed = torch.empty(N * Hh * Wh, 64, dtype=BF16, device=dev)
+            packed = ops.alloc_pt(N * Hh * Wh, 64, self.ph, dev)
             for k, g in enumerate(gs):
                 co = arch.HEADS[k][1]
-                view = packed[:, self.HEAD_OFF[k]:self.HEAD_OFF[k] + self.HEAD_PAD[k]]
+                view = packed.cols(self.HEAD_OFF[k], self.HEAD_OFF[k] + self.HEAD_PAD[k])
                 if g is None:
-                    view.zero_()
+                    for p in range(view.P):
+                        view.plane(p).zero_()
                 else:
                     prob = self.maps[3 * lvl] if k == 0 else None
                     ops.grad_pack(g.contiguous().float(), prob, view, N, co, Hh, Wh, self.HEAD_PAD[k])
             slot["grad"] = packed
         for fv, g in zip(self.feats, feat_grads):
             if g is not None:
-                fv.add_grad(g, masked=False)
+                gp = ops.alloc_pt(fv.rows, fv.C, fv.P, g.device)
+                ops.f32_to_planes(g, gp, fv.C)
+                fv.add_grad(gp, masked=False)
         hook = self.grad_hook
         for fn in reversed(self.tape):
             n0 = len(self.param_grads)

@@ -13,6 +13,7 @@ from ._lib import c_int, c_long, c_float, c_double, ptr, stream_ptr
 
 BF16 = torch.bfloat16
 _scratch = {}
+PARAM_EPOCH = [0]      # bumped whenever parameters / running statistics are written behind PyTorch's version counters (engine.prepare)
 
 
 def scratch_f32(nfloats, dev, tag="default"):
@@ -35,13 +36,85 @@ def h2d(arr, dev):
     return st.to(dev, non_blocking=True)
 
 
+class PT:
+    """Rows tensor in split-bf16 storage (csrc/kg_common.h "planes"): value = sum of P bf16 planes.  `t` is the [rows, C] view
+    of plane 0 (row stride ld, possibly a column slice of a wider buffer); plane p starts `ps` elements after plane p-1.
+    Every wrapper below takes a plain bf16 tensor (P = 1) or a PT for its rows operands."""
+    __slots__ = ("t", "P", "ps")
+
+    def __init__(self, t, P=1, ps=0):
+        self.t, self.P, self.ps = t, P, (ps if P > 1 else 0)
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def cols(self, a, b):
+        return PT(self.t[:, a:b], self.P, self.ps)
+
+    def rows(self, a, b=None):
+        return PT(self.t[a:b], self.P, self.ps)
+
+    def hi(self):
+        """plane 0 alone: the bf16 rounding of the value (what a single-plane consumer multiplies)"""
+        return self.t
+
+    def plane(self, p):
+        return self.t.as_strided(self.t.shape, self.t.stride(), self.t.storage_offset() + p * self.ps)
+
+
+def alloc_pt(rows, C, P, dev, zero=False):
+    """[rows, C] in P planes: one [rows, P*C] buffer, plane p = columns p*C .. (p+1)*C."""
+    buf = (torch.zeros if zero else torch.empty)(rows, P * C, dtype=BF16, device=dev)
+    return PT(buf[:, :C], P, C)
+
+
+def base(x):
+    return x.t if isinstance(x, PT) else x
+
+
+def nplanes(x):
+    return (x.P, x.ps) if isinstance(x, PT) else (1, 0)
+
+
+class _Planes(_lib.ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("a_planes", "a_pstride", "b_planes", "b_pstride", "c_planes", "c_pstride",
+                                     "y_planes", "y_pstride", "w_planes")]
+
+
+_PL_CACHE = {}
+
+
+def pl(a=None, b=None, c=None, y=None, w=1):
+    """kg_planes_t* for a call (None when every operand is single-plane bf16).  a / b / c / y: rows operands (tensor, PT or None)."""
+    key = nplanes(a) + nplanes(b) + nplanes(c) + nplanes(y) + (w,)
+    if key == (1, 0, 1, 0, 1, 0, 1, 0, 1):
+        return None
+    st = _PL_CACHE.get(key)
+    if st is None:
+        st = _lib.ctypes.pointer(_Planes(*key))
+        _PL_CACHE[key] = st
+    return st
+
+
+def vplanes(xP, wP):
+    """number of virtual channel planes of a packed weight = kept products x_i * w_j, i + j < max(xP, wP) (csrc/kg_common.h kg_plane_pairs)"""
+    T = max(xP, wP)
+    return sum(1 for i in range(xP) for j in range(wP) if i + j < T)
+
+
 def _rows(t):
+    t = base(t)
     assert t.dim() == 2 and t.dtype == BF16 and (t.shape[1] == 1 or t.stride(1) == 1), (t.shape, t.stride(), t.dtype)
     return t
 
 
 def ld(t):
-    return t.stride(0)
+    return base(t).stride(0)
 
 
 def round_up(a, b):
@@ -58,12 +131,12 @@ class PackQueue:
         self.jobs, self.keep = [], []
         self.sig, self.table = None, None
 
-    def add(self, w, pw, row0, c0, transposed, rowmap):
+    def add(self, w, pw, row0, c0, transposed, rowmap, tap_stride=0):
         Cout, Cin, KH, KW = w.shape
         gx = (Cout + 63) // 64 if transposed else Cout
         gy = Cin if transposed else (Cin + 63) // 64
         self.jobs.append((w.data_ptr(), pw.buf.data_ptr(), rowmap.data_ptr() if rowmap is not None else 0, Cout, Cin, KH * KW,
-                          pw.K, pw.cin_pad, row0, c0, 1 if transposed else 0, gx, gx * gy))
+                          pw.K, pw.cin_pad, row0, c0, 1 if transposed else 0, gx, gx * gy, pw.xP, pw.wP, tap_stride))
         self.keep.append((w, pw, rowmap))
 
     def flush(self):
@@ -71,11 +144,11 @@ class PackQueue:
             return
         import numpy as np
         dt = np.dtype([("w", "<u8"), ("dst", "<u8"), ("rowmap", "<u8")] + [(n, "<i4") for n in
-                      ("Cout", "Cin", "taps", "K", "cin_pad", "row0", "c0", "transposed", "gx", "blk0")])
+                      ("Cout", "Cin", "taps", "K", "cin_pad", "row0", "c0", "transposed", "gx", "blk0", "xP", "wP", "tap_stride", "pad_")])
         arr = np.zeros(len(self.jobs), dt)
         blk = 0
         for i, j in enumerate(self.jobs):
-            arr[i] = j[:12] + (blk,)
+            arr[i] = j[:12] + (blk,) + j[13:16] + (0,)
             blk += j[12]
         dev = self.keep[0][0].device
         sig = arr.tobytes()
@@ -90,39 +163,47 @@ PACKQ = PackQueue()
 
 
 class PackedWeight:
-    """bf16 [rows_pad][K] matrix for kg_conv2d_igemm: K = taps * cin_pad (padded to 64)."""
+    """bf16 [rows_pad][K] matrix for the conv kernels: K = taps * vplanes * cin_pad (padded to 64).  xP / wP: split-bf16 planes of
+    the activations it multiplies / of the weights themselves (csrc/kg_common.h): per tap the row holds the virtual channels
+    of the kept products x_i * w_j (smallest first), a copy of w plane j of cin_pad channels each; groups > 1: that many such blocks side by side
+    (the fused second-layer heads), tap stride = groups * vplanes * cin_pad."""
 
-    def __init__(self, rows, taps, cin_pad, dev):
-        self.rows, self.taps, self.cin_pad = rows, taps, cin_pad
-        self.K = round_up(taps * cin_pad, 64)
+    def __init__(self, rows, taps, cin_pad, dev, xP=1, wP=1, groups=1):
+        self.rows, self.taps, self.cin_pad, self.xP, self.wP, self.groups = rows, taps, cin_pad, xP, wP, groups
+        self.vp = vplanes(xP, wP)
+        self.tap_stride = groups * self.vp * cin_pad
+        self.K = round_up(taps * self.tap_stride, 64)
         self.buf = torch.zeros(round_up(rows, 384), self.K, dtype=BF16, device=dev)   # rows cover any 64/128/192 cout tile
 
     def pack(self, w, row0=0, c0=0, transposed=False):
         """w: fp32 OIHW parameter.  forward: rows=Cout, channels=Cin; transposed (dgrad): rows=Cin, channels=Cout."""
         Cout, Cin, KH, KW = w.shape
         assert w.dtype == torch.float32 and w.is_contiguous()
+        assert self.groups == 1
         if PACKQ.defer:
             PACKQ.add(w, self, row0, c0, transposed, None)
             return
         _lib.call("kg_pack_weight", ptr(w), ptr(self.buf), Cout, Cin, KH, KW, self.K, self.cin_pad, row0, c0,
-                  1 if transposed else 0, stream_ptr())
+                  1 if transposed else 0, self.xP, self.wP, stream_ptr())
 
 
     def rows_from(self, r0):
         """View of the packed matrix starting at row r0 (a cout-block-aligned slice of a fused weight)."""
         v = PackedWeight.__new__(PackedWeight)
         v.rows, v.taps, v.cin_pad, v.K, v.buf = self.rows - r0, self.taps, self.cin_pad, self.K, self.buf[r0:]
+        v.xP, v.wP, v.groups, v.vp, v.tap_stride = self.xP, self.wP, self.groups, self.vp, self.tap_stride
         return v
 
-    def pack_rows(self, w, rowmap, c0=0):
-        """forward packing of w (fp32 OIHW) with output channel co going to packed row rowmap[co] (device int32)."""
+    def pack_rows(self, w, rowmap, group=0):
+        """forward packing of w (fp32 OIHW) into plane group `group`, output channel co going to packed row rowmap[co] (device int32)."""
         Cout, Cin, KH, KW = w.shape
         assert w.dtype == torch.float32 and w.is_contiguous() and rowmap.dtype == torch.int32 and rowmap.numel() == Cout
+        c0 = group * self.vp * self.cin_pad
         if PACKQ.defer:
-            PACKQ.add(w, self, 0, c0, False, rowmap)
+            PACKQ.add(w, self, 0, c0, False, rowmap, self.tap_stride)
             return
         _lib.call("kg_pack_weight_rows", ptr(w), ptr(self.buf), Cout, Cin, KH, KW, self.K, self.cin_pad, ptr(rowmap), c0,
-                  stream_ptr())
+                  self.xP, self.wP, self.tap_stride, stream_ptr())
 
 
 def heads2_layout():
@@ -139,14 +220,14 @@ def heads2_layout():
     return rows, vmap
 
 
-def conv_halo_heads2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C):
+def conv_halo_heads2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C, kp_sigmoid=True):
     """kg_conv2d_halo_heads2: x = fused hidden rows [N*H*W, >=3C]; kp/sh/md fp32 NCHW outputs (kp gets the sigmoid)."""
     if PACKQ.jobs:
         PACKQ.flush()
-    _rows(x)
     assert kp.is_contiguous() and sh.is_contiguous() and md.is_contiguous() and vmap.dtype == torch.int32
-    _lib.call("kg_conv2d_halo_heads2", ptr(x), ptr(pw.buf), ptr(bias64), ptr(vmap), ptr(kp), ptr(sh), ptr(md), N, H, W, C,
-              ld(x), pw.K, stream_ptr())
+    assert nplanes(x)[0] == pw.xP and pw.groups == 3
+    _lib.call("kg_conv2d_halo_heads2", ptr(_rows(x)), ptr(pw.buf), ptr(bias64), ptr(vmap), ptr(kp), ptr(sh), ptr(md), N, H, W, C,
+              ld(x), pw.K, 1 if kp_sigmoid else 0, pl(a=x, w=pw.wP), stream_ptr())
 
 
 def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, mode=0,
@@ -155,15 +236,15 @@ def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=
     if PACKQ.jobs:
         PACKQ.flush()
     M, H, W, OH, OW, KH, KW, stride, pad = geom
-    _rows(x)
+    assert nplanes(x)[0] == pw.xP, (nplanes(x), pw.xP)
     f32_C = 0
     if y_f32 is not None:
         assert y_f32.dtype == torch.float32 and y_f32.is_contiguous()
         f32_C = y_f32.shape[1] if y_f32.dim() == 4 else 1
-    _lib.call("kg_conv2d_igemm", ptr(x), ptr(pw.buf), ptr(bias), ptr(y), ptr(y_f32), ptr(res), ptr(mask), ptr(rowdesc),
+    _lib.call("kg_conv2d_igemm", ptr(_rows(x)), ptr(pw.buf), ptr(bias), ptr(base(y)), ptr(y_f32), ptr(base(res)), ptr(base(mask)), ptr(rowdesc),
               M, H, W, OH, OW, pw.cin_pad, ld(x), cout, ld(y) if y is not None else 0,
               ld(res) if res is not None else 0, ld(mask) if mask is not None else 0, pw.K, KH, KW, stride, pad, 1,
-              mode, 1 if relu else 0, f32_C, tile, stream_ptr())
+              mode, 1 if relu else 0, f32_C, tile, pl(a=x, b=res, y=y, w=pw.wP), stream_ptr())
 
 
 USE_HALO = True
@@ -183,7 +264,10 @@ def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None,
     algo_cin: number of input channels that carry data (FLOP accounting of bench.py's timer; unused here)."""
     if PACKQ.jobs:
         PACKQ.flush()
-    if (USE_C3 and KS == 3 and pw.cin_pad == 64 and y is not None and y_f32 is None and wc == 0 and HALO_WC == 0
+    assert nplanes(x)[0] == pw.xP, (nplanes(x), pw.xP)
+    planes = pl(a=x, b=res, y=y, w=pw.wP)
+    x, y, res, mask = base(x), base(y), base(res), base(mask)
+    if (USE_C3 and planes is None and KS == 3 and pw.cin_pad == 64 and y is not None and y_f32 is None and wc == 0 and HALO_WC == 0
             and (tiletab is None or tiletab16 is not None)):
         # 64 input channels: persistent kernel with resident weights and double-buffered halos (conv3_c64.hip)
         if PACKQ.jobs:
@@ -202,7 +286,7 @@ def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None,
     _lib.call("kg_conv2d_halo", ptr(_rows(x)), ptr(pw.buf), ptr(bias), ptr(y), ptr(y_f32), ptr(res), ptr(mask), N, H, W,
               pw.cin_pad, ld(x), cout, ld(y) if y is not None else 0, ld(res) if res is not None else 0,
               ld(mask) if mask is not None else 0, pw.K, KS, 1 if flip else 0, 1 if relu else 0, f32_C, wc, ptr(tiletab),
-              tiletab.shape[0] if tiletab is not None else 0, total_rows, stream_ptr())
+              tiletab.shape[0] if tiletab is not None else 0, total_rows, planes, stream_ptr())
 
 
 USE_1X1 = True
@@ -210,15 +294,19 @@ GATHER_1X1 = __import__("os").environ.get("KG_GATHER_1X1", "1") == "1"
 
 
 def conv1x1(x, pw, cout, y, bias=None, res=None, mask=None, relu=False):
-    """1x1 stride-1 conv / input gradient as a streaming GEMM over the rows of x (kg_conv1x1)."""
+    """1x1 stride-1 conv / input gradient as a streaming GEMM over the rows of x (kg_conv1x1); single-plane bf16 only."""
     if PACKQ.jobs:
         PACKQ.flush()
+    assert pw.vp == 1 and all(nplanes(t)[0] == 1 for t in (x, y, res))
+    x, y, res, mask = base(x), base(y), base(res), base(mask)
     _lib.call("kg_conv1x1", ptr(_rows(x)), ptr(pw.buf), ptr(bias), ptr(_rows(y)), ptr(res), ptr(mask), c_long(x.shape[0]),
               pw.cin_pad, pw.K, ld(x), cout, ld(y), ld(res) if res is not None else 0, ld(mask) if mask is not None else 0,
               1 if relu else 0, stream_ptr())
 
 
-def can_1x1(x, pw, KH, stride, pad, y, y_f32):
+def can_1x1(x, pw, KH, stride, pad, y, y_f32, res=None):
+    if pw.vp > 1 or any(nplanes(t)[0] > 1 for t in (x, y, res)):
+        return False      # split-bf16 planes: the gather kernel (conv_gather.hip) walks the virtual channels
     if GATHER_1X1 and pw.cin_pad >= 192 and pw.rows > 64:
         return False      # compute-heavy 1x1 (K >= 192, Cout > 64): the LDS-ring gather kernel (conv_gather.hip) is faster
     return (USE_1X1 and KH == 1 and stride == 1 and pad == 0 and y is not None and y_f32 is None and pw.cin_pad % 64 == 0
@@ -230,10 +318,10 @@ def conv_auto(x, pw, cout, geom, N, y=None, y_f32=None, bias=None, res=None, mas
     "same" 3x3/7x7 convs over 64-channel-aligned inputs, else the gather implicit GEMM."""
     M, H, W, OH, OW, KH, KW, stride, pad = geom
     if (USE_HALO and stride == 1 and KH == KW and KH in (3, 7) and pad == KH // 2 and pw.cin_pad % 64 == 0
-            and x.shape[1] >= pw.cin_pad):
+            and x.shape[1] >= pw.cin_pad and not (y_f32 is not None and (res is not None or mask is not None))):
         conv_halo(x, pw, cout, N, OH, OW, KH, y=y, y_f32=y_f32, bias=bias, res=res, mask=mask, relu=relu, flip=transposed)
         return "halo"
-    if KH == KW and can_1x1(x, pw, KH, stride, pad, y, y_f32):
+    if KH == KW and can_1x1(x, pw, KH, stride, pad, y, y_f32, res):
         conv1x1(x, pw, cout, y, bias=bias, res=res, mask=mask, relu=relu)
         return "1x1"
     conv_igemm(x, pw, cout, geom, y=y, y_f32=y_f32, bias=bias, res=res, mask=mask, relu=relu, mode=1 if transposed else 0, tile=tile)
@@ -268,51 +356,69 @@ def halo_wgrad_splits(nblk, tiles, cit, taps, nelem, cus=256):
     return best
 
 
+def wgrad_pairs(x, dy):
+    """(x plane, dY plane) products of a weight gradient over split-bf16 operands: i + j < max(xP, dP)."""
+    xP, dP = nplanes(x)[0], nplanes(dy)[0]
+    T = max(xP, dP)
+    return sorted(((i, j) for j in range(dP) for i in range(xP) if i + j < T), key=lambda p: -(p[0] + p[1]))      # smallest products first
+
+
 def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=False, N=None, tiletab16=None, bias_out=None):
     """grads: list of (fp32 OIHW grad tensor, cout_offset, cout_count) sharing x (fused heads) or one entry.
     Dense stride-1 "same" 3x3/7x7 convs (N given) use the LDS-halo kernel, everything else the gather kernel.
     bias_out (fp32 [cout], optional): receives the bias gradient (sum of dy over rows) -- for free inside the halo kernel
-    (one more all-ones unit on a wave with an idle unit slot), with kg_bias_grad otherwise."""
+    (one more all-ones unit on a wave with an idle unit slot), with kg_bias_grad otherwise.
+    x / dy may be split-bf16 (PT): every kept plane product is one more set of pixel-split partials for the fixed-order reduction."""
     M, H, W, OH, OW, KH, KW, stride, pad = geom
-    _rows(x); _rows(dy)
-    if IM2COL_WGRAD and mode == 0 and N is not None and cin <= 4 and KH * KW >= 25 and len(grads) == 1 and not accumulate:
+    pairs = wgrad_pairs(x, dy)
+    xps, dps = nplanes(x)[1], nplanes(dy)[1]
+    planed = len(pairs) > 1 or nplanes(x)[0] > 1 or nplanes(dy)[0] > 1
+    xb, dyb = _rows(x), _rows(dy)
+    if IM2COL_WGRAD and not planed and mode == 0 and N is not None and cin <= 4 and KH * KW >= 25 and len(grads) == 1 and not accumulate:
         # stem conv1 (3 -> 64, 7x7 s2): im2col to [M][taps*cin] and ONE 1x1 weight-gradient GEMM instead of 49 per-tap launches
         # that pad 3 channels to a 64-wide tile
         Kc = KH * KW * cin
         Kpad = round_up(Kc, 8)
-        col = torch.zeros(M, Kpad, dtype=BF16, device=x.device) if Kpad != Kc else torch.empty(M, Kpad, dtype=BF16, device=x.device)
-        _lib.call("kg_im2col_small", ptr(x), ptr(col), N, H, W, OH, OW, KH, KW, stride, pad, cin, ld(x), Kpad, stream_ptr())
+        col = torch.zeros(M, Kpad, dtype=BF16, device=xb.device) if Kpad != Kc else torch.empty(M, Kpad, dtype=BF16, device=xb.device)
+        _lib.call("kg_im2col_small", ptr(xb), ptr(col), N, H, W, OH, OW, KH, KW, stride, pad, cin, ld(xb), Kpad, stream_ptr())
         g, off, cnt = grads[0]
-        tmp = torch.empty(cout, Kc, 1, 1, dtype=torch.float32, device=x.device)
-        conv_wgrad(col, dy, Kc, cout, (M, OH, OW, OH, OW, 1, 1, 1, 0), [(tmp, off, cnt)])
+        tmp = torch.empty(cout, Kc, 1, 1, dtype=torch.float32, device=xb.device)
+        conv_wgrad(col, dyb, Kc, cout, (M, OH, OW, OH, OW, 1, 1, 1, 0), [(tmp, off, cnt)])
         g.copy_(tmp.view(cnt, KH * KW, cin).permute(0, 2, 1).reshape(g.shape))     # [co][tap][ci] -> OIHW
         if bias_out is not None:
-            bias_grad(dy, cout, bias_out)
+            bias_grad(dyb, cout, bias_out)
         return "im2col"
-    cin_lim = min(round_up(cin, 8), x.shape[1])
-    cout_lim = min(round_up(cout, 8), dy.shape[1])
+    cin_lim = min(round_up(cin, 8), xb.shape[1])
+    cout_lim = min(round_up(cout, 8), dyb.shape[1])
     nelem = cout * KH * KW * cin
     halo = (USE_HALO and stride == 1 and KH == KW and KH in (3, 7) and pad == KH // 2
             and ((mode == 0 and N is not None) or (mode == 2 and tiletab16 is not None)))
+    np_ = len(pairs)
     if halo:
-        cit = (32 if (cout_lim <= 16 and cin_lim >= 32 and bias_out is not None) else 16) if KH == 7 else 64   # input channels per workgroup (wgrad_halo.hip)
+        cit = (32 if (cout_lim <= 16 and cin_lim >= 32 and bias_out is not None and not planed) else 16) if KH == 7 else 64   # input channels per workgroup (wgrad_halo.hip)
         nblk = math.ceil(cin_lim / cit) * math.ceil(cout_lim / 64)
         tiles = tiletab16.shape[0] if tiletab16 is not None else N * math.ceil(H / 16) * math.ceil(W / 16)
-        S = halo_wgrad_splits(nblk, tiles, cit, KH * KW, nelem)
-        part = scratch_f32(S * nelem, x.device, "wgrad")
-        dbp = scratch_f32(S * cout, x.device, "wgrad_bias") if (bias_out is not None and KH == 7) else None
-        wgrad_halo(x, dy, part, N or 0, H, W, cin, cout, cin_lim, cout_lim, KH, S, nelem, tiletab16, dbp)
+        S = halo_wgrad_splits(nblk * np_, tiles, cit, KH * KW, nelem * np_)
+        part = scratch_f32(S * np_ * nelem, xb.device, "wgrad")
+        fused_bias = bias_out is not None and KH == 7 and not planed
+        dbp = scratch_f32(S * cout, xb.device, "wgrad_bias") if fused_bias else None
+        for k, (i, j) in enumerate(pairs):
+            _lib.call("kg_conv2d_wgrad_halo", ctypes_offset(xb, i * xps), ctypes_offset(dyb, j * dps), ctypes_offset(part, k * S * nelem),
+                      N or 0, H, W, ld(xb), ld(dyb), cin, cout, cin_lim, cout_lim, KH, S, c_long(nelem), ptr(tiletab16),
+                      tiletab16.shape[0] if tiletab16 is not None else 0, ptr(dbp), stream_ptr())
         if dbp is not None:
             _lib.call("kg_bias_grad_final", ptr(dbp), ptr(bias_out), S, cout, 1 if accumulate else 0, stream_ptr())
         elif bias_out is not None:       # 3x3: the extra accumulators would spill in that kernel variant
             bias_grad(dy, cout, bias_out, accumulate=accumulate)
     else:
-        S = wgrad_splits(M, cin_lim, cout_lim, KH * KW, nelem)
-        part = scratch_f32(S * nelem, x.device, "wgrad")
-        _lib.call("kg_conv2d_wgrad", ptr(x), ptr(dy), ptr(part), ptr(rowdesc), M, H, W, OH, OW, ld(x), ld(dy), cin, cout,
-                  cin_lim, cout_lim, KH, KW, stride, pad, 1, mode, S, c_long(nelem), stream_ptr())
+        S = wgrad_splits(M, cin_lim, cout_lim, KH * KW * np_, nelem * np_)
+        part = scratch_f32(S * np_ * nelem, xb.device, "wgrad")
+        for k, (i, j) in enumerate(pairs):
+            _lib.call("kg_conv2d_wgrad", ctypes_offset(xb, i * xps), ctypes_offset(dyb, j * dps), ctypes_offset(part, k * S * nelem), ptr(rowdesc),
+                      M, H, W, OH, OW, ld(xb), ld(dyb), cin, cout, cin_lim, cout_lim, KH, KW, stride, pad, 1, mode, S, c_long(nelem), stream_ptr())
         if bias_out is not None:
             bias_grad(dy, cout, bias_out, accumulate=accumulate)
+    S *= np_
     contiguous = all(grads[i][1] + grads[i][2] == grads[i + 1][1] for i in range(len(grads) - 1))
     if 1 < len(grads) <= 4 and contiguous:      # heads fused along Cout: one reduction launch for all of them
         import ctypes
@@ -337,27 +443,32 @@ def ctypes_offset(t, elem_off):
 
 
 def bias_grad(dy, C, db, accumulate=False):
-    _rows(dy)
-    sc = scratch_f32(2048 * max(C, 1), dy.device, "bias")
-    _lib.call("kg_bias_grad", ptr(dy), ptr(db), ptr(sc), sc.numel(), dy.shape[0], C, ld(dy), 1 if accumulate else 0, stream_ptr())
+    """db[c] (+)= sum over rows of dy (every plane of a split-bf16 dy is summed in fp32 and added)."""
+    P, ps = nplanes(dy)
+    dyb = _rows(dy)
+    sc = scratch_f32(2048 * max(C, 1), dyb.device, "bias")
+    for p in range(P):
+        _lib.call("kg_bias_grad", ctypes_offset(dyb, p * ps), ptr(db), ptr(sc), sc.numel(), dyb.shape[0], C, ld(dyb),
+                  1 if (accumulate or p > 0) else 0, stream_ptr())
 
 
-def img_pack(img):
+def img_pack(img, P=1):
+    """fp32 NCHW image -> [N*H*W, 8] rows (3 real channels + zero padding) in P planes."""
     N, C, H, W = img.shape
     img = img.contiguous().float()
-    out = torch.empty(N * H * W, 8, dtype=BF16, device=img.device)
-    _lib.call("kg_img_pack", ptr(img), ptr(out), N, C, H, W, stream_ptr())
-    return out
+    out = alloc_pt(N * H * W, 8, P, img.device)
+    _lib.call("kg_img_pack", ptr(img), ptr(out.t), ld(out), N, C, H, W, pl(y=out), stream_ptr())
+    return out if P > 1 else out.t
 
 
 def bn_stats_train(x, C, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5):
     """Returns (mean, invstd, scale, shift) fp32 [C]; updates running stats in place (may be None)."""
-    _rows(x)
-    dev = x.device
+    xb = _rows(x)
+    dev = xb.device
     st = torch.empty(4, C, dtype=torch.float32, device=dev)
     sc = scratch_f32(2 * C * 512, dev, "bn")
-    _lib.call("kg_bn_stats_train", ptr(x), ld(x), x.shape[0], C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
-              c_float(momentum), c_float(eps), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), ptr(sc), sc.numel(), stream_ptr())
+    _lib.call("kg_bn_stats_train", ptr(xb), ld(xb), xb.shape[0], C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+              c_float(momentum), c_float(eps), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), ptr(sc), sc.numel(), pl(a=x), stream_ptr())
     return st[0], st[1], st[2], st[3]
 
 
@@ -368,42 +479,51 @@ def bn_scale_shift_eval(C, gamma, beta, rmean, rvar, eps=1e-5):
 
 
 def bn_apply(x, C, scale, shift, y, res=None, relu=False):
-    _rows(x); _rows(y)
-    _lib.call("kg_bn_apply", ptr(x), ld(x), ptr(scale), ptr(shift), ptr(res), ld(res) if res is not None else 0, ptr(y), ld(y),
-              x.shape[0], C, 1 if relu else 0, stream_ptr())
+    _lib.call("kg_bn_apply", ptr(_rows(x)), ld(x), ptr(scale), ptr(shift), ptr(base(res)), ld(res) if res is not None else 0, ptr(_rows(y)), ld(y),
+              base(x).shape[0], C, 1 if relu else 0, pl(a=x, b=res, y=y), stream_ptr())
 
 
 def bn_bwd(x, dy, C, gamma, mean, invstd, dgamma, dbeta, dx, accumulate=False):
-    _rows(x); _rows(dy); _rows(dx)
-    sc = scratch_f32(2 * C * 512 + 3 * C, x.device, "bn")
-    _lib.call("kg_bn_bwd", ptr(x), ld(x), ptr(dy), ld(dy), ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
-              1 if accumulate else 0, ptr(dx), ld(dx), x.shape[0], C, ptr(sc), sc.numel(), stream_ptr())
+    sc = scratch_f32(2 * C * 512 + 3 * C, base(x).device, "bn")
+    _lib.call("kg_bn_bwd", ptr(_rows(x)), ld(x), ptr(_rows(dy)), ld(dy), ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
+              1 if accumulate else 0, ptr(_rows(dx)), ld(dx), base(x).shape[0], C, ptr(sc), sc.numel(), pl(a=x, b=dy, y=dx), stream_ptr())
 
 
 def maxpool_fwd(x, y, N, H, W, C):
-    _lib.call("kg_maxpool3s2_fwd", ptr(_rows(x)), ld(x), ptr(_rows(y)), ld(y), N, H, W, C, stream_ptr())
+    _lib.call("kg_maxpool3s2_fwd", ptr(_rows(x)), ld(x), ptr(_rows(y)), ld(y), N, H, W, C, pl(a=x, y=y), stream_ptr())
 
 
 def maxpool_bwd(x, dy, dx, N, H, W, C):
-    _lib.call("kg_maxpool3s2_bwd", ptr(_rows(x)), ld(x), ptr(_rows(dy)), ld(dy), ptr(_rows(dx)), ld(dx), N, H, W, C, stream_ptr())
+    _lib.call("kg_maxpool3s2_bwd", ptr(_rows(x)), ld(x), ptr(_rows(dy)), ld(dy), ptr(_rows(dx)), ld(dx), N, H, W, C, pl(a=x, b=dy, y=dx), stream_ptr())
 
 
 def bilinear_fwd(x, y, N, IH, IW, OH, OW, C, boxdesc=None, row2box=None):
-    rows = y.shape[0] if boxdesc is not None else 0
+    rows = base(y).shape[0] if boxdesc is not None else 0
     _lib.call("kg_bilinear_fwd", ptr(_rows(x)), ld(x), ptr(_rows(y)), ld(y), N, IH, IW, OH, OW, C, ptr(boxdesc), ptr(row2box),
-              c_long(rows), stream_ptr())
+              c_long(rows), pl(a=x, y=y), stream_ptr())
 
 
 def bilinear_bwd(dy, dx, N, IH, IW, OH, OW, C, boxdesc=None, row2box=None, mask=None):
-    rows = dx.shape[0] if boxdesc is not None else 0
+    rows = base(dx).shape[0] if boxdesc is not None else 0
     _lib.call("kg_bilinear_bwd", ptr(_rows(dy)), ld(dy), ptr(_rows(dx)), ld(dx), N, IH, IW, OH, OW, C, ptr(boxdesc), ptr(row2box),
-              c_long(rows), ptr(mask), ld(mask) if mask is not None else 0, stream_ptr())
+              c_long(rows), ptr(base(mask)), ld(mask) if mask is not None else 0, pl(a=dy, y=dx), stream_ptr())
 
 
 def add_rows(a, b, y, C, mask=None):
     """y = (a + b) [masked by mask > 0]; b may be None."""
-    _lib.call("kg_add_rows", ptr(_rows(a)), ld(a), ptr(b), ld(b) if b is not None else 0, ptr(mask),
-              ld(mask) if mask is not None else 0, ptr(_rows(y)), ld(y), c_long(a.shape[0]), C, stream_ptr())
+    _lib.call("kg_add_rows", ptr(_rows(a)), ld(a), ptr(base(b)), ld(b) if b is not None else 0, ptr(base(mask)),
+              ld(mask) if mask is not None else 0, ptr(_rows(y)), ld(y), c_long(base(a).shape[0]), C, pl(a=a, b=b, y=y), stream_ptr())
+
+
+def planes_to_f32(x, C, out):
+    """out [rows, C] fp32 (row stride out.stride(0)) = sum of the planes of x."""
+    _lib.call("kg_planes_to_f32", ptr(_rows(x)), ld(x), ptr(out), out.stride(0), c_long(base(x).shape[0]), C, pl(a=x), stream_ptr())
+
+
+def f32_to_planes(acc, y, C, addto=None):
+    """y (planes) = acc [rows, C] fp32 (+ addto planes)."""
+    _lib.call("kg_f32_to_planes", ptr(acc), acc.stride(0), ptr(_rows(y)), ld(y), ptr(base(addto)), ld(addto) if addto is not None else 0,
+              c_long(acc.shape[0]), C, pl(b=addto, y=y), stream_ptr())
 
 
 def sigmoid_(x):
@@ -412,4 +532,4 @@ def sigmoid_(x):
 
 
 def grad_pack(g, prob, out, N, C, H, W, cpad):
-    _lib.call("kg_grad_pack", ptr(g), ptr(prob), ptr(_rows(out)), N, C, H, W, ld(out), cpad, stream_ptr())
+    _lib.call("kg_grad_pack", ptr(g), ptr(prob), ptr(_rows(out)), N, C, H, W, ld(out), cpad, pl(y=out), stream_ptr())

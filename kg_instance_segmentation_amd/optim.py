@@ -66,4 +66,5 @@ class Adam(torch.optim.Optimizer):
                 with torch.cuda.device(dev):
                     _lib.call("kg_adam_step", ptr(ent[1]), len(plist), blk, c_float(beta1), c_float(beta2), c_float(group["eps"]),
                               c_float(group["lr"] / bc1), c_float(math.sqrt(bc2)), c_float(group["weight_decay"]), stream_ptr())
+        ops.PARAM_EPOCH[0] += 1      # raw-pointer writes do not bump tensor versions: packed bf16 weight copies are stale now
         return loss

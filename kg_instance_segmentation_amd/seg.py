@@ -11,7 +11,9 @@ import torch
 
 from . import arch, ops, _lib
 from ._lib import ptr, stream_ptr, c_long
-from .ops import BF16, PackedWeight
+from .ops import BF16, PT, PackedWeight
+
+BIN_SIZE = (16, 16, 8, 4, 4)      # bins of the crop-gradient reduction per pyramid level (box sides halve with every level)
 
 
 def crop_rects(boxes, h0, w0, sizes):
@@ -107,7 +109,15 @@ class SegBranch:
                 self.param_keys += [f"skip_combine.{i}.{sub}.0.weight", f"skip_combine.{i}.{sub}.0.bias"]
         self.param_keys += ["seg_head.0.weight", "seg_head.0.bias", "seg_head.2.weight", "seg_head.2.bias"]
         self.packed = {}
-        self.train_steps, self.stamp = 0, ("e", 0)     # see Engine.prepare: training forwards always repack
+        self.train_steps, self.stamp = 0, ("e", 0, 0)     # see Engine.prepare: training forwards always repack
+
+    @property
+    def P_(self):
+        """planes of the seg branch's activations / weights (engine.PRECISIONS)"""
+        return self.m._engine.pseg
+
+    def invalidate_caches(self):
+        self.packed = {}
 
     def P(self, k):
         return self.m.get_tensor(k)
@@ -128,13 +138,13 @@ class SegBranch:
         e = self.packed.get(key)
         cout, cin, k, _ = w.shape
         if e is None or e["ver"] != ver or e["pw"].buf.device != w.device:
-            pw = e["pw"] if e is not None and e["pw"].buf.device == w.device else PackedWeight(cout, k * k, ops.round_up(cin, 8), w.device)
+            pw = e["pw"] if e is not None and e["pw"].buf.device == w.device else PackedWeight(cout, k * k, ops.round_up(cin, 8), w.device, xP=self.P_, wP=self.P_)
             pw.pack(w.detach())
             e = {"ver": ver, "pw": pw, "pwT": e["pwT"] if e is not None and e["pw"].buf.device == w.device else None, "T_ok": False}
             self.packed[key] = e
         if need_T and not e["T_ok"]:
             if e["pwT"] is None:
-                e["pwT"] = PackedWeight(cin, k * k, ops.round_up(cout, 8), w.device)
+                e["pwT"] = PackedWeight(cin, k * k, ops.round_up(cout, 8), w.device, xP=self.P_, wP=self.P_)
             e["pwT"].pack(w.detach(), transposed=True)
             e["T_ok"] = True
         e["need_T"] = bool(need_T) or e.get("need_T", False)
@@ -207,7 +217,32 @@ class SegBranch:
             np.cumsum(((h + th - 1) // th) * ((w + tw - 1) // tw), out=c[1:])
             return c
         p.t32_cum = [cum(l, 16, 32) for l in range(5)]; p.t16_cum = [cum(l, 16, 16) for l in range(5)]
-        blob = np.concatenate([t.ravel() for t in tabs] + [b.ravel() for b in bil] + [t.ravel() for t in t32] + [t.ravel() for t in t16]).astype(np.int32)
+        # bin grid of the deterministic crop-gradient reduction (kg_crop_grad_reduce): per level, CSR lists of the boxes that
+        # touch each BIN x BIN bin of each image, in ascending box order
+        bin_start, bin_boxes = [], []
+        for l in range(5):
+            nb = p.nb[l]
+            H, W = sizes[l]
+            BS = BIN_SIZE[l]
+            BY, BX = (H + BS - 1) // BS, (W + BS - 1) // BS
+            nbins = p.nimg * BY * BX
+            if nb == 0:
+                bin_start.append(np.zeros(nbins + 1, np.int32)); bin_boxes.append(np.zeros(0, np.int32))
+                continue
+            t = tabs[l]
+            by0, bx0 = t[:, 1] // BS, t[:, 2] // BS
+            nyb = (t[:, 1] + t[:, 3] - 1) // BS - by0 + 1
+            nxb = (t[:, 2] + t[:, 4] - 1) // BS - bx0 + 1
+            cnt = (nyb * nxb).astype(np.int64)
+            b = np.repeat(np.arange(nb), cnt)
+            k = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+            bins = (t[b, 0].astype(np.int64) * BY + by0[b] + k // nxb[b]) * BX + bx0[b] + k % nxb[b]
+            order = np.argsort(bins, kind="stable")
+            st = np.zeros(nbins + 1, np.int64)
+            np.cumsum(np.bincount(bins, minlength=nbins), out=st[1:])
+            bin_start.append(st.astype(np.int32)); bin_boxes.append(b[order].astype(np.int32))
+        blob = np.concatenate([t.ravel() for t in tabs] + [b.ravel() for b in bil] + [t.ravel() for t in t32] + [t.ravel() for t in t16]
+                              + bin_start + bin_boxes).astype(np.int32)
         dblob = ops.h2d(blob, dev)
         off = 0
         p.tab_d, p.bil_d = [], []
@@ -220,6 +255,11 @@ class SegBranch:
             p.t32_d.append(dblob[off:off + t.size].view(-1, 4)); off += t.size
         for t in t16:
             p.t16_d.append(dblob[off:off + t.size].view(-1, 4)); off += t.size
+        p.bin_start_d, p.bin_boxes_d = [], []
+        for t in bin_start:
+            p.bin_start_d.append(dblob[off:off + t.size]); off += t.size
+        for t in bin_boxes:
+            p.bin_boxes_d.append(dblob[off:off + max(t.size, 0)]); off += t.size
         p.rows = [int(p.row0[l][-1]) for l in range(5)]
         p.rowdesc, p.row2box, p.srcrow = [], [], []
         for l in range(5):
@@ -235,16 +275,29 @@ class SegBranch:
     # ---- device work --------------------------------------------------------------------------------
     @staticmethod
     def feat_rows(f):
+        """fp32 [N*H*W, C] rows of a feature map given as the reference gives it (fp32 NCHW, KGnet.py:318); forward_dec's own
+        outputs are channels-last in memory, so this is a view for them."""
         n, c, h, w = f.shape
-        r = f.permute(0, 2, 3, 1)
-        if r.dtype != BF16:
-            r = r.to(BF16)
-        return r.reshape(n * h * w, c) if r.is_contiguous() or r.stride(3) == 1 else r.contiguous().reshape(n * h * w, c)
+        r = f.detach().permute(0, 2, 3, 1)
+        if r.dtype != torch.float32:
+            r = r.float()
+        return r.reshape(n * h * w, c) if r.is_contiguous() else r.contiguous().view(n * h * w, c)
 
     def gather(self, frows, srcrow, dst, nrows, C, row_off=0):
+        """dst (PT rows) = the crop rows of the fp32 feature rows frows"""
         if nrows:
-            _lib.call("kg_rows_gather", ptr(frows), ops.ld(frows), _lib.c_void_p(srcrow.data_ptr() + 4 * row_off),
-                      ptr(dst), ops.ld(dst), c_long(nrows), C, stream_ptr())
+            _lib.call("kg_rows_gather_f32", ptr(frows), frows.stride(0), _lib.c_void_p(srcrow.data_ptr() + 4 * row_off),
+                      ptr(ops.base(dst)), ops.ld(dst), c_long(nrows), C, ops.pl(y=dst), stream_ptr())
+
+    @staticmethod
+    def _head(t, M):
+        """first M rows of a rows tensor (torch tensor or ops.PT)"""
+        if t is None:
+            return None
+        return t.rows(0, M) if isinstance(t, PT) else t[:M]
+
+    def alloc(self, rows, C, dev):
+        return ops.alloc_pt(rows, C, self.P_, dev)
 
     def rconv(self, x, pw, cout, rowdesc, M, k, y=None, y_f32=None, bias=None, relu=False, mask=None, mode=2, tiles=None, tiles16=None):
         """Ragged conv (mode 2) or its input gradient (mode 3).  3x3 convs over 64-channel-aligned inputs run on the
@@ -255,8 +308,8 @@ class SegBranch:
             ops.conv_halo(x, pw, cout, 0, 0, 0, 3, y=y, y_f32=y_f32, bias=bias, relu=relu, mask=mask, flip=(mode == 3),
                           tiletab=tiles, total_rows=M, tiletab16=tiles16)
             return
-        if k == 1 and y is not None and ops.can_1x1(x[:M], pw, 1, 1, 0, y[:M], y_f32):
-            ops.conv1x1(x[:M], pw, cout, y[:M], bias=bias, mask=mask[:M] if mask is not None else None, relu=relu)
+        if k == 1 and y is not None and ops.can_1x1(self._head(x, M), pw, 1, 1, 0, self._head(y, M), y_f32):
+            ops.conv1x1(ops.base(x)[:M], pw, cout, ops.base(y)[:M], bias=bias, mask=mask[:M] if mask is not None else None, relu=relu)
             return
         geom = (M, 0, 0, M, 1, k, k, 1, (k - 1) // 2)
         ops.conv_igemm(x, pw, cout, geom, y=y, y_f32=y_f32, bias=bias, relu=relu, mask=mask, mode=mode, rowdesc=rowdesc)
@@ -275,41 +328,42 @@ class SegBranch:
             return torch.zeros(0, dtype=torch.float32, device=dev), None
         if record:
             self.train_steps += 1
-        self.stamp = ("t" if record else "e", self.train_steps)
+        self.stamp = ("t" if record else "e", self.train_steps, ops.PARAM_EPOCH[0])
         self.prepare_all(record)
         fr = [self.feat_rows(f) for f in feats]
         CH = arch.FEAT_CH
         pre = [None] * 5
         cats, uins = [None] * 4, [None] * 4
         top = max(l for l in range(5) if plan.nb[l] > 0)
-        pre[top] = torch.empty(plan.rows[top], CH[top], dtype=BF16, device=dev)
+        pre[top] = self.alloc(plan.rows[top], CH[top], dev)
         self.gather(fr[top], plan.srcrow[top], pre[top], plan.rows[top], CH[top])
         for l in range(top - 1, -1, -1):
             cin, cout, ccat = arch.SKIP[l]
             nc = plan.nb[l + 1]
             rowsC = int(plan.row0[l][nc])
             rows = plan.rows[l]
-            pre[l] = torch.empty(rows, CH[l], dtype=BF16, device=dev)
+            pre[l] = self.alloc(rows, CH[l], dev)
             if nc:
-                uin = torch.empty(rowsC, CH[l + 1], dtype=BF16, device=dev)
+                uin = self.alloc(rowsC, CH[l + 1], dev)
                 ops.bilinear_fwd(pre[l + 1], uin, 0, 0, 0, 0, 0, CH[l + 1], boxdesc=plan.bil_d[l], row2box=plan.row2box[l])
-                cat = torch.empty(rowsC, ccat, dtype=BF16, device=dev)
+                cat = self.alloc(rowsC, ccat, dev)
                 pw, _, b = self.packw(f"skip_combine.{l}.up.0", record)
-                self.rconv(uin, pw, cout, plan.rowdesc[l], rowsC, 3, y=cat[:, CH[l]:CH[l] + cout], bias=b, relu=True,
+                self.rconv(uin, pw, cout, plan.rowdesc[l], rowsC, 3, y=cat.cols(CH[l], CH[l] + cout), bias=b, relu=True,
                            tiles=self.T32(plan, l, nc), tiles16=self.T16(plan, l, nc))
-                self.gather(fr[l], plan.srcrow[l], cat[:, 0:CH[l]], rowsC, CH[l])
+                self.gather(fr[l], plan.srcrow[l], cat.cols(0, CH[l]), rowsC, CH[l])
                 pw, _, b = self.packw(f"skip_combine.{l}.cat_conv.0", record)
-                self.rconv(cat, pw, cout, plan.rowdesc[l], rowsC, 1, y=pre[l][:rowsC], bias=b, relu=True)
+                self.rconv(cat, pw, cout, plan.rowdesc[l], rowsC, 1, y=pre[l].rows(0, rowsC), bias=b, relu=True)
                 cats[l], uins[l] = cat, uin
-            self.gather(fr[l], plan.srcrow[l], pre[l][rowsC:], rows - rowsC, CH[l], row_off=rowsC)
+            self.gather(fr[l], plan.srcrow[l], pre[l].rows(rowsC), rows - rowsC, CH[l], row_off=rowsC)
         rows0 = plan.rows[0]
-        hid = torch.empty(rows0, 64, dtype=BF16, device=dev)
+        hid = self.alloc(rows0, 64, dev)
         pw, _, b = self.packw("seg_head.0", record)
         self.rconv(pre[0], pw, 64, plan.rowdesc[0], rows0, 3, y=hid, bias=b, relu=True, tiles=self.T32(plan, 0, plan.nb[0]),
                    tiles16=self.T16(plan, 0, plan.nb[0]))
         flat = torch.empty(rows0, dtype=torch.float32, device=dev)
         pw, _, b = self.packw("seg_head.2", record)
         self.rconv(hid, pw, 1, plan.rowdesc[0], rows0, 3, y_f32=flat, bias=b, tiles=self.T32(plan, 0, plan.nb[0]))
+        self.last_logits = flat.clone() if getattr(self, "keep_logits", False) else None     # test hook: pre-sigmoid values
         ops.sigmoid_(flat)
         saved = (pre, cats, uins, hid, flat, top) if record else None
         return flat, saved
@@ -334,50 +388,46 @@ class SegBranch:
         CH = arch.FEAT_CH
         pgrads = {}
         rows0 = plan.rows[0]
-        gz = torch.empty(rows0, 8, dtype=BF16, device=dev)
+        gz = self.alloc(rows0, 8, dev)
         ops.grad_pack(gflat, flat, gz, 1, 1, rows0, 1, 8)
-        dhid = torch.empty(rows0, 64, dtype=BF16, device=dev)
+        dhid = self.alloc(rows0, 64, dev)
         t32_0, t16_0 = self.T32(plan, 0, plan.nb[0]), self.T16(plan, 0, plan.nb[0])
-        self.conv_bwd("seg_head.2", hid, gz, plan.rowdesc[0], rows0, 3, pgrads, dx=dhid, mask=hid, t32=t32_0, t16=t16_0)
-        dpre = torch.empty(rows0, 64, dtype=BF16, device=dev)
-        self.conv_bwd("seg_head.0", pre[0], dhid, plan.rowdesc[0], rows0, 3, pgrads, dx=dpre, mask=pre[0], t32=t32_0, t16=t16_0)
-        acc = []
-        for l in range(5):
-            n, c, h, w = feat_shapes[l]
-            acc.append(torch.zeros(n * h * w, c, dtype=BF16, device=dev) if plan.nb[l] else None)
+        self.conv_bwd("seg_head.2", hid, gz, plan.rowdesc[0], rows0, 3, pgrads, dx=dhid, mask=hid.hi(), t32=t32_0, t16=t16_0)
+        dpre = self.alloc(rows0, 64, dev)
+        self.conv_bwd("seg_head.0", pre[0], dhid, plan.rowdesc[0], rows0, 3, pgrads, dx=dpre, mask=pre[0].hi(), t32=t32_0, t16=t16_0)
+        # Gradient w.r.t. the feature maps: per level the crop-gradient rows of the combine boxes (columns 0..C of the concat
+        # gradient, rows [0, rowsC)) and of the boxes that end at this level (dpre rows [rowsC, rows)); reduced per feature
+        # pixel in fixed box order with fp32 accumulation (kg_crop_grad_reduce) -- no atomics, bit-reproducible.
+        gfeats = [None] * 5
 
-        def scatter(g, l, nrows, row_off=0):
-            if nrows:
-                _lib.call("kg_rows_scatter_add_bf16", ptr(g), ops.ld(g), _lib.c_void_p(plan.srcrow[l].data_ptr() + 4 * row_off),
-                          ptr(acc[l]), CH[l], c_long(nrows), CH[l], stream_ptr())
+        def reduce_level(l, ga, rows_a, gb):
+            n, c, h, w = feat_shapes[l]
+            out = torch.empty(n * h * w, c, dtype=torch.float32, device=dev)
+            _lib.call("kg_crop_grad_reduce", ptr(ops.base(ga)), ops.ld(ga) if ga is not None else 0, ptr(ops.base(gb)),
+                      ops.ld(gb) if gb is not None else 0, c_long(rows_a), ptr(plan.tab_d[l]), ptr(plan.bin_start_d[l]),
+                      ptr(plan.bin_boxes_d[l]), BIN_SIZE[l], n, h, w, c, ptr(out), ops.pl(a=ga if ga is not None else gb, b=gb if gb is not None else ga), stream_ptr())
+            gfeats[l] = out.view(n, h, w, c).permute(0, 3, 1, 2)
 
         for l in range(0, top):
             cin, cout, ccat = arch.SKIP[l]
             nc = plan.nb[l + 1]
             rowsC = int(plan.row0[l][nc])
             rows = plan.rows[l]
-            scatter(dpre[rowsC:], l, rows - rowsC, row_off=rowsC)
-            nxt = None
+            nxt, dcat = None, None
             if nc:
                 cat, uin = cats[l], uins[l]
-                dcat = torch.empty(rowsC, ccat, dtype=BF16, device=dev)
-                self.conv_bwd(f"skip_combine.{l}.cat_conv.0", cat, dpre[:rowsC], plan.rowdesc[l], rowsC, 1, pgrads, dx=dcat, mask=cat)
-                scatter(dcat[:, 0:CH[l]], l, rowsC)
-                duin = torch.empty(rowsC, CH[l + 1], dtype=BF16, device=dev)
-                self.conv_bwd(f"skip_combine.{l}.up.0", uin, dcat[:, CH[l]:CH[l] + cout], plan.rowdesc[l], rowsC, 3, pgrads, dx=duin,
+                dcat = self.alloc(rowsC, ccat, dev)
+                self.conv_bwd(f"skip_combine.{l}.cat_conv.0", cat, dpre.rows(0, rowsC), plan.rowdesc[l], rowsC, 1, pgrads, dx=dcat, mask=cat.hi())
+                duin = self.alloc(rowsC, CH[l + 1], dev)
+                self.conv_bwd(f"skip_combine.{l}.up.0", uin, dcat.cols(CH[l], CH[l] + cout), plan.rowdesc[l], rowsC, 3, pgrads, dx=duin,
                               t32=self.T32(plan, l, nc), t16=self.T16(plan, l, nc))
-                nxt = torch.empty(plan.rows[l + 1], CH[l + 1], dtype=BF16, device=dev)
-                ops.bilinear_bwd(duin, nxt, 0, 0, 0, 0, 0, CH[l + 1], boxdesc=plan.bil_d[l], row2box=plan.row2box[l + 1], mask=pre[l + 1])
+                nxt = self.alloc(plan.rows[l + 1], CH[l + 1], dev)
+                ops.bilinear_bwd(duin, nxt, 0, 0, 0, 0, 0, CH[l + 1], boxdesc=plan.bil_d[l], row2box=plan.row2box[l + 1], mask=pre[l + 1].hi())
+            reduce_level(l, dcat.cols(0, CH[l]) if dcat is not None else None, rowsC if dcat is not None else 0,
+                         dpre.rows(rowsC) if rows > rowsC else None)
             dpre = nxt
         if dpre is not None:
-            scatter(dpre, top, plan.rows[top])
-        gfeats = []
-        for l in range(5):
-            n, c, h, w = feat_shapes[l]
-            if acc[l] is None:
-                gfeats.append(None)
-                continue
-            gfeats.append(acc[l].view(n, h, w, c).permute(0, 3, 1, 2))
+            reduce_level(top, None, 0, dpre)
         # parameters of levels that no box reached get zero gradients (autograd accumulates nothing for None)
         return gfeats, pgrads
 

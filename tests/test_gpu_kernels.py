@@ -446,7 +446,7 @@ def test_conv_halo_heads2(case):
     hid = bfr(torch.randn(N, 3 * C, H, W, generator=g).clamp_min(0))
     rows, vmap = ops.heads2_layout()
     assert sorted(v for v in vmap if v >= 0) == list(range(55)) and [len(r) for r in rows] == [5, 10, 40]
-    pw = PackedWeight(64, 49, 3 * C, DEV)
+    pw = PackedWeight(64, 49, C, DEV, groups=3)
     vm = torch.tensor(vmap, dtype=torch.int32, device=DEV)
     bias64 = torch.zeros(64, device=DEV)
     refs, outs = [], []
@@ -456,7 +456,7 @@ def test_conv_halo_heads2(case):
         r = F.conv2d(hid[:, k * C:(k + 1) * C].double(), w.double(), b.double(), 1, 3)
         refs.append(torch.sigmoid(r) if k == 0 else r)
         rm = torch.tensor(rows[k], dtype=torch.int32, device=DEV)
-        pw.pack_rows(w.to(DEV), rm, c0=k * C)
+        pw.pack_rows(w.to(DEV), rm, group=k)
         bias64[rm.long()] = b.to(DEV)
         outs.append(torch.full((N, co, H, W), float("nan"), dtype=torch.float32, device=DEV))
     ops.conv_halo_heads2(rows_of(hid).to(DEV), pw, bias64, vm, outs[0], outs[1], outs[2], N, H, W, C)

@@ -1,14 +1,16 @@
 """GPU parity tests of the drop-in KGnet module (forward_dec / forward_seg / train step) against the
 golden fixtures generated from the reference.
 
-Stated tolerance of the bf16-MFMA path (fp32 accumulation, bf16 activations, fp32 master weights):
-  * short/mid maps: relative L2 error <= 3e-2 per map; kp probabilities: |dp| > 0.05 on <= 3 % of the
-    pixels (the seeded random-init weights give logits of order +-500, so probabilities are 0/1 except on
-    sign changes of the logit, where a 1 % logit error flips the pixel)
+This file uses the RAW random-init fixture (kaiming weights, logits of order +-500: sigmoids saturated, and in train mode a
+perturbation grows ~x1.2 per layer through the 43 batch-statistics BatchNorm layers).  Element-wise parity on unsaturated
+logits is asserted in test_gpu_parity.py on the calibrated fixture; here, for the default "mixed" precision (trunk in hi + lo
+bf16 planes, heads bf16):
+  * short/mid maps: relative L2 error <= 3e-2 per map; kp probabilities: |dp| > 0.05 on <= 3 % of the pixels (probabilities
+    are 0/1 except on sign changes of the logit, where a 1 % logit error flips the pixel)
   * seg probabilities: max-abs <= 5e-2
-  * losses: 5e-2 relative; parameter gradients: norms within 35 % of the fp32 reference, cosine >= 0.93 on the
-    shallow (head/decoder) parameters vs the bf16-emulating oracle; deep-backbone gradients of this random-init
-    fixture are chaotic under bf16 storage for ANY implementation (tight per-block checks: test_gpu_blocks.py)
+  * train step: losses 1e-2 relative; EVERY parameter gradient against the fp32 oracle / reference: cosine >= 0.98, norm
+    within 5 % (with plain bf16 storage of the trunk -- precision "bf16" -- the same comparison gives cosines of 0.2-0.6 in
+    layer1/2 for ANY implementation, which is why the trunk is kept in two planes)
 (bit-exactness is only claimed for the integer/float64 post-processing on identical head tensors)."""
 import hashlib
 
@@ -121,8 +123,8 @@ def test_train_step_matches_golden(golden, model, state_dict0):
     l2 = lseg(pred, gt_masks, gt_boxes)
     print("loss_dec", [float(v) for v in l1], "ref", g["train.loss_dec"], "loss_seg", float(l2), float(g["train.loss_seg"]))
     assert [len(p) for p in pred[0]] == list(g["train.npatch"])
-    np.testing.assert_allclose([float(v) for v in l1], g["train.loss_dec"], rtol=5e-2)
-    assert abs(float(l2) - float(g["train.loss_seg"])) <= 5e-2 * abs(float(g["train.loss_seg"]))
+    np.testing.assert_allclose([float(v) for v in l1], g["train.loss_dec"], rtol=1e-2)
+    assert abs(float(l2) - float(g["train.loss_seg"])) <= 1e-2 * abs(float(g["train.loss_seg"]))
     (sum(l1) + l2).backward()
     torch.cuda.synchronize()
     names = [str(n) for n in g["train.grad_names"]]
@@ -134,16 +136,13 @@ def test_train_step_matches_golden(golden, model, state_dict0):
     worst = np.argsort(-np.abs(np.log(ratio + 1e-12)))[:8]
     print("grad norm ratio: median %.4f min %.4f max %.4f" % (np.median(ratio), ratio.min(), ratio.max()))
     print("worst:", [(names[i], float(ratio[i])) for i in worst])
-    # every parameter gradient against the CPU oracle's autograd on the same batch, with the oracle rounding
-    # its stored tensors to bf16 where the HIP engine does (oracle/net_bf16.py; see DESIGN.md "Numerics":
-    # against the pure-fp32 oracle the deep-backbone gradients of this random-init net decorrelate for ANY
-    # bf16-storage implementation, which the second table documents)
+    # every parameter gradient against the fp32 CPU oracle's autograd on the same batch (the oracle is pinned to the reference's
+    # gradients by tests/test_oracle_net.py) and the stored reference gradients themselves
     from oracle import net as onet
-    from oracle.net_bf16 import NetBF16
     osd = {k: v.clone() for k, v in state_dict0.items()}
     for n in names:
         osd[n].requires_grad_(True)
-    onet_ = NetBF16(osd, training=True)
+    onet_ = onet.Net(osd, training=True)
     o0, o1, o2, o3, opred = onet_.forward(x, gt_boxes)
     ol = sum(onet.detection_loss(p, t) for p, t in zip((o0, o1, o2, o3), gt_lv)) + onet.seg_loss(opred, gt_masks, gt_boxes, H, W)
     ol.backward()
@@ -152,11 +151,8 @@ def test_train_step_matches_golden(golden, model, state_dict0):
         ref = osd[n].grad.numpy().ravel().astype(np.float64); got = params[n].grad.cpu().numpy().ravel().astype(np.float64)
         cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
         rows.append((cos, n, rel_l2(got, ref), float(np.linalg.norm(ref))))
-    print("per-parameter gradient parity (network order):")
-    for cos, n, e, nr in rows:
-        print(f"   ALL cos={cos:.5f} rel_l2={e:.4f} |ref|={nr:.3e}  {n}")
     rows.sort()
-    print("per-parameter gradient parity (worst 30 by cosine):")
+    print("per-parameter gradient parity vs fp32 (worst 30 by cosine):")
     for cos, n, e, nr in rows[:30]:
         print(f"   cos={cos:.5f} rel_l2={e:.4f} |ref|={nr:.3e}  {n}")
     print("   cosine quantiles: min %.5f p10 %.5f median %.5f" % (rows[0][0], rows[len(rows) // 10][0], rows[len(rows) // 2][0]))
@@ -164,18 +160,13 @@ def test_train_step_matches_golden(golden, model, state_dict0):
               "c0_conv.0.weight", "layer1.0.conv1.weight"):
         ref = g[f"train.grad.{k}"].ravel().astype(np.float64); got = params[k].grad.cpu().numpy().ravel().astype(np.float64)
         cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
-        print(f"[grad {k} vs fp32 golden] cos={cos:.5f} rel_l2={rel_l2(got, ref):.4f}")
-    # Whole-network gradients of this random-init fixture are chaotic under bf16 storage (ReLU-mask flips and
-    # L1-sign flips compound over ~60 layers: the CPU bf16 emulation itself only reaches cos ~0.3 against fp32 in
-    # layer1).  The tight gradient checks live in test_gpu_blocks.py; here we bound the gross behaviour.
-    by = {n: c for c, n, e, nr in rows}
-    shallow = [n for n in names if ("_head_c" in n or "cat_refine" in n or "up_conv" in n or n.startswith("seg_head") or n.startswith("skip_combine.0"))]
-    assert min(by[n] for n in shallow) >= 0.93, sorted((by[n], n) for n in shallow)[:5]
-    assert rows[len(rows) // 2][0] >= 0.6
-    assert np.all(np.abs(ratio - 1) <= 0.35), "gradient norms off vs the fp32 reference"
+        print(f"[grad {k} vs the reference's] cos={cos:.5f} rel_l2={rel_l2(got, ref):.4f}")
+        assert cos >= 0.98, k
+    assert rows[0][0] >= 0.98, rows[:5]
+    assert np.all(np.abs(ratio - 1) <= 0.05), "gradient norms off vs the fp32 reference"
     sd = model.state_dict()
     for k in ("bn1.running_mean", "bn1.running_var", "layer3.5.bn3.running_mean", "layer3.5.bn3.running_var", "layer2.0.downsample.1.running_var"):
-        np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"train.stat.{k}"], rtol=3e-2, atol=3e-3)
+        np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"train.stat.{k}"], rtol=5e-3, atol=5e-4)
     assert int(sd["bn1.num_batches_tracked"]) == 1
 
 

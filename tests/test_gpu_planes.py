@@ -1,0 +1,267 @@
+"""GPU parity tests of the split-bf16 ("planes") storage through the C ABI: a tensor is P bf16 planes whose sum is the value
+(csrc/kg_common.h); P = 3 reproduces fp32 tensors exactly, P = 2 keeps 16 significant bits.
+
+Checker: torch fp64 CPU primitives on the SAME fp32 inputs (no bf16 pre-rounding: that is the point).  Stated tolerances,
+relative to max|ref| of the tensor:  P = 3 (6 MFMA products, fp32 accumulation): 3e-6;  P = 2 (3 products): 1.5e-4 -- against
+2^-9 = 2e-3 for plain bf16 operands."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from kg_instance_segmentation_amd import _lib, ops  # noqa: E402
+from kg_instance_segmentation_amd.ops import BF16, PT, PackedWeight  # noqa: E402
+
+DEV = "cuda"
+TOL = {1: 6e-3, 2: 1.5e-4, 3: 3e-6}
+
+
+def to_pt(rows_f32, P, ctot=None, c0=0):
+    """fp32 [rows, C] (device) -> PT with P planes (optionally a column slice c0.. of a wider [rows, ctot] plane)."""
+    rows, C = rows_f32.shape
+    ctot = ctot or C
+    buf = torch.zeros(rows, P * ctot, dtype=BF16, device=rows_f32.device)
+    r = rows_f32.clone()
+    for p in range(P):
+        h = r.to(BF16)
+        buf[:, p * ctot + c0:p * ctot + c0 + C] = h
+        r = r - h.float()
+    return PT(buf[:, c0:c0 + C], P, ctot)
+
+
+def from_pt(pt):
+    out = pt.plane(pt.P - 1).float()
+    for p in range(pt.P - 2, -1, -1):
+        out = out + pt.plane(p).float()
+    return out
+
+
+def rows_f32(x):
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n * h * w, c).contiguous()
+
+
+def nchw(rows, n, h, w):
+    return rows.view(n, h, w, -1).permute(0, 3, 1, 2)
+
+
+def check(name, got, ref, rel):
+    got = got.detach().double().cpu(); ref = ref.detach().double().cpu()
+    scale = float(ref.abs().max()) + 1e-30
+    err = float((got - ref).abs().max()) / scale
+    print(f"[{name}] max_abs_err / max|ref| = {err:.3e} (bound {rel:.1e}), max|ref| = {scale:.3e}")
+    assert err <= rel, name
+
+
+def test_split_roundtrip_exact():
+    """P = 3 planes written by the kernels hold fp32 values exactly (kg_f32_to_planes -> kg_planes_to_f32), including tiny and huge
+    magnitudes; P = 2 keeps 16 bits."""
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(1000, 64, generator=g) * torch.exp(torch.randn(1000, 64, generator=g) * 8)).to(DEV)
+    x = torch.where(x.abs() < 1e-30, torch.full_like(x, 1e-30), x)       # (residual planes of values near FLT_MIN are denormal: flushed)
+    x[0, :6] = torch.tensor([0.0, -0.0, 1.0, -1.0, 1.0e38, 1.0 + 2.0 ** -23], device=DEV)
+    for P in (1, 2, 3):
+        pt = ops.alloc_pt(1000, 64, P, DEV)
+        ops.f32_to_planes(x, pt, 64)
+        back = torch.empty_like(x)
+        ops.planes_to_f32(pt, 64, back)
+        torch.testing.assert_close(from_pt(pt), back, rtol=0, atol=0)
+        rel = ((back - x).abs() / x.abs().clamp_min(1e-37)).max().item()
+        print(f"P={P}: max relative round-trip error {rel:.3e}")
+        assert rel <= {1: 2.0 ** -8, 2: 2.0 ** -16, 3: 0.0}[P]
+        assert torch.equal(back[0, :2], x[0, :2])
+
+
+PLANE_CONV_CASES = [
+    # cin, cout, k, stride, pad, N, H, W, relu, bias     (route)
+    (64, 64, 3, 1, 1, 2, 20, 28, True, True),        # conv_halo<3>, 64 channels (conv3_c64 is bf16-only)
+    (256, 128, 3, 1, 1, 1, 12, 20, True, True),      # conv_halo<3>
+    (64, 192, 7, 1, 3, 1, 16, 24, True, True),       # conv_halo<7>
+    (128, 64, 1, 1, 0, 2, 16, 16, True, True),       # 1x1 -> conv_gather (64 couts)
+    (64, 256, 1, 1, 0, 2, 16, 16, False, False),     # 1x1 -> conv_gather
+    (128, 128, 3, 2, 1, 2, 18, 22, False, False),    # strided 3x3 -> conv_gather
+    (256, 512, 1, 2, 0, 1, 16, 24, False, False),    # strided 1x1
+    (3, 64, 7, 2, 3, 2, 32, 40, False, False),       # image input -> conv_igemm
+    (3, 64, 3, 1, 1, 1, 24, 24, True, True),
+]
+
+
+@pytest.mark.parametrize("P", [2, 3])
+@pytest.mark.parametrize("case", PLANE_CONV_CASES)
+def test_conv_forward_dgrad_wgrad_planes(case, P):
+    cin, cout, k, stride, pad, N, H, W, relu, bias = case
+    g = torch.Generator().manual_seed(abs(hash(case)) % 1000 + P)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    b = torch.randn(cout, generator=g) if bias else None
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    xd = x.double().requires_grad_(True); wd = w.double().requires_grad_(True)
+    pre = F.conv2d(xd, wd, b.double() if bias else None, stride, pad)
+    ref = F.relu(pre) if relu else pre
+    dy = torch.randn(N, cout, OH, OW, generator=g)
+    dyu = dy * (pre.detach() > 0) if relu else dy                     # gradient w.r.t. the pre-activation
+    ref.backward(dy.double())
+    cin_pad = ops.round_up(cin, 8)
+    xr = rows_f32(x)
+    if cin_pad != cin:
+        xr = torch.cat([xr, torch.zeros(xr.shape[0], cin_pad - cin)], 1)
+    xp = to_pt(xr.to(DEV), P, ctot=cin_pad + 16, c0=8)                 # a column slice of a wider buffer: ld != C, ps != C
+    pw = PackedWeight(cout, k * k, cin_pad, DEV, xP=P, wP=P)
+    pw.pack(w.to(DEV))
+    y = ops.alloc_pt(N * OH * OW, cout, P, DEV)
+    geom = (N * OH * OW, H, W, OH, OW, k, k, stride, pad)
+    route = ops.conv_auto(xp, pw, cout, geom, N, y=y, bias=b.to(DEV) if bias else None, relu=relu)
+    torch.cuda.synchronize()
+    check(f"fwd {route} P={P} {case}", nchw(from_pt(y), N, OH, OW), ref, TOL[P])
+    # input gradient (with the residual operand accumulating onto an existing gradient)
+    if cin >= 8:
+        pwT = PackedWeight(cin, k * k, ops.round_up(cout, 8), DEV, xP=P, wP=P)
+        pwT.pack(w.to(DEV), transposed=True)
+        gp = to_pt(rows_f32(dyu.float()).to(DEV), P)
+        prev = torch.randn(N * H * W, cin, generator=g)
+        dx = to_pt(prev.to(DEV), P)
+        gin = (N * H * W, OH, OW, H, W, k, k, stride, pad)
+        ops.conv_auto(gp, pwT, cin, gin, N, y=dx, res=dx, transposed=True)
+        torch.cuda.synchronize()
+        check(f"dgrad P={P} {case}", nchw(from_pt(dx), N, H, W), xd.grad + nchw(prev.double(), N, H, W), TOL[P])
+    # weight / bias gradient
+    gw = torch.empty(cout, cin, k, k, device=DEV)
+    db = torch.empty(cout, device=DEV)
+    gp = to_pt(rows_f32(dyu.float()).to(DEV), P)
+    ops.conv_wgrad(xp, gp, cin, cout, geom, [(gw, 0, cout)], N=N, bias_out=db)
+    torch.cuda.synchronize()
+    check(f"wgrad P={P} {case}", gw, wd.grad, TOL[P] * 2)
+    check(f"bias grad P={P} {case}", db, dyu.double().sum((0, 2, 3)), TOL[P] * 2)
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_mixed_plane_counts(P):
+    """The head convs of the "mixed" policy: a single-plane conv reads plane 0 of a P-plane trunk tensor, and its input gradient
+    (single-plane dY and weights) is written back as P planes straight from the fp32 accumulators."""
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W, k = 1, 64, 16, 24, 7
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, C, k, k, generator=g) / math.sqrt(C * k * k)
+    xp = to_pt(rows_f32(x).to(DEV), P)
+    x1 = PT(xp.t, 1, 0)
+    pw = PackedWeight(C, k * k, C, DEV)
+    pw.pack(w.to(DEV))
+    y = torch.empty(N * H * W, C, dtype=BF16, device=DEV)
+    geom = (N * H * W, H, W, H, W, k, k, 1, 3)
+    ops.conv_auto(x1, pw, C, geom, N, y=y)
+    ref = F.conv2d(xp.plane(0).float().cpu().view(N, H, W, C).permute(0, 3, 1, 2).double(), w.to(BF16).double(), None, 1, 3)
+    check("bf16 conv on plane 0", nchw(y.float(), N, H, W), ref, 6e-3)
+    dy = torch.randn(N, C, H, W, generator=g).to(BF16)
+    pwT = PackedWeight(C, k * k, C, DEV)
+    pwT.pack(w.to(DEV), transposed=True)
+    dx = ops.alloc_pt(N * H * W, C, P, DEV)
+    ops.conv_auto(rows_f32(dy).to(DEV), pwT, C, geom, N, y=dx, transposed=True)
+    refd = torch.nn.grad.conv2d_input((N, C, H, W), w.to(BF16).double(), dy.double(), 1, 3)
+    check("P-plane store of a bf16 dgrad", nchw(from_pt(dx), N, H, W), refd, TOL[P])
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_elementwise_planes(P):
+    g = torch.Generator().manual_seed(9)
+    N, C, H, W = 2, 64, 18, 22
+    x = torch.randn(N, C, H, W, generator=g) * 3 + 1
+    r = torch.randn(N, C, H, W, generator=g)
+    xp, rp = to_pt(rows_f32(x).to(DEV), P, ctot=C + 64, c0=64), to_pt(rows_f32(r).to(DEV), P)
+    M = N * H * W
+    # BatchNorm train forward + backward
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, invstd, scale, shift = ops.bn_stats_train(xp, C, gamma.to(DEV), beta.to(DEV), rm, rv)
+    y = ops.alloc_pt(M, C, P, DEV)
+    ops.bn_apply(xp, C, scale, shift, y, res=rp, relu=True)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    pre = F.batch_norm(xd, None, None, gd, bd, True, 0.1, 1e-5) + r.double()
+    ref = F.relu(pre)
+    check(f"bn fwd P={P}", nchw(from_pt(y), N, H, W), ref, TOL[P])
+    check("bn running_var", rv, 0.9 + 0.1 * x.double().var((0, 2, 3), unbiased=True), 1e-5)
+    dy = torch.randn(N, C, H, W, generator=g)
+    dyu = dy * (pre.detach() > 0)
+    ref.backward(dy.double())
+    dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dx = ops.alloc_pt(M, C, P, DEV)
+    ops.bn_bwd(xp, to_pt(rows_f32(dyu.float()).to(DEV), P), C, gamma.to(DEV), mean, invstd, dg, db, dx)
+    check(f"bn bwd dx P={P}", nchw(from_pt(dx), N, H, W), xd.grad, TOL[P] * 4)
+    check(f"bn bwd dgamma P={P}", dg, gd.grad, TOL[P] * 4)
+    # max pool
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    yp = ops.alloc_pt(N * OH * OW, C, P, DEV)
+    ops.maxpool_fwd(xp, yp, N, H, W, C)
+    xq = from_pt(xp).cpu()                                        # the value the planes hold (P = 2: 16-bit rounding of x)
+    xq4 = nchw(xq, N, H, W).double().requires_grad_(True)
+    refp = F.max_pool2d(xq4, 3, 2, 1)
+    check(f"maxpool fwd P={P}", nchw(from_pt(yp), N, OH, OW), refp, 1e-7 if P == 3 else TOL[P])
+    dyp = torch.randn(N, C, OH, OW, generator=g)
+    refp.backward(dyp.double())
+    dxp = ops.alloc_pt(M, C, P, DEV)
+    ops.maxpool_bwd(xp, to_pt(rows_f32(dyp).to(DEV), P), dxp, N, H, W, C)
+    check(f"maxpool bwd P={P}", nchw(from_pt(dxp), N, H, W), xq4.grad, TOL[P])
+    # bilinear 2x up + backward
+    up = ops.alloc_pt(N * 4 * H * W, C, P, DEV)
+    ops.bilinear_fwd(xp, up, N, H, W, 2 * H, 2 * W, C)
+    xu = x.double().requires_grad_(True)
+    refu = F.interpolate(xu, (2 * H, 2 * W), mode="bilinear", align_corners=False)
+    check(f"bilinear fwd P={P}", nchw(from_pt(up), N, 2 * H, 2 * W), refu, TOL[P])
+    dyu2 = torch.randn(N, C, 2 * H, 2 * W, generator=g)
+    refu.backward(dyu2.double())
+    dxu = ops.alloc_pt(M, C, P, DEV)
+    ops.bilinear_bwd(to_pt(rows_f32(dyu2).to(DEV), P), dxu, N, H, W, 2 * H, 2 * W, C)
+    check(f"bilinear bwd P={P}", nchw(from_pt(dxu), N, H, W), xu.grad, TOL[P])
+    # gradient join with ReLU mask
+    out = ops.alloc_pt(M, C, P, DEV)
+    ops.add_rows(xp, rp, out, C, mask=rp.hi())
+    check(f"add_rows P={P}", nchw(from_pt(out), N, H, W), (x.double() + r.double()) * (r.to(BF16).double() > 0), TOL[P])
+    # image pack
+    img = torch.rand(2, 3, 16, 24, generator=g) - 0.5
+    ip = ops.img_pack(img.to(DEV), P)
+    check(f"img_pack P={P}", from_pt(ip)[:, :3], rows_f32(img), TOL[P] / 4)
+    assert float(from_pt(ip)[:, 3:].abs().max()) == 0.0
+
+
+def test_crop_grad_reduce_matches_index_add_and_is_deterministic():
+    """kg_crop_grad_reduce (gradient of get_patches' slicing, KGnet.py:246-256) against index_add_ in fp64 on heavily overlapping
+    boxes, twice bit-identically; built through SegBranch.make_plan so that the host-side bin tables are covered too."""
+    from kg_instance_segmentation_amd import KGnet
+    m = KGnet.resnet50(pretrained=False).to(DEV)
+    rng = np.random.default_rng(3)
+    N, H, W = 2, 64, 96
+    feats = [torch.zeros(N, c, H >> l, W >> l, device=DEV) for l, c in enumerate((64, 64, 256, 512, 1024))]
+    boxes = []
+    for i in range(N):
+        y1 = rng.uniform(0, H - 24, 40); x1 = rng.uniform(0, W - 24, 40)
+        bb = np.stack([y1, x1, y1 + rng.uniform(6, 40, 40), x1 + rng.uniform(6, 40, 40), np.ones(40)], 1).astype(np.float32)
+        bb[:10, :2] = bb[0, :2]; bb[:10, 2:4] = bb[0, 2:4] + np.arange(10)[:, None]      # nested boxes
+        boxes.append(bb)
+    seg = m._seg
+    plan = seg.make_plan(feats, boxes)
+    from kg_instance_segmentation_amd import _lib as L
+    for l in range(3):
+        C = feats[l].shape[1]
+        rows = plan.rows[l]
+        h, w = H >> l, W >> l
+        for P in (1, 3):
+            gfull = torch.randn(rows, C, device=DEV)
+            rows_a = int(plan.row0[l][plan.nb[l] // 2])
+            ga = to_pt(gfull[:rows_a], P, ctot=C + 64, c0=0) if rows_a else None
+            gb = to_pt(gfull[rows_a:], P)
+            outs = []
+            for rep in range(2):
+                out = torch.empty(N * h * w, C, device=DEV)
+                L.call("kg_crop_grad_reduce", L.ptr(ops.base(ga)), ops.ld(ga) if ga is not None else 0, L.ptr(ops.base(gb)), ops.ld(gb),
+                       L.c_long(rows_a), L.ptr(plan.tab_d[l]), L.ptr(plan.bin_start_d[l]), L.ptr(plan.bin_boxes_d[l]),
+                       __import__("kg_instance_segmentation_amd.seg", fromlist=["BIN_SIZE"]).BIN_SIZE[l], N, h, w, C, L.ptr(out),
+                       ops.pl(a=ga if ga is not None else gb, b=gb), L.stream_ptr())
+                outs.append(out.clone())
+            assert torch.equal(outs[0], outs[1])
+            vals = torch.cat([from_pt(ga), from_pt(gb)]) if ga is not None else from_pt(gb)
+            ref = torch.zeros(N * h * w, C, dtype=torch.float64, device=DEV).index_add_(0, plan.srcrow[l][:rows].long(), vals.double())
+            check(f"crop_grad_reduce level {l} P={P}", outs[0], ref, 2e-6)
