@@ -83,7 +83,7 @@ class KernelTimer:
             tile = k.get("tile", 0) or (1 if cout <= 16 else 2 if cout <= 32 else 3 if cout <= 64 else 4)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); r = orig_conv(x, pw, cout, geom, *a, **k); e.record()
-            timer.rec.append((f"conv_igemm_tile{tile}", 2.0 * M * cout * KH * KW * pw.cin_pad, s, e, f"M={M} cout={cout} k={KH} cinp={pw.cin_pad} mode={k.get('mode', 0)}"))
+            timer.rec.append((f"conv_igemm_tile{tile}", 2.0 * M * cout * KH * KW * getattr(pw, "cin_real", pw.cin_pad), s, e, f"M={M} cout={cout} k={KH} cinp={pw.cin_pad} mode={k.get('mode', 0)}"))
             return r
 
         def wgrad(x, dy, cin, cout, geom, grads, *a, **k):
@@ -102,7 +102,7 @@ class KernelTimer:
             wc = 1
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); r = orig_halo(x, pw, cout, N, H, W, KS, *a, **k); e.record()
-            cin = k.get("algo_cin") or pw.cin_pad     # fused second-layer head dgrad: 5 / 10 / 40 real dY channels per head
+            cin = k.get("algo_cin") or getattr(pw, "cin_real", pw.cin_pad)     # real channels (not the 8 / 64 padding, not the plane copies); fused second-layer head dgrad: 5 / 10 / 40 real dY channels per head
             timer.rec.append((f"conv_halo<{KS},{wc}>" + ("k1skip" if k.get("k1skip") else ""), 2.0 * N * H * W * cout * KS * KS * cin, s, e, f"N={N} H={H} cout={cout} cinp={pw.cin_pad}" + (f" algo_cin={cin}" if "algo_cin" in k else "")))
             return r
         orig_1x1 = ops.conv1x1
@@ -112,7 +112,7 @@ class KernelTimer:
                 return orig_1x1(x, pw, cout, y, *a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); r = orig_1x1(x, pw, cout, y, *a, **k); e.record()
-            timer.rec.append(("conv1x1", 2.0 * x.shape[0] * cout * pw.cin_pad, s, e, f"M={x.shape[0]} cout={cout} K={pw.cin_pad}"))
+            timer.rec.append(("conv1x1", 2.0 * x.shape[0] * cout * getattr(pw, "cin_real", pw.cin_pad), s, e, f"M={x.shape[0]} cout={cout} K={pw.cin_pad}"))
             return r
         orig_h2 = ops.conv_halo_heads2
 
@@ -350,6 +350,10 @@ def main():
     ap.add_argument("--boxes", type=int, default=300)
     ap.add_argument("--mode", choices=["train", "eval", "gt"], default="train",
                     help="eval: inference path (BASELINE configs[4]); gt: ground-truth map generation (SURVEY 8f N1); 1 GPU")
+    ap.add_argument("--precision", choices=["mixed", "fp32", "bf16"], default=os.environ.get("KG_PRECISION", "mixed"),
+                    help="storage precision of the network (engine.PRECISIONS); the headline is `mixed`, an fp32-faithful companion "
+                         "line is measured beside it at 1 GPU")
+    ap.add_argument("--no-companion", action="store_true", help="skip the fp32-faithful companion measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -375,75 +379,105 @@ def main():
         if rank == 0:
             gt_bench(args, dev)
         return
-    torch.manual_seed(1234)
-    model = KGnet.resnet50(pretrained=False).to(dev).train()
-    parallel.broadcast_parameters(model)
-    # train.py:71 (torch.optim.Adam is caller code; `fused=True` selects PyTorch's single-kernel multi-tensor implementation)
-    if os.environ.get("KG_ADAM", "hip") == "hip":     # the build's one-launch Adam (kg_adam_step), same update rule
-        from kg_instance_segmentation_amd.optim import Adam
-        opt = Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4)
-    else:
-        opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4, fused=os.environ.get("KG_ADAM_FUSED", "1") == "1")
-    ldec, lseg = DetectionLossAll(kp_radius=5), SEG_loss(height=args.size, width=args.size)
     x, gt, gt_masks, gt_boxes = make_batch(args.batch, args.size, args.boxes, 100 + rank, dev)
     den = parallel.detection_denominators(gt) if world > 1 else None
-    reducer = parallel.GradReducer(model.parameters()).attach(model) if world > 1 else None
     timer = KernelTimer()
     if not args.no_kernel_timer:
         timer.install()
+    ldec, lseg = DetectionLossAll(kp_radius=5), SEG_loss(height=args.size, width=args.size)
 
-    def step():
-        opt.zero_grad()
-        p0, p1, p2, p3, pred = model(x, gt_boxes)
-        if den is None:
-            l1 = ldec(p0, gt[0]) + ldec(p1, gt[1]) + ldec(p2, gt[2]) + ldec(p3, gt[3])
+    def run_train(precision, steps, warmup, sync_each_step, kernel_timer):
+        """K timed train steps of a fresh seeded model in `precision`; returns (seconds for the K steps = max over ranks, last loss,
+        per-step losses, dominant-kernel records)."""
+        torch.manual_seed(1234)
+        model = KGnet.resnet50(pretrained=False, precision=precision).to(dev).train()
+        parallel.broadcast_parameters(model)
+        # train.py:71 (torch.optim.Adam is caller code; `fused=True` selects PyTorch's single-kernel multi-tensor implementation)
+        if os.environ.get("KG_ADAM", "hip") == "hip":     # the build's one-launch Adam (kg_adam_step, SURVEY 8f N3), same update rule
+            from kg_instance_segmentation_amd.optim import Adam
+            opt = Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4)
         else:
-            l1 = sum(ldec(p, g, denominators=den[i]) for i, (p, g) in enumerate(zip((p0, p1, p2, p3), gt)))
-        l2 = lseg(pred, gt_masks, gt_boxes)
-        loss = l1 if l2 is None else l1 + l2 / world
-        loss.backward()
-        if reducer is not None:
-            reducer.reduce()
-        opt.step()
-        return loss.item() if STEP_SYNC else loss.detach()
+            opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4, fused=os.environ.get("KG_ADAM_FUSED", "1") == "1")
+        reducer = parallel.GradReducer(model.parameters()).attach(model) if world > 1 else None
 
-    # The K timed steps are enqueued back to back and the losses are read back after the closing synchronize.  KG_BENCH_SYNC=1 reads
-    # the loss back every step like train.py:156 (`running_loss += loss.item()`): one host sync per step, after which the GPU runs
-    # dry while the host enqueues the first (short) backbone kernels of the next step: -3.4 % (167 vs 173 img/s on the same box).
-    STEP_SYNC = os.environ.get("KG_BENCH_SYNC", "0") == "1"
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    timer.on = not args.no_kernel_timer
-    timer.only_dominant = True
-    t0 = time.perf_counter()
-    last = None
-    marks, losses = [], []
-    for _ in range(args.steps):
-        last = step()
-        marks.append(time.perf_counter())
-        losses.append(last)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    timer.on = False
-    last = float(last)
-    losses = [float(v) for v in losses]
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    dom_rec, timer.rec = timer.rec, []
+        def step(sync):
+            opt.zero_grad()
+            p0, p1, p2, p3, pred = model(x, gt_boxes)
+            if den is None:
+                l1 = ldec(p0, gt[0]) + ldec(p1, gt[1]) + ldec(p2, gt[2]) + ldec(p3, gt[3])
+            else:
+                l1 = sum(ldec(p, g, denominators=den[i]) for i, (p, g) in enumerate(zip((p0, p1, p2, p3), gt)))
+            l2 = lseg(pred, gt_masks, gt_boxes)
+            loss = l1 if l2 is None else l1 + l2 / world
+            loss.backward()
+            if reducer is not None:
+                reducer.reduce()
+            opt.step()
+            return loss.item() if sync else loss.detach()      # train.py:156 reads the loss back every step
+
+        def timed(K, sync):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ls, mk = [], []
+            for _ in range(K):
+                ls.append(step(sync))
+                mk.append(time.perf_counter())
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt_ = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt_], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_ = float(t.item())
+            return dt_, [float(v) for v in ls], [t0] + mk
+
+        for _ in range(warmup):
+            step(sync_each_step)
+        timer.on, timer.only_dominant, timer.rec = kernel_timer, True, []
+        dt_, ls, mk = timed(steps, sync_each_step)
+        timer.on = False
+        res = {"dt": dt_, "losses": ls, "marks": mk, "dom_rec": timer.rec, "step": step, "timed": timed}
+        timer.rec = []
+        return res
+
+    # Headline: the K timed steps read the loss back EVERY step like train.py:156 (`running_loss += loss.item()`); KG_BENCH_SYNC=0
+    # defers the read-back past the timed region instead (the host then enqueues step k+1 while the GPU still runs step k).
+    STEP_SYNC = os.environ.get("KG_BENCH_SYNC", "1") == "1"
+    main_run = run_train(args.precision, args.steps, args.warmup, STEP_SYNC, not args.no_kernel_timer)
+    dt, losses, marks = main_run["dt"], main_run["losses"], main_run["marks"][1:]
+    t0 = main_run["marks"][0]
+    last = losses[-1]
+    dom_rec = main_run["dom_rec"]
+    other_dt, _, _ = main_run["timed"](args.steps, not STEP_SYNC)      # the other loss-read-back policy, reported as a note
     prof_steps = 0
     if not args.no_kernel_timer:      # per-kernel breakdown: extra, untimed steps with events around every conv launch
         timer.on, timer.only_dominant, prof_steps = True, False, 2
         for _ in range(prof_steps):
-            step()
+            main_run["step"](True)
         torch.cuda.synchronize()
         timer.on = False
+    prof_rec, timer.rec = timer.rec, []
+    companion = None
+    if world == 1 and not args.no_companion and args.precision != "fp32":
+        main_run = None
+        torch.cuda.empty_cache()
+        ksteps = max(2, min(args.steps, 5))
+        comp = run_train("fp32", ksteps, 2, STEP_SYNC, not args.no_kernel_timer)
+        dsum = timer.summary(comp["dom_rec"]).get(KernelTimer.DOMINANT)
+        companion = {"precision": "fp32", "dtype": "fp32 values as 3 bf16 planes (hi + mid + lo), 6 bf16 MFMA products per multiply, fp32 accumulation",
+                     "value": args.batch * ksteps / comp["dt"], "unit": "imgs/s", "ms_per_step": 1e3 * comp["dt"] / ksteps, "steps": ksteps, "warmup": 2,
+                     "last_loss": comp["losses"][-1],
+                     "parity": "tests/test_gpu_parity.py: pre-sigmoid logits within rtol 1e-4 / atol 1e-5 of the reference, every parameter gradient cosine >= 0.9999"}
+        if dsum:
+            ach = dsum["flops"] / dsum["seconds"] / 1e12
+            companion["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel<7,1,8,0>", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS / 6.0,
+                                     "unit": "TFLOP/s", "frac": ach / (MFMA_BF16_PEAK_TFLOPS / 6.0), "traffic": None,
+                                     "avg_launch_ms": 1e3 * dsum["seconds"] / dsum["launches"], "launches": dsum["launches"],
+                                     "note": "achieved = algorithmic (fp32) conv FLOPs / HIP-event time; peak = dense bf16 MFMA peak / 6 products per fp32 multiply"}
+        comp = None
     if rank != 0:
         return
     if os.environ.get("KG_BENCH_VERBOSE"):
@@ -452,13 +486,22 @@ def main():
     imgs = args.batch * world * args.steps
     out = {"metric": "imgs/s (train fwd+bwd) at 512x512", "value": imgs / dt, "unit": "imgs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None,
+           "dtype": {"mixed": "bf16", "bf16": "bf16", "fp32": "fp32 as 3 bf16 planes"}[args.precision], "data": "synthetic",
            "config": {"workload": f"KGnet train step (forward_dec+forward_seg, 4x DetectionLossAll + SEG_loss, backward, Adam), "
                                   f"batch {args.batch}/GPU, 3x{args.size}x{args.size}, {args.boxes} GT boxes/img, full HIP path",
+                      "precision": {"mixed": "bf16 MFMA, fp32 accumulation; trunk (stem, layer1-3, decoder) stored and multiplied as hi + lo bf16 planes "
+                                             "(3 products), 7x7 heads and seg branch single-plane bf16",
+                                    "bf16": "bf16 MFMA, fp32 accumulation, single-plane bf16 storage everywhere",
+                                    "fp32": "fp32 values as 3 bf16 planes, 6 bf16 MFMA products per multiply, fp32 accumulation"}[args.precision],
                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "last_loss": last,
-                      "loss_readback": "every step" if STEP_SYNC else "after the timed region"}}
+                      "loss_readback": "every step (train.py:156)" if STEP_SYNC else "after the timed region",
+                      "other_readback_policy_imgs_per_s": imgs / other_dt}}
+    if companion is not None:
+        out["fp32_companion"] = companion
     if not args.no_kernel_timer:
         if os.environ.get("KG_BENCH_DUMP"):
+            timer.rec = prof_rec
             timer.dump(os.environ["KG_BENCH_DUMP"], prof_steps)
         dom = timer.summary(dom_rec).get(KernelTimer.DOMINANT)
         if dom:
@@ -473,7 +516,7 @@ def main():
                                                        "active cycles per launch / this run's launch time (DVFS: below 2.4 GHz under MFMA load)"),
                                "note": "achieved = algorithmic conv FLOPs (2*N*H*W*Cout*49*Cin) of the launches / their HIP-event time, "
                                        "measured inside the timed region; traffic = HBM bytes per launch from the committed PMC pass"}
-        summ = timer.summary()
+        summ = timer.summary(prof_rec)
         if summ:
             out["kernels"] = {k: {"ms_per_step": 1e3 * v["seconds"] / prof_steps, "tflops": v["flops"] / max(v["seconds"], 1e-12) / 1e12,
                                   "launches_per_step": v["launches"] / prof_steps} for k, v in summ.items()}

@@ -266,7 +266,7 @@ extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, 
     }
     static const int use_small = getenv("KG_CONV_SMALL") ? atoi(getenv("KG_CONV_SMALL")) : 6;   // (6: the stride-2 7x7 stem too)
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (use_small && vplanes == 1 && pp.y_planes == 1 && pp.b_planes == 1 && tile == 0 && cin_pad == 8 && KH * KW <= use_small * 9 && y && !y_f32 && Cout % 8 == 0 && ldy % 8 == 0 && al16(y) &&
+    if (use_small && tile == 0 && cin_pad == 8 && (vplanes == 1 || K >= 32 * vplanes * ((KH * KW + 3) / 4)) && KH * KW <= use_small * 9 && y && !y_f32 && Cout % 8 == 0 && ldy % 8 == 0 && al16(y) &&
         (!res || (ldres % 8 == 0 && al16(res))) && (!mask || (ldmask % 8 == 0 && al16(mask))) && dil == 1)
         return kg_launch_conv_small(a, st);   // <= 8 input channels: direct VALU kernel (conv_small.hip)
     // tile: 0 auto; 1 = 16 couts x 256 px; 2 = 32 x 256; 3 = 64 x 256; 4 = 128 x 128; 5 = 64 x 128

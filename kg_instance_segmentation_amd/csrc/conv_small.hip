@@ -160,8 +160,9 @@ __global__ __launch_bounds__(256) void conv_small_mfma_kernel(const ConvArgs a) 
         }
     }
     const bf16_t* wrow[4];
+    const int nv = a.km.total;      // split-bf16 planes: nv virtual planes of 8 channels per tap (kg_common.h), k-step = (tap quad, virtual plane)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wrow[i] = a.w + (long)(c0 + (lm >> 2) * 16 + i * 4 + (lm & 3)) * a.K + 8 * g;   // rows / columns past the tensor are zero
+    for (int i = 0; i < 4; ++i) wrow[i] = a.w + (long)(c0 + (lm >> 2) * 16 + i * 4 + (lm & 3)) * a.K + 8 * g * nv;   // rows / columns past the tensor are zero
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -172,9 +173,7 @@ __global__ __launch_bounds__(256) void conv_small_mfma_kernel(const ConvArgs a) 
         const int tap = 4 * s + g;
         const int dy = tap / a.KW, dx = tap - dy * a.KW;
         const int dyo = dy - a.pad, dxo = dx - a.pad;
-        bf16x8 af[4], bfr[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wrow[i] + 32 * s);
+        long srow[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bool ok = pbase[j] >= 0 && tap < a.ntaps;
@@ -195,18 +194,29 @@ __global__ __launch_bounds__(256) void conv_small_mfma_kernel(const ConvArgs a) 
                 ok = ok && (unsigned)iy < (unsigned)ph[j] && (unsigned)ix < (unsigned)pw[j];
                 row = pbase[j] + (long)sy * pw[j] + sx;
             }
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *reinterpret_cast<const uint4*>(a.x + row * a.ldx);
-            bfr[j] = *reinterpret_cast<const bf16x8*>(&v);
+            srow[j] = ok ? row : -1;
         }
+        for (int vq = 0; vq < nv; ++vq) {
+            bf16x8 af[4], bfr[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(wrow[i] + (32 * s) * nv + 8 * vq);
+            const int xo = a.km.xoff(vq);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (srow[j] >= 0) v = *reinterpret_cast<const uint4*>(a.x + srow[j] * a.ldx + xo);
+                bfr[j] = *reinterpret_cast<const bf16x8*>(&v);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
     }
     // ---- epilogue: lane owns pixel row m and couts cb .. cb+15 (Cout % 8 == 0, 16-byte aligned rows: checked by the caller) ----
     const int cb = c0 + g * 16;
     if (cb >= a.Cout) return;
+    const EpiArgs ep = kg_epi(a);
     float bv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
@@ -214,38 +224,19 @@ __global__ __launch_bounds__(256) void conv_small_mfma_kernel(const ConvArgs a) 
     for (int j = 0; j < 4; ++j) {
         const long m = m0 + j * 16 + lm;
         if (m >= a.M) continue;
+        float v[16];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {            // two 8-cout halves
-            if (cb + h * 8 >= a.Cout) continue;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = acc[h * 2 + (e >> 2)][j][e & 3] + bv[h * 8 + e];
-            if (a.res) {
-                const uint4 rv = *reinterpret_cast<const uint4*>(a.res + m * a.ldres + cb + h * 8);
-                const bf16_t* rs = reinterpret_cast<const bf16_t*>(&rv);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bf2f(rs[e]);
-            }
-            if (a.relu) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-            }
-            if (a.mask) {
-                const uint4 mv = *reinterpret_cast<const uint4*>(a.mask + m * a.ldmask + cb + h * 8);
-                const bf16_t* ms = reinterpret_cast<const bf16_t*>(&mv);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = bf2f(ms[e]) > 0.f ? v[e] : 0.f;
-            }
-            *reinterpret_cast<uint4*>(a.y + m * a.ldy + cb + h * 8) =
-                make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-        }
+        for (int e = 0; e < 16; ++e) v[e] = acc[e >> 2][j][e & 3] + bv[e];
+        kg_conv_epilogue<16>(ep, m, cb, v);
     }
 }
 
 // cin_pad == 8, Cout % 8 == 0, bf16 row output with 16-byte aligned rows (checked by the caller, kg_conv2d_igemm)
 int kg_launch_conv_small(const ConvArgs& a, hipStream_t st) {
     static const int use_mfma = getenv("KG_CONV_SMALL_MFMA") ? atoi(getenv("KG_CONV_SMALL_MFMA")) : 1;
-    if (use_mfma && a.K >= 32 * ((a.ntaps + 3) / 4)) {
+    const bool planed = a.km.total > 1 || a.yP > 1 || a.rP > 1;
+    if (planed && !(a.K >= 32 * a.km.total * ((a.ntaps + 3) / 4))) { kg_set_error("conv_small: packed rows too short for the plane layout"); return KG_ERR_ARG; }
+    if ((use_mfma || planed) && a.K >= 32 * a.km.total * ((a.ntaps + 3) / 4)) {
         hipLaunchKernelGGL(conv_small_mfma_kernel, dim3((unsigned)((a.M + 255) / 256), kg_cdiv(a.Cout, 64)), dim3(256), 0, st, a);
         KG_CHECK_LAUNCH("conv_small_mfma");
         return KG_OK;

@@ -7,12 +7,14 @@ write straight into column slices of the concat buffer.  ReLU backward is folded
 data-gradient kernels' epilogue (mask operand) whenever every contribution passes through one.
 
 Precision (ops.PT, csrc/kg_common.h "planes"): the reference is fp32 (KGnet.py:22-29).  A tensor is stored as P planes of
-bf16 whose sum is the value and multiplied with bf16 MFMA products accumulated in fp32:
-  "mixed" (default): trunk = stem, c0_conv, layer1-3 and the top-down decoder (14 % of the FLOPs, 43 BatchNorm layers whose
-           train-mode statistics amplify a storage error ~x1.2 per layer) in P = 2 (hi + lo, 3 products); the two 7x7 head
-           layers (86 % of the FLOPs, two layers deep) and the seg branch in P = 1 (plain bf16);
-  "fp32":  P = 3 everywhere (hi + mid + lo == the fp32 value exactly, 6 products): fp32-faithful results;
-  "bf16":  P = 1 everywhere.
+bf16 whose sum is the value and multiplied with bf16 MFMA products accumulated in fp32.  Planes of (backbone = stem conv1 +
+layer1-3 with their 43 BatchNorm layers | c0_conv + top-down decoder | the two 7x7 head layers | seg branch):
+  "mixed" (default) (2, 1, 1, 1): only the BatchNorm backbone -- 2.5 % of the FLOPs, but its train-mode batch statistics
+           amplify a storage error ~x1.2 per layer (x3600 over the 45 layers at random init) -- is kept in hi + lo planes
+           (3 products); everything after it is at most 8 layers deep and plain bf16;
+  "trunk2" (2, 2, 1, 1): c0_conv and the decoder in two planes as well (halves the forward error of "mixed", +40 % step time);
+  "fp32"   (3, 3, 3, 3): hi + mid + lo == the fp32 value exactly, 6 products: fp32-faithful results;
+  "bf16"   (1, 1, 1, 1).
 """
 import os
 
@@ -21,7 +23,7 @@ import torch
 from . import arch, ops
 from .ops import BF16, PT, PackedWeight
 
-PRECISIONS = {"bf16": (1, 1, 1), "mixed": (2, 1, 1), "fp32": (3, 3, 3)}      # planes of (trunk, heads, seg branch)
+PRECISIONS = {"bf16": (1, 1, 1, 1), "mixed": (2, 1, 1, 1), "trunk2": (2, 2, 1, 1), "fp32": (3, 3, 3, 3)}   # (backbone, c0 + decoder, heads, seg)
 
 
 def default_precision():
@@ -128,7 +130,7 @@ class Engine:
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)} (got {precision!r})")
         self.precision = precision
-        self.pt, self.ph, self.pseg = PRECISIONS[precision]
+        self.pt, self.pd, self.ph, self.pseg = PRECISIONS[precision]
         self.invalidate_caches()
 
     def invalidate_caches(self):
@@ -176,6 +178,7 @@ class Engine:
         if s.pw is None or s.versions != ver or s.pw.buf.device != dev:
             if s.pw is None or s.pw.buf.device != dev:
                 s.pw = PackedWeight(s.cout, taps, s.cin_pad, dev, xP=s.P, wP=s.P)
+                s.pw.cin_real = s.cin          # (FLOP accounting of bench.py: real channels, not the padding / plane copies)
                 s.pwT = None
             r = 0
             for w, co in zip(ws, s.couts):
@@ -190,6 +193,7 @@ class Engine:
         if need_T and (s.pwT is None or getattr(s.pwT, "stale", True)):
             if s.pwT is None:
                 s.pwT = PackedWeight(s.cin, taps, ops.round_up(s.cout, 8), dev, xP=s.gP, wP=s.P)
+                s.pwT.cin_real = s.cout
             r = 0
             for w, co in zip(ws, s.couts):
                 s.pwT.pack(w.detach(), c0=r, transposed=True)
@@ -206,8 +210,8 @@ class Engine:
         OW = (W + 2 * s.pad - s.k) // s.stride + 1
         M = N * OH * OW
         dev = xv.t.device
-        oP = s.P if oP is None else oP
-        assert oP == s.gP, "the gradient of a conv output carries the output's planes"
+        oP = s.gP if oP is None else oP
+        assert oP >= s.gP
         if y_f32 is None and out is None:
             out = ops.alloc_pt(M, s.cout, oP, dev)
         geom = (M, H, W, OH, OW, s.k, s.k, s.stride, s.pad)
@@ -219,6 +223,7 @@ class Engine:
                 g = yv.take_grad()
                 if g is None:
                     return
+                g = trunc(g, s.gP)       # (an output stored in more planes than this conv computes in: its gradient is rounded alike)
                 grads, off = [], 0
                 for n, co in zip(s.names, s.couts):
                     w = self.P(n + ".weight")
@@ -304,9 +309,9 @@ class Engine:
             self.tape.append(bwd)
         return yv, OH, OW
 
-    def upsample(self, xv, N, IH, IW, OH, OW):
+    def upsample(self, xv, N, IH, IW, OH, OW, P=None):
         C = xv.C
-        out = ops.alloc_pt(N * OH * OW, C, xv.P, xv.t.device)
+        out = ops.alloc_pt(N * OH * OW, C, xv.P if P is None else P, xv.t.device)
         ops.bilinear_fwd(xv.t, out, N, IH, IW, OH, OW, C)
         yv = Var(out, C, relu=False)
         if self.tape is not None:
@@ -365,13 +370,13 @@ class Engine:
             self.train_steps += 1
         self.stamp = ("t" if record else "e", self.train_steps, ops.PARAM_EPOCH[0])
         self.prepare_all(record)
-        pt = self.pt
-        x8 = Var(ops.img_pack(img, pt), 8, relu=False, req=False)
+        pt, pd = self.pt, self.pd
+        x8 = Var(ops.img_pack(img, max(pt, pd)), 8, relu=False, req=False)
         dims = [(H, W)]
         # c0 branch (KGnet.py:276): both convs at full resolution; c0 lands in cat0[:, 64:128]
-        cat0 = ops.alloc_pt(N * H * W, 128, pt, dev)
-        c0a, _, _ = self.conv(x8, self.spec("c0_conv.0", 3, 64, 3, 1, 1), N, H, W, True)
-        c0, _, _ = self.conv(c0a, self.spec("c0_conv.2", 64, 64, 3, 1, 1), N, H, W, True, out=cat0.cols(64, 128))
+        cat0 = ops.alloc_pt(N * H * W, 128, pd, dev)
+        c0a, _, _ = self.conv(x8, self.spec("c0_conv.0", 3, 64, 3, 1, 1, P=pd), N, H, W, True)
+        c0, _, _ = self.conv(c0a, self.spec("c0_conv.2", 64, 64, 3, 1, 1, P=pd), N, H, W, True, out=cat0.cols(64, 128))
         # stem (KGnet.py:278-282)
         s1, H1, W1 = self.conv(x8, self.spec("conv1", 3, 64, 7, 2, 3, bias=False), N, H, W, False)
         cat1 = ops.alloc_pt(N * H1 * W1, 128, pt, dev)
@@ -399,11 +404,11 @@ class Engine:
         for lvl in (3, 2, 1, 0):
             (IH, IW), (OH, OW) = dims[lvl + 1], dims[lvl]
             cin, cu = up_ch[lvl]
-            u_in = self.upsample(cur, N, IH, IW, OH, OW)
-            buf = cats[lvl]
-            u, _, _ = self.conv(u_in, self.spec(f"c{lvl + 1}_up_conv.0", cin, cu, 3, 1, 1), N, OH, OW, True, out=buf.cols(0, cu))
+            u_in = self.upsample(cur, N, IH, IW, OH, OW, P=pd)
+            buf = cats[lvl]        # (planes of the skip tensor: the decoder convs write / read their own pd planes of it)
+            u, _, _ = self.conv(u_in, self.spec(f"c{lvl + 1}_up_conv.0", cin, cu, 3, 1, 1, P=pd), N, OH, OW, True, out=buf.cols(0, cu), oP=buf.P)
             cv = self.concat(buf, [u, feats[lvl]])
-            cur, _, _ = self.conv(cv, self.spec(f"c{lvl}_cat_refine.0", buf.shape[1], cu, 1), N, OH, OW, True)
+            cur, _, _ = self.conv(cv, self.spec(f"c{lvl}_cat_refine.0", buf.shape[1], cu, 1, P=pd), N, OH, OW, True)
             catv[lvl] = cur
         # heads (KGnet.py:300-316): three first 7x7 convs fused along Cout, three second convs
         maps = []

@@ -172,7 +172,8 @@ class PackedWeight:
         self.rows, self.taps, self.cin_pad, self.xP, self.wP, self.groups = rows, taps, cin_pad, xP, wP, groups
         self.vp = vplanes(xP, wP)
         self.tap_stride = groups * self.vp * cin_pad
-        self.K = round_up(taps * self.tap_stride, 64)
+        # (8-channel inputs: conv_small.hip reads whole tap quads)
+        self.K = round_up((round_up(taps, 4) if cin_pad == 8 else taps) * self.tap_stride, 64)
         self.buf = torch.zeros(round_up(rows, 384), self.K, dtype=BF16, device=dev)   # rows cover any 64/128/192 cout tile
 
     def pack(self, w, row0=0, c0=0, transposed=False):
@@ -374,19 +375,22 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
     xps, dps = nplanes(x)[1], nplanes(dy)[1]
     planed = len(pairs) > 1 or nplanes(x)[0] > 1 or nplanes(dy)[0] > 1
     xb, dyb = _rows(x), _rows(dy)
-    if IM2COL_WGRAD and not planed and mode == 0 and N is not None and cin <= 4 and KH * KW >= 25 and len(grads) == 1 and not accumulate:
+    if IM2COL_WGRAD and mode == 0 and N is not None and cin <= 4 and KH * KW >= 25 and len(grads) == 1 and not accumulate:
         # stem conv1 (3 -> 64, 7x7 s2): im2col to [M][taps*cin] and ONE 1x1 weight-gradient GEMM instead of 49 per-tap launches
-        # that pad 3 channels to a 64-wide tile
+        # that pad 3 channels to a 64-wide tile (planes: im2col is a gather, so every plane is gathered separately)
         Kc = KH * KW * cin
         Kpad = round_up(Kc, 8)
-        col = torch.zeros(M, Kpad, dtype=BF16, device=xb.device) if Kpad != Kc else torch.empty(M, Kpad, dtype=BF16, device=xb.device)
-        _lib.call("kg_im2col_small", ptr(xb), ptr(col), N, H, W, OH, OW, KH, KW, stride, pad, cin, ld(xb), Kpad, stream_ptr())
+        xP = nplanes(x)[0]
+        col = alloc_pt(M, Kpad, xP, xb.device, zero=Kpad != Kc)
+        for p_ in range(xP):
+            _lib.call("kg_im2col_small", ctypes_offset(xb, p_ * xps), ctypes_offset(col.t, p_ * col.ps), N, H, W, OH, OW, KH, KW, stride, pad, cin,
+                      ld(xb), ld(col), stream_ptr())
         g, off, cnt = grads[0]
         tmp = torch.empty(cout, Kc, 1, 1, dtype=torch.float32, device=xb.device)
-        conv_wgrad(col, dyb, Kc, cout, (M, OH, OW, OH, OW, 1, 1, 1, 0), [(tmp, off, cnt)])
+        conv_wgrad(col if xP > 1 else col.t, dy, Kc, cout, (M, OH, OW, OH, OW, 1, 1, 1, 0), [(tmp, off, cnt)])
         g.copy_(tmp.view(cnt, KH * KW, cin).permute(0, 2, 1).reshape(g.shape))     # [co][tap][ci] -> OIHW
         if bias_out is not None:
-            bias_grad(dyb, cout, bias_out)
+            bias_grad(dy, cout, bias_out)
         return "im2col"
     cin_lim = min(round_up(cin, 8), xb.shape[1])
     cout_lim = min(round_up(cout, 8), dyb.shape[1])

@@ -17,6 +17,15 @@ def create_position_index(height, width):
 
 
 def _device(device):
+    try:
+        from torch.utils.data import get_worker_info
+        in_worker = get_worker_info() is not None
+    except Exception:
+        in_worker = False
+    if in_worker:
+        raise _lib.KGLibraryError("preprocessing.get_ground_truth (MI355X build) was called inside a DataLoader worker process; "
+                                  "workers cannot use the GPU: build the DataLoader with num_workers=0 (dropin/run.py does so under "
+                                  "KG_GPU_GT=1) or keep the reference's host preprocessing module for the workers")
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     if dev.type != "cuda":
         raise _lib.KGLibraryError("preprocessing (MI355X build) needs a GPU device")

@@ -130,7 +130,10 @@ def test_dropin_shims_expose_the_reference_module_surface():
             "preprocessing": ["get_ground_truth", "create_position_index"],
             "eval_parts": ["mask_iou", "voc_ap", "bbox_evaluation", "seg_evaluation"]}
     for name, syms in want.items():
-        spec = importlib.util.spec_from_file_location(f"_dropin_{name}", os.path.join(root, "dropin", f"{name}.py"))
+        # `preprocessing` is opt-in (dropin/optin/, KG_GPU_GT=1): the reference calls it inside DataLoader workers, which cannot use the GPU
+        sub = "optin" if name == "preprocessing" else ""
+        assert os.path.exists(os.path.join(root, "dropin", f"{name}.py")) == (name != "preprocessing")
+        spec = importlib.util.spec_from_file_location(f"_dropin_{name}", os.path.join(root, "dropin", sub, f"{name}.py"))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         for sym in syms:
@@ -179,3 +182,40 @@ def test_dropin_launcher_shadows_the_scripts_own_modules(tmp_path):
     assert r.returncode == 0, r.stderr
     lines = r.stdout.strip().splitlines()
     assert lines[0] == os.path.join(root, "dropin", "config.py") and lines[1] == "module that is not replaced" and lines[2] == "['--flag', '7']"
+
+
+def test_pretrained_loads_a_torchvision_keyed_checkpoint(tmp_path, monkeypatch):
+    """KGnet.resnet50(pretrained=True) (KGnet.py:377-386: load_state_dict(torchvision resnet50, strict=False)): a checkpoint with
+    torchvision's key set -- conv1 / bn1 / layer1..4 / fc, i.e. MORE than KGnet builds (layer4, fc) and LESS than it has (decoder,
+    heads, seg branch) -- loads through KG_RESNET50_PTH: shared keys are overwritten, the rest keeps its init, nothing raises."""
+    import torch
+    from kg_instance_segmentation_amd import KGnet
+    from oracle import weightgen
+    torch.manual_seed(0)
+    ref = KGnet.resnet50(pretrained=False)
+    own = {k: v.clone() for k, v in ref.state_dict().items()}
+    tv = {}
+    src = weightgen.gen_state_dict(7)
+    for k, v in src.items():                     # the trunk keys KGnet shares with torchvision's resnet50
+        if k.startswith(("conv1.", "bn1.", "layer1.", "layer2.", "layer3.")):
+            tv[k] = v
+    tv["layer4.0.conv1.weight"] = torch.randn(512, 1024, 1, 1)      # keys KGnet does not have
+    tv["fc.weight"] = torch.randn(1000, 2048); tv["fc.bias"] = torch.randn(1000)
+    path = tmp_path / "resnet50-tv.pth"
+    torch.save(tv, path)
+    monkeypatch.setenv("KG_RESNET50_PTH", str(path))
+    torch.manual_seed(0)
+    m = KGnet.resnet50(pretrained=True)
+    sd = m.state_dict()
+    assert len(sd) == 346
+    for k, v in sd.items():
+        if k in tv:
+            assert torch.equal(v, tv[k]), k
+        else:
+            assert torch.equal(v, own[k]), k       # same seed -> same init for everything the checkpoint does not cover
+    monkeypatch.delenv("KG_RESNET50_PTH")
+    import warnings
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        KGnet.resnet50(pretrained=True)
+    assert any("KG_RESNET50_PTH" in str(x.message) for x in w)

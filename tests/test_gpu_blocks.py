@@ -17,7 +17,7 @@ from kg_instance_segmentation_amd.ops import BF16, PT  # noqa: E402
 from oracle import net as onet  # noqa: E402
 
 DEV = "cuda"
-THR = {"bf16": 0.985, "mixed": 0.99995, "fp32": 0.9999999}
+THR = {"bf16": 0.985, "mixed": 0.99995, "trunk2": 0.99995, "fp32": 0.9999999}
 
 
 def to_pt(x_nchw, P):
