@@ -398,7 +398,7 @@ def main():
             opt = Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4)
         else:
             opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4, fused=os.environ.get("KG_ADAM_FUSED", "1") == "1")
-        reducer = parallel.GradReducer(model.parameters()).attach(model) if world > 1 else None
+        reducer = parallel.FlatGradReducer().attach(model) if world > 1 else None
 
         def step(sync):
             opt.zero_grad()
@@ -411,7 +411,7 @@ def main():
             loss = l1 if l2 is None else l1 + l2 / world
             loss.backward()
             if reducer is not None:
-                reducer.reduce()
+                reducer.finish()
             opt.step()
             return loss.item() if sync else loss.detach()      # train.py:156 reads the loss back every step
 

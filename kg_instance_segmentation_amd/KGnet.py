@@ -62,8 +62,12 @@ class _DecFunction(torch.autograd.Function):
         with torch.cuda.device(next(g for g in grads if g is not None).device):
             pg = eng.backward_dec(list(grads[:12]), fg)
         out = [None, None, None]
+        store = eng.grad_store
         for k in ctx.keys:
-            out.append(pg.get(k))
+            g = pg.get(k)
+            if store is not None and g is not None and store.owns(k, g):
+                g = store.deliver(k, ctx.model.get_tensor(k))      # the flat slot becomes .grad itself: autograd gets nothing to accumulate
+            out.append(g)
         return tuple(out)
 
 

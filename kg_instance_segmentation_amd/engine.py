@@ -124,6 +124,7 @@ class Engine:
         self.train_steps, self.stamp = 0, ("e", 0, 0)
         self.generation = 0        # bumped by every forward_dec: a backward must belong to the latest recorded forward
         self.raw_kp_logits = False   # test hook: inference-only export of the kp LOGITS instead of sigmoid(logits) (KGnet.py:300)
+        self.grad_store = None     # parallel.FlatGradReducer: key -> persistent fp32 view the gradient kernels write into directly
         self.grad_hook = None      # parallel.GradReducer.attach: called with [(key, grad)] as backward produces them
 
     def set_precision(self, precision):
@@ -141,6 +142,24 @@ class Engine:
     # ---- parameters ---------------------------------------------------------------------------
     def P(self, key):
         return self.m.get_tensor(key)
+
+    def new_grad(self, key, like):
+        """Destination of a parameter gradient: a fresh tensor, or -- data parallel -- the parameter's slot in the persistent flat
+        gradient buffer (parallel.FlatGradReducer), which RCCL reduces in place and the optimizer reads in place."""
+        if self.grad_store is not None:
+            v = self.grad_store.get(key)
+            if v is not None:
+                return v
+        return torch.empty_like(like)
+
+    def place_grad(self, key, g):
+        """a small (bias / BatchNorm) gradient vector produced as a slice of a shared buffer: copied into its flat slot if there is one"""
+        if self.grad_store is not None:
+            v = self.grad_store.get(key)
+            if v is not None:
+                v.copy_(g)
+                return v
+        return g
 
     def spec(self, key, cin, cout, k, stride=1, pad=0, bias=True, fused=None, P=None, gP=None):
         s = self.specs.get(key)
@@ -227,7 +246,7 @@ class Engine:
                 grads, off = [], 0
                 for n, co in zip(s.names, s.couts):
                     w = self.P(n + ".weight")
-                    gw = torch.empty_like(w)
+                    gw = self.new_grad(n + ".weight", w)
                     self.param_grads[n + ".weight"] = gw
                     grads.append((gw, off, co))
                     off += co
@@ -236,7 +255,7 @@ class Engine:
                 if s.has_bias:
                     off = 0
                     for n, co in zip(s.names, s.couts):
-                        self.param_grads[n + ".bias"] = db[off:off + co]
+                        self.param_grads[n + ".bias"] = self.place_grad(n + ".bias", db[off:off + co])
                         off += co
                 if xv.req:
                     existing = xv.grad if xv.parent is None else None
@@ -280,8 +299,8 @@ class Engine:
                 g = yv.take_grad()
                 if g is None:
                     return
-                dg = torch.empty(C, dtype=torch.float32, device=dev)
-                db = torch.empty(C, dtype=torch.float32, device=dev)
+                dg = self.new_grad(p + ".weight", gamma)
+                db = self.new_grad(p + ".bias", beta)
                 dx = ops.alloc_pt(xv.rows, C, xv.P, dev)
                 ops.bn_bwd(xv.t, g, C, gamma.detach(), mean, invstd, dg, db, dx)
                 self.param_grads[p + ".weight"] = dg
@@ -368,6 +387,8 @@ class Engine:
         self.stats_written = False
         if record:
             self.train_steps += 1
+            if self.grad_store is not None:
+                self.grad_store.begin_step()
         self.stamp = ("t" if record else "e", self.train_steps, ops.PARAM_EPOCH[0])
         self.prepare_all(record)
         pt, pd = self.pt, self.pd
@@ -500,8 +521,8 @@ class Engine:
                 for k, ((h, co), s) in enumerate(zip(arch.HEADS, specs)):
                     gk = g.cols(self.HEAD_OFF[k], self.HEAD_OFF[k] + self.HEAD_PAD[k])
                     w = self.P(s.names[0] + ".weight")
-                    gw = torch.empty_like(w)
-                    db = torch.empty(co, dtype=torch.float32, device=dev)      # bias gradient: a free unit of the wgrad kernel
+                    gw = self.new_grad(s.names[0] + ".weight", w)
+                    db = self.new_grad(s.names[0] + ".bias", self.P(s.names[0] + ".bias"))      # bias gradient: a free unit of the wgrad kernel
                     ops.conv_wgrad(hid.t.cols(k * C, (k + 1) * C), gk, C, co, geom, [(gw, 0, co)], N=N, bias_out=db)
                     self.param_grads[s.names[0] + ".weight"] = gw
                     self.param_grads[s.names[0] + ".bias"] = db
@@ -524,6 +545,8 @@ class Engine:
 
     def backward_dec(self, map_grads, feat_grads):
         """map_grads: 12 fp32 NCHW (or None); feat_grads: 5 fp32 [rows, C] tensors (or None)."""
+        if self.grad_store is not None:
+            self.grad_store.dense_backward_started()
         for (slot, lvl, N, Hh, Wh) in self.head_slots:
             gs = map_grads[3 * lvl:3 * lvl + 3]
             if all(g is None for g in gs):

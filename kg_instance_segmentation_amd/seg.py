@@ -95,8 +95,14 @@ class _SegFunction(torch.autograd.Function):
             raise RuntimeError("forward_seg was run without gradient recording")
         gfeats, pgrads = ctx.branch.run_backward(ctx.plan, ctx.saved, gflat.contiguous().float(), ctx.feat_shapes)
         out = [None, None, None] + gfeats
+        store = ctx.branch.m._engine.grad_store
         for k in ctx.branch.param_keys:
-            out.append(pgrads.get(k))
+            g = pgrads.get(k)
+            if store is not None and g is not None and store.owns(k, g):
+                g = store.deliver(k, ctx.branch.P(k))
+            out.append(g)
+        if store is not None:
+            store.seg_done()
         return tuple(out)
 
 
@@ -373,9 +379,10 @@ class SegBranch:
         w = self.P(key + ".weight")
         cout, cin = w.shape[0], w.shape[1]
         geom = (M, 0, 0, M, 1, k, k, 1, (k - 1) // 2)
-        gw = torch.empty_like(w)
+        eng = self.m._engine
+        gw = eng.new_grad(key + ".weight", w)
         use16 = t16 if (k == 3 and t16 is not None and M >= 0.35 * t16.shape[0] * 256) else None
-        db = torch.empty(cout, dtype=torch.float32, device=w.device)
+        db = eng.new_grad(key + ".bias", self.P(key + ".bias"))
         ops.conv_wgrad(x, g, cin, cout, geom, [(gw, 0, cout)], mode=2, rowdesc=rowdesc, tiletab16=use16, bias_out=db)
         pgrads[key + ".weight"], pgrads[key + ".bias"] = gw, db
         if dx is not None:

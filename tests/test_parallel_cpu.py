@@ -126,3 +126,87 @@ def test_overlapped_reducer_gloo_world2():
     out = mgr.dict()
     mp.spawn(_overlap_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert all(out[(r, s)] for r in range(world) for s in range(2))
+
+
+def _flat_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from kg_instance_segmentation_amd import parallel
+    parallel.init_from_env(backend="gloo")
+
+    class Eng:
+        grad_hook = None
+        grad_store = None
+
+    class Seg:
+        param_keys = ["seg_head.0.weight", "seg_head.0.bias"]
+
+    class Node(torch.nn.Module):
+        pass
+
+    class Model(torch.nn.Module):
+        """parameter names of the real network's stages (FlatGradReducer orders its buffer by them)"""
+        def __init__(self):
+            super().__init__()
+            shapes = {"conv1.weight": (8, 3, 7, 7), "layer1.0.conv1.weight": (300000,), "c0_conv.0.weight": (64, 3, 3, 3), "c4_up_conv.0.weight": (200000,),
+                      "c0_cat_refine.0.weight": (64, 128), "kp_head_c0.0.weight": (50000,), "mid_offset_head_c3.2.weight": (400000,),
+                      "seg_head.0.weight": (64, 64, 3, 3), "seg_head.0.bias": (64,)}
+            self._param_keys = list(shapes)
+            for k, shp in shapes.items():
+                node = self
+                parts = k.split(".")
+                for q in parts[:-1]:
+                    if q not in node._modules:
+                        node.add_module(q, Node())
+                    node = node._modules[q]
+                node.register_parameter(parts[-1], torch.nn.Parameter(torch.zeros(shp)))
+            self._engine, self._seg = Eng(), Seg()
+
+        def get_tensor(self, k):
+            return dict(self.named_parameters())[k]
+
+    m = Model()
+    red = parallel.FlatGradReducer(bucket_mb=1).attach(m)
+    names = dict(m.named_parameters())
+    assert red.keys[:2] == Seg.param_keys and red.keys[2] == "mid_offset_head_c3.2.weight" and red.keys[-1] == "c0_conv.0.weight"
+    assert red.flat.numel() == sum(p.numel() for p in m.parameters()) and len(red.buckets) >= 2
+    eng = m._engine
+    ok = True
+    for step in range(2):
+        red.begin_step()
+        base = red.flat.data_ptr()
+        # seg backward runs on rank 0 only (rank 1 has no valid box): its slots must count as zeros there
+        if rank == 0:
+            for k in Seg.param_keys:
+                g = eng.grad_store.get(k); g.fill_(7.0 * (step + 1))
+                assert red.owns(k, g) and red.deliver(k, names[k]) is None
+            red.seg_done()
+        red.dense_backward_started()                       # engine.backward_dec does this on every rank
+        order = [k for k in red.keys if k not in Seg.param_keys]
+        for i, k in enumerate(order):
+            g = eng.grad_store.get(k)                     # the gradient kernel's destination IS the flat slot
+            g.fill_(float((rank + 1) * (i + 1) * (step + 1)))
+            assert red.deliver(k, names[k]) is None
+            eng.grad_hook([(k, g)], False)
+        eng.grad_hook([], True)
+        red.finish()
+        assert red.flat.data_ptr() == base
+        for i, k in enumerate(order):
+            ok = ok and names[k].grad.data_ptr() == red.get(k).data_ptr()            # .grad is the slot: nothing was copied
+            ok = ok and float((names[k].grad - 3.0 * (i + 1) * (step + 1)).abs().max()) == 0.0
+        for k in Seg.param_keys:
+            ok = ok and names[k].grad is not None and float((names[k].grad - 7.0 * (step + 1)).abs().max()) == 0.0
+        for p in m.parameters():
+            p.grad = None                                  # optimizer.zero_grad(set_to_none=True)
+    out[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_flat_grad_reducer_gloo_world2():
+    """FlatGradReducer: one persistent flat gradient buffer in backward order; gradient "kernels" write into the slots, the slot is
+    installed as .grad without a copy, buckets are all-reduced in place as they complete, a rank without seg backward contributes
+    zeros, and two consecutive steps give the exact sums."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_flat_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(out[r] for r in range(world))
