@@ -202,6 +202,15 @@ int kg_crop_grad_reduce(const void* ga, int lda, const void* gb, int ldb, long r
                         const int* bin_boxes, int bin_size, int N, int H, int W, int C, float* out,
                         const kg_planes_t* planes, void* stream);
 
+
+/* ---- mask paste-back of the inference driver (test.py:127-157): cv2.resize(patch, box size) -> paste into a zero
+ * (input_h, input_w) mask -> cv2.resize(mask, (image_w, image_h)) -> mask >= seg_thresh, for all detections in one launch.
+ * flat = forward_seg's fp32 patch probabilities; dets = device int32 [nd][8] {patch offset, patch h, patch w, y1, x1, y2, x2, 0}
+ * (box rounded / clamped as test.py:138-141); out = [nd][image_h][image_w] float32 (out_is_u8 = 0) or bytes.  The interpolation
+ * is OpenCV's published generic INTER_LINEAR float path (oracle/paste.py) ---- */
+int kg_mask_paste(const float* flat, const int* dets, int nd, int input_h, int input_w, int image_h, int image_w,
+                  float seg_thresh, void* out, int out_is_u8, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,7 @@ _SIGS = {
     "kg_rows_gather_f32": [P, c_int, P, P, c_int, c_long, c_int, P, P],
     "kg_planes_to_f32": [P, c_int, P, c_int, c_long, c_int, P, P],
     "kg_f32_to_planes": [P, c_int, P, c_int, P, c_int, c_long, c_int, P, P],
+    "kg_mask_paste": [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P, c_int, P],
     "kg_crop_grad_reduce": [P, c_int, P, c_int, c_long, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P],
 }
 _RESTYPE = {"kg_postproc_workspace_bytes": c_long}

@@ -31,6 +31,7 @@ SOURCES = {
     "evalmetrics.hip": [],
     "optim.hip": ["-ffp-contract=off"],
     "seg.hip": [],
+    "paste.hip": ["-ffp-contract=off"],
 }
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

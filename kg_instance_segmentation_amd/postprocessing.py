@@ -6,7 +6,7 @@ the host, where the reference's list-of-ndarray return types are rebuilt."""
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import ptr, stream_ptr, c_double, c_long
 
 PEAK_THRESH = 0.004   # postprocessing.py:145
@@ -152,3 +152,32 @@ def detect(dec, nms_thresh=0.5):
     if k == 0:
         return None
     return out[:k].cpu().numpy()
+
+
+def paste_masks(predictions, input_h, input_w, image_w, image_h, seg_thresh, device_u8=False):
+    """== the reference driver's `post_processing` (test.py:127-157) for the predictions of `model.forward_seg`: every mask patch is
+    resized to its (rounded, clamped) box, pasted into an (input_h, input_w) canvas, resized to the image and thresholded -- in one
+    kernel launch for all detections (kg_mask_paste) instead of two cv2.resize calls and a full-size host array per detection.
+    Returns [masks float32 [n, image_h, image_w] in {0, 1}, dets float32 [n, 5] = (y1, x1, y2, x2, conf) in image pixels] like the
+    reference, or None; device_u8=True keeps the masks on the GPU as bytes (what eval_parts.seg_evaluation consumes)."""
+    if predictions is None:
+        return None
+    meta = getattr(predictions, "kg_meta", None)
+    if meta is None:
+        raise _lib.KGLibraryError("paste_masks needs the predictions object returned by this package's forward_seg")
+    n = len(meta["off"])
+    flat = meta["flat"]
+    dev = flat.device
+    b = np.asarray(meta["boxes"], np.float32).reshape(-1, 5)
+    y1 = np.maximum(0, np.round(b[:, 0]).astype(np.int32)); x1 = np.maximum(0, np.round(b[:, 1]).astype(np.int32))
+    y2 = np.minimum(np.round(b[:, 2]).astype(np.int32), input_h - 1); x2 = np.minimum(np.round(b[:, 3]).astype(np.int32), input_w - 1)
+    tab = np.stack([np.asarray(meta["off"], np.int64), np.asarray(meta["h"], np.int64), np.asarray(meta["w"], np.int64), y1, x1, y2, x2,
+                    np.zeros(n, np.int64)], 1).astype(np.int32)
+    dets = np.stack([y1.astype(np.float64) / input_h * image_h, x1.astype(np.float64) / input_w * image_w,
+                     y2.astype(np.float64) / input_h * image_h, x2.astype(np.float64) / input_w * image_w, b[:, 4].astype(np.float64)], 1).astype(np.float32)
+    out = torch.empty(n, int(image_h), int(image_w), dtype=torch.uint8 if device_u8 else torch.float32, device=dev)
+    if n:
+        with torch.cuda.device(dev):
+            _lib.call("kg_mask_paste", ptr(flat), ptr(ops.h2d(tab.reshape(-1), dev)), n, int(input_h), int(input_w), int(image_h), int(image_w),
+                      _lib.c_float(float(seg_thresh)), ptr(out), 1 if device_u8 else 0, stream_ptr())
+    return [out if device_u8 else out.cpu().numpy(), dets]

@@ -159,3 +159,34 @@ def test_empty_maps():
     assert kpp.get_skeletons_and_masks(*z) == []
     assert kpp.gather_skeleton([], [], [], []).shape == (0,)
     assert kpp.detect([z, z, z, z]) is None
+
+
+@pytest.mark.parametrize("image_hw", [(512, 512), (520, 696), (300, 200)])
+def test_paste_masks_vs_oracle(image_hw):
+    """kg_mask_paste (test.py:127-157 in one launch) against oracle/paste.py (OpenCV's published INTER_LINEAR float rule) bit for
+    bit: same masks after the >= seg_thresh cut, same scaled boxes -- with boxes whose crop size differs from the patch size
+    (so that the first resize is a genuine interpolation), boxes on the border and an identity-size image."""
+    from kg_instance_segmentation_amd import KGnet
+    from oracle import paste as opaste, weightgen
+    S = 512
+    m = KGnet.resnet50(pretrained=False)
+    m.load_state_dict(weightgen.gen_state_dict(0, variant="cal"))
+    m = m.to(DEV).eval()
+    x = (torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(3)) - 0.5).to(DEV)
+    bx = synth.random_boxes(S, S, 40, 11)
+    bx = np.concatenate([bx, [[0.4, 0.6, 30.5, 41.5], [470.5, 480.2, 511.0, 511.0], [100.5, 100.5, 131.5, 140.49]]], 0)
+    boxes = [np.concatenate([bx, np.linspace(0.9, 0.3, len(bx))[:, None]], 1).astype(np.float32)]
+    with torch.no_grad():
+        feats = m.forward_dec(x)[4]
+        pred = m.forward_seg(feats, boxes)
+    ih, iw = image_hw
+    got = kpp.paste_masks(pred, S, S, iw, ih, 0.5)
+    ref = opaste.paste_masks([[[p.cpu().numpy() for p in pp] for pp in pred[0]], [[d.numpy() for d in dd] for dd in pred[1]]], S, S, iw, ih, 0.5)
+    assert got[0].shape == ref[0].shape == (len(bx), ih, iw) and got[0].dtype == np.float32
+    nbad = int((got[0] != ref[0]).sum())
+    print(f"paste {image_hw}: {len(bx)} masks, {int(ref[0].sum())} foreground pixels, {nbad} mismatching pixels")
+    assert nbad == 0
+    assert np.array_equal(got[1], ref[1])
+    dev_masks, _ = kpp.paste_masks(pred, S, S, iw, ih, 0.5, device_u8=True)
+    assert dev_masks.dtype == torch.uint8 and np.array_equal(dev_masks.cpu().numpy().astype(np.float32), ref[0])
+    assert kpp.paste_masks(None, S, S, iw, ih, 0.5) is None
