@@ -92,11 +92,12 @@ int kg_im2col_small(const void* x, void* out, int N, int H, int W, int OH, int O
 /* weight gradient (autograd of nn.Conv2d at train.py:153): partial sums [nsplit][Cout][taps][Cin] fp32 */
 int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const int* rowdesc, int M, int H, int W, int OH, int OW,
                     int ldx, int lddy, int Cin, int Cout, int cin_lim, int cout_lim, int KH, int KW, int stride, int pad,
-                    int dil, int mode, int nsplit, long split_stride, void* stream);
+                    int dil, int mode, int nsplit, long split_stride, const kg_planes_t* planes, void* stream);
+                    /* planes: a = x, b = dy: the kept plane products x_i * dY_j are further passes over the pixels in the same launch */
 /* weight gradient of a dense stride-1 "same" 3x3 / 7x7 conv with dY tile + X halo resident in LDS (all taps per staging pass) */
 int kg_conv2d_wgrad_halo(const void* x, const void* dy, float* dwp, int N, int H, int W, int ldx, int lddy, int Cin, int Cout,
                          int cin_lim, int cout_lim, int KS, int nsplit, long split_stride, const int* tiletab16, int ntiles,
-                         float* dbp, void* stream);   /* tiletab16 != NULL: ragged boxes, one entry per 16x16 tile;
+                         float* dbp, const kg_planes_t* planes, void* stream);   /* planes: a = x, b = dy.  tiletab16 != NULL: ragged boxes, one entry per 16x16 tile;
                          dbp != NULL: also writes the bias-gradient partials [nsplit][Cout] (sum over pixels of dy) */
 int kg_bias_grad_final(const float* part, float* db, int nsplit, int C, int accumulate, void* stream);
 int kg_wgrad_reduce(const float* part, float* grad_oihw, int Cout, int Cin, int KH, int KW, int nsplit, long split_stride,

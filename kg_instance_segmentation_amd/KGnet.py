@@ -71,6 +71,51 @@ class _DecFunction(torch.autograd.Function):
         return tuple(out)
 
 
+class _NetFunction(torch.autograd.Function):
+    """forward(x, bboxes) (KGnet.py:269-272) as ONE autograd node: forward_dec, then the seg branch straight on the engine's own
+    split-bf16 feature rows (no fp32 export of c0..c4, no autograd hop between the two halves); backward runs the seg branch's
+    backward, hands its fp32 feature gradients to the dense backward and returns every parameter gradient at once."""
+
+    @staticmethod
+    def forward(ctx, model, record, holder, x, *params):
+        eng, seg = model._engine, model._seg
+        maps, feats, dims = eng.forward_dec(x, record)
+        # (the box tables are built on the host AFTER the dense forward is enqueued: the GPU is busy meanwhile)
+        plan = seg.make_plan(None, holder["bboxes"], sizes=dims, dev=x.device)
+        plan.rows_only = True
+        holder["plan"] = plan
+        flat, saved = seg.run_forward(plan, [fv.t for fv in feats], record)
+        ctx.model, ctx.recorded, ctx.generation, ctx.plan, ctx.saved = model, record, eng.generation, plan, saved
+        ctx.feat_shapes = [(x.shape[0], fv.C, h, w) for fv, (h, w) in zip(feats, dims)]
+        return tuple(maps) + (flat,)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if not ctx.recorded:
+            raise RuntimeError("KGnet forward was run without gradient recording")
+        model = ctx.model
+        eng, seg = model._engine, model._seg
+        if ctx.generation != eng.generation or eng.tape is None:
+            raise RuntimeError("KGnet backward: the engine keeps the activations of the LATEST forward only; another "
+                               "forward ran on this model between this loss's forward and its backward")
+        dev = next(g for g in grads if g is not None).device
+        with torch.cuda.device(dev):
+            gflat = grads[12]
+            fg, spg = [None] * 5, {}
+            if gflat is not None and ctx.saved is not None:
+                fg, spg = seg.run_backward(ctx.plan, ctx.saved, gflat.contiguous().float(), ctx.feat_shapes)
+            pg = eng.backward_dec(list(grads[:12]), fg)
+        pg.update(spg)
+        out = [None, None, None, None]
+        store = eng.grad_store
+        for k in model._all_param_keys:
+            g = pg.get(k)
+            if store is not None and g is not None and store.owns(k, g):
+                g = store.deliver(k, model.get_tensor(k))
+            out.append(g)
+        return tuple(out)
+
+
 class ResNet(nn.Module):
     """KGnet (ResNet-50[:layer3] + top-down decoder + 12 heads + per-box seg branch)."""
 
@@ -118,6 +163,7 @@ class ResNet(nn.Module):
                     nn.init.constant_(self.get_tensor(f"{name}.{b}.bn3.weight"), 0)
         self._engine = Engine(self, precision)
         self._seg = SegBranch(self)
+        self._all_param_keys = list(self._param_keys)      # (the seg branch's parameters are part of _param_keys: one list for the fused forward)
 
     # ---- precision / cache control (extensions; the reference has neither) --------------------------
     @property
@@ -170,9 +216,18 @@ class ResNet(nn.Module):
             return self._seg.forward(feat_seg, bboxes)
 
     def forward(self, x, bboxes):
-        dec0, dec1, dec2, dec3, feat_seg = self.forward_dec(x)
-        seg = self.forward_seg(feat_seg, bboxes)
-        return dec0, dec1, dec2, dec3, seg
+        """KGnet.py:269-272: (dec0, dec1, dec2, dec3, [mask_patches, mask_dets])."""
+        self._check_input(x)
+        with torch.cuda.device(x.device):
+            params = [self.get_tensor(k) for k in self._all_param_keys]
+            record = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+            holder = {"bboxes": bboxes}
+            outs = _NetFunction.apply(self, record, holder, x, *params)
+        d = [list(outs[3 * i:3 * i + 3]) for i in range(4)]
+        plan = holder["plan"]
+        if plan.nb[0] == 0:          # no valid box anywhere: the seg branch contributes nothing (KGnet.py:339-340)
+            return d[0], d[1], d[2], d[3], [[[] for _ in bboxes], [[] for _ in bboxes]]
+        return d[0], d[1], d[2], d[3], self._seg.predictions(plan, outs[12], len(bboxes))
 
 
 def _load_pretrained(model):

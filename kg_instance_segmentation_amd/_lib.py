@@ -27,8 +27,8 @@ _SIGS = {
     "kg_im2col_small": [P, P] + [c_int] * 12 + [P],
     "kg_conv2d_halo_heads2": [P, P, P, P, P, P, P] + [c_int] * 7 + [P, P],
     "kg_set_wgrad_tr": [c_int],
-    "kg_conv2d_wgrad": [P, P, P, P] + [c_int] * 18 + [c_long, P],
-    "kg_conv2d_wgrad_halo": [P, P, P] + [c_int] * 11 + [c_long, P, c_int, P, P],
+    "kg_conv2d_wgrad": [P, P, P, P] + [c_int] * 18 + [c_long, P, P],
+    "kg_conv2d_wgrad_halo": [P, P, P] + [c_int] * 11 + [c_long, P, c_int, P, P, P],
     "kg_bias_grad_final": [P, P, c_int, c_int, c_int, P],
     "kg_wgrad_reduce": [P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, P],
     "kg_wgrad_reduce_multi": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, P],

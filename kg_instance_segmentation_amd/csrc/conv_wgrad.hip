@@ -19,6 +19,8 @@ struct WgradArgs {
     int ntaps, KW, stride_log2, pad, dil, mode;
     int chunks_per_split;   // 64-pixel chunks per z-split
     long split_stride;      // elements between partial buffers
+    WgPairs wp;             // split-bf16 operand planes (kg_common.h): the chunk index runs over wp.n * chunks_per_plane virtual chunks
+    int chunks_per_plane;
 };
 
 __device__ __forceinline__ int tr_f(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); }
@@ -70,14 +72,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int ohw = a.OH * a.OW;
 
     uint4 xr[NI], yr[NI];
-    auto load_chunk = [&](int chunk) {
+    auto load_chunk = [&](int vchunk) {
+        const int pr = vchunk / a.chunks_per_plane, chunk = vchunk - pr * a.chunks_per_plane;   // (product, chunk): uniform
+        const bf16_t* xpl = a.x + a.wp.xoff[pr];
+        const bf16_t* dpl = a.dy + a.wp.doff[pr];
         const int mbase = chunk * PX;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int m = mbase + prow + 32 * i;
             uint4 xv = make_uint4(0, 0, 0, 0), yv = make_uint4(0, 0, 0, 0);
             if (m < a.M) {
-                if (y_c_ok) yv = *reinterpret_cast<const uint4*>(a.dy + (long)m * a.lddy + co0 + c8 * 8);
+                if (y_c_ok) yv = *reinterpret_cast<const uint4*>(dpl + (long)m * a.lddy + co0 + c8 * 8);
                 if (x_c_ok) {
                     long row; bool ok;
                     if (a.mode >= 2) {
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                         ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                         row = ((long)n * a.H + iy) * a.W + ix;
                     }
-                    if (ok) xv = *reinterpret_cast<const uint4*>(a.x + row * a.ldx + ci0 + c8 * 8);
+                    if (ok) xv = *reinterpret_cast<const uint4*>(xpl + row * a.ldx + ci0 + c8 * 8);
                 }
             }
             xr[i] = xv; yr[i] = yv;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int total_chunks = (a.M + PX - 1) / PX;
+    const int total_chunks = a.wp.n * a.chunks_per_plane;
     const int cbeg = split * a.chunks_per_split;
     int cend = cbeg + a.chunks_per_split;
     if (cend > total_chunks) cend = total_chunks;
@@ -193,13 +198,16 @@ __global__ __launch_bounds__(256) void conv_wgrad128_kernel(const WgradArgs a) {
     const int ohw = a.OH * a.OW;
 
     uint4 xr[4], yr[4];
-    auto load_chunk = [&](int chunk) {
+    auto load_chunk = [&](int vchunk) {
+        const int pr = vchunk / a.chunks_per_plane, chunk = vchunk - pr * a.chunks_per_plane;   // (product, chunk): uniform
+        const bf16_t* xpl = a.x + a.wp.xoff[pr];
+        const bf16_t* dpl = a.dy + a.wp.doff[pr];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = chunk * 64 + prow + 16 * i;
             uint4 xv = make_uint4(0, 0, 0, 0), yv = make_uint4(0, 0, 0, 0);
             if (m < a.M) {
-                if (y_c_ok) yv = *reinterpret_cast<const uint4*>(a.dy + (long)m * a.lddy + co0 + c16 * 8);
+                if (y_c_ok) yv = *reinterpret_cast<const uint4*>(dpl + (long)m * a.lddy + co0 + c16 * 8);
                 if (x_c_ok) {
                     long row; bool ok;
                     if (a.mode >= 2) {
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(256) void conv_wgrad128_kernel(const WgradArgs a) {
                         ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                         row = ((long)n * a.H + iy) * a.W + ix;
                     }
-                    if (ok) xv = *reinterpret_cast<const uint4*>(a.x + row * a.ldx + ci0 + c16 * 8);
+                    if (ok) xv = *reinterpret_cast<const uint4*>(xpl + row * a.ldx + ci0 + c16 * 8);
                 }
             }
             xr[i] = xv; yr[i] = yv;
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256) void conv_wgrad128_kernel(const WgradArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int total_chunks = (a.M + 63) / 64;
+    const int total_chunks = a.wp.n * a.chunks_per_plane;
     const int cbeg = split * a.chunks_per_split;
     int cend = cbeg + a.chunks_per_split;
     if (cend > total_chunks) cend = total_chunks;
@@ -283,9 +291,13 @@ extern "C" int kg_set_wgrad_tr(int use_tr) { g_wgrad_use_tr = use_tr; return KG_
 extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const int* rowdesc, int M, int H, int W,
                                int OH, int OW, int ldx, int lddy, int Cin, int Cout, int cin_lim, int cout_lim,
                                int KH, int KW, int stride, int pad, int dil, int mode, int nsplit,
-                               long split_stride, void* stream) {
+                               long split_stride, const kg_planes_t* planes, void* stream) {
+    // planes: a = x, b = dy: every kept plane product x_i * dY_j is one more pass over the pixels inside the same launch
     WgradArgs a;
     memset(&a, 0, sizeof(a));
+    const kg_planes_t pp = kg_planes_or_default(planes);
+    KG_CHECK_ARG(kg_planes_ok(pp), "kg_conv2d_wgrad: bad kg_planes_t");
+    a.wp = kg_make_wgpairs(pp.a_planes, pp.a_pstride, pp.b_planes, pp.b_pstride);
     KG_CHECK_ARG(x && dy && dwp, "kg_conv2d_wgrad: null pointer");
     KG_CHECK_ARG(ldx % 8 == 0 && lddy % 8 == 0 && cin_lim % 8 == 0 && cout_lim % 8 == 0, "kg_conv2d_wgrad: ld/lim must be multiples of 8");
     KG_CHECK_ARG(stride == 1 || stride == 2, "kg_conv2d_wgrad: stride must be 1 or 2");
@@ -295,7 +307,8 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
     a.M = M; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.ldx = ldx; a.lddy = lddy; a.Cin = Cin; a.Cout = Cout;
     a.cin_lim = cin_lim; a.cout_lim = cout_lim; a.ntaps = KH * KW; a.KW = KW; a.stride_log2 = stride == 2 ? 1 : 0;
     a.pad = pad; a.dil = dil; a.mode = mode;
-    int total_chunks = (M + 63) / 64;        // chunks of the kernel's PX = 64 pixels
+    a.chunks_per_plane = (M + 63) / 64;      // chunks of the kernel's PX = 64 pixels
+    const int total_chunks = a.wp.n * a.chunks_per_plane;
     a.chunks_per_split = (total_chunks + nsplit - 1) / nsplit;
     a.split_stride = split_stride;
     static const int use128 = getenv("KG_WGRAD128") ? atoi(getenv("KG_WGRAD128")) : 1;

@@ -147,6 +147,21 @@ static inline KMap kg_make_kmap(int C, int unit, int xP, int xps, int wP) {
     return m;
 }
 
+// Weight gradients over planed operands: dW = sum over the kept products x_i * dY_j (i + j < max(xP, dP), smallest first).  The
+// reduction dimension (pixels) is simply walked once per product: "virtual" pixel chunk / tile q -> (product q / per_plane,
+// chunk q % per_plane), operands offset by the product's plane strides.  One launch, one set of fp32 accumulators, no extra partials.
+struct WgPairs {
+    int n;              // products (1 = single-plane operands)
+    int xoff[6], doff[6];   // element offsets of the product's x / dY plane
+};
+static inline WgPairs kg_make_wgpairs(int xP, int xps, int dP, int dps) {
+    WgPairs w;
+    int xi[6], dj[6];
+    w.n = kg_plane_pairs(xP < 1 ? 1 : xP, dP < 1 ? 1 : dP, xi, dj);
+    for (int k = 0; k < 6; ++k) { w.xoff[k] = k < w.n ? xi[k] * xps : 0; w.doff[k] = k < w.n ? dj[k] * dps : 0; }
+    return w;
+}
+
 // fp32 -> P planes (round-to-nearest-even at every level: the residual of each plane is exact in fp32)
 template <int NV>
 __device__ __forceinline__ void kg_store_planes(bf16_t* yp, int P, int ps, float (&v)[NV], bool vec) {

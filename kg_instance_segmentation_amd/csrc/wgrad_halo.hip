@@ -28,6 +28,7 @@ struct WgHaloArgs {
     int Cin, Cout, cin_lim, cout_lim, nsplit;
     long split_stride;
     float* dbp;       // optional bias-gradient partials [nsplit][Cout]: db[co] = sum over pixels of dY (KGnet's convs with bias)
+    WgPairs wp;       // split-bf16 operand planes (kg_common.h): the tile index runs over wp.n * tiles_total virtual tiles
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     }
 
     uint4 dyr[DYPT], xr[XPT];
-    const int tiles_total = a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y;
+    const int tiles_plane = a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y;
+    const int tiles_total = a.wp.n * tiles_plane;
 
     // per-thread staging coordinates (tile independent): dividing per element and tile cost ~260 VALU per tile and wave,
     // a third of the tile's MFMA time
@@ -133,7 +135,8 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
         x_hx[k] = p - hy * HWD - PAD;
         x_c[k] = ci0 + c * 8;
     }
-    auto load_tile = [&](int t) {
+    auto load_tile = [&](int vt) {
+        const int pr = vt / tiles_plane, t = vt - pr * tiles_plane;     // (product, tile): uniform
         int oy0, ox0, Hd, Wd; long rowbase;
         if (a.tiletab) {
             const int4 tt = a.tiletab[t];
@@ -145,8 +148,8 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
             oy0 = ty * 16; ox0 = tx * 16; Hd = a.H; Wd = a.W; rowbase = (long)n * a.H * a.W;
         }
         const long base = rowbase + (long)oy0 * Wd + ox0;
-        const bf16_t* dyb = a.dy + base * a.lddy + dy_c;
-        const bf16_t* xb = a.x + base * a.ldx;
+        const bf16_t* dyb = a.dy + a.wp.doff[pr] + base * a.lddy + dy_c;
+        const bf16_t* xb = a.x + a.wp.xoff[pr] + base * a.ldx;
         const int hrem = Hd - oy0, wrem = Wd - ox0;
 #pragma unroll
         for (int k = 0; k < DYPT; ++k) {
@@ -269,9 +272,14 @@ static int launch_wg(const WgHaloArgs& a, hipStream_t st) {
 // dwp receives nsplit partial tensors [Cout][KS*KS][Cin] (fp32), split_stride elements apart.
 extern "C" int kg_conv2d_wgrad_halo(const void* x, const void* dy, float* dwp, int N, int H, int W, int ldx, int lddy,
                                     int Cin, int Cout, int cin_lim, int cout_lim, int KS, int nsplit, long split_stride,
-                                    const int* tiletab, int ntiles, float* dbp, void* stream) {
+                                    const int* tiletab, int ntiles, float* dbp, const kg_planes_t* planes, void* stream) {
+    // planes: a = x, b = dy (dbp, the fused bias gradient, needs single-plane dy: the all-ones unit would count every product)
     WgHaloArgs a;
     memset(&a, 0, sizeof(a));
+    const kg_planes_t pp = kg_planes_or_default(planes);
+    KG_CHECK_ARG(kg_planes_ok(pp), "kg_conv2d_wgrad_halo: bad kg_planes_t");
+    a.wp = kg_make_wgpairs(pp.a_planes, pp.a_pstride, pp.b_planes, pp.b_pstride);
+    KG_CHECK_ARG(!dbp || a.wp.n == 1, "kg_conv2d_wgrad_halo: the fused bias gradient needs single-plane operands");
     KG_CHECK_ARG(x && dy && dwp, "kg_conv2d_wgrad_halo: null pointer");
     KG_CHECK_ARG(KS == 3 || KS == 7, "kg_conv2d_wgrad_halo: kernel size must be 3 or 7");
     KG_CHECK_ARG(ldx % 8 == 0 && lddy % 8 == 0 && cin_lim % 8 == 0 && cout_lim % 8 == 0, "kg_conv2d_wgrad_halo: ld/lim must be multiples of 8");

@@ -398,31 +398,28 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
     halo = (USE_HALO and stride == 1 and KH == KW and KH in (3, 7) and pad == KH // 2
             and ((mode == 0 and N is not None) or (mode == 2 and tiletab16 is not None)))
     np_ = len(pairs)
+    planes = pl(a=x, b=dy)
     if halo:
         cit = (32 if (cout_lim <= 16 and cin_lim >= 32 and bias_out is not None and not planed) else 16) if KH == 7 else 64   # input channels per workgroup (wgrad_halo.hip)
         nblk = math.ceil(cin_lim / cit) * math.ceil(cout_lim / 64)
         tiles = tiletab16.shape[0] if tiletab16 is not None else N * math.ceil(H / 16) * math.ceil(W / 16)
-        S = halo_wgrad_splits(nblk * np_, tiles, cit, KH * KW, nelem * np_)
-        part = scratch_f32(S * np_ * nelem, xb.device, "wgrad")
+        S = halo_wgrad_splits(nblk, tiles * np_, cit, KH * KW, nelem)      # (plane products = more tiles to walk)
+        part = scratch_f32(S * nelem, xb.device, "wgrad")
         fused_bias = bias_out is not None and KH == 7 and not planed
         dbp = scratch_f32(S * cout, xb.device, "wgrad_bias") if fused_bias else None
-        for k, (i, j) in enumerate(pairs):
-            _lib.call("kg_conv2d_wgrad_halo", ctypes_offset(xb, i * xps), ctypes_offset(dyb, j * dps), ctypes_offset(part, k * S * nelem),
-                      N or 0, H, W, ld(xb), ld(dyb), cin, cout, cin_lim, cout_lim, KH, S, c_long(nelem), ptr(tiletab16),
-                      tiletab16.shape[0] if tiletab16 is not None else 0, ptr(dbp), stream_ptr())
+        _lib.call("kg_conv2d_wgrad_halo", ptr(xb), ptr(dyb), ptr(part), N or 0, H, W, ld(xb), ld(dyb), cin, cout, cin_lim, cout_lim, KH, S,
+                  c_long(nelem), ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, ptr(dbp), planes, stream_ptr())
         if dbp is not None:
             _lib.call("kg_bias_grad_final", ptr(dbp), ptr(bias_out), S, cout, 1 if accumulate else 0, stream_ptr())
         elif bias_out is not None:       # 3x3: the extra accumulators would spill in that kernel variant
             bias_grad(dy, cout, bias_out, accumulate=accumulate)
     else:
-        S = wgrad_splits(M, cin_lim, cout_lim, KH * KW * np_, nelem * np_)
-        part = scratch_f32(S * np_ * nelem, xb.device, "wgrad")
-        for k, (i, j) in enumerate(pairs):
-            _lib.call("kg_conv2d_wgrad", ctypes_offset(xb, i * xps), ctypes_offset(dyb, j * dps), ctypes_offset(part, k * S * nelem), ptr(rowdesc),
-                      M, H, W, OH, OW, ld(xb), ld(dyb), cin, cout, cin_lim, cout_lim, KH, KW, stride, pad, 1, mode, S, c_long(nelem), stream_ptr())
+        S = wgrad_splits(M * np_, cin_lim, cout_lim, KH * KW, nelem)
+        part = scratch_f32(S * nelem, xb.device, "wgrad")
+        _lib.call("kg_conv2d_wgrad", ptr(xb), ptr(dyb), ptr(part), ptr(rowdesc), M, H, W, OH, OW, ld(xb), ld(dyb), cin, cout, cin_lim, cout_lim,
+                  KH, KW, stride, pad, 1, mode, S, c_long(nelem), planes, stream_ptr())
         if bias_out is not None:
             bias_grad(dy, cout, bias_out, accumulate=accumulate)
-    S *= np_
     contiguous = all(grads[i][1] + grads[i][2] == grads[i + 1][1] for i in range(len(grads) - 1))
     if 1 < len(grads) <= 4 and contiguous:      # heads fused along Cout: one reduction launch for all of them
         import ctypes
@@ -439,7 +436,7 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
 
 def wgrad_halo(x, dy, part, N, H, W, cin, cout, cin_lim, cout_lim, KS, S, nelem, tiletab16=None, dbp=None):
     _lib.call("kg_conv2d_wgrad_halo", ptr(x), ptr(dy), ptr(part), N, H, W, ld(x), ld(dy), cin, cout, cin_lim, cout_lim, KS, S,
-              c_long(nelem), ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, ptr(dbp), stream_ptr())
+              c_long(nelem), ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, ptr(dbp), None, stream_ptr())
 
 
 def ctypes_offset(t, elem_off):

@@ -157,9 +157,11 @@ class SegBranch:
         return e["pw"], e["pwT"], self.P(key + ".bias").detach()
 
     # ---- planning (host) ----------------------------------------------------------------------------
-    def make_plan(self, feats, bboxes):
-        dev = feats[0].device
-        sizes = [tuple(f.shape[2:]) for f in feats]
+    def make_plan(self, feats, bboxes, sizes=None, dev=None):
+        """feats: the five feature maps (or None with sizes = [(h, w)] * 5 and dev given)"""
+        if sizes is None:
+            dev = feats[0].device
+            sizes = [tuple(f.shape[2:]) for f in feats]
         h0, w0 = sizes[0]
         img_idx, box_idx, allb = [], [], []
         for i, bb in enumerate(bboxes):
@@ -290,10 +292,22 @@ class SegBranch:
         return r.reshape(n * h * w, c) if r.is_contiguous() else r.contiguous().view(n * h * w, c)
 
     def gather(self, frows, srcrow, dst, nrows, C, row_off=0):
-        """dst (PT rows) = the crop rows of the fp32 feature rows frows"""
-        if nrows:
-            _lib.call("kg_rows_gather_f32", ptr(frows), frows.stride(0), _lib.c_void_p(srcrow.data_ptr() + 4 * row_off),
-                      ptr(ops.base(dst)), ops.ld(dst), c_long(nrows), C, ops.pl(y=dst), stream_ptr())
+        """dst (PT rows) = the crop rows of the feature rows frows: fp32 rows (a feature map handed to forward_seg), or the
+        engine's own split-bf16 rows (ops.PT; the fused training forward, plane by plane -- a plane the branch does not
+        carry is dropped, one it carries beyond the source's is zero)"""
+        if not nrows:
+            return
+        sr = _lib.c_void_p(srcrow.data_ptr() + 4 * row_off)
+        if isinstance(frows, PT):
+            for p_ in range(dst.P):
+                if p_ < frows.P:
+                    _lib.call("kg_rows_gather", ops.ctypes_offset(frows.t, p_ * frows.ps), ops.ld(frows), sr,
+                              ops.ctypes_offset(ops.base(dst), p_ * dst.ps), ops.ld(dst), c_long(nrows), C, stream_ptr())
+                else:
+                    dst.plane(p_)[:nrows].zero_()
+            return
+        _lib.call("kg_rows_gather_f32", ptr(frows), frows.stride(0), sr, ptr(ops.base(dst)), ops.ld(dst), c_long(nrows), C,
+                  ops.pl(y=dst), stream_ptr())
 
     @staticmethod
     def _head(t, M):
@@ -336,7 +350,7 @@ class SegBranch:
             self.train_steps += 1
         self.stamp = ("t" if record else "e", self.train_steps, ops.PARAM_EPOCH[0])
         self.prepare_all(record)
-        fr = [self.feat_rows(f) for f in feats]
+        fr = [f if isinstance(f, PT) else self.feat_rows(f) for f in feats]
         CH = arch.FEAT_CH
         pre = [None] * 5
         cats, uins = [None] * 4, [None] * 4
@@ -407,13 +421,15 @@ class SegBranch:
         # pixel in fixed box order with fp32 accumulation (kg_crop_grad_reduce) -- no atomics, bit-reproducible.
         gfeats = [None] * 5
 
+        rows_only = getattr(plan, "rows_only", False)      # fused training forward: hand the engine fp32 rows, not NCHW views
+
         def reduce_level(l, ga, rows_a, gb):
             n, c, h, w = feat_shapes[l]
             out = torch.empty(n * h * w, c, dtype=torch.float32, device=dev)
             _lib.call("kg_crop_grad_reduce", ptr(ops.base(ga)), ops.ld(ga) if ga is not None else 0, ptr(ops.base(gb)),
                       ops.ld(gb) if gb is not None else 0, c_long(rows_a), ptr(plan.tab_d[l]), ptr(plan.bin_start_d[l]),
                       ptr(plan.bin_boxes_d[l]), BIN_SIZE[l], n, h, w, c, ptr(out), ops.pl(a=ga if ga is not None else gb, b=gb if gb is not None else ga), stream_ptr())
-            gfeats[l] = out.view(n, h, w, c).permute(0, 3, 1, 2)
+            gfeats[l] = out if rows_only else out.view(n, h, w, c).permute(0, 3, 1, 2)
 
         for l in range(0, top):
             cin, cout, ccat = arch.SKIP[l]
@@ -448,6 +464,11 @@ class SegBranch:
         params = [self.P(k) for k in self.param_keys]
         record = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or any(f.requires_grad for f in feat_seg))
         flat = _SegFunction.apply(self, plan, record, *feat_seg, *params)
+        return self.predictions(plan, flat, nimg)
+
+    @staticmethod
+    def predictions(plan, flat, nimg):
+        """[mask_patches, mask_dets] exactly as the reference returns them (KGnet.py:350) over the flat probability buffer."""
         h0, w0 = plan.hw[0]
         r0 = plan.row0[0]
         # emit in the reference's order: image by image, boxes in input order (lazily: see LazyList)
