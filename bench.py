@@ -350,13 +350,17 @@ def main():
     ap.add_argument("--boxes", type=int, default=300)
     ap.add_argument("--mode", choices=["train", "eval", "gt"], default="train",
                     help="eval: inference path (BASELINE configs[4]); gt: ground-truth map generation (SURVEY 8f N1); 1 GPU")
-    ap.add_argument("--precision", choices=["mixed", "fp32", "bf16"], default=os.environ.get("KG_PRECISION", "mixed"),
+    ap.add_argument("--precision", choices=["mixed", "trunk2", "fp32", "bf16"], default=os.environ.get("KG_PRECISION", "mixed"),
                     help="storage precision of the network (engine.PRECISIONS); the headline is `mixed`, an fp32-faithful companion "
                          "line is measured beside it at 1 GPU")
     ap.add_argument("--no-companion", action="store_true", help="skip the fp32-faithful companion measurement")
+    ap.add_argument("--profile-run", action="store_true", help="warmup + timed steps only (no companion, no second read-back policy, "
+                    "no per-kernel pass, no CPU baseline): the command rocprofv3 wraps, so that steps + warmup launches are traced")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
+    if args.profile_run:
+        args.no_companion = args.no_cpu_baseline = args.no_kernel_timer = True
 
     from kg_instance_segmentation_amd import KGnet, parallel
     from kg_instance_segmentation_amd.loss import DetectionLossAll
@@ -451,7 +455,9 @@ def main():
     t0 = main_run["marks"][0]
     last = losses[-1]
     dom_rec = main_run["dom_rec"]
-    other_dt, _, _ = main_run["timed"](args.steps, not STEP_SYNC)      # the other loss-read-back policy, reported as a note
+    other_dt = dt
+    if not args.profile_run:
+        other_dt, _, _ = main_run["timed"](args.steps, not STEP_SYNC)      # the other loss-read-back policy, reported as a note
     prof_steps = 0
     if not args.no_kernel_timer:      # per-kernel breakdown: extra, untimed steps with events around every conv launch
         timer.on, timer.only_dominant, prof_steps = True, False, 2
@@ -487,11 +493,12 @@ def main():
     out = {"metric": "imgs/s (train fwd+bwd) at 512x512", "value": imgs / dt, "unit": "imgs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
-           "dtype": {"mixed": "bf16", "bf16": "bf16", "fp32": "fp32 as 3 bf16 planes"}[args.precision], "data": "synthetic",
+           "dtype": {"mixed": "bf16", "trunk2": "bf16", "bf16": "bf16", "fp32": "fp32 as 3 bf16 planes"}[args.precision], "data": "synthetic",
            "config": {"workload": f"KGnet train step (forward_dec+forward_seg, 4x DetectionLossAll + SEG_loss, backward, Adam), "
                                   f"batch {args.batch}/GPU, 3x{args.size}x{args.size}, {args.boxes} GT boxes/img, full HIP path",
-                      "precision": {"mixed": "bf16 MFMA, fp32 accumulation; trunk (stem, layer1-3, decoder) stored and multiplied as hi + lo bf16 planes "
-                                             "(3 products), 7x7 heads and seg branch single-plane bf16",
+                      "precision": {"mixed": "bf16 MFMA, fp32 accumulation; the BatchNorm backbone (stem conv1, layer1-3) stored and multiplied as hi + lo bf16 planes "
+                                             "(3 products), c0_conv / decoder / 7x7 heads / seg branch single-plane bf16",
+                                    "trunk2": "as mixed, with c0_conv and the decoder in hi + lo planes as well",
                                     "bf16": "bf16 MFMA, fp32 accumulation, single-plane bf16 storage everywhere",
                                     "fp32": "fp32 values as 3 bf16 planes, 6 bf16 MFMA products per multiply, fp32 accumulation"}[args.precision],
                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "last_loss": last,

@@ -124,9 +124,9 @@ int kg_bn_apply(const void* x, int ldx, const float* scale, const float* shift, 
 int kg_bn_bwd(const void* x, int ldx, const void* dy, int lddy, const float* gamma, const float* mean,
               const float* invstd, float* dgamma, float* dbeta, int accumulate, void* dx, int lddx, int M, int C,
               float* scratch, int scratch_floats, const kg_planes_t* planes, void* stream);
-int kg_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, const kg_planes_t* planes, void* stream);
-int kg_maxpool3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C,
-                      const kg_planes_t* planes, void* stream);
+int kg_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, void* argmax_u8, int N, int H, int W, int C, const kg_planes_t* planes, void* stream);
+int kg_maxpool3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, const void* argmax_u8, int N, int H, int W, int C,
+                      const kg_planes_t* planes, void* stream);   /* argmax_u8 (optional): [N*OH*OW][C] winning taps written by the forward */
 int kg_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, int IH, int IW, int OH, int OW, int C,
                     const int* boxdesc, const int* row2box, long total_out_rows, const kg_planes_t* planes, void* stream);
 int kg_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int IH, int IW, int OH, int OW, int C,
@@ -200,8 +200,8 @@ int kg_f32_to_planes(const float* acc, int ldacc, void* out, int ldout, const vo
  * per box; bin_start / bin_boxes = CSR lists of the boxes touching each bin_size x bin_size bin of each image.
  * planes: a = ga, b = gb */
 int kg_crop_grad_reduce(const void* ga, int lda, const void* gb, int ldb, long rows_a, const int* boxtab, const int* bin_start,
-                        const int* bin_boxes, int bin_size, int N, int H, int W, int C, float* out,
-                        const kg_planes_t* planes, void* stream);
+                        const int* bin_boxes, int bin_size, int N, int H, int W, int C, float* out, void* out_rows, int ldout,
+                        const kg_planes_t* planes, void* stream);   /* exactly one of out (fp32) / out_rows (split-bf16 rows, planes y) */
 
 
 /* ---- mask paste-back of the inference driver (test.py:127-157): cv2.resize(patch, box size) -> paste into a zero

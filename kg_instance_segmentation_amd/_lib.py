@@ -38,8 +38,8 @@ _SIGS = {
     "kg_bn_scale_shift_eval": [c_int, P, P, P, P, c_float, P, P, P],
     "kg_bn_apply": [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P, P],
     "kg_bn_bwd": [P, c_int, P, c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_int, P, c_int, P, P],
-    "kg_maxpool3s2_fwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P],
-    "kg_maxpool3s2_bwd": [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P, P],
+    "kg_maxpool3s2_fwd": [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P],
+    "kg_maxpool3s2_bwd": [P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P],
     "kg_bilinear_fwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_long, P, P],
     "kg_bilinear_bwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_long, P, c_int, P, P],
     "kg_add_rows": [P, c_int, P, c_int, P, c_int, P, c_int, c_long, c_int, P, P],
@@ -67,7 +67,7 @@ _SIGS = {
     "kg_planes_to_f32": [P, c_int, P, c_int, c_long, c_int, P, P],
     "kg_f32_to_planes": [P, c_int, P, c_int, P, c_int, c_long, c_int, P, P],
     "kg_mask_paste": [P, P, c_int, c_int, c_int, c_int, c_int, c_float, P, c_int, P],
-    "kg_crop_grad_reduce": [P, c_int, P, c_int, c_long, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P],
+    "kg_crop_grad_reduce": [P, c_int, P, c_int, c_long, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P],
 }
 _RESTYPE = {"kg_postproc_workspace_bytes": c_long}
 SYMBOLS = tuple(_SIGS) + ("kg_last_error",)

@@ -291,7 +291,7 @@ __device__ __forceinline__ void pool_window_max(const RowsR& x, long nbase, int 
         }
     }
 }
-__global__ void maxpool_fwd_kernel(const RowsR x, const RowsW y, int N, int H,
+__global__ void maxpool_fwd_kernel(const RowsR x, const RowsW y, unsigned char* __restrict__ argout, int N, int H,
                                    int W, int OH, int OW, int C8) {
     long total = (long)N * OH * OW * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -300,10 +300,16 @@ __global__ void maxpool_fwd_kernel(const RowsR x, const RowsW y, int N, int H,
         float best[8]; int arg[8];
         pool_window_max(x, n * H * W, H, W, oy, ox, c, best, arg);
         wr8(y, p, c, best);
+        if (argout) {      // winning tap (kh*3+kw) per output element: the backward pass reads it instead of re-scanning the windows
+            uint2 pk;
+            pk.x = (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
+            pk.y = (unsigned)arg[4] | ((unsigned)arg[5] << 8) | ((unsigned)arg[6] << 16) | ((unsigned)arg[7] << 24);
+            *reinterpret_cast<uint2*>(argout + p * (long)(C8 * 8) + c) = pk;
+        }
     }
 }
 // gather-form backward: each input pixel sums dy of the (<=4) windows whose argmax it is.
-__global__ void maxpool_bwd_kernel(const RowsR x, const RowsR dy,
+__global__ void maxpool_bwd_kernel(const RowsR x, const RowsR dy, const unsigned char* __restrict__ argin,
                                    const RowsW dx, int N, int H, int W, int OH, int OW, int C8) {
     long total = (long)N * H * W * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -322,7 +328,12 @@ __global__ void maxpool_bwd_kernel(const RowsR x, const RowsR dy,
                 int kw = ix - (ox * 2 - 1);
                 if (kw < 0 || kw > 2) continue;
                 float best[8]; int arg[8];
-                pool_window_max(x, n * H * W, H, W, oy, ox, c, best, arg);
+                if (argin) {
+                    const uint2 pk = *reinterpret_cast<const uint2*>(argin + ((n * OH + oy) * OW + ox) * (long)(C8 * 8) + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { arg[e] = (pk.x >> (8 * e)) & 255; arg[4 + e] = (pk.y >> (8 * e)) & 255; }
+                } else
+                    pool_window_max(x, n * H * W, H, W, oy, ox, c, best, arg);
                 float ds[8];
                 rd8(dy, (n * OH + oy) * OW + ox, c, ds);
 #pragma unroll
@@ -334,19 +345,20 @@ __global__ void maxpool_bwd_kernel(const RowsR x, const RowsR dy,
     }
 }
 // planes: a = x, y = y
-extern "C" int kg_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, const kg_planes_t* planes, void* stream) {
+// argmax (optional): bytes [N*OH*OW][C], the winning tap of every output element, for kg_maxpool3s2_bwd
+extern "C" int kg_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, void* argmax, int N, int H, int W, int C, const kg_planes_t* planes, void* stream) {
     KG_CHECK_ARG(x && y && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "kg_maxpool3s2_fwd: bad args");
     KG_PLANES(planes);
     int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     long total = (long)N * OH * OW * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, RowsR{(const bf16_t*)x, ldx, pp.a_planes, pp.a_pstride},
-                       RowsW{(bf16_t*)y, ldy, pp.y_planes, pp.y_pstride}, N, H, W, OH, OW, C / 8);
+                       RowsW{(bf16_t*)y, ldy, pp.y_planes, pp.y_pstride}, (unsigned char*)argmax, N, H, W, OH, OW, C / 8);
     KG_CHECK_LAUNCH("maxpool_fwd");
     return KG_OK;
 }
 // planes: a = x, b = dy, y = dx
-extern "C" int kg_maxpool3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H,
+extern "C" int kg_maxpool3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, const void* argmax, int N, int H,
                                  int W, int C, const kg_planes_t* planes, void* stream) {
     KG_CHECK_ARG(x && dy && dx && C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "kg_maxpool3s2_bwd: bad args");
     KG_PLANES(planes);
@@ -354,7 +366,7 @@ extern "C" int kg_maxpool3s2_bwd(const void* x, int ldx, const void* dy, int ldd
     long total = (long)N * H * W * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, RowsR{(const bf16_t*)x, ldx, pp.a_planes, pp.a_pstride},
-                       RowsR{(const bf16_t*)dy, lddy, pp.b_planes, pp.b_pstride}, RowsW{(bf16_t*)dx, lddx, pp.y_planes, pp.y_pstride}, N, H, W, OH, OW, C / 8);
+                       RowsR{(const bf16_t*)dy, lddy, pp.b_planes, pp.b_pstride}, (const unsigned char*)argmax, RowsW{(bf16_t*)dx, lddx, pp.y_planes, pp.y_pstride}, N, H, W, OH, OW, C / 8);
     KG_CHECK_LAUNCH("maxpool_bwd");
     return KG_OK;
 }

@@ -231,7 +231,7 @@ extern "C" int kg_f32_to_planes(const float* acc, int ldacc, void* out, int ldou
 __global__ void crop_grad_reduce_kernel(const bf16_t* __restrict__ ga, int lda, const bf16_t* __restrict__ gb, int ldb, int gP, int gps_a,
                                         int gps_b, long rows_a, const int* __restrict__ boxtab, const int* __restrict__ bin_start,
                                         const int* __restrict__ bin_boxes, int BS, int BY, int BX, int H, int W,
-                                        float* __restrict__ out, long npix, int C8) {
+                                        float* __restrict__ out, bf16_t* __restrict__ outp, int ldo, int oP, int ops_, long npix, int C8) {
     long total = npix * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long p = i / C8; int c = (int)(i - p * C8) * 8;
@@ -249,15 +249,18 @@ __global__ void crop_grad_reduce_kernel(const bf16_t* __restrict__ ga, int lda, 
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += v[e];
         }
+        if (outp) { kg_store_planes<8>(outp + p * ldo + c, oP, ops_, acc, true); continue; }
         float4* op = reinterpret_cast<float4*>(out + p * (long)(C8 * 8) + c);
         op[0] = make_float4(acc[0], acc[1], acc[2], acc[3]); op[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
 }
-// planes: a = ga, b = gb (same plane count)
+// planes: a = ga, b = gb (same plane count); y = out_rows.  Exactly one of out (fp32 [N*H*W][C]) / out_rows (split-bf16 rows, ld
+// ldout: the engine's own gradient storage, fused training forward) is written.
 extern "C" int kg_crop_grad_reduce(const void* ga, int lda, const void* gb, int ldb, long rows_a, const int* boxtab, const int* bin_start,
-                                   const int* bin_boxes, int bin_size, int N, int H, int W, int C, float* out,
+                                   const int* bin_boxes, int bin_size, int N, int H, int W, int C, float* out, void* out_rows, int ldout,
                                    const kg_planes_t* planes, void* stream) {
-    KG_CHECK_ARG(boxtab && bin_start && bin_boxes && out && C % 8 == 0 && bin_size > 0 && N > 0 && H > 0 && W > 0, "kg_crop_grad_reduce: bad args");
+    KG_CHECK_ARG(boxtab && bin_start && bin_boxes && ((out != nullptr) != (out_rows != nullptr)) && C % 8 == 0 && bin_size > 0 && N > 0 && H > 0 && W > 0, "kg_crop_grad_reduce: bad args");
+    KG_CHECK_ARG(!out_rows || ldout % 8 == 0, "kg_crop_grad_reduce: bad output rows");
     KG_CHECK_ARG((!ga || lda % 8 == 0) && (!gb || ldb % 8 == 0) && (ga || gb), "kg_crop_grad_reduce: bad gradient operands");
     const kg_planes_t pp = kg_planes_or_default(planes);
     KG_CHECK_ARG(kg_planes_ok(pp) && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "kg_crop_grad_reduce: bad planes / alignment");
@@ -266,7 +269,7 @@ extern "C" int kg_crop_grad_reduce(const void* ga, int lda, const void* gb, int 
     int blocks = (int)((total + 255) / 256); if (blocks > 32768) blocks = 32768;
     hipLaunchKernelGGL(crop_grad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)ga, lda, (const bf16_t*)gb, ldb,
                        pp.a_planes, pp.a_pstride, pp.b_pstride, ga ? rows_a : 0, boxtab, bin_start, bin_boxes, bin_size, kg_cdiv(H, bin_size),
-                       kg_cdiv(W, bin_size), H, W, out, npix, C / 8);
+                       kg_cdiv(W, bin_size), H, W, out, (bf16_t*)out_rows, ldout, pp.y_planes, pp.y_pstride, npix, C / 8);
     KG_CHECK_LAUNCH("crop_grad_reduce");
     return KG_OK;
 }

@@ -315,7 +315,8 @@ class Engine:
         C = xv.C
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         out = ops.alloc_pt(N * OH * OW, C, xv.P, xv.t.device)
-        ops.maxpool_fwd(xv.t, out, N, H, W, C)
+        arg = torch.empty(N * OH * OW, C, dtype=torch.uint8, device=xv.t.device) if self.tape is not None else None
+        ops.maxpool_fwd(xv.t, out, N, H, W, C, argmax=arg)
         yv = Var(out, C, relu=False)
         if self.tape is not None:
             def bwd():
@@ -323,7 +324,7 @@ class Engine:
                 if g is None:
                     return
                 dx = ops.alloc_pt(xv.rows, C, xv.P, xv.t.device)
-                ops.maxpool_bwd(xv.t, g, dx, N, H, W, C)
+                ops.maxpool_bwd(xv.t, g, dx, N, H, W, C, argmax=arg)
                 xv.add_grad(dx, masked=False)
             self.tape.append(bwd)
         return yv, OH, OW
@@ -564,10 +565,14 @@ class Engine:
                     ops.grad_pack(g.contiguous().float(), prob, view, N, co, Hh, Wh, self.HEAD_PAD[k])
             slot["grad"] = packed
         for fv, g in zip(self.feats, feat_grads):
-            if g is not None:
-                gp = ops.alloc_pt(fv.rows, fv.C, fv.P, g.device)
-                ops.f32_to_planes(g, gp, fv.C)
-                fv.add_grad(gp, masked=False)
+            if g is None:
+                continue
+            if isinstance(g, PT):              # the fused forward's seg backward already wrote split-bf16 rows
+                fv.add_grad(g, masked=False)
+                continue
+            gp = ops.alloc_pt(fv.rows, fv.C, fv.P, g.device)
+            ops.f32_to_planes(g, gp, fv.C)
+            fv.add_grad(gp, masked=False)
         hook = self.grad_hook
         for fn in reversed(self.tape):
             n0 = len(self.param_grads)

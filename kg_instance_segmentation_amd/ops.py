@@ -490,12 +490,14 @@ def bn_bwd(x, dy, C, gamma, mean, invstd, dgamma, dbeta, dx, accumulate=False):
               1 if accumulate else 0, ptr(_rows(dx)), ld(dx), base(x).shape[0], C, ptr(sc), sc.numel(), pl(a=x, b=dy, y=dx), stream_ptr())
 
 
-def maxpool_fwd(x, y, N, H, W, C):
-    _lib.call("kg_maxpool3s2_fwd", ptr(_rows(x)), ld(x), ptr(_rows(y)), ld(y), N, H, W, C, pl(a=x, y=y), stream_ptr())
+def maxpool_fwd(x, y, N, H, W, C, argmax=None):
+    """argmax (optional uint8 [N*OH*OW, C]): receives the winning tap of every output element for maxpool_bwd."""
+    _lib.call("kg_maxpool3s2_fwd", ptr(_rows(x)), ld(x), ptr(_rows(y)), ld(y), ptr(argmax), N, H, W, C, pl(a=x, y=y), stream_ptr())
 
 
-def maxpool_bwd(x, dy, dx, N, H, W, C):
-    _lib.call("kg_maxpool3s2_bwd", ptr(_rows(x)), ld(x), ptr(_rows(dy)), ld(dy), ptr(_rows(dx)), ld(dx), N, H, W, C, pl(a=x, b=dy, y=dx), stream_ptr())
+def maxpool_bwd(x, dy, dx, N, H, W, C, argmax=None):
+    _lib.call("kg_maxpool3s2_bwd", ptr(_rows(x)), ld(x), ptr(_rows(dy)), ld(dy), ptr(_rows(dx)), ld(dx), ptr(argmax), N, H, W, C,
+              pl(a=x, b=dy, y=dx), stream_ptr())
 
 
 def bilinear_fwd(x, y, N, IH, IW, OH, OW, C, boxdesc=None, row2box=None):

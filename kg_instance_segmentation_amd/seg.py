@@ -157,8 +157,9 @@ class SegBranch:
         return e["pw"], e["pwT"], self.P(key + ".bias").detach()
 
     # ---- planning (host) ----------------------------------------------------------------------------
-    def make_plan(self, feats, bboxes, sizes=None, dev=None):
-        """feats: the five feature maps (or None with sizes = [(h, w)] * 5 and dev given)"""
+    def make_plan(self, feats, bboxes, sizes=None, dev=None, need_bins=True):
+        """feats: the five feature maps (or None with sizes = [(h, w)] * 5 and dev given); need_bins: the bin tables of the
+        crop-gradient reduction (backward only)"""
         if sizes is None:
             dev = feats[0].device
             sizes = [tuple(f.shape[2:]) for f in feats]
@@ -234,8 +235,8 @@ class SegBranch:
             BS = BIN_SIZE[l]
             BY, BX = (H + BS - 1) // BS, (W + BS - 1) // BS
             nbins = p.nimg * BY * BX
-            if nb == 0:
-                bin_start.append(np.zeros(nbins + 1, np.int32)); bin_boxes.append(np.zeros(0, np.int32))
+            if nb == 0 or not need_bins:
+                bin_start.append(np.zeros(nbins + 1 if need_bins else 1, np.int32)); bin_boxes.append(np.zeros(0, np.int32))
                 continue
             t = tabs[l]
             by0, bx0 = t[:, 1] // BS, t[:, 2] // BS
@@ -421,15 +422,20 @@ class SegBranch:
         # pixel in fixed box order with fp32 accumulation (kg_crop_grad_reduce) -- no atomics, bit-reproducible.
         gfeats = [None] * 5
 
-        rows_only = getattr(plan, "rows_only", False)      # fused training forward: hand the engine fp32 rows, not NCHW views
+        out_planes = getattr(plan, "out_planes", None)      # fused training forward: write the engine's split-bf16 gradient rows directly
 
         def reduce_level(l, ga, rows_a, gb):
             n, c, h, w = feat_shapes[l]
-            out = torch.empty(n * h * w, c, dtype=torch.float32, device=dev)
+            out = outp = None
+            if out_planes is not None:
+                outp = ops.alloc_pt(n * h * w, c, out_planes[l], dev)
+            else:
+                out = torch.empty(n * h * w, c, dtype=torch.float32, device=dev)
             _lib.call("kg_crop_grad_reduce", ptr(ops.base(ga)), ops.ld(ga) if ga is not None else 0, ptr(ops.base(gb)),
                       ops.ld(gb) if gb is not None else 0, c_long(rows_a), ptr(plan.tab_d[l]), ptr(plan.bin_start_d[l]),
-                      ptr(plan.bin_boxes_d[l]), BIN_SIZE[l], n, h, w, c, ptr(out), ops.pl(a=ga if ga is not None else gb, b=gb if gb is not None else ga), stream_ptr())
-            gfeats[l] = out if rows_only else out.view(n, h, w, c).permute(0, 3, 1, 2)
+                      ptr(plan.bin_boxes_d[l]), BIN_SIZE[l], n, h, w, c, ptr(out), ptr(ops.base(outp)), ops.ld(outp) if outp is not None else 0,
+                      ops.pl(a=ga if ga is not None else gb, b=gb if gb is not None else ga, y=outp), stream_ptr())
+            gfeats[l] = outp if outp is not None else out.view(n, h, w, c).permute(0, 3, 1, 2)
 
         for l in range(0, top):
             cin, cout, ccat = arch.SKIP[l]
@@ -457,7 +463,7 @@ class SegBranch:
     # ---- reference API --------------------------------------------------------------------------------
     def forward(self, feat_seg, bboxes):
         """== ResNet.forward_seg (KGnet.py:321-350): returns [mask_patches, mask_dets]."""
-        plan = self.make_plan(feat_seg, bboxes)
+        plan = self.make_plan(feat_seg, bboxes, need_bins=torch.is_grad_enabled())
         nimg = len(bboxes)
         if plan.nb[0] == 0:
             return [[[] for _ in range(nimg)], [[] for _ in range(nimg)]]

@@ -195,7 +195,8 @@ def test_elementwise_planes(P):
     # max pool
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     yp = ops.alloc_pt(N * OH * OW, C, P, DEV)
-    ops.maxpool_fwd(xp, yp, N, H, W, C)
+    arg = torch.empty(N * OH * OW, C, dtype=torch.uint8, device=DEV)
+    ops.maxpool_fwd(xp, yp, N, H, W, C, argmax=arg)
     xq = from_pt(xp).cpu()                                        # the value the planes hold (P = 2: 16-bit rounding of x)
     xq4 = nchw(xq, N, H, W).double().requires_grad_(True)
     refp = F.max_pool2d(xq4, 3, 2, 1)
@@ -205,6 +206,9 @@ def test_elementwise_planes(P):
     dxp = ops.alloc_pt(M, C, P, DEV)
     ops.maxpool_bwd(xp, to_pt(rows_f32(dyp).to(DEV), P), dxp, N, H, W, C)
     check(f"maxpool bwd P={P}", nchw(from_pt(dxp), N, H, W), xq4.grad, TOL[P])
+    dxa = ops.alloc_pt(M, C, P, DEV)
+    ops.maxpool_bwd(xp, to_pt(rows_f32(dyp).to(DEV), P), dxa, N, H, W, C, argmax=arg)      # the stored winning taps give the same gradient
+    assert torch.equal(from_pt(dxa), from_pt(dxp))
     # bilinear 2x up + backward
     up = ops.alloc_pt(N * 4 * H * W, C, P, DEV)
     ops.bilinear_fwd(xp, up, N, H, W, 2 * H, 2 * W, C)
@@ -258,10 +262,17 @@ def test_crop_grad_reduce_matches_index_add_and_is_deterministic():
                 out = torch.empty(N * h * w, C, device=DEV)
                 L.call("kg_crop_grad_reduce", L.ptr(ops.base(ga)), ops.ld(ga) if ga is not None else 0, L.ptr(ops.base(gb)), ops.ld(gb),
                        L.c_long(rows_a), L.ptr(plan.tab_d[l]), L.ptr(plan.bin_start_d[l]), L.ptr(plan.bin_boxes_d[l]),
-                       __import__("kg_instance_segmentation_amd.seg", fromlist=["BIN_SIZE"]).BIN_SIZE[l], N, h, w, C, L.ptr(out),
+                       __import__("kg_instance_segmentation_amd.seg", fromlist=["BIN_SIZE"]).BIN_SIZE[l], N, h, w, C, L.ptr(out), None, 0,
                        ops.pl(a=ga if ga is not None else gb, b=gb), L.stream_ptr())
                 outs.append(out.clone())
             assert torch.equal(outs[0], outs[1])
             vals = torch.cat([from_pt(ga), from_pt(gb)]) if ga is not None else from_pt(gb)
             ref = torch.zeros(N * h * w, C, dtype=torch.float64, device=DEV).index_add_(0, plan.srcrow[l][:rows].long(), vals.double())
             check(f"crop_grad_reduce level {l} P={P}", outs[0], ref, 2e-6)
+            if P == 3:      # the split-bf16 output mode writes the same sums as planes
+                outp = ops.alloc_pt(N * h * w, C, 3, DEV)
+                L.call("kg_crop_grad_reduce", L.ptr(ops.base(ga)), ops.ld(ga) if ga is not None else 0, L.ptr(ops.base(gb)), ops.ld(gb),
+                       L.c_long(rows_a), L.ptr(plan.tab_d[l]), L.ptr(plan.bin_start_d[l]), L.ptr(plan.bin_boxes_d[l]),
+                       __import__("kg_instance_segmentation_amd.seg", fromlist=["BIN_SIZE"]).BIN_SIZE[l], N, h, w, C, None, L.ptr(outp.t), ops.ld(outp),
+                       ops.pl(a=ga if ga is not None else gb, b=gb, y=outp), L.stream_ptr())
+                assert torch.equal(from_pt(outp), outs[0])
