@@ -82,7 +82,7 @@ class _NetFunction(torch.autograd.Function):
         maps, feats, dims = eng.forward_dec(x, record)
         # (the box tables are built on the host AFTER the dense forward is enqueued: the GPU is busy meanwhile)
         plan = seg.make_plan(None, holder["bboxes"], sizes=dims, dev=x.device, need_bins=record)
-        plan.out_planes = [fv.P for fv in feats]      # the seg backward writes the engine's gradient rows directly
+        plan.out_planes = [fv.gP for fv in feats]     # the seg backward writes the engine's gradient rows directly
         holder["plan"] = plan
         flat, saved = seg.run_forward(plan, [fv.t for fv in feats], record)
         ctx.model, ctx.recorded, ctx.generation, ctx.plan, ctx.saved = model, record, eng.generation, plan, saved
