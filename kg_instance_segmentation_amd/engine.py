@@ -17,9 +17,11 @@ layer1-3 with their 43 BatchNorm layers | c0_conv + top-down decoder | the two 7
   "bf16"   (1, 1, 1, 1).
 Gradients: the backward pass is linear in the incoming gradient, so its storage error does not compound through the BatchNorm
 statistics the way the forward's does (oracle emulation: two-plane forward + single-plane gradients gives the same gradient cosines
-as two planes throughout, min 0.993 / 0.996 on the raw / calibrated fixture).  "mixed" and "trunk2" therefore keep data gradients
-in ONE plane everywhere: input gradients multiply dY(1 plane) x W(2 planes) = 2 products, weight gradients X(2) x dY(1) = 2 products;
-"fp32" keeps three planes.
+as two planes throughout, min 0.993 / 0.996 on the raw / calibrated fixture).  Likewise the OPERANDS of the backward convolutions: the input gradient with
+bf16(W) and the weight gradient with bf16(X) -- the hi planes, i.e. what any bf16 mixed-precision trainer multiplies -- leave the
+cosines unchanged in the emulation (0.9930 / 0.9961 either way).  "mixed" and "trunk2" therefore run the whole backward pass
+single-plane (one product per multiply, gradients stored in one plane); only the forward of the backbone, whose errors are the ones
+the batch statistics amplify, pays for two planes.  "fp32" keeps three planes everywhere.
 """
 import os
 
@@ -28,7 +30,7 @@ import torch
 from . import arch, ops
 from .ops import BF16, PT, PackedWeight
 
-# planes of (backbone, c0 + decoder, heads, seg branch, GRADIENTS flowing through backbone / decoder)
+# planes of (backbone, c0 + decoder, heads, seg branch, GRADIENTS flowing through backbone / decoder = operands of the backward convs)
 PRECISIONS = {"bf16": (1, 1, 1, 1, 1), "mixed": (2, 1, 1, 1, 1), "trunk2": (2, 2, 1, 1, 1), "fp32": (3, 3, 3, 3, 3)}
 
 
@@ -218,7 +220,7 @@ class Engine:
                 s.pwT.stale = True
         if need_T and (s.pwT is None or getattr(s.pwT, "stale", True)):
             if s.pwT is None:
-                s.pwT = PackedWeight(s.cin, taps, ops.round_up(s.cout, 8), dev, xP=s.gP, wP=s.P)
+                s.pwT = PackedWeight(s.cin, taps, ops.round_up(s.cout, 8), dev, xP=s.gP, wP=min(s.P, s.gP))    # backward operands: gP planes
                 s.pwT.cin_real = s.cout
             r = 0
             for w, co in zip(ws, s.couts):
@@ -257,7 +259,7 @@ class Engine:
                     grads.append((gw, off, co))
                     off += co
                 db = torch.empty(s.cout, dtype=torch.float32, device=dev) if s.has_bias else None
-                ops.conv_wgrad(xin, g, s.cin, s.cout, geom, grads, N=N, bias_out=db)
+                ops.conv_wgrad(trunc(xin, s.gP), g, s.cin, s.cout, geom, grads, N=N, bias_out=db)
                 if s.has_bias:
                     off = 0
                     for n, co in zip(s.names, s.couts):
