@@ -11,8 +11,9 @@ Stated tolerances |got - ref| <= atol + rtol * |ref|  (rms = root mean square of
             bound the CPU oracle is held to against the reference (tests/test_oracle_net.py);
   precision "trunk2" (whole trunk in hi+lo planes, heads bf16): rtol 2e-2, atol 3e-2 * rms (two bf16 head layers:
             ~0.5 % of rms per element, 5-6 sigma over the 1.4 M elements of a 512 x 512 map);
-  precision "mixed" (default: BatchNorm backbone in hi+lo planes; c0_conv, decoder and heads bf16 = 8 bf16 layers):
-            rtol 2e-2, atol 5e-2 * rms;
+  precision "mixed" (default: BatchNorm backbone in hi+lo planes while it normalises with batch statistics; c0_conv, decoder and
+            heads bf16 = 8 bf16 layers): train-mode maps rtol 2e-2, atol 5e-2 * rms; eval mode (running statistics: the backbone
+            runs in bf16 too) atol 7e-2 * rms;
   precision "bf16":  rtol 2e-2, atol 1e-1 * rms (60 layers of bf16 storage).
 Parameter gradients (train step 2 x 128 x 128): cosine against the reference per parameter >= 0.9999 / 0.99 / 0.85
 (measured on MI355X: 0.99999 / 0.9992 / 0.856 minimum over the 217 parameters)."""
@@ -30,7 +31,7 @@ from kg_instance_segmentation_amd.seg_loss import SEG_loss  # noqa: E402
 from oracle import synth, weightgen  # noqa: E402
 
 DEV = "cuda"
-EVAL_TOL = {"fp32": (1e-4, 1e-5, 0.0), "trunk2": (2e-2, 0.0, 3e-2), "mixed": (2e-2, 0.0, 5e-2), "bf16": (2e-2, 0.0, 1e-1)}     # rtol, atol, atol as a fraction of rms
+EVAL_TOL = {"fp32": (1e-4, 1e-5, 0.0), "trunk2": (2e-2, 0.0, 3e-2), "mixed": (2e-2, 0.0, 7e-2), "bf16": (2e-2, 0.0, 1e-1)}     # rtol, atol, atol as a fraction of rms
 TRAIN_TOL = {"fp32": (1e-3, 1e-4, 0.0), "trunk2": (2e-2, 0.0, 3e-2), "mixed": (2e-2, 0.0, 5e-2), "bf16": (2e-2, 0.0, 1.5e-1)}
 GRAD_COS = {"fp32": 0.9999, "trunk2": 0.99, "mixed": 0.99, "bf16": 0.85}
 
