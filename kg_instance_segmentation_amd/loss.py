@@ -13,8 +13,9 @@ class _DetLossFn(torch.autograd.Function):
         dev = kp.device
         sc = ops.scratch_f32(5 * 1024, dev, "loss")
         out8 = torch.empty(8, dtype=torch.float32, device=dev)
-        _lib.call("kg_detection_loss_fwd", ptr(kp), ptr(short), ptr(mid), ptr(gt), N, H, W, c_float(kp_radius), ptr(den),
-                  ptr(sc), sc.numel(), ptr(out8), stream_ptr())
+        with torch.cuda.device(dev):      # (launch on the tensors' device, whatever the "current" one is)
+            _lib.call("kg_detection_loss_fwd", ptr(kp), ptr(short), ptr(mid), ptr(gt), N, H, W, c_float(kp_radius), ptr(den),
+                      ptr(sc), sc.numel(), ptr(out8), stream_ptr())
         ctx.save_for_backward(kp, short, mid, gt, out8)
         ctx.kp_radius = kp_radius
         return out8[0].clone()
@@ -25,8 +26,9 @@ class _DetLossFn(torch.autograd.Function):
         N, _, H, W = kp.shape
         g_kp, g_sh, g_md = torch.empty_like(kp), torch.empty_like(short), torch.empty_like(mid)
         go = go.contiguous().float()
-        _lib.call("kg_detection_loss_bwd", ptr(kp), ptr(short), ptr(mid), ptr(gt), N, H, W, c_float(ctx.kp_radius), ptr(out8),
-                  ptr(go), ptr(g_kp), ptr(g_sh), ptr(g_md), stream_ptr())
+        with torch.cuda.device(kp.device):
+            _lib.call("kg_detection_loss_bwd", ptr(kp), ptr(short), ptr(mid), ptr(gt), N, H, W, c_float(ctx.kp_radius), ptr(out8),
+                      ptr(go), ptr(g_kp), ptr(g_sh), ptr(g_md), stream_ptr())
         return g_kp, g_sh, g_md, None, None, None
 
 

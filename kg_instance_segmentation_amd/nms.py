@@ -12,7 +12,8 @@ def nms_device(boxes_d, nbox_d, cap, thresh):
     ws = torch.empty(cap * 9 + 1024, dtype=torch.uint8, device=dev)
     out = torch.empty(cap, 5, dtype=torch.float64, device=dev)
     nk = torch.zeros(1, dtype=torch.int32, device=dev)
-    _lib.call("kg_nms", ptr(boxes_d), ptr(nbox_d), cap, c_double(thresh), ptr(ws), c_long(ws.numel()), ptr(out), ptr(nk), stream_ptr())
+    with torch.cuda.device(dev):
+        _lib.call("kg_nms", ptr(boxes_d), ptr(nbox_d), cap, c_double(thresh), ptr(ws), c_long(ws.numel()), ptr(out), ptr(nk), stream_ptr())
     return out, nk
 
 

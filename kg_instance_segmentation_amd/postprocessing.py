@@ -51,8 +51,9 @@ def skeletons_device(kp, short, mid, debug=False):
                "peaks": torch.empty(3, peak_cap, dtype=torch.int32, device=dev), "conf": torch.empty(peak_cap, dtype=torch.float64, device=dev),
                "npeaks": torch.zeros(1, dtype=torch.int32, device=dev)}
         args = [ptr(dbg["heat"]), ptr(dbg["blur"]), ptr(dbg["peaks"]), ptr(dbg["conf"]), ptr(dbg["npeaks"])]
-    _lib.call("kg_postproc_scale", ptr(kp0), ptr(sh0), ptr(md0), H, W, c_double(PEAK_THRESH), ptr(ws), c_long(ws.numel()), peak_cap,
-              skel_cap, ptr(skel), ptr(nsk), *args, stream_ptr())
+    with torch.cuda.device(dev):      # (launch on the tensors' device, whatever the "current" one is)
+        _lib.call("kg_postproc_scale", ptr(kp0), ptr(sh0), ptr(md0), H, W, c_double(PEAK_THRESH), ptr(ws), c_long(ws.numel()), peak_cap,
+                  skel_cap, ptr(skel), ptr(nsk), *args, stream_ptr())
     return (skel, nsk, dbg) if debug else (skel, nsk)
 
 
@@ -82,7 +83,8 @@ def _boxes_device(skel_list, scale, boxes, nbox, cap, dev):
         return
     sk = torch.from_numpy(np.ascontiguousarray(np.asarray(skel_list, np.float64).reshape(n, 15))).to(dev)
     ns = torch.tensor([n], dtype=torch.int32, device=dev)
-    _lib.call("kg_skeleton_boxes", ptr(sk), ptr(ns), n, c_double(scale), 0, ptr(boxes), ptr(nbox), cap, stream_ptr())
+    with torch.cuda.device(dev):
+        _lib.call("kg_skeleton_boxes", ptr(sk), ptr(ns), n, c_double(scale), 0, ptr(boxes), ptr(nbox), cap, stream_ptr())
 
 
 def skeleton_to_box(skeletons, scale):
@@ -146,7 +148,8 @@ def detect(dec, nms_thresh=0.5):
     boxes = torch.empty(cap, 5, dtype=torch.float64, device=dev)
     nbox = torch.zeros(1, dtype=torch.int32, device=dev)
     for (skel, nsk), scale in zip(sks, (1, 2, 4, 8)):
-        _lib.call("kg_skeleton_boxes", ptr(skel), ptr(nsk), skel.shape[0], c_double(scale), 1, ptr(boxes), ptr(nbox), cap, stream_ptr())
+        with torch.cuda.device(dev):
+            _lib.call("kg_skeleton_boxes", ptr(skel), ptr(nsk), skel.shape[0], c_double(scale), 1, ptr(boxes), ptr(nbox), cap, stream_ptr())
     out, nk = _nms.nms_device(boxes, nbox, cap, float(nms_thresh))
     k = int(nk.item())
     if k == 0:

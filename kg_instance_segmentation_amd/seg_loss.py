@@ -37,7 +37,8 @@ class _SegLossFn(torch.autograd.Function):
         dev = flat.device
         part = torch.empty(npatches, dtype=torch.float32, device=dev)
         out = torch.empty(1, dtype=torch.float32, device=dev)
-        _lib.call("kg_seg_loss", ptr(flat), ptr(tgt), ptr(patches), ptr(pairs), npatches, ptr(part), ptr(out), None, None, stream_ptr())
+        with torch.cuda.device(dev):
+            _lib.call("kg_seg_loss", ptr(flat), ptr(tgt), ptr(patches), ptr(pairs), npatches, ptr(part), ptr(out), None, None, stream_ptr())
         ctx.save_for_backward(flat, tgt, patches, pairs)
         ctx.npatches = npatches
         return out[0].clone()
@@ -47,7 +48,8 @@ class _SegLossFn(torch.autograd.Function):
         flat, tgt, patches, pairs = ctx.saved_tensors
         g = torch.zeros_like(flat)
         go = go.contiguous().float()
-        _lib.call("kg_seg_loss", ptr(flat), ptr(tgt), ptr(patches), ptr(pairs), ctx.npatches, None, None, ptr(go), ptr(g), stream_ptr())
+        with torch.cuda.device(flat.device):
+            _lib.call("kg_seg_loss", ptr(flat), ptr(tgt), ptr(patches), ptr(pairs), ctx.npatches, None, None, ptr(go), ptr(g), stream_ptr())
         return g, None, None, None, None
 
 

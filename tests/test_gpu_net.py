@@ -390,3 +390,28 @@ def test_training_trajectory_vs_oracle(state_dict0):
         assert abs(a - c) <= 0.12 * abs(c), (got, ref16)
         assert abs(a - b) <= 0.12 * abs(b), (got, ref32)
     assert got[-1] < 0.7 * got[0] and ref32[-1] < 0.7 * ref32[0]
+
+
+def test_inference_sees_an_optimizer_step_without_a_training_forward(state_dict0):
+    """eval forward -> this package's fused Adam step (raw-pointer writes: no tensor version bump) -> eval forward: the packed bf16
+    weight copies must follow (ops.PARAM_EPOCH); the same after model.invalidate_caches() for writes nothing can see."""
+    from kg_instance_segmentation_amd.optim import Adam
+    m = KGnet.resnet50(pretrained=False)
+    m.load_state_dict(state_dict0)
+    m = m.to(DEV)
+    x = torch.rand(1, 3, 64, 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)) - 0.5
+    m.train()
+    d0 = m.forward_dec(x)[0]
+    sum(t.float().abs().mean() for t in d0[1:]).backward()
+    opt = Adam([p for p in m.parameters() if p.grad is not None], lr=1e-2)
+    m.eval()
+    with torch.no_grad():
+        a = m.forward_dec(x)[0][1].clone()
+        opt.step()                                   # writes the parameters through raw pointers
+        b = m.forward_dec(x)[0][1].clone()
+        assert float((a - b).abs().max()) > 1e-4 * float(a.abs().max())
+        for p in m.parameters():
+            p.data.mul_(0.5)                         # invisible to every counter ...
+        m.invalidate_caches()                        # ... so the caller says so
+        c = m.forward_dec(x)[0][1]
+        assert float((c - b).abs().max()) > 1e-4 * float(b.abs().max())
