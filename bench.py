@@ -247,8 +247,11 @@ def eval_bench(args, dev):
     """--mode eval: the test.py:97-123 inference path per image -- forward_dec (eval BN), post-processing of the 4 scales +
     NMS (bit-exact fp64 on the GPU), forward_seg on the detected boxes -- at 256 / 512 / 1024 with ~300 instances."""
     from kg_instance_segmentation_amd import KGnet, postprocessing as kpp
-    torch.manual_seed(1234)
-    model = KGnet.resnet50(pretrained=False).to(dev).eval()
+    from oracle import weightgen           # generator of the calibrated synthetic weights only (no oracle compute in the timed legs)
+    sd = weightgen.gen_state_dict(0, variant="cal")
+    model = KGnet.resnet50(pretrained=False)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
     per = {}
     for S in (256, 512, 1024):
         dec_np, boxes = eval_inputs(S, 300, 5)
@@ -267,8 +270,10 @@ def eval_bench(args, dev):
             t_pp, det = timed(lambda: kpp.detect(dec), args.steps)
             t_fd, out = timed(lambda: model.forward_dec(x), args.steps)
             bb = (det if det is not None else np.zeros((0, 5))).astype(np.float32)   # [y1,x1,y2,x2,score] in pixels (test.py:119-123)
-            t_fs, _ = timed(lambda: model.forward_seg(out[4], [bb]), args.steps)
-        per[S] = {"postproc_nms_ms": 1e3 * t_pp, "forward_dec_ms": 1e3 * t_fd, "forward_seg_ms": 1e3 * t_fs, "detections": 0 if det is None else len(det),
+            t_fs, pred = timed(lambda: model.forward_seg(out[4], [bb]), args.steps)
+            t_pm, pasted = timed(lambda: kpp.paste_masks(pred, S, S, S, S, 0.5, device_u8=True), args.steps)
+        per[S] = {"paste_masks_ms": 1e3 * t_pm, "_x": x.cpu(), "_bb": bb, "_masks": None if pasted is None else pasted[0].cpu().numpy(),
+                  "postproc_nms_ms": 1e3 * t_pp, "forward_dec_ms": 1e3 * t_fd, "forward_seg_ms": 1e3 * t_fs, "detections": 0 if det is None else len(det),
                   "imgs_per_s_postproc": 1.0 / t_pp, "imgs_per_s_end_to_end": 1.0 / (t_pp + t_fd + t_fs), "_det": det, "_dec": dec_np}
     out = {"metric": "imgs/s (eval: forward_dec + post-proc x4 + NMS + forward_seg) at 512x512, ~300 instances", "value": per[512]["imgs_per_s_end_to_end"],
            "unit": "imgs/s", "n_gpus": 1, "steps": args.steps, "warmup": 2, "ms_per_step": 1e3 / per[512]["imgs_per_s_end_to_end"],
@@ -286,8 +291,27 @@ def eval_bench(args, dev):
             cb[S] = {"oracle_ms": 1e3 * dtc, "ref_boxes": nref, "identical_boxes": same, "grouping_match_rate": same / max(nref, 1)}
         out["cpu_baseline"] = {"value": 1e3 / cb[512]["oracle_ms"], "unit": "imgs/s (post-proc + NMS only)", "cores": 1, "kind": "port",
                                "sample": "one image per size, oracle/kg_oracle.c via oracle/postproc.py", "per_size": cb}
+        # mask IoU against the fp32 oracle network on the same image and boxes (256 and 512: seconds of CPU work)
+        from oracle import net as onet, paste as opaste
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        net = onet.Net({k: v.clone() for k, v in sd.items()}, training=False)
+        for S in (256, 512):
+            if per[S]["_masks"] is None:
+                continue
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                of = net.forward_dec(per[S]["_x"])[4]
+                op_ = net.forward_seg(of, [per[S]["_bb"]])
+            ref = opaste.paste_masks([[[p.numpy() for p in pp] for pp in op_[0]], [[np.asarray(d) for d in dd] for dd in op_[1]]], S, S, S, S, 0.5)
+            dtc = time.perf_counter() - t0
+            a, b = per[S]["_masks"] > 0, ref[0] > 0
+            inter = (a & b).reshape(len(a), -1).sum(1).astype(np.float64); uni = (a | b).reshape(len(a), -1).sum(1).astype(np.float64)
+            iou = inter / np.maximum(uni, 1)
+            cb[S].update({"mask_iou_vs_oracle_mean": float(iou.mean()), "mask_iou_vs_oracle_min": float(iou.min()), "masks": int(len(a)),
+                          "oracle_network_s": dtc})
     for S in per:
-        per[S].pop("_det"); per[S].pop("_dec")
+        for k in ("_det", "_dec", "_x", "_bb", "_masks"):
+            per[S].pop(k)
     out["per_size"] = per
     print(json.dumps(out))
 
