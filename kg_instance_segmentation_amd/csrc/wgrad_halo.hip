@@ -10,7 +10,7 @@
 // workgroup: the (tap, ci-fragment) units are dealt round-robin to the 8 waves; each wave keeps its <= 7 units x 4
 // co-fragments of fp32 accumulators in registers across all tiles and writes them once at the end to the
 // [split][co][tap][ci] partial buffer that kg_wgrad_reduce sums (fixed order => reproducible).
-// Tiles are double-buffered through registers (loads of tile t+1 are in flight while tile t is multiplied).
+// Tiles are double-buffered in LDS (the LDS-direct loads of tile t+1 are in flight while tile t is multiplied).
 //
 // LDS layouts are chosen so that (a) the 32-lane halves of a transpose read hit disjoint banks and (b) every fragment
 // address is  lane-constant register + k-step immediate:  the k-step loop contains no address arithmetic.
@@ -19,6 +19,9 @@
 //   X halo  : [HWD rows][PITCH], PITCH = HWD*32*CIF rounded up to 128 (mod 256) so consecutive rows alternate bank
 //             halves; CIF == 4: 32-byte unit XOR (x & 3)
 #include "kg_common.h"
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 struct WgHaloArgs {
     const bf16_t* x; const bf16_t* dy; float* dwp;
@@ -45,17 +48,35 @@ struct WgGeom {
 };
 
 // NCF = 16-wide output-channel fragments that are computed (4 = all 64; 1 / 3 for the 5-, 10- and 40-channel second
-// head convs, whose dY tile is mostly padding: KGnet.py:161-209 `.2` layers)
+// head convs, whose dY tile is mostly padding: KGnet.py:161-209 `.2` layers).  Staging and fragment reads:
+//   * the dY tile and the X halo of tile t+1 go global -> LDS with LDS-direct loads (global_load_lds_dwordx4) while tile t is
+//     multiplied: no staging registers, no ds_write phase, no wave ever waits for a global load (the tile barrier does);
+//     the destination of a wave's load is lane-linear, so the 32-byte-unit swizzles are applied to the SOURCE piece;
+//   * the transpose reads are issued from inline asm, two (tap, ci-fragment) units ahead of the MFMAs, behind hand-counted
+//     s_waitcnt lgkmcnt(N): with an LDS-DMA pending hipcc turns every LDS wait into lgkmcnt(0) (kg_common.h), which made a first
+//     LDS-direct version with compiler-scheduled reads 8 % SLOWER than staging through registers (this one: 3-4 % faster).
+__device__ uint4 kg_wg_zero_line[8];
+
+template <int OFF>
+__device__ __forceinline__ void lds_rd_tr64(bf16x4& d, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_n() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void tie(bf16x4& v) { asm volatile("" : "+v"(v)); }
+
 template <int KS, int CIF, int NCF = 4, bool BIAS = false>
 __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     using GE = WgGeom<KS, CIF>;
-    constexpr int PAD = GE::PAD, HWD = GE::HWD, HPIX = HWD * HWD, T = GE::T, XB = GE::XB, PITCH = GE::PITCH;
+    constexpr int PAD = GE::PAD, HWD = GE::HWD, T = GE::T, XB = GE::XB, PITCH = GE::PITCH;
     constexpr int DY_BYTES = GE::DY_BYTES, BUF = GE::BUF, UNITS = GE::UNITS, UPW = GE::UPW;
-    constexpr int DYPT = 256 * 8 / 512;                // dY 16-byte chunks per thread (4)
-    constexpr int XCH = HPIX * 2 * CIF, XPT = (XCH + 511) / 512;
+    constexpr int DQ = 256 * 8 / 512;                   // dY 16-byte slots per thread (4)
+    constexpr int XROW = PITCH / 16, XREAL = HWD * 2 * CIF, XSL = HWD * XROW, XQ = (XSL + 511) / 512;
+    static_assert(PITCH % 16 == 0 && BUF % 16 == 0 && DY_BYTES % 1024 == 0, "16-byte LDS-direct destinations");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // (a readfirstlane'd wave id schedules 4 % slower)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int n_ci_tiles = (a.cin_lim + 16 * CIF - 1) / (16 * CIF);
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in linear-id order, and all
     // (co, ci) blocks of one pixel split read the SAME dY tiles / X halos.  Put the blocks of a split on one XCD so that its
@@ -74,14 +95,9 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     for (int q = 0; q < UPW; ++q)
 #pragma unroll
         for (int c = 0; c < NCF; ++c) acc[q][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Bias gradient for free: db[co] = sum_px dY[px][co] is the weight gradient of a constant-1 input channel, i.e. one more
-    // (tap, ci-fragment) unit with an all-ones B fragment.  49 (7x7) and 36 (3x3) units leave a wave with a free unit slot
-    // (BW, slot BQ < UPW), so the extra NCF MFMAs per k-step do not lengthen the workgroup's critical path.
     constexpr int BW = UNITS % 8, BQ = UNITS / 8;
     static_assert(BQ < UPW, "no free unit slot for the bias-gradient unit");
-    const bool do_bias = BIAS && ci0 == 0 && wave == BW;   // (a separate instantiation: the extra accumulators cost the 3x3
-                                                           // variant 23 spilled registers, so only the 7x7 kernels carry the unit)
+    const bool do_bias = BIAS && ci0 == 0 && wave == BW;
     f32x4 accb[BIAS ? NCF : 1];
 #pragma unroll
     for (int c = 0; c < (BIAS ? NCF : 1); ++c) accb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -89,17 +105,16 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
-    // ---- lane-constant fragment addresses (k-step 0); k-step s adds an immediate ------------------------------------
-    // dY^T fragment c (co block), half h: tile row r = (G&1)*16 + (G>>1)*8 + h*4 + (i16>>2)   (+ s*32)
-    int ay[4][2];
+    // lane-constant fragment addresses of buffer 0 (absolute LDS byte addresses; k-step s adds an immediate, buffer 1 adds BUF)
+    const unsigned lds0 = lds_addr(smem);
+    unsigned ay[NCF][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int r = (G & 1) * 16 + (G >> 1) * 8 + h * 4 + (i16 >> 2);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ay[c][h] = r * 128 + ((c ^ dyf(r)) * 32) + (i16 & 3) * 8;
+        for (int c = 0; c < NCF; ++c) ay[c][h] = lds0 + r * 128 + ((c ^ dyf(r)) * 32) + (i16 & 3) * 8;
     }
-    // X^T fragment of unit q (tap, ci block f), half h: halo row (G&1) + ky (+ 2s), column (G>>1)*8 + h*4 + (i16>>2) + kx
-    int bx[UPW][2];
+    unsigned bx[UPW][2];
 #pragma unroll
     for (int q = 0; q < UPW; ++q) {
         int u = wave + 8 * q;
@@ -110,32 +125,36 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
         for (int h = 0; h < 2; ++h) {
             const int xh = (G >> 1) * 8 + h * 4 + (i16 >> 2) + kx;
             const int unit = CIF == 1 ? 0 : (f ^ (xh & (CIF - 1)));
-            bx[q][h] = ((G & 1) + ky) * PITCH + xh * XB + unit * 32 + (i16 & 3) * 8;
+            bx[q][h] = lds0 + DY_BYTES + ((G & 1) + ky) * PITCH + xh * XB + unit * 32 + (i16 & 3) * 8;
         }
     }
 
-    uint4 dyr[DYPT], xr[XPT];
     const int tiles_plane = a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y;
     const int tiles_total = a.wp.n * tiles_plane;
 
-    // per-thread staging coordinates (tile independent): dividing per element and tile cost ~260 VALU per tile and wave,
-    // a third of the tile's MFMA time
-    int dy_ry[DYPT], dy_rx[DYPT];
+    // per-thread staging coordinates (tile independent).  LDS slot e (16 bytes) of the dY tile is row r = e >> 3, piece p = e & 7
+    // and holds source channel piece ((p >> 1) ^ f(r)) * 2 + (p & 1); slot e of the halo is row e / XROW, piece w = e % XROW
+    // (w >= XREAL: row padding, never read) = pixel hx = w / (2 CIF), source piece ((c >> 1) ^ (hx & (CIF-1))) * 2 + (c & 1).
+    int dy_ry[DQ], dy_rx[DQ], dy_c[DQ];
 #pragma unroll
-    for (int k = 0; k < DYPT; ++k) { const int r = (tid + k * 512) >> 3; dy_ry[k] = r >> 4; dy_rx[k] = r & 15; }
-    const int dy_c = co0 + (tid & 7) * 8;
-    const bool dy_cok = dy_c < a.cout_lim;
-    int x_hy[XPT], x_hx[XPT], x_c[XPT];
-#pragma unroll
-    for (int k = 0; k < XPT; ++k) {
-        const int e = tid + k * 512;
-        const int p = e / (2 * CIF), c = e - p * (2 * CIF);
-        const int hy = p / HWD;
-        x_hy[k] = e < XCH ? hy - PAD : -(1 << 20);      // out-of-range elements fail the bounds test below
-        x_hx[k] = p - hy * HWD - PAD;
-        x_c[k] = ci0 + c * 8;
+    for (int k = 0; k < DQ; ++k) {
+        const int e = tid + k * 512, r = e >> 3, pc = e & 7;
+        dy_ry[k] = r >> 4; dy_rx[k] = r & 15;
+        dy_c[k] = co0 + ((((pc >> 1) ^ dyf(r)) << 1) | (pc & 1)) * 8;
     }
-    auto load_tile = [&](int vt) {
+    int x_hy[XQ], x_hx[XQ], x_c[XQ];
+#pragma unroll
+    for (int k = 0; k < XQ; ++k) {
+        const int e = tid + k * 512;
+        const int hy = e / XROW, w = e - hy * XROW;
+        const int hx = w / (2 * CIF), c = w - hx * (2 * CIF);
+        const int unit = CIF == 1 ? 0 : ((c >> 1) ^ (hx & (CIF - 1)));
+        x_hy[k] = (e < XSL && w < XREAL) ? hy - PAD : (1 << 20);     // (1 << 20): no load at all
+        x_hx[k] = hx - PAD;
+        x_c[k] = ci0 + (unit * 2 + (c & 1)) * 8;
+    }
+    const bf16_t* zline = reinterpret_cast<const bf16_t*>(kg_wg_zero_line);
+    auto stage = [&](int vt, int buf) {
         const int pr = vt / tiles_plane, t = vt - pr * tiles_plane;     // (product, tile): uniform
         int oy0, ox0, Hd, Wd; long rowbase;
         if (a.tiletab) {
@@ -148,84 +167,93 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
             oy0 = ty * 16; ox0 = tx * 16; Hd = a.H; Wd = a.W; rowbase = (long)n * a.H * a.W;
         }
         const long base = rowbase + (long)oy0 * Wd + ox0;
-        const bf16_t* dyb = a.dy + a.wp.doff[pr] + base * a.lddy + dy_c;
+        const bf16_t* dyb = a.dy + a.wp.doff[pr] + base * a.lddy;
         const bf16_t* xb = a.x + a.wp.xoff[pr] + base * a.ldx;
         const int hrem = Hd - oy0, wrem = Wd - ox0;
-#pragma unroll
-        for (int k = 0; k < DYPT; ++k) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (dy_ry[k] < hrem && dy_rx[k] < wrem && dy_cok)
-                v = *reinterpret_cast<const uint4*>(dyb + (long)(dy_ry[k] * Wd + dy_rx[k]) * a.lddy);
-            dyr[k] = v;
-        }
-#pragma unroll
-        for (int k = 0; k < XPT; ++k) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if ((unsigned)(oy0 + x_hy[k]) < (unsigned)Hd && (unsigned)(ox0 + x_hx[k]) < (unsigned)Wd && x_c[k] < a.cin_lim)
-                v = *reinterpret_cast<const uint4*>(xb + (long)(x_hy[k] * Wd + x_hx[k]) * a.ldx + x_c[k]);
-            xr[k] = v;
-        }
-    };
-    auto store_tile = [&](int buf) {
         unsigned char* sy = smem + buf * BUF;
         unsigned char* sx = sy + DY_BYTES;
 #pragma unroll
-        for (int k = 0; k < DYPT; ++k) {
-            const int e = tid + k * 512, r = e >> 3, c8 = e & 7;
-            *reinterpret_cast<uint4*>(sy + r * 128 + (((c8 >> 1) ^ dyf(r)) * 32) + (c8 & 1) * 16) = dyr[k];
+        for (int k = 0; k < DQ; ++k) {
+            const bf16_t* src = zline;
+            if (dy_ry[k] < hrem && dy_rx[k] < wrem && dy_c[k] < a.cout_lim) src = dyb + (long)(dy_ry[k] * Wd + dy_rx[k]) * a.lddy + dy_c[k];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(sy + (k * 512 + wave_u * 64) * 16), 16, 0, 0);
         }
 #pragma unroll
-        for (int k = 0; k < XPT; ++k) {
-            const int e = tid + k * 512;
-            if (e < XCH) {
-                const int p = e / (2 * CIF), c = e - p * (2 * CIF);
-                const int hy = p / HWD, hx = p - hy * HWD;
-                const int unit = CIF == 1 ? 0 : ((c >> 1) ^ (hx & (CIF - 1)));
-                *reinterpret_cast<uint4*>(sx + hy * PITCH + hx * XB + unit * 32 + (c & 1) * 16) = xr[k];
+        for (int k = 0; k < XQ; ++k) {
+            if (x_hy[k] != (1 << 20)) {
+                const bf16_t* src = zline;
+                if ((unsigned)(oy0 + x_hy[k]) < (unsigned)Hd && (unsigned)(ox0 + x_hx[k]) < (unsigned)Wd && x_c[k] < a.cin_lim)
+                    src = xb + (long)(x_hy[k] * Wd + x_hx[k]) * a.ldx + x_c[k];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(sx + (k * 512 + wave_u * 64) * 16), 16, 0, 0);
             }
         }
     };
 
+    // fragment reads of k-step s: dY^T fragments c (2 transpose reads each), X^T fragment of unit q (2 reads)
+    auto rdA = [&](auto sc, bf16x4 (&f)[NCF][2]) {
+        constexpr int S = decltype(sc)::value;
+#pragma unroll
+        for (int c = 0; c < NCF; ++c) { lds_rd_tr64<S * 32 * 128>(f[c][0], ay[c][0]); lds_rd_tr64<S * 32 * 128>(f[c][1], ay[c][1]); }
+    };
+    auto rdB = [&](auto sc, auto qc, bf16x4 (&f)[2]) {
+        constexpr int S = decltype(sc)::value, Q = decltype(qc)::value;
+        lds_rd_tr64<S * 2 * PITCH>(f[0], bx[Q][0]); lds_rd_tr64<S * 2 * PITCH>(f[1], bx[Q][1]);
+    };
+    auto cat = [](const bf16x4 (&f)[2]) { return __builtin_shufflevector(f[0], f[1], 0, 1, 2, 3, 4, 5, 6, 7); };
+
     int t = split;
-    int cur = 0;
-    if (t < tiles_total) { load_tile(t); store_tile(0); }
+    int cur = 0;                                     // ay / bx always point into the current buffer
+    if (t < tiles_total) stage(t, 0);
     for (; t < tiles_total; t += a.nsplit) {
-        __syncthreads();
+        __syncthreads();                             // (s_waitcnt vmcnt(0) + barrier): this tile has landed, the other buffer is free
         const int tn = t + a.nsplit;
-        if (tn < tiles_total) load_tile(tn);
-        const unsigned char* sy = smem + cur * BUF;
-        const unsigned char* sx = sy + DY_BYTES;
+        if (tn < tiles_total) stage(tn, cur ^ 1);
+        // The (k-step s, unit q) pairs form one sequence I = s * UPW + q; read group R_I = the 2 transpose reads of unit I's X^T
+        // fragment, preceded by the 2 NCF reads of the k-step's dY^T fragments when q == 0.  R_{I+2} is issued before the MFMAs
+        // of unit I (two units = 8 MFMAs of LDS latency cover), LDS reads return in order, so "R_I has landed" is
+        // lgkmcnt(|R_{I+1}| + |R_{I+2}|), a compile-time constant.
+        bf16x4 fa[2][NCF][2], fb[3][2];              // fragments: A by k-step parity, B by unit index mod 3
+        constexpr int NU = 8 * UPW;
+        auto issue = [&](auto ic) {
+            constexpr int I = decltype(ic)::value, S = I / UPW, Q = I % UPW;
+            if constexpr (Q == 0) rdA(std::integral_constant<int, S>{}, fa[S & 1]);
+            rdB(std::integral_constant<int, S>{}, std::integral_constant<int, Q>{}, fb[I % 3]);
+        };
+        issue(std::integral_constant<int, 0>{});
+        issue(std::integral_constant<int, 1>{});
+        auto step = [&](auto ic) {
+            constexpr int I = decltype(ic)::value, S = I / UPW, Q = I % UPW;
+            constexpr int n1 = I + 1 < NU ? 2 + ((I + 1) % UPW == 0 ? 2 * NCF : 0) : 0;
+            constexpr int n2 = I + 2 < NU ? 2 + ((I + 2) % UPW == 0 ? 2 * NCF : 0) : 0;
+            if constexpr (I + 2 < NU) issue(std::integral_constant<int, I + 2>{});
+            lgkm_wait_n<n1 + n2>();
+            if constexpr (Q == 0) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {       // k-step: the 32 pixels of tile rows 2s, 2s+1 (all offsets are immediates)
-            bf16x8 af[NCF];
+                for (int c = 0; c < NCF; ++c) { tie(fa[S & 1][c][0]); tie(fa[S & 1][c][1]); }
+                if (BIAS && do_bias) {               // wave-uniform
 #pragma unroll
-            for (int c = 0; c < NCF; ++c)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sy + ay[c][h] + s * 32 * 128));
-                    af[c][h * 4 + 0] = v[0]; af[c][h * 4 + 1] = v[1]; af[c][h * 4 + 2] = v[2]; af[c][h * 4 + 3] = v[3];
-                }
-            if (BIAS && do_bias) {                     // wave-uniform
-#pragma unroll
-                for (int c = 0; c < (BIAS ? NCF : 1); ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], ones, accb[c], 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < UPW; ++q) {
-                if (wave + 8 * q < UNITS) {            // wave-uniform
-                    bf16x8 bfr;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sx + bx[q][h] + s * 2 * PITCH));
-                        bfr[h * 4 + 0] = v[0]; bfr[h * 4 + 1] = v[1]; bfr[h * 4 + 2] = v[2]; bfr[h * 4 + 3] = v[3];
-                    }
-#pragma unroll
-                    for (int c = 0; c < NCF; ++c)
-                        acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfr, acc[q][c], 0, 0, 0);
+                    for (int c = 0; c < (BIAS ? NCF : 1); ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat(fa[S & 1][c]), ones, accb[c], 0, 0, 0);
                 }
             }
+            tie(fb[I % 3][0]); tie(fb[I % 3][1]);
+            if (Q < UNITS / 8 || wave + 8 * Q < UNITS) {   // (wave-uniform; only the last slot can be idle)
+                const bf16x8 bfr = cat(fb[I % 3]);
+#pragma unroll
+                for (int c = 0; c < NCF; ++c) acc[Q][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat(fa[S & 1][c]), bfr, acc[Q][c], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);       // keep the unit's MFMAs between its wait and the next unit's reads
+        };
+        [&]<int... Is>(std::integer_sequence<int, Is...>) { (step(std::integral_constant<int, Is>{}), ...); }(std::make_integer_sequence<int, NU>{});
+        {   // the other buffer becomes current
+            const int delta = cur ? -BUF : BUF;
+#pragma unroll
+            for (int c = 0; c < NCF; ++c) { ay[c][0] += delta; ay[c][1] += delta; }
+#pragma unroll
+            for (int q = 0; q < UPW; ++q) { bx[q][0] += delta; bx[q][1] += delta; }
+            cur ^= 1;
         }
-        if (tn < tiles_total) store_tile(cur ^ 1);
-        cur ^= 1;
     }
 
     if (BIAS && do_bias && i16 == 0) {     // every column of the unit's result holds the same sum

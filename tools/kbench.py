@@ -34,7 +34,9 @@ def main():
     kind, N, H, cin, cout, k = CASES[name]
     dev = "cuda"
     M = N * H * H
-    x = (torch.randn(M, cin, device=dev) * 0.5).to(BF16)
+    const = os.environ.get("KG_KBENCH_CONST") == "1"     # constant operands: the clock the chip sustains depends on the data toggling
+    rnd = (lambda *sh: torch.full(sh, 1.0, device=dev)) if const else (lambda *sh: torch.randn(*sh, device=dev))
+    x = (rnd(M, cin) * 0.5).to(BF16)
     geom = (M, H, H, H, H, k, k, 1, k // 2)
     flops = 2.0 * M * cout * k * k * cin
     if kind in ("fwd", "igemm"):
@@ -47,7 +49,7 @@ def main():
         else:
             fn = lambda: ops.conv_igemm(x, pw, cout, geom, y=y, bias=bias, relu=True)
     else:
-        dy = (torch.randn(M, cout, device=dev) * 0.5).to(BF16)
+        dy = (rnd(M, cout) * 0.5).to(BF16)
         gw = torch.empty(cout, cin, k, k, device=dev)
         fn = lambda: ops.conv_wgrad(x, dy, cin, cout, geom, [(gw, 0, cout)], N=N)
     for _ in range(2):

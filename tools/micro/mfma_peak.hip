@@ -13,10 +13,25 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 template <int MODE, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k(const uint4* __restrict__ g, float* out, int iters) {
+__global__ __launch_bounds__(WAVES * 64) void k(const uint4* __restrict__ g, float* out, int iters, int data) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 120 * 1024 / 16; i += WAVES * 64) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0x3c003c00, 0x3c003c00, 0x3c003c00, 0x3c003c00);
+    // data 0: every operand element the same constant; 1: pseudo-random bf16 in (-1, 1) (all mantissa bits toggle: the clock the chip
+    // sustains under its power limit depends on the operand data); 2: the random values with 60 % zeros (post-ReLU activations)
+    for (int i = tid; i < 120 * 1024 / 16; i += WAVES * 64) {
+        uint4 v = make_uint4(0x3c003c00, 0x3c003c00, 0x3c003c00, 0x3c003c00);
+        if (data) {
+            unsigned r[4];
+            for (int q = 0; q < 4; ++q) {
+                unsigned h = (unsigned)(i * 4 + q) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+                unsigned lo = 0x3f00u - (h & 0x1ff) + ((h >> 9) & 1) * 0x8000u, hi = 0x3f00u - ((h >> 10) & 0x1ff) + ((h >> 19) & 1) * 0x8000u;
+                if (data == 2) { if (((h >> 20) & 15) < 10) lo = 0; if (((h >> 24) & 15) < 10) hi = 0; }
+                r[q] = lo | (hi << 16);
+            }
+            v = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+        reinterpret_cast<uint4*>(smem)[i] = v;
+    }
     __syncthreads();
     f32x4 acc[4][4];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
@@ -71,17 +86,17 @@ __global__ __launch_bounds__(WAVES * 64) void k(const uint4* __restrict__ g, flo
 }
 
 template <int MODE, int WAVES>
-static void run(const uint4* g, float* out, int blocks, int iters) {
+static void run(const uint4* g, float* out, int blocks, int iters, int data = 0) {
     hipFuncSetAttribute((const void*)k<MODE, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
     hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
-    k<MODE, WAVES><<<blocks, WAVES * 64, 155 * 1024>>>(g, out, iters);
+    k<MODE, WAVES><<<blocks, WAVES * 64, 155 * 1024>>>(g, out, iters, data);
     hipDeviceSynchronize();
     hipEventRecord(s);
-    k<MODE, WAVES><<<blocks, WAVES * 64, 155 * 1024>>>(g, out, iters);
+    k<MODE, WAVES><<<blocks, WAVES * 64, 155 * 1024>>>(g, out, iters, data);
     hipEventRecord(e); hipEventSynchronize(e);
     float ms; hipEventElapsedTime(&ms, s, e);
     const double fl = (double)blocks * WAVES * iters * 32 * 16384.0;
-    printf("mode %d waves %d blocks %d: %.3f ms  %.1f TFLOP/s (%s)\n", MODE, WAVES, blocks, ms, fl / ms / 1e9, hipGetErrorString(hipGetLastError()));
+    printf("data %d mode %d waves %d blocks %d: %.3f ms  %.1f TFLOP/s (%s)\n", data, MODE, WAVES, blocks, ms, fl / ms / 1e9, hipGetErrorString(hipGetLastError()));
 }
 
 int main(int argc, char** argv) {
@@ -92,5 +107,7 @@ int main(int argc, char** argv) {
     run<0, 8>(g, out, 256, iters); run<1, 8>(g, out, 256, iters); run<2, 8>(g, out, 256, iters); run<3, 8>(g, out, 256, iters); run<4, 8>(g, out, 256, iters);
     run<0, 4>(g, out, 256, iters); run<1, 4>(g, out, 256, iters);
     run<0, 8>(g, out, 2048, iters / 4); run<3, 8>(g, out, 2048, iters / 4); run<4, 8>(g, out, 2048, iters / 4);
+    for (int data = 1; data <= 2; ++data) { run<0, 8>(g, out, 256, iters, data); run<1, 8>(g, out, 256, iters, data); run<4, 8>(g, out, 256, iters, data); }
+    run<0, 8>(g, out, 256, iters * 8, 1); run<4, 8>(g, out, 256, iters * 8, 1); run<4, 8>(g, out, 256, iters * 8, 0);   // ~20 ms launches: the steady-state clock
     return 0;
 }
