@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkgnet_hip.so")
+# KG_LIB_PATH: another build of the SAME library (kernel A/B tuning on one GPU box); it must export the whole C ABI like the default
+LIB_PATH = os.environ.get("KG_LIB_PATH") or os.path.join(_HERE, "libkgnet_hip.so")
 
 c_int, c_long, c_float, c_double, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 P = c_void_p

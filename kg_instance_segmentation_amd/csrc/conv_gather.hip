@@ -122,6 +122,7 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nstage = a.ntaps * ncc;
+    const unsigned lds0 = lds_addr(smem);
     issue();
     if (nstage > 1) issue();
     int c_slot = 0;
@@ -132,23 +133,28 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (s + 2 < nstage) issue();          // into the slot of stage s-1, which every wave has finished reading
-        const unsigned char* st = smem + c_slot * STAGE;
+        // fragment reads from inline asm with hand-counted waits (with an LDS-DMA pending hipcc waits lgkmcnt(0) for every LDS
+        // read, kg_common.h): the 8 reads of k-step 1 stay in flight behind the 16 MFMAs of k-step 0
+        const unsigned sb = lds0 + c_slot * STAGE;
         bf16x8 af[2][4], bfr[2][4];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[k][i] = *reinterpret_cast<const bf16x8*>(st + a_off[i][k]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[k][j] = *reinterpret_cast<const bf16x8*>(st + b_off[j][k]);
+            const unsigned aa = sb + a_off[0][k], ba = sb + b_off[0][k];
+            lds_rd128<0>(af[k][0], aa); lds_rd128<512>(af[k][1], aa); lds_rd128<1024>(af[k][2], aa); lds_rd128<1536>(af[k][3], aa);
+            lds_rd128<0>(bfr[k][0], ba); lds_rd128<2048>(bfr[k][1], ba); lds_rd128<4096>(bfr[k][2], ba); lds_rd128<6144>(bfr[k][3], ba);
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 2; ++k) {
+            if (k == 0) lgkm_wait<8>(af[0], bfr[0]);
+            else lgkm_wait<0>(af[1], bfr[1]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k][i], bfr[k][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // the MFMAs of k-step 0 stay in front of the wait for k-step 1
+        }
         __builtin_amdgcn_s_setprio(0);
         c_slot = c_slot == NS - 1 ? 0 : c_slot + 1;
     }
