@@ -317,7 +317,6 @@ extern "C" int kg_conv2d_wgrad_halo(const void* x, const void* dy, float* dwp, i
     a.cin_lim = cin_lim; a.cout_lim = cout_lim; a.nsplit = nsplit; a.split_stride = split_stride;
     a.tiletab = (const int4*)tiletab; a.ntiles = ntiles; a.dbp = dbp;
     hipStream_t st = (hipStream_t)stream;
-    KG_CHECK_ARG(!dbp || KS == 7, "kg_conv2d_wgrad_halo: the fused bias gradient is only built for 7x7");
     if (KS == 7) {
         if (dbp) {
             // 5- / 10-cout second head layers: 32 input channels per workgroup (the dY tile is staged once per 32 instead of 16)
@@ -330,6 +329,7 @@ extern "C" int kg_conv2d_wgrad_halo(const void* x, const void* dy, float* dwp, i
         if (cout_lim <= 48) return launch_wg<7, 1, 3>(a, st);
         return launch_wg<7, 1>(a, st);
     }
+    if (dbp) return cout_lim <= 16 ? launch_wg<3, 4, 1, true>(a, st) : launch_wg<3, 4, 4, true>(a, st);
     if (cout_lim <= 16) return launch_wg<3, 4, 1>(a, st);   // seg_head.2 (64 -> 1)
     return launch_wg<3, 4>(a, st);
 }

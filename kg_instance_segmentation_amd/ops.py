@@ -405,13 +405,13 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
         tiles = tiletab16.shape[0] if tiletab16 is not None else N * math.ceil(H / 16) * math.ceil(W / 16)
         S = halo_wgrad_splits(nblk, tiles * np_, cit, KH * KW, nelem)      # (plane products = more tiles to walk)
         part = scratch_f32(S * nelem, xb.device, "wgrad")
-        fused_bias = bias_out is not None and KH == 7 and not planed
+        fused_bias = bias_out is not None and not planed
         dbp = scratch_f32(S * cout, xb.device, "wgrad_bias") if fused_bias else None
         _lib.call("kg_conv2d_wgrad_halo", ptr(xb), ptr(dyb), ptr(part), N or 0, H, W, ld(xb), ld(dyb), cin, cout, cin_lim, cout_lim, KH, S,
                   c_long(nelem), ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, ptr(dbp), planes, stream_ptr())
         if dbp is not None:
             _lib.call("kg_bias_grad_final", ptr(dbp), ptr(bias_out), S, cout, 1 if accumulate else 0, stream_ptr())
-        elif bias_out is not None:       # 3x3: the extra accumulators would spill in that kernel variant
+        elif bias_out is not None:       # planed operands: the all-ones unit would count every plane product
             bias_grad(dy, cout, bias_out, accumulate=accumulate)
     else:
         S = wgrad_splits(M * np_, cin_lim, cout_lim, KH * KW, nelem)
