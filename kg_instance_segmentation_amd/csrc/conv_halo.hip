@@ -15,6 +15,7 @@
 // Wave tile = 64 couts x 64 pixels (4 rows of the 16x16 tile), 16 v_mfma_f32_16x16x32_bf16 per 32-wide k-step.
 #include "conv_args.h"
 #include <type_traits>
+#include <utility>
 #include <stdlib.h>
 #ifndef KG_HALO_SETPRIO
 #define KG_HALO_SETPRIO 0
@@ -196,6 +197,80 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)(halo + (q * NT + wave_u * 64) * 16), 16, 0, 0);
                 }
+            }
+        }
+        if constexpr (GM == 1) {
+            // ---- kp / short chunks (heads 0, 1): ONE MFMA row group is live, so a tap needs only its 16 weight rows (2 KB, not the
+            // 8 KB slice of the ring below) and 4 MFMAs per k-step -- with the two-taps-per-barrier ring the chunk is bound by the
+            // barrier cadence (16 MFMAs between barriers), not by MFMAs or LDS.  Here a whole KERNEL ROW of 16-row slices (7 taps,
+            // 14 KB) is one ring stage: 3 stages in the ring's LDS, rows ky+1, ky+2 in flight while row ky is multiplied, one barrier
+            // per 7 taps; fragment reads from inline asm one k-step ahead (5 reads per 4 MFMAs: the LDS pipe is the bound).
+            const int head_n = cc / a.grp_chunks;                 // uniform
+            if (head_n < 2) {
+                constexpr int ROWB = 7 * 2048;
+                const int wave_n = __builtin_amdgcn_readfirstlane(wave);
+                const bf16_t* nsrc[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {                     // piece e of a row: tap kx = e >> 7, row rho = (e >> 3) & 15, 16-byte slot e & 7
+                    const int e = tid + k * 512, kxl = e >> 7, rho = (e >> 3) & 15, sl = e & 7;
+                    const int r = 16 * (rho >> 2) + 4 * head_n + (rho & 3);
+                    const int key = 2 * (rho >> 2) + ((rho >> 1) & 1);
+                    nsrc[k] = a.w + (long)r * a.K + (long)kxl * a.cin_pad + cc * 64 + ((sl ^ key) * 8);
+                }
+                auto nload = [&](int ky) {                        // kernel row ky -> stage ky % 3 (896 pieces: waves 0..5 issue two loads, 6..7 one)
+                    unsigned char* dst = wbuf + (ky % 3) * ROWB + wave_n * 1024;
+                    const long ro = (long)ky * 7 * a.cin_pad;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nsrc[0] + ro),
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                    if (wave_n < 6)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nsrc[1] + ro),
+                                                         (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
+                };
+                nload(0); nload(1);
+                int a_n[2];
+                {
+                    const int keyl = 2 * (lm >> 2) + ((lm >> 1) & 1);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) a_n[s2] = lm * 128 + (((4 * s2 + g) ^ keyl) * 16);
+                }
+                const unsigned ldsn = lds_addr(smem);
+                auto narrow = [&](auto hc) {
+                    constexpr int HD = decltype(hc)::value;
+#pragma unroll 1
+                    for (int ky = 0; ky < KS; ++ky) {
+                        if (ky + 1 < KS) {                        // row ky has landed; the loads of row ky+1 may stay in flight
+                            if (wave_n < 6) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        if (ky + 2 < KS) nload(ky + 2);           // into the stage of row ky-1, which every wave has left
+                        const unsigned wa = ldsn + HALO_BYTES + (ky % 3) * ROWB;
+                        const unsigned hrow = ldsn + ky * (HWD * 128);
+                        bf16x8 fa[2], fb[2][4];
+                        auto rd = [&](auto nc) {
+                            constexpr int N = decltype(nc)::value, KX = N >> 1, S2 = N & 1, B = N & 1;
+                            lds_rd128<KX * 2048>(fa[B], wa + a_n[S2]);
+                            const unsigned ba = hrow + kb[KX][S2];
+                            lds_rd128<KX * 128>(fb[B][0], ba); lds_rd128<KX * 128 + HWD * 128>(fb[B][1], ba);
+                            lds_rd128<KX * 128 + 2 * HWD * 128>(fb[B][2], ba); lds_rd128<KX * 128 + 3 * HWD * 128>(fb[B][3], ba);
+                        };
+                        auto stepn = [&](auto nc) {
+                            constexpr int N = decltype(nc)::value, B = N & 1;
+                            if constexpr (N + 1 < 2 * KS) { rd(std::integral_constant<int, N + 1>{}); asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); }
+                            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            asm volatile("" : "+v"(fa[B]), "+v"(fb[B][0]), "+v"(fb[B][1]), "+v"(fb[B][2]), "+v"(fb[B][3]));
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[HD][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[B], fb[B][j], acc[HD][j], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        };
+                        rd(std::integral_constant<int, 0>{});
+                        [&]<int... Ns>(std::integer_sequence<int, Ns...>) { (stepn(std::integral_constant<int, Ns>{}), ...); }(std::make_integer_sequence<int, 2 * KS>{});
+                    }
+                };
+                if (head_n == 0) narrow(std::integral_constant<int, 0>{});
+                else narrow(std::integral_constant<int, 1>{});
+                continue;
             }
         }
         auto wload = [&](int tap) {
