@@ -527,7 +527,8 @@ def main():
                                     "fp32": "fp32 values as 3 bf16 planes, 6 bf16 MFMA products per multiply, fp32 accumulation"}[args.precision],
                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "last_loss": last,
                       "loss_readback": "every step (train.py:156)" if STEP_SYNC else "after the timed region",
-                      "other_readback_policy_imgs_per_s": imgs / other_dt}}
+                      "other_readback_policy_imgs_per_s": imgs / other_dt,
+                      "step_ms": [round(1e3 * (b - a), 2) for a, b in zip([t0] + marks[:-1], marks)]}}
     if companion is not None:
         out["fp32_companion"] = companion
     if not args.no_kernel_timer:

@@ -173,6 +173,9 @@ int kg_adam_step(const void* jobs, int njobs, int total_blocks, float beta1, flo
 /* ---- host glue of SEG_loss (seg_loss.py:57-80), pure host code: crops of the matched ground-truth masks (float32 [n][H][W] per
  * image), nearest-resized to the patch size, as bytes.  work = int32 [nwork][9]: (img, gt, y1, y2, x1, x2, h1, w1, out offset) ---- */
 int kg_host_crop_masks(const float* const* masks, const int* work, int nwork, int H, int W, unsigned char* out);
+/* matching of seg_loss.py:14-29,55-56 (jaccard_numpy >= thresh over all predicted x ground-truth boxes of an image), pure host code,
+ * float32 in the reference's operation order: pairs = int32 [cap][2] (patch, gt) row-major, *count = matches */
+int kg_host_match_boxes(const float* pb, int P, const float* gb, int G, int gstride, float thresh, int* pairs, int cap, int* count);
 
 /* ---- evaluation metrics (eval_parts.mask_iou inside seg_evaluation, eval_parts.py:4-9,98-150): exact pixel counts.
  * masks = device bytes [n][ld], ld % 16 == 0, non-zero byte = foreground, padding zero ---- */

@@ -56,6 +56,7 @@ _SIGS = {
     "kg_gt_maps": [P, c_int, c_int, c_int, P, P],
     "kg_adam_step": [P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, P],
     "kg_host_crop_masks": [P, P, c_int, c_int, c_int, P],
+    "kg_host_match_boxes": [P, c_int, P, c_int, c_int, c_float, P, c_int, P],
     "kg_mask_areas": [P, c_int, c_long, P, P],
     "kg_mask_inter_pairs": [P, P, P, c_int, c_long, P, P],
     "kg_f64_probe": [P, P, P, c_int, P],

@@ -46,6 +46,39 @@ extern "C" int kg_tr_probe(void* out, void* stream) {
 // out[off + y*w1 + x] = (uint8) masks[img][g][y1 + sy][x1 + sx] with sy = min(floor(y * (y2-y1)/h1), y2-y1-1) (cv2 INTER_NEAREST rule
 // as stated in seg_loss.nearest_resize), identity when the crop already has the patch size.
 #include <math.h>
+// ---- host glue of SEG_loss (seg_loss.py:14-29, 55-56): which (predicted box, ground-truth box) pairs overlap with IoU >= thresh.
+// float32 arithmetic in the operation order of the reference's jaccard_numpy (areas, clamped intersection sides, union <= 2 -> 0).
+// pb = float32 [P][4], gb = float32 [G][gstride] (first 4 columns y1, x1, y2, x2); pairs = int32 [cap][2] receives (patch, gt) in
+// row-major order; *count = number of matches (the call fails when they do not fit cap).  300 x 300 boxes: 0.3 ms as NumPy
+// broadcasting per image, ~40 us here.
+extern "C" int kg_host_match_boxes(const float* pb, int P, const float* gb, int G, int gstride, float thresh, int* pairs, int cap, int* count) {
+#pragma clang fp contract(off)
+    KG_CHECK_ARG(pb && gb && pairs && count && P >= 0 && G >= 0 && gstride >= 4 && cap >= 0, "kg_host_match_boxes: bad arguments");
+    int n = 0;
+    for (int j = 0; j < P; ++j) {
+        const float a0 = pb[4 * j], a1 = pb[4 * j + 1], a2 = pb[4 * j + 2], a3 = pb[4 * j + 3];
+        const float area_a = (a2 - a0) * (a3 - a1);
+        for (int g = 0; g < G; ++g) {
+            const float* b = gb + (long)g * gstride;
+            const float area_b = (b[2] - b[0]) * (b[3] - b[1]);
+            float ih = (a2 < b[2] ? a2 : b[2]) - (a0 > b[0] ? a0 : b[0]);
+            float iw = (a3 < b[3] ? a3 : b[3]) - (a1 > b[1] ? a1 : b[1]);
+            if (thresh > 0.f && (!(ih > 0.f) || !(iw > 0.f))) continue;      // disjoint boxes: inter = 0 -> IoU 0 (most pairs)
+            if (!(ih > 0.f)) ih = 0.f;
+            if (!(iw > 0.f)) iw = 0.f;
+            const float inter = ih * iw;
+            const float uni = area_a + area_b - inter;
+            const float iou = uni <= 2.f ? 0.f : inter / uni;
+            if (iou >= thresh) {
+                if (n >= cap) { kg_set_error("kg_host_match_boxes: more than %d matches", cap); return KG_ERR_ARG; }
+                pairs[2 * n] = j; pairs[2 * n + 1] = g; ++n;
+            }
+        }
+    }
+    *count = n;
+    return KG_OK;
+}
+
 extern "C" int kg_host_crop_masks(const float* const* masks, const int* work, int nwork, int H, int W, unsigned char* out) {
     KG_CHECK_ARG(masks && work && out && nwork >= 0 && H > 0 && W > 0, "kg_host_crop_masks: bad arguments");
     for (int k = 0; k < nwork; ++k) {

@@ -23,48 +23,73 @@ class Adam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
         self._tables = {}
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._shadow = {}                    # the Python-side step counters follow the loaded `step` tensors
+        self._tables = {}
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        shadow = self.__dict__.setdefault("_shadow", {})
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
             beta1, beta2 = group["betas"]
-            by_step = {}
+            steps = []
             for p in ps:
-                if not p.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32:
-                    raise _lib.KGLibraryError("the fused HIP Adam needs fp32 parameters and gradients on the GPU")
                 st = self.state[p]
                 if not st:
+                    if not p.is_cuda or p.dtype != torch.float32:
+                        raise _lib.KGLibraryError("the fused HIP Adam needs fp32 parameters and gradients on the GPU")
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                by_step.setdefault(int(st["step"]), []).append(p)
+                steps.append(st["step"])
+            torch._foreach_add_(steps, 1)              # one call for the ~160 host-side counters (torch.optim.Adam's state layout)
+            by_step = {}
+            for p, sv in zip(ps, steps):
+                t = shadow.get(id(p))
+                t = int(sv) if t is None else t + 1    # (shadow: an int() per CPU tensor costs more than the whole table)
+                shadow[id(p)] = t
+                by_step.setdefault(t, []).append(p)
             for t, plist in by_step.items():           # (parameters that joined later have their own bias correction)
-                arr = np.zeros(len(plist), _JOB)
-                blk = 0
-                for i, p in enumerate(plist):
-                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                    st = self.state[p]
-                    arr[i] = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), blk, 0)
-                    if g is not p.grad:
-                        st["_g"] = g           # keep the temporary alive until the launch is enqueued
-                    blk += (p.numel() + 4095) // 4096
-                dev = plist[0].device
-                key, sig = (gi, t == 0, len(plist)), arr.tobytes()
+                key = (gi, t == 0, len(plist))
                 ent = self._tables.get(key)
-                if ent is None or ent[0] != sig:
-                    ent = (sig, ops.h2d(arr.view(np.uint8).reshape(-1), dev))
+                sts = [self.state[p] for p in plist]
+                ids = ([p.data_ptr() for p in plist], [st["exp_avg"].data_ptr() for st in sts], [st["exp_avg_sq"].data_ptr() for st in sts])
+                if ent is None or ent["ids"] != ids:   # rarely-changing columns of the job table: parameter, moments, sizes, first workgroup
+                    arr = np.zeros(len(plist), _JOB)
+                    blk = 0
+                    for i, p in enumerate(plist):
+                        st = self.state[p]
+                        arr[i] = (p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), blk, 0)
+                        blk += (p.numel() + 4095) // 4096
+                    ent = {"ids": ids, "arr": arr, "blk": blk, "gptr": None, "dev": None}
                     self._tables[key] = ent
+                keep = []
+                gptr = []
+                for p in plist:
+                    g = p.grad
+                    if g.dtype != torch.float32 or not g.is_cuda:
+                        raise _lib.KGLibraryError("the fused HIP Adam needs fp32 parameters and gradients on the GPU")
+                    if not g.is_contiguous():
+                        g = g.contiguous(); keep.append(g)         # alive until the launch is enqueued
+                    gptr.append(g.data_ptr())
+                dev = plist[0].device
+                if ent["gptr"] != gptr:                # (gradients living in persistent slots, parallel.FlatGradReducer: the table is reused)
+                    ent["arr"]["g"] = gptr
+                    ent["gptr"] = gptr
+                    ent["dev"] = ops.h2d(ent["arr"].view(np.uint8).reshape(-1), dev)
                 bc1 = 1.0 - beta1 ** t
                 bc2 = 1.0 - beta2 ** t
                 with torch.cuda.device(dev):
-                    _lib.call("kg_adam_step", ptr(ent[1]), len(plist), blk, c_float(beta1), c_float(beta2), c_float(group["eps"]),
+                    _lib.call("kg_adam_step", ptr(ent["dev"]), len(plist), ent["blk"], c_float(beta1), c_float(beta2), c_float(group["eps"]),
                               c_float(group["lr"] / bc1), c_float(math.sqrt(bc2)), c_float(group["weight_decay"]), stream_ptr())
+                del keep
         ops.PARAM_EPOCH[0] += 1      # raw-pointer writes do not bump tensor versions: packed bf16 weight copies are stale now
         return loss

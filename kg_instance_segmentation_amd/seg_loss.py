@@ -65,6 +65,29 @@ def jaccard_matrix(a, b):
         return np.where(union <= 2, np.float32(0.), inter / union)
 
 
+def match_boxes(pb, gb, thresh=0.5):
+    """(patch, gt) index pairs with jaccard_numpy(patch box, gt box) >= thresh (seg_loss.py:55-56) through the native host matcher
+    (kg_host_match_boxes: the same float32 operation order as jaccard_matrix, without the [P, G] temporaries)."""
+    import ctypes
+    pb = np.ascontiguousarray(pb, np.float32).reshape(-1, 4); gb = np.ascontiguousarray(gb, np.float32)
+    gb = gb.reshape(len(gb), -1)
+    P, G = len(pb), len(gb)
+    cap = max(64, 4 * max(P, G))
+    while True:
+        pairs = np.empty((cap, 2), np.int32)
+        cnt = ctypes.c_int(0)
+        try:
+            _lib.call("kg_host_match_boxes", ctypes.c_void_p(pb.ctypes.data), P, ctypes.c_void_p(gb.ctypes.data), G, gb.shape[1], _lib.c_float(thresh),
+                      ctypes.c_void_p(pairs.ctypes.data), cap, ctypes.byref(cnt))
+            break
+        except _lib.KGLibraryError:
+            if cap >= P * G:
+                raise
+            cap = P * G                      # dense overlaps: every pair may match
+    n = cnt.value
+    return pairs[:n, 0].astype(np.int64), pairs[:n, 1].astype(np.int64)
+
+
 class SEG_loss(nn.Module):
     def __init__(self, height, width):
         super().__init__()
@@ -100,8 +123,7 @@ class SEG_loss(nn.Module):
             gb = np.asarray(gt_boxes[i], np.float32).reshape(-1, 5) if len(gt_boxes[i]) else np.zeros((0, 5), np.float32)
             if len(pb) == 0 or len(gb) == 0:
                 continue
-            match = jaccard_matrix(pb, gb[:, :4]) >= 0.5                       # seg_loss.py:55-56
-            js, gs = np.nonzero(match)                                          # row-major: patch asc, gt asc
+            js, gs = match_boxes(pb, gb)                                        # seg_loss.py:55-56, row-major: patch asc, gt asc
             nobj = len(js)
             if nobj == 0:
                 continue

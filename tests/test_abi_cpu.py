@@ -118,6 +118,27 @@ def test_vectorised_matcher_equals_scalar():
     assert all(np.float32(m[i, j]) == np.float32(jaccard_numpy(a[i], b[j])) for i in range(40) for j in range(30))
 
 
+def test_native_matcher_equals_scalar_rule(lib):
+    """kg_host_match_boxes (pure host code inside the library) returns exactly the (patch, gt) pairs with jaccard_numpy >= 0.5
+    (seg_loss.py:14-29, 55-56), in row-major order -- near-threshold overlaps, tiny unions (<= 2 -> 0), empty inputs, dense overlaps."""
+    from kg_instance_segmentation_amd.seg_loss import jaccard_numpy, match_boxes
+    rng = np.random.default_rng(2)
+    for trial in range(12):
+        P, G = int(rng.integers(0, 60)), int(rng.integers(0, 60))
+        a = rng.uniform(0, 80, (P, 4)).astype(np.float32); a[:, 2:] += a[:, :2]
+        b = rng.uniform(0, 80, (G, 5)).astype(np.float32); b[:, 2:4] += b[:, :2]
+        k = min(P, G)
+        b[:k, :4] = a[:k] + rng.choice([0.0, 0.3, 1.5, 6.0], (k, 1)).astype(np.float32)     # overlaps around the 0.5 threshold
+        if G > 2:
+            b[-1, :4] = [1, 1, 2, 2]; b[-2, :4] = [1, 1, 2.5, 2.2]                              # union <= 2
+        js, gs = match_boxes(a, b)
+        ref = [(i, j) for i in range(P) for j in range(G) if jaccard_numpy(a[i], b[j, :4]) >= 0.5]
+        assert list(zip(js.tolist(), gs.tolist())) == ref, trial
+    a = np.tile(np.array([[10, 10, 40, 40]], np.float32), (30, 1))
+    js, gs = match_boxes(a, np.concatenate([a, np.ones((30, 1), np.float32)], 1))             # all 900 pairs match: the pair buffer grows
+    assert len(js) == 900 and js[31] == 1 and gs[31] == 1
+
+
 def test_dropin_shims_expose_the_reference_module_surface():
     """dropin/<module>.py (what `import KGnet` etc. resolve to when dropin/ precedes the reference on sys.path)
     re-export the symbols the reference drivers use (train.py:3-11, test.py:3-12, dataset_base.py:6)."""

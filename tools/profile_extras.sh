@@ -1,0 +1,13 @@
+#!/bin/bash
+# The side measurements quoted in DESIGN.md / README.md (run after tools/profile_round.sh, same box):  bash tools/profile_extras.sh r02
+tag=${1:-r02}
+O=$PWD/gpurun_out
+mkdir -p $O
+python bench.py --steps 10 --warmup 3 --precision bf16 --no-companion --no-cpu-baseline > $O/${tag}_bench_bf16.json 2>/dev/null
+python bench.py --steps 10 --warmup 3 --precision trunk2 --no-companion --no-cpu-baseline > $O/${tag}_bench_trunk2.json 2>/dev/null
+python bench.py --steps 6 --warmup 2 --batch 16 --no-companion --no-cpu-baseline > $O/${tag}_bench_bs16.json 2>/dev/null
+KG_BENCH_SYNC=0 python bench.py --steps 10 --warmup 3 --no-companion --no-cpu-baseline > $O/${tag}_bench_nosync.json 2>/dev/null
+python bench.py --mode eval --steps 10 > $O/${tag}_eval.json 2>/dev/null
+python bench.py --mode gt --steps 5 > $O/${tag}_gt.json 2>/dev/null
+for m in mfma_peak wgrad_skel c3_parts; do [ -x tools/micro/$m ] && timeout 120 tools/micro/$m > $O/${tag}_micro_$m.txt 2>&1; done
+for f in bf16 trunk2 bs16 nosync; do python -c "import json,sys; d=json.load(open('$O/${tag}_bench_$f.json')); print('$f', round(d['value'],1), 'img/s', round(d['ms_per_step'],2), 'ms')"; done
