@@ -4,6 +4,7 @@ Activations are 2-D bf16 "rows" tensors [rows, C] with unit channel stride; the 
 exceed C when the tensor is a channel slice of a wider (concat) buffer.  PyTorch only owns memory
 and streams here; every arithmetic kernel is hand-written HIP behind the C ABI.
 """
+import functools
 import math
 
 import torch
@@ -339,6 +340,7 @@ def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):
     return s
 
 
+@functools.lru_cache(maxsize=4096)      # (the search walks up to 2048 candidates; ~110 calls per step with a few dozen distinct shapes)
 def halo_wgrad_splits(nblk, tiles, cit, taps, nelem, cus=256):
     """Pixel splits of kg_conv2d_wgrad_halo: one workgroup per CU is resident (2 x 47..78 KB of LDS + ~250 VGPRs x 8 waves), so
     the launch runs in ceil(nblk * S / 256) rounds; pick S by a small cost model (round count x tiles per workgroup + per-workgroup

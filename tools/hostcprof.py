@@ -42,3 +42,23 @@ pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(28)
+# the backward pass runs on autograd's thread: profile the engine's backward there
+from kg_instance_segmentation_amd import KGnet as K
+pb = cProfile.Profile()
+orig = K._NetFunction.backward
+
+
+def wrapped(ctx, *grads):
+    pb.enable()
+    try:
+        return orig(ctx, *grads)
+    finally:
+        pb.disable()
+
+
+K._NetFunction.backward = staticmethod(wrapped)
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+print("---- _NetFunction.backward (3 steps) ----")
+pstats.Stats(pb).sort_stats("tottime").print_stats(30)
