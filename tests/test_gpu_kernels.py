@@ -437,7 +437,8 @@ def test_conv1x1_streaming(case):
     assert float(ybuf[:, :32].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("case", [(64, 2, 40, 44), (128, 1, 16, 32), (256, 1, 33, 20)])
+@pytest.mark.parametrize("case", [(64, 2, 40, 44), (128, 1, 16, 32), (256, 1, 33, 20),
+                                  (64, 1, 272, 500)])      # >= 256 pixel tiles: one workgroup walks the three heads (no head split), ragged right edge
 def test_conv_halo_heads2(case):
     """kg_conv2d_halo_heads2 (the three second-layer 7x7 head convs of one scale as ONE grouped launch, KGnet.py:161-209
     `.2` + sigmoid :300) vs three fp64 F.conv2d on the slices of the fused hidden tensor."""
