@@ -35,6 +35,9 @@ struct WgHaloArgs {
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+#ifndef KG_WG_LOOKAHEAD
+#define KG_WG_LOOKAHEAD 2
+#endif
 __device__ __forceinline__ int dyf(int r) { return ((r >> 1) & 1) | (((r >> 4) & 1) << 1); }
 
 template <int KS, int CIF>
@@ -211,24 +214,23 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
         const int tn = t + a.nsplit;
         if (tn < tiles_total) stage(tn, cur ^ 1);
         // The (k-step s, unit q) pairs form one sequence I = s * UPW + q; read group R_I = the 2 transpose reads of unit I's X^T
-        // fragment, preceded by the 2 NCF reads of the k-step's dY^T fragments when q == 0.  R_{I+2} is issued before the MFMAs
-        // of unit I (two units = 8 MFMAs of LDS latency cover), LDS reads return in order, so "R_I has landed" is
-        // lgkmcnt(|R_{I+1}| + |R_{I+2}|), a compile-time constant.
-        bf16x4 fa[2][NCF][2], fb[3][2];              // fragments: A by k-step parity, B by unit index mod 3
+        // fragment, preceded by the 2 NCF reads of the k-step's dY^T fragments when q == 0.  R_{I+LA} is issued before the MFMAs
+        // of unit I (LA = 2 units = 8 MFMAs of LDS latency cover; 3 measured 1 % slower), LDS reads return in order, so "R_I has
+        // landed" is lgkmcnt(|R_{I+1}| + ... + |R_{I+LA}|), a compile-time constant.
+        constexpr int LA = KG_WG_LOOKAHEAD;           // read groups in flight ahead of the MFMAs
+        bf16x4 fa[2][NCF][2], fb[LA + 1][2];         // fragments: A by k-step parity, B by unit index mod (LA + 1)
         constexpr int NU = 8 * UPW;
         auto issue = [&](auto ic) {
             constexpr int I = decltype(ic)::value, S = I / UPW, Q = I % UPW;
             if constexpr (Q == 0) rdA(std::integral_constant<int, S>{}, fa[S & 1]);
-            rdB(std::integral_constant<int, S>{}, std::integral_constant<int, Q>{}, fb[I % 3]);
+            rdB(std::integral_constant<int, S>{}, std::integral_constant<int, Q>{}, fb[I % (LA + 1)]);
         };
-        issue(std::integral_constant<int, 0>{});
-        issue(std::integral_constant<int, 1>{});
+        [&]<int... Ds>(std::integer_sequence<int, Ds...>) { (issue(std::integral_constant<int, Ds>{}), ...); }(std::make_integer_sequence<int, LA>{});
         auto step = [&](auto ic) {
             constexpr int I = decltype(ic)::value, S = I / UPW, Q = I % UPW;
-            constexpr int n1 = I + 1 < NU ? 2 + ((I + 1) % UPW == 0 ? 2 * NCF : 0) : 0;
-            constexpr int n2 = I + 2 < NU ? 2 + ((I + 2) % UPW == 0 ? 2 * NCF : 0) : 0;
-            if constexpr (I + 2 < NU) issue(std::integral_constant<int, I + 2>{});
-            lgkm_wait_n<n1 + n2>();
+            constexpr int ahead = []() { int n = 0; for (int d = 1; d <= LA; ++d) if (I + d < NU) n += 2 + ((I + d) % UPW == 0 ? 2 * NCF : 0); return n; }();
+            if constexpr (I + LA < NU) issue(std::integral_constant<int, I + LA>{});
+            lgkm_wait_n<ahead>();
             if constexpr (Q == 0) {
 #pragma unroll
                 for (int c = 0; c < NCF; ++c) { tie(fa[S & 1][c][0]); tie(fa[S & 1][c][1]); }
@@ -237,9 +239,9 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
                     for (int c = 0; c < (BIAS ? NCF : 1); ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat(fa[S & 1][c]), ones, accb[c], 0, 0, 0);
                 }
             }
-            tie(fb[I % 3][0]); tie(fb[I % 3][1]);
+            tie(fb[I % (LA + 1)][0]); tie(fb[I % (LA + 1)][1]);
             if (Q < UNITS / 8 || wave + 8 * Q < UNITS) {   // (wave-uniform; only the last slot can be idle)
-                const bf16x8 bfr = cat(fb[I % 3]);
+                const bf16x8 bfr = cat(fb[I % (LA + 1)]);
 #pragma unroll
                 for (int c = 0; c < NCF; ++c) acc[Q][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat(fa[S & 1][c]), bfr, acc[Q][c], 0, 0, 0);
             }
