@@ -138,23 +138,24 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     // per-thread staging coordinates (tile independent).  LDS slot e (16 bytes) of the dY tile is row r = e >> 3, piece p = e & 7
     // and holds source channel piece ((p >> 1) ^ f(r)) * 2 + (p & 1); slot e of the halo is row e / XROW, piece w = e % XROW
     // (w >= XREAL: row padding, never read) = pixel hx = w / (2 CIF), source piece ((c >> 1) ^ (hx & (CIF-1))) * 2 + (c & 1).
-    int dy_ry[DQ], dy_rx[DQ], dy_c[DQ];
+    // (packed: the three coordinates of a piece share one register -- they stay live across the whole tile loop)
+    int dy_p[DQ];                 // ry | rx << 8 | source 16-byte piece << 16 (piece 255: channel beyond cout_lim -> zero line)
 #pragma unroll
     for (int k = 0; k < DQ; ++k) {
         const int e = tid + k * 512, r = e >> 3, pc = e & 7;
-        dy_ry[k] = r >> 4; dy_rx[k] = r & 15;
-        dy_c[k] = co0 + ((((pc >> 1) ^ dyf(r)) << 1) | (pc & 1)) * 8;
+        const int cp = (((pc >> 1) ^ dyf(r)) << 1) | (pc & 1);
+        dy_p[k] = (r >> 4) | ((r & 15) << 8) | ((co0 + cp * 8 < a.cout_lim ? cp : 255) << 16);
     }
-    int x_hy[XQ], x_hx[XQ], x_c[XQ];
+    int x_p[XQ];                  // (hy + 8) | (hx + 8) << 8 | source piece << 16 | flags << 24 (1: load, 2: channel inside cin_lim)
 #pragma unroll
     for (int k = 0; k < XQ; ++k) {
         const int e = tid + k * 512;
         const int hy = e / XROW, w = e - hy * XROW;
         const int hx = w / (2 * CIF), c = w - hx * (2 * CIF);
         const int unit = CIF == 1 ? 0 : ((c >> 1) ^ (hx & (CIF - 1)));
-        x_hy[k] = (e < XSL && w < XREAL) ? hy - PAD : (1 << 20);     // (1 << 20): no load at all
-        x_hx[k] = hx - PAD;
-        x_c[k] = ci0 + (unit * 2 + (c & 1)) * 8;
+        const int sp = unit * 2 + (c & 1);
+        const int fl = ((e < XSL && w < XREAL) ? 1 : 0) | ((ci0 + sp * 8 < a.cin_lim) ? 2 : 0);
+        x_p[k] = ((hy - PAD + 8) & 255) | (((hx - PAD + 8) & 255) << 8) | (sp << 16) | (fl << 24);
     }
     const bf16_t* zline = reinterpret_cast<const bf16_t*>(kg_wg_zero_line);
     auto stage = [&](int vt, int buf) {
@@ -175,19 +176,25 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
         const int hrem = Hd - oy0, wrem = Wd - ox0;
         unsigned char* sy = smem + buf * BUF;
         unsigned char* sx = sy + DY_BYTES;
+        int lz = 0;
+        asm volatile("" : "+v"(lz));   // opaque zero: the unpacked coordinates below must not be hoisted out of the tile loop (registers)
 #pragma unroll
         for (int k = 0; k < DQ; ++k) {
+            const int dp = dy_p[k] | lz;
+            const int ry = dp & 255, rx = (dp >> 8) & 255, cp = dp >> 16;
             const bf16_t* src = zline;
-            if (dy_ry[k] < hrem && dy_rx[k] < wrem && dy_c[k] < a.cout_lim) src = dyb + (long)(dy_ry[k] * Wd + dy_rx[k]) * a.lddy + dy_c[k];
+            if (ry < hrem && rx < wrem && cp != 255) src = dyb + (long)(ry * Wd + rx) * a.lddy + co0 + cp * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(sy + (k * 512 + wave_u * 64) * 16), 16, 0, 0);
         }
 #pragma unroll
         for (int k = 0; k < XQ; ++k) {
-            if (x_hy[k] != (1 << 20)) {
+            if (x_p[k] & (1 << 24)) {
+                const int xp = x_p[k] | lz;
+                const int hy = (xp & 255) - 8, hx = ((xp >> 8) & 255) - 8, sp = (xp >> 16) & 255;
                 const bf16_t* src = zline;
-                if ((unsigned)(oy0 + x_hy[k]) < (unsigned)Hd && (unsigned)(ox0 + x_hx[k]) < (unsigned)Wd && x_c[k] < a.cin_lim)
-                    src = xb + (long)(x_hy[k] * Wd + x_hx[k]) * a.ldx + x_c[k];
+                if ((unsigned)(oy0 + hy) < (unsigned)Hd && (unsigned)(ox0 + hx) < (unsigned)Wd && (xp & (2 << 24)))
+                    src = xb + (long)(hy * Wd + hx) * a.ldx + ci0 + sp * 8;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(sx + (k * 512 + wave_u * 64) * 16), 16, 0, 0);
             }
@@ -211,8 +218,11 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     if (t < tiles_total) stage(t, 0);
     for (; t < tiles_total; t += a.nsplit) {
         __syncthreads();                             // (s_waitcnt vmcnt(0) + barrier): this tile has landed, the other buffer is free
+        // The next tile's loads are ~290 instructions per wave (tile geometry on the scalar unit, 7 address computations); right after the
+        // barrier BOTH waves of a SIMD would run them at the same time with the MFMA pipe idle.  The first wave of every SIMD (waves 0..3)
+        // issues its share here, the second one (waves 4..7) half-way through the tile, each under the other's MFMAs.
         const int tn = t + a.nsplit;
-        if (tn < tiles_total) stage(tn, cur ^ 1);
+        if (tn < tiles_total && wave_u < 4) stage(tn, cur ^ 1);
         // The (k-step s, unit q) pairs form one sequence I = s * UPW + q; read group R_I = the 2 transpose reads of unit I's X^T
         // fragment, preceded by the 2 NCF reads of the k-step's dY^T fragments when q == 0.  R_{I+LA} is issued before the MFMAs
         // of unit I (LA = 2 units = 8 MFMAs of LDS latency cover; 3 measured 1 % slower), LDS reads return in order, so "R_I has
@@ -246,6 +256,10 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
                 for (int c = 0; c < NCF; ++c) acc[Q][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat(fa[S & 1][c]), bfr, acc[Q][c], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);       // keep the unit's MFMAs between its wait and the next unit's reads
+            if constexpr (I == 3 * UPW) {
+                if (tn < tiles_total && wave_u >= 4) stage(tn, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         };
         [&]<int... Is>(std::integer_sequence<int, Is...>) { (step(std::integral_constant<int, Is>{}), ...); }(std::make_integer_sequence<int, NU>{});
         {   // the other buffer becomes current
