@@ -132,7 +132,10 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + 2 < nstage) issue();          // into the slot of stage s-1, which every wave has finished reading
+        // into the slot of stage s-1, which every wave has finished reading.  The first wave of every SIMD (waves 0..3) issues its loads
+        // here, the second one behind the MFMAs of k-step 0 below: right after the barrier both would compute addresses at the same
+        // time with the MFMA pipe idle (same idea as in wgrad_halo.hip)
+        if (s + 2 < nstage && wave < 4) issue();
         // fragment reads from inline asm with hand-counted waits (with an LDS-DMA pending hipcc waits lgkmcnt(0) for every LDS
         // read, kg_common.h): the 8 reads of k-step 1 stay in flight behind the 16 MFMAs of k-step 0
         const unsigned sb = lds0 + c_slot * STAGE;
@@ -154,6 +157,7 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k][i], bfr[k][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);   // the MFMAs of k-step 0 stay in front of the wait for k-step 1
+            if (k == 0 && s + 2 < nstage && wave >= 4) { issue(); __builtin_amdgcn_sched_barrier(0); }
         }
         __builtin_amdgcn_s_setprio(0);
         c_slot = c_slot == NS - 1 ? 0 : c_slot + 1;
