@@ -19,6 +19,8 @@ CASES = {
     "halo7_c3": ("fwd", 8, 64, 512, 1536, 7),
     "halo7_c3d": ("fwd", 8, 64, 1536, 512, 7),
     "halo3_c0": ("fwd", 8, 512, 64, 64, 3),
+    "halo3_c2": ("fwd", 8, 128, 256, 512, 3),
+    "halo3_c3": ("fwd", 8, 64, 512, 1024, 3),
     "halo3_l2": ("fwd", 8, 64, 128, 128, 3),
     "halo3_l3": ("fwd", 8, 32, 256, 256, 3),
     "wg7_c0": ("wgrad", 8, 512, 64, 192, 7),
