@@ -13,6 +13,7 @@ whole-job imgs/s, the roofline of the dominant kernel (HIP events around its lau
 CPU baseline (the oracle's torch restatement of the same step, timed on the host cores, bounded sample).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -444,6 +445,16 @@ def main():
             return loss.item() if sync else loss.detach()      # train.py:156 reads the loss back every step
 
         def timed(K, sync):
+            # the K timed steps run with Python's cyclic collector parked (gc.freeze + disable, as training loops at scale do: a gen-2
+            # pass over the model's ~10^5 objects is a multi-ms host stall at a random step); the step itself leaves no cycles behind
+            # (tools/cycle_probe.py), so memory does not grow meanwhile
+            gc.collect(); gc.freeze(); gc.disable()
+            try:
+                return timed_(K, sync)
+            finally:
+                gc.enable(); gc.unfreeze()
+
+        def timed_(K, sync):
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()

@@ -386,7 +386,9 @@ class SegBranch:
         self.rconv(hid, pw, 1, plan.rowdesc[0], rows0, 3, y_f32=flat, bias=b, tiles=self.T32(plan, 0, plan.nb[0]))
         self.last_logits = flat.clone() if getattr(self, "keep_logits", False) else None     # test hook: pre-sigmoid values
         ops.sigmoid_(flat)
-        saved = (pre, cats, uins, hid, flat, top) if record else None
+        # (flat.detach(): `flat` itself becomes an OUTPUT of the autograd node that keeps `saved`; holding the output object there is a
+        # reference cycle node -> saved -> flat -> grad_fn = node that only the cyclic GC can free -- with it a whole step's activations)
+        saved = (pre, cats, uins, hid, flat.detach(), top) if record else None
         return flat, saved
 
     def conv_bwd(self, key, x, g, rowdesc, M, k, pgrads, dx=None, mask=None, t32=None, t16=None):
