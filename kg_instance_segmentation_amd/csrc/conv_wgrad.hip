@@ -21,6 +21,8 @@ struct WgradArgs {
     long split_stride;      // elements between partial buffers
     WgPairs wp;             // split-bf16 operand planes (kg_common.h): the chunk index runs over wp.n * chunks_per_plane virtual chunks
     int chunks_per_plane;
+    int direct;             // 1x1 stride-1 dense conv: input row of output pixel m is m itself (no (n, oy, ox) decomposition: two integer
+                            // divisions per staged row were more VALU work than the chunk's 32 MFMAs per wave)
 };
 
 __device__ __forceinline__ int tr_f(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); }
@@ -85,7 +87,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                 if (y_c_ok) yv = *reinterpret_cast<const uint4*>(dpl + (long)m * a.lddy + co0 + c8 * 8);
                 if (x_c_ok) {
                     long row; bool ok;
-                    if (a.mode >= 2) {
+                    if (a.direct) {
+                        ok = true; row = m;
+                    } else if (a.mode >= 2) {
                         int2 d = a.rowdesc[m];
                         int y = (d.x >> 16) + d_y, x = (d.x & 0xffff) + d_x, h = d.y >> 16, w = d.y & 0xffff;
                         ok = (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
@@ -210,7 +214,9 @@ __global__ __launch_bounds__(256) void conv_wgrad128_kernel(const WgradArgs a) {
                 if (y_c_ok) yv = *reinterpret_cast<const uint4*>(dpl + (long)m * a.lddy + co0 + c16 * 8);
                 if (x_c_ok) {
                     long row; bool ok;
-                    if (a.mode >= 2) {
+                    if (a.direct) {
+                        ok = true; row = m;
+                    } else if (a.mode >= 2) {
                         const int2 d = a.rowdesc[m];
                         const int y = (d.x >> 16) + d_y, x = (d.x & 0xffff) + d_x, h = d.y >> 16, w = d.y & 0xffff;
                         ok = (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w;
@@ -307,6 +313,7 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
     a.M = M; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.ldx = ldx; a.lddy = lddy; a.Cin = Cin; a.Cout = Cout;
     a.cin_lim = cin_lim; a.cout_lim = cout_lim; a.ntaps = KH * KW; a.KW = KW; a.stride_log2 = stride == 2 ? 1 : 0;
     a.pad = pad; a.dil = dil; a.mode = mode;
+    a.direct = mode == 0 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && OH == H && OW == W;
     a.chunks_per_plane = (M + 63) / 64;      // chunks of the kernel's PX = 64 pixels
     const int total_chunks = a.wp.n * a.chunks_per_plane;
     a.chunks_per_split = (total_chunks + nsplit - 1) / nsplit;

@@ -26,6 +26,10 @@ CASES = {
     "wg7_c0": ("wgrad", 8, 512, 64, 192, 7),
     "wg7_c3": ("wgrad", 8, 64, 512, 1536, 7),
     "wg3_c0": ("wgrad", 8, 512, 64, 64, 3),
+    "wg1_l1": ("wgrad", 8, 128, 64, 256, 1),
+    "wg1_l1b": ("wgrad", 8, 128, 256, 64, 1),
+    "wg1_l3": ("wgrad", 8, 32, 256, 1024, 1),
+    "wg1_c0": ("wgrad", 8, 512, 128, 64, 1),
     "igemm1_c0": ("igemm", 8, 512, 128, 64, 1),
     "igemm3_deep": ("igemm", 8, 64, 512, 256, 3),
     "igemm3_deep2": ("igemm", 8, 32, 1024, 512, 3),
