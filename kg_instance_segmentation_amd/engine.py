@@ -591,14 +591,16 @@ class Engine:
             ops.f32_to_planes(g, gp, fv.C)
             fv.add_grad(gp, masked=False)
         hook = self.grad_hook
-        for fn in reversed(self.tape):
+        tape, self.tape = self.tape, None
+        while tape:                              # (popped as they run: a closure and the activations only it still holds die right away)
+            fn = tape.pop()
             n0 = len(self.param_grads)
             fn()
+            del fn
             if hook is not None and len(self.param_grads) > n0:      # data-parallel: parameter gradients whose kernels are
                 hook(list(self.param_grads.items())[n0:], False)    # enqueued go to the bucketed all-reduce right away
         if hook is not None:
             hook([], True)
-        self.tape = None
         grads = self.param_grads
         self.param_grads = {}
         return grads
