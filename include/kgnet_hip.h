@@ -106,6 +106,10 @@ int kg_wgrad_reduce(const float* part, float* grad_oihw, int Cout, int Cin, int 
    grads / counts are HOST arrays */
 int kg_wgrad_reduce_multi(const float* part, float* const* grads_oihw, const int* counts, int ngrads, int Cin, int KH, int KW,
                           int nsplit, long split_stride, int accumulate, void* stream);
+/* kg_wgrad_reduce_multi + the bias gradient of the same conv in the same launch: bias_part = the [nsplit][bias_C] partials of
+   kg_conv2d_wgrad_halo (dbp), db [bias_C]; bias_part == NULL: weights only */
+int kg_wgrad_reduce_bias(const float* part, float* const* grads_oihw, const int* counts, int ngrads, int Cin, int KH, int KW,
+                         int nsplit, long split_stride, int accumulate, const float* bias_part, float* db, int bias_C, void* stream);
 int kg_bias_grad(const void* dy, float* db, float* scratch, int scratch_floats, int M, int C, int ld, int accumulate,
                  void* stream);
 int kg_set_wgrad_tr(int use_transpose_read);   /* test switch: LDS transpose-read vs scalar fragment loads */

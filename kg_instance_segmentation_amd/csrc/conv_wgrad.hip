@@ -337,7 +337,7 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
 // Sum the split partials [S][Cout][taps][Cin] and write the OIHW fp32 gradient [Cout][Cin][taps]
 // (accumulate != 0: grad += sum).  Fixed summation order => bitwise reproducible gradients.  One block per
 // (co, 64-channel ci chunk): coalesced reads along ci, transpose through LDS, coalesced writes along (ci,tap).
-struct ReduceDst { float* g[4]; int end[4]; };   // output tensor k holds the rows [end[k-1], end[k]) of the fused conv (heads sharing an input)
+struct ReduceDst { float* g[4]; int end[4]; const float* bias_part; float* db; int bias_C; };   // bias_part != null: one more block row sums the bias partials [S][bias_C]   // output tensor k holds the rows [end[k-1], end[k]) of the fused conv (heads sharing an input)
 // G = blockDim.x / (taps * CH) >= 2 (small layers with many splits, e.g. 3x3 64 -> 64 with 256 splits): G thread groups each sum a
 // contiguous range of the splits in order, then group 0 adds the G partial sums in group order -- still one fixed summation order.
 template <int CH>   // ci chunk per block: 64 for big layers, 16 to get enough blocks on small ones
@@ -346,6 +346,18 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
                                                             int accumulate) {
     __shared__ float tile[49 * (CH + 1)];
     __shared__ float red[1024];
+    if ((int)blockIdx.x >= Cout) {   // the bias-gradient partials of the same conv (kg_conv2d_wgrad_halo's all-ones unit): one wave per channel,
+        if (blockIdx.y != 0) return; // lanes stride over the splits, as bias_grad_final_kernel sums them (same order, same bits)
+        const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;     // (whole waves only: blockDim.x need not be a multiple of 64)
+        const int c = ((int)blockIdx.x - Cout) * nw + (int)(threadIdx.x >> 6);
+        if ((int)(threadIdx.x >> 6) >= nw || c >= dst4.bias_C) return;
+        float sb = 0.f;
+        for (int b = lane; b < S; b += 64) sb += dst4.bias_part[(long)b * dst4.bias_C + c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sb += __shfl_down(sb, o, 64);
+        if (lane == 0) dst4.db[c] = accumulate ? dst4.db[c] + sb : sb;
+        return;
+    }
     const int co = blockIdx.x, ci0 = blockIdx.y * CH;
     int k = 0, row0 = 0;
     while (k < 3 && co >= dst4.end[k]) { row0 = dst4.end[k]; ++k; }
@@ -401,9 +413,12 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 
 static int launch_reduce(const float* part, const ReduceDst& d, int Cout, int Cin, int taps, int nsplit, long split_stride, int accumulate,
                          hipStream_t st) {
-    if ((long)Cout * ((Cin + 63) / 64) >= 2048)
-        hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(Cout, (Cin + 63) / 64), dim3(256), 0, st, part, d, Cout, Cin, taps, nsplit,
+    // (bias partials: extra block columns after the Cout weight rows, one wave per channel)
+    if ((long)Cout * ((Cin + 63) / 64) >= 2048) {
+        const int xb = Cout + (d.bias_part ? (d.bias_C + 3) / 4 : 0);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(xb, (Cin + 63) / 64), dim3(256), 0, st, part, d, Cout, Cin, taps, nsplit,
                            split_stride, accumulate);
+    }
     else {
         int nt = 256;
         const int E = taps * 16;
@@ -412,7 +427,8 @@ static int launch_reduce(const float* part, const ReduceDst& d, int Cout, int Ci
             if (G > nsplit / 8) G = nsplit / 8;
             if (G >= 2) nt = E * G;
         }
-        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(Cout, (Cin + 15) / 16), dim3(nt), 0, st, part, d, Cout, Cin, taps, nsplit,
+        const int xb = Cout + (d.bias_part ? (d.bias_C + nt / 64 - 1) / (nt / 64) : 0);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(xb, (Cin + 15) / 16), dim3(nt), 0, st, part, d, Cout, Cin, taps, nsplit,
                            split_stride, accumulate);
     }
     KG_CHECK_LAUNCH("wgrad_reduce");
@@ -425,22 +441,35 @@ extern "C" int kg_wgrad_reduce(const float* part, float* grad, int Cout, int Cin
     KG_CHECK_ARG(KH * KW <= 49, "kg_wgrad_reduce: at most 49 taps");
     ReduceDst d;
     for (int k = 0; k < 4; ++k) { d.g[k] = grad; d.end[k] = Cout; }
-    d.end[0] = Cout;
+    d.end[0] = Cout; d.bias_part = nullptr; d.db = nullptr; d.bias_C = 0;
     return launch_reduce(part, d, Cout, Cin, KH * KW, nsplit, split_stride, accumulate, (hipStream_t)stream);
 }
 
+extern "C" int kg_wgrad_reduce_bias(const float* part, float* const* grads, const int* counts, int ngrads, int Cin, int KH, int KW,
+                                    int nsplit, long split_stride, int accumulate, const float* bias_part, float* db, int bias_C, void* stream);
 // Same for a conv fused along Cout (heads that share their input, KGnet.py:161-209): ngrads <= 4 gradient tensors, tensor k = the
 // next counts[k] output rows of the fused conv.  One launch instead of one per head.
 extern "C" int kg_wgrad_reduce_multi(const float* part, float* const* grads, const int* counts, int ngrads, int Cin, int KH, int KW,
                                      int nsplit, long split_stride, int accumulate, void* stream) {
     KG_CHECK_ARG(part && grads && counts && ngrads >= 1 && ngrads <= 4, "kg_wgrad_reduce_multi: 1..4 gradient tensors");
     KG_CHECK_ARG(KH * KW <= 49, "kg_wgrad_reduce_multi: at most 49 taps");
+    return kg_wgrad_reduce_bias(part, grads, counts, ngrads, Cin, KH, KW, nsplit, split_stride, accumulate, nullptr, nullptr, 0, stream);
+}
+
+// kg_wgrad_reduce_multi + the bias gradient of the same conv in the SAME launch: bias_part = [nsplit][bias_C] partials written by
+// kg_conv2d_wgrad_halo (dbp), db [bias_C] (accumulate applies to it too); bias_part == NULL: weights only.
+extern "C" int kg_wgrad_reduce_bias(const float* part, float* const* grads, const int* counts, int ngrads, int Cin, int KH, int KW,
+                                    int nsplit, long split_stride, int accumulate, const float* bias_part, float* db, int bias_C, void* stream) {
+    KG_CHECK_ARG(part && grads && counts && ngrads >= 1 && ngrads <= 4, "kg_wgrad_reduce_bias: 1..4 gradient tensors");
+    KG_CHECK_ARG(KH * KW <= 49, "kg_wgrad_reduce_bias: at most 49 taps");
+    KG_CHECK_ARG(!bias_part || (db && bias_C >= 1), "kg_wgrad_reduce_bias: bias partials without an output");
     ReduceDst d;
     int end = 0;
     for (int k = 0; k < 4; ++k) {
-        if (k < ngrads) { KG_CHECK_ARG(grads[k] && counts[k] > 0, "kg_wgrad_reduce_multi: bad tensor %d", k); end += counts[k]; }
+        if (k < ngrads) { KG_CHECK_ARG(grads[k] && counts[k] > 0, "kg_wgrad_reduce_bias: bad tensor %d", k); end += counts[k]; }
         d.g[k] = grads[k < ngrads ? k : ngrads - 1]; d.end[k] = end;
     }
+    d.bias_part = bias_part; d.db = db; d.bias_C = bias_C;
     return launch_reduce(part, d, end, Cin, KH * KW, nsplit, split_stride, accumulate, (hipStream_t)stream);
 }
 

@@ -411,11 +411,10 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
         dbp = scratch_f32(S * cout, xb.device, "wgrad_bias") if fused_bias else None
         _lib.call("kg_conv2d_wgrad_halo", ptr(xb), ptr(dyb), ptr(part), N or 0, H, W, ld(xb), ld(dyb), cin, cout, cin_lim, cout_lim, KH, S,
                   c_long(nelem), ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, ptr(dbp), planes, stream_ptr())
-        if dbp is not None:
-            _lib.call("kg_bias_grad_final", ptr(dbp), ptr(bias_out), S, cout, 1 if accumulate else 0, stream_ptr())
-        elif bias_out is not None:       # planed operands: the all-ones unit would count every plane product
+        if dbp is None and bias_out is not None:       # planed operands: the all-ones unit would count every plane product
             bias_grad(dy, cout, bias_out, accumulate=accumulate)
     else:
+        dbp = None
         S = wgrad_splits(M * np_, cin_lim, cout_lim, KH * KW, nelem)
         part = scratch_f32(S * nelem, xb.device, "wgrad")
         _lib.call("kg_conv2d_wgrad", ptr(xb), ptr(dyb), ptr(part), ptr(rowdesc), M, H, W, OH, OW, ld(xb), ld(dyb), cin, cout, cin_lim, cout_lim,
@@ -423,16 +422,18 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
         if bias_out is not None:
             bias_grad(dy, cout, bias_out, accumulate=accumulate)
     contiguous = all(grads[i][1] + grads[i][2] == grads[i + 1][1] for i in range(len(grads) - 1))
-    if 1 < len(grads) <= 4 and contiguous:      # heads fused along Cout: one reduction launch for all of them
-        import ctypes
+    import ctypes
+    acc = 1 if accumulate else 0
+    if len(grads) <= 4 and contiguous:      # one reduction launch: all heads fused along Cout, and the bias partials of the halo kernel with them
         gp = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g, _, _ in grads])
         cn = (ctypes.c_int * len(grads))(*[cnt for _, _, cnt in grads])
-        _lib.call("kg_wgrad_reduce_multi", ctypes_offset(part, grads[0][1] * KH * KW * cin), gp, cn, len(grads), cin, KH, KW, S,
-                  c_long(nelem), 1 if accumulate else 0, stream_ptr())
+        _lib.call("kg_wgrad_reduce_bias", ctypes_offset(part, grads[0][1] * KH * KW * cin), gp, cn, len(grads), cin, KH, KW, S,
+                  c_long(nelem), acc, ptr(dbp), ptr(bias_out) if dbp is not None else None, cout if dbp is not None else 0, stream_ptr())
     else:
+        if dbp is not None:
+            _lib.call("kg_bias_grad_final", ptr(dbp), ptr(bias_out), S, cout, acc, stream_ptr())
         for g, off, cnt in grads:
-            _lib.call("kg_wgrad_reduce", ctypes_offset(part, off * KH * KW * cin), ptr(g), cnt, cin, KH, KW, S, c_long(nelem),
-                      1 if accumulate else 0, stream_ptr())
+            _lib.call("kg_wgrad_reduce", ctypes_offset(part, off * KH * KW * cin), ptr(g), cnt, cin, KH, KW, S, c_long(nelem), acc, stream_ptr())
     return "halo" if halo else "gather"
 
 
