@@ -9,5 +9,8 @@ python bench.py --steps 6 --warmup 2 --batch 16 --no-companion --no-cpu-baseline
 KG_BENCH_SYNC=0 python bench.py --steps 10 --warmup 3 --no-companion --no-cpu-baseline > $O/${tag}_bench_nosync.json 2>/dev/null
 python bench.py --mode eval --steps 10 > $O/${tag}_eval.json 2>/dev/null
 python bench.py --mode gt --steps 5 > $O/${tag}_gt.json 2>/dev/null
-for m in mfma_peak wgrad_skel c3_parts; do [ -x tools/micro/$m ] && timeout 120 tools/micro/$m > $O/${tag}_micro_$m.txt 2>&1; done
+for m in mfma_peak wgrad_skel c3_parts; do
+  [ -x tools/micro/$m ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-unused-value tools/micro/$m.hip -o tools/micro/$m > /dev/null 2>&1
+  [ -x tools/micro/$m ] && timeout 120 tools/micro/$m > $O/${tag}_micro_$m.txt 2>&1
+done
 for f in bf16 trunk2 bs16 nosync; do python -c "import json,sys; d=json.load(open('$O/${tag}_bench_$f.json')); print('$f', round(d['value'],1), 'img/s', round(d['ms_per_step'],2), 'ms')"; done
