@@ -177,6 +177,12 @@ int kg_adam_step(const void* jobs, int njobs, int total_blocks, float beta1, flo
 /* ---- host glue of SEG_loss (seg_loss.py:57-80), pure host code: crops of the matched ground-truth masks (float32 [n][H][W] per
  * image), nearest-resized to the patch size, as bytes.  work = int32 [nwork][9]: (img, gt, y1, y2, x1, x2, h1, w1, out offset) ---- */
 int kg_host_crop_masks(const float* const* masks, const int* work, int nwork, int H, int W, unsigned char* out);
+/* box tables of the per-box seg branch (host glue of KGnet.py:258-267,321-350; pure host code, integer arithmetic).
+ * kg_host_tile_table: one {row0, (h << 16) | w, (oy0 << 16) | ox0, 0} entry per th x tw tile of every box (box-major); returns the count.
+ * kg_host_bin_csr: per BS x BS bin of each image the ascending list of boxes touching it (tab = int32 [nb][8] rows {img, y1, x1, h, w, ..});
+ * returns the number of (box, bin) incidences.  Both return -1 when the output does not fit cap. */
+int kg_host_tile_table(const int* h, const int* w, const long* row0, int nb, int th, int tw, int* out, int cap);
+int kg_host_bin_csr(const int* tab, int nb, int BS, int BY, int BX, int nbins, int* bin_start, int* bin_boxes, int cap);
 /* matching of seg_loss.py:14-29,55-56 (jaccard_numpy >= thresh over all predicted x ground-truth boxes of an image), pure host code,
  * float32 in the reference's operation order: pairs = int32 [cap][2] (patch, gt) row-major, *count = matches */
 int kg_host_match_boxes(const float* pb, int P, const float* gb, int G, int gstride, float thresh, int* pairs, int cap, int* count);

@@ -58,6 +58,8 @@ _SIGS = {
     "kg_adam_step": [P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, P],
     "kg_host_crop_masks": [P, P, c_int, c_int, c_int, P],
     "kg_host_match_boxes": [P, c_int, P, c_int, c_int, c_float, P, c_int, P],
+    "kg_host_tile_table": [P, P, P, c_int, c_int, c_int, P, c_int],                       # (these two return a COUNT, -1 on overflow:
+    "kg_host_bin_csr": [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int],               #  call them through load(), not call())
     "kg_mask_areas": [P, c_int, c_long, P, P],
     "kg_mask_inter_pairs": [P, P, P, c_int, c_long, P, P],
     "kg_f64_probe": [P, P, P, c_int, P],

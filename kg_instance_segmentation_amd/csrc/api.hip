@@ -46,6 +46,58 @@ extern "C" int kg_tr_probe(void* out, void* stream) {
 // out[off + y*w1 + x] = (uint8) masks[img][g][y1 + sy][x1 + sx] with sy = min(floor(y * (y2-y1)/h1), y2-y1-1) (cv2 INTER_NEAREST rule
 // as stated in seg_loss.nearest_resize), identity when the crop already has the patch size.
 #include <math.h>
+// ---- host glue of the per-box seg branch (KGnet.py:258-267, 321-350): box tables of seg.make_plan.  Pure host code, integer
+// arithmetic; 10 tile tables + 5 bin lists per step cost 2.2 ms as NumPy repeat / argsort chains for 2400 boxes.
+// kg_host_tile_table: one {row0, (h << 16) | w, (oy0 << 16) | ox0, 0} entry per th x tw tile of every box, box-major, tile rows
+// first; returns the number of entries (the caller sizes `out` from its own count), -1 on overflow of cap.
+extern "C" int kg_host_tile_table(const int* h, const int* w, const long* row0, int nb, int th, int tw, int* out, int cap) {
+    if (!h || !w || !row0 || !out || nb < 0 || th < 1 || tw < 1) return -1;
+    int n = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int ny = (h[b] + th - 1) / th, nx = (w[b] + tw - 1) / tw;
+        for (int ty = 0; ty < ny; ++ty)
+            for (int tx = 0; tx < nx; ++tx) {
+                if (n >= cap) return -1;
+                int* o = out + 4 * (long)n++;
+                o[0] = (int)row0[b]; o[1] = (h[b] << 16) | w[b]; o[2] = ((ty * th) << 16) | (tx * tw); o[3] = 0;
+            }
+    }
+    return n;
+}
+// kg_host_bin_csr: CSR lists of the boxes touching each BS x BS bin of each image (the deterministic crop-gradient reduction,
+// kg_crop_grad_reduce): tab = int32 [nb][8] rows {img, y1, x1, h, w, ...} of one pyramid level; bin index = (img * BY + by) * BX + bx;
+// bin_start [nbins + 1], bin_boxes in ascending box order inside a bin.  Returns the number of (box, bin) incidences, -1 on overflow.
+extern "C" int kg_host_bin_csr(const int* tab, int nb, int BS, int BY, int BX, int nbins, int* bin_start, int* bin_boxes, int cap) {
+    if (!tab || !bin_start || (!bin_boxes && cap > 0) || nb < 0 || BS < 1 || nbins < 0) return -1;
+    for (int i = 0; i <= nbins; ++i) bin_start[i] = 0;
+    long total = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int* t = tab + 8 * (long)b;
+        const int by0 = t[1] / BS, bx0 = t[2] / BS, by1 = (t[1] + t[3] - 1) / BS, bx1 = (t[2] + t[4] - 1) / BS;
+        for (int by = by0; by <= by1; ++by)
+            for (int bx = bx0; bx <= bx1; ++bx) {
+                const long bin = ((long)t[0] * BY + by) * BX + bx;
+                if (bin < 0 || bin >= nbins) return -1;
+                ++bin_start[bin + 1]; ++total;
+            }
+    }
+    if (total > cap) return -1;
+    for (int i = 0; i < nbins; ++i) bin_start[i + 1] += bin_start[i];
+    // fill: a cursor per bin (reuses bin_start shifted by one step: fill from the front, then restore)
+    for (int b = 0; b < nb; ++b) {
+        const int* t = tab + 8 * (long)b;
+        const int by0 = t[1] / BS, bx0 = t[2] / BS, by1 = (t[1] + t[3] - 1) / BS, bx1 = (t[2] + t[4] - 1) / BS;
+        for (int by = by0; by <= by1; ++by)
+            for (int bx = bx0; bx <= bx1; ++bx) {
+                const long bin = ((long)t[0] * BY + by) * BX + bx;
+                bin_boxes[bin_start[bin]++] = b;
+            }
+    }
+    for (int i = nbins; i > 0; --i) bin_start[i] = bin_start[i - 1];     // cursors ended at the next bin's start: shift back
+    bin_start[0] = 0;
+    return (int)total;
+}
+
 // ---- host glue of SEG_loss (seg_loss.py:14-29, 55-56): which (predicted box, ground-truth box) pairs overlap with IoU >= thresh.
 // float32 arithmetic in the operation order of the reference's jaccard_numpy (areas, clamped intersection sides, union <= 2 -> 0).
 // pb = float32 [P][4], gb = float32 [G][gstride] (first 4 columns y1, x1, y2, x2); pairs = int32 [cap][2] receives (patch, gt) in

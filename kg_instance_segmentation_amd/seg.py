@@ -6,6 +6,8 @@ inside a box); the top-down combine and the seg head are a handful of ragged imp
 Host glue (this file) only computes the integer crop rectangles with the reference's float32
 rounding rules and uploads the box tables.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -204,19 +206,24 @@ class SegBranch:
             (hi, wi), (ho, wo) = p.hw[l + 1], p.hw[l]
             bil.append(np.stack([p.row0[l + 1][:nc].astype(np.int32), hi[:nc], wi[:nc], p.row0[l][:nc].astype(np.int32),
                                  ho[:nc], wo[:nc]], 1).astype(np.int32))
-        # tile tables for the LDS-halo kernels: one {row0, (h<<16)|w, (oy0<<16)|ox0, 0} entry per tile of every box
+        # tile tables for the LDS-halo kernels: one {row0, (h<<16)|w, (oy0<<16)|ox0, 0} entry per tile of every box (native host code:
+        # kg_host_tile_table; as NumPy repeat / cumsum chains the ten tables of a step cost 1 ms)
+        lib = _lib.load()
+
+        def vp(a):
+            return ctypes.c_void_p(a.ctypes.data)
+
         def tile_table(l, th, tw):
             h, w = p.hw[l]
-            r0 = p.row0[l][:-1]
-            ny, nx = (h + th - 1) // th, (w + tw - 1) // tw
-            cnt = ny * nx
-            if cnt.sum() == 0:
-                return np.zeros((0, 4), np.int32)
-            b = np.repeat(np.arange(len(h)), cnt)
-            k = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
-            ty, tx = k // nx[b], k % nx[b]
-            return np.stack([r0[b].astype(np.int64), (h[b].astype(np.int64) << 16) | w[b], ((ty * th).astype(np.int64) << 16) | (tx * tw),
-                             np.zeros(len(b), np.int64)], 1).astype(np.int32)
+            nb = len(h)
+            cnt = int((((h + th - 1) // th) * ((w + tw - 1) // tw)).sum()) if nb else 0
+            out = np.empty((cnt, 4), np.int32)
+            if cnt:
+                r0 = np.ascontiguousarray(p.row0[l][:-1], np.int64)
+                got = lib.kg_host_tile_table(vp(np.ascontiguousarray(h, np.int32)), vp(np.ascontiguousarray(w, np.int32)), vp(r0), nb, th, tw, vp(out), cnt)
+                if got != cnt:
+                    raise _lib.KGLibraryError(f"kg_host_tile_table: {got} entries, expected {cnt}")
+            return out
         t32 = [tile_table(l, 16, 32) for l in range(5)]
         t16 = [tile_table(l, 16, 16) for l in range(5)]
 
@@ -238,18 +245,14 @@ class SegBranch:
             if nb == 0 or not need_bins:
                 bin_start.append(np.zeros(nbins + 1 if need_bins else 1, np.int32)); bin_boxes.append(np.zeros(0, np.int32))
                 continue
-            t = tabs[l]
-            by0, bx0 = t[:, 1] // BS, t[:, 2] // BS
-            nyb = (t[:, 1] + t[:, 3] - 1) // BS - by0 + 1
-            nxb = (t[:, 2] + t[:, 4] - 1) // BS - bx0 + 1
-            cnt = (nyb * nxb).astype(np.int64)
-            b = np.repeat(np.arange(nb), cnt)
-            k = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
-            bins = (t[b, 0].astype(np.int64) * BY + by0[b] + k // nxb[b]) * BX + bx0[b] + k % nxb[b]
-            order = np.argsort(bins, kind="stable")
-            st = np.zeros(nbins + 1, np.int64)
-            np.cumsum(np.bincount(bins, minlength=nbins), out=st[1:])
-            bin_start.append(st.astype(np.int32)); bin_boxes.append(b[order].astype(np.int32))
+            t = np.ascontiguousarray(tabs[l], np.int32)
+            cap = int((((t[:, 1] + t[:, 3] - 1) // BS - t[:, 1] // BS + 1) * ((t[:, 2] + t[:, 4] - 1) // BS - t[:, 2] // BS + 1)).sum())
+            st = np.empty(nbins + 1, np.int32)
+            bb = np.empty(cap, np.int32)
+            got = lib.kg_host_bin_csr(vp(t), nb, BS, BY, BX, nbins, vp(st), vp(bb), cap)     # counting sort: boxes ascending inside a bin
+            if got != cap:
+                raise _lib.KGLibraryError(f"kg_host_bin_csr: {got} incidences, expected {cap}")
+            bin_start.append(st); bin_boxes.append(bb)
         blob = np.concatenate([t.ravel() for t in tabs] + [b.ravel() for b in bil] + [t.ravel() for t in t32] + [t.ravel() for t in t16]
                               + bin_start + bin_boxes).astype(np.int32)
         dblob = ops.h2d(blob, dev)

@@ -139,6 +139,50 @@ def test_native_matcher_equals_scalar_rule(lib):
     assert len(js) == 900 and js[31] == 1 and gs[31] == 1
 
 
+def test_native_seg_tables_equal_the_numpy_formulation(lib):
+    """kg_host_tile_table / kg_host_bin_csr (host glue of seg.make_plan) against the NumPy repeat / stable-argsort formulation they
+    replace: same tile entries in the same order, same CSR lists (boxes ascending inside a bin), incl. empty levels and 1-pixel boxes."""
+    import ctypes
+    rng = np.random.default_rng(5)
+
+    def vp(a):
+        return ctypes.c_void_p(a.ctypes.data)
+    for trial in range(8):
+        nb = int(rng.integers(0, 200)) if trial else 0
+        H, W, nimg = 128, 96, 3
+        y1 = rng.integers(0, H - 1, nb); x1 = rng.integers(0, W - 1, nb)
+        h = np.minimum(rng.integers(1, 70, nb), H - y1).astype(np.int32); w = np.minimum(rng.integers(1, 50, nb), W - x1).astype(np.int32)
+        img = np.sort(rng.integers(0, nimg, nb)).astype(np.int32)
+        row0 = np.zeros(nb + 1, np.int64); np.cumsum(h.astype(np.int64) * w, out=row0[1:])
+        for th, tw in ((16, 32), (16, 16)):
+            ny, nx = (h + th - 1) // th, (w + tw - 1) // tw
+            cnt = ny * nx
+            b = np.repeat(np.arange(nb), cnt)
+            k = np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+            ty, tx = (k // nx[b], k % nx[b]) if nb else (k, k)
+            ref = np.stack([row0[:-1][b], (h[b].astype(np.int64) << 16) | w[b], ((ty * th).astype(np.int64) << 16) | (tx * tw),
+                            np.zeros(len(b), np.int64)], 1).astype(np.int32)
+            out = np.empty((int(cnt.sum()), 4), np.int32)
+            got = lib.kg_host_tile_table(vp(h), vp(w), vp(np.ascontiguousarray(row0[:-1])), nb, th, tw, vp(out), len(out))
+            assert got == len(ref) and np.array_equal(out, ref)
+            assert nb == 0 or lib.kg_host_tile_table(vp(h), vp(w), vp(np.ascontiguousarray(row0[:-1])), nb, th, tw, vp(out), len(out) - 1) == -1
+        tab = np.stack([img, y1, x1, h, w, row0[:-1], np.full(nb, H), np.full(nb, W)], 1).astype(np.int32) if nb else np.zeros((0, 8), np.int32)
+        for BS in (16, 8, 4):
+            BY, BX = (H + BS - 1) // BS, (W + BS - 1) // BS
+            nbins = nimg * BY * BX
+            by0, bx0 = tab[:, 1] // BS, tab[:, 2] // BS
+            nyb = (tab[:, 1] + tab[:, 3] - 1) // BS - by0 + 1; nxb = (tab[:, 2] + tab[:, 4] - 1) // BS - bx0 + 1
+            cnt = (nyb * nxb).astype(np.int64)
+            b = np.repeat(np.arange(nb), cnt)
+            k = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+            bins = (tab[b, 0].astype(np.int64) * BY + by0[b] + k // nxb[b]) * BX + bx0[b] + k % nxb[b] if nb else np.zeros(0, np.int64)
+            order = np.argsort(bins, kind="stable")
+            ref_st = np.zeros(nbins + 1, np.int64); np.cumsum(np.bincount(bins, minlength=nbins), out=ref_st[1:])
+            st = np.empty(nbins + 1, np.int32); bb = np.empty(int(cnt.sum()), np.int32)
+            got = lib.kg_host_bin_csr(vp(np.ascontiguousarray(tab)), nb, BS, BY, BX, nbins, vp(st), vp(bb), len(bb))
+            assert got == len(bb) and np.array_equal(st, ref_st.astype(np.int32)) and np.array_equal(bb, b[order].astype(np.int32))
+
+
 def test_dropin_shims_expose_the_reference_module_surface():
     """dropin/<module>.py (what `import KGnet` etc. resolve to when dropin/ precedes the reference on sys.path)
     re-export the symbols the reference drivers use (train.py:3-11, test.py:3-12, dataset_base.py:6)."""
