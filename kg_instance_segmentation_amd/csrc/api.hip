@@ -40,12 +40,6 @@ extern "C" int kg_tr_probe(void* out, void* stream) {
     return KG_OK;
 }
 
-// ---- host glue of SEG_loss (seg_loss.py:57-80): crops of the matched ground-truth masks, nearest-resized to the patch size,
-// written as bytes into one (pinned) staging buffer.  Pure host code: 2400 crops per step cost 7 ms as a Python loop.
-// masks[i] = float32 [n_i][H][W] (C order); work = int32 [nwork][9] rows (img, gt index, y1, y2, x1, x2, h1, w1, out offset):
-// out[off + y*w1 + x] = (uint8) masks[img][g][y1 + sy][x1 + sx] with sy = min(floor(y * (y2-y1)/h1), y2-y1-1) (cv2 INTER_NEAREST rule
-// as stated in seg_loss.nearest_resize), identity when the crop already has the patch size.
-#include <math.h>
 // ---- host glue of the per-box seg branch (KGnet.py:258-267, 321-350): box tables of seg.make_plan.  Pure host code, integer
 // arithmetic; 10 tile tables + 5 bin lists per step cost 2.2 ms as NumPy repeat / argsort chains for 2400 boxes.
 // kg_host_tile_table: one {row0, (h << 16) | w, (oy0 << 16) | ox0, 0} entry per th x tw tile of every box, box-major, tile rows
@@ -106,31 +100,54 @@ extern "C" int kg_host_bin_csr(const int* tab, int nb, int BS, int BY, int BX, i
 extern "C" int kg_host_match_boxes(const float* pb, int P, const float* gb, int G, int gstride, float thresh, int* pairs, int cap, int* count) {
 #pragma clang fp contract(off)
     KG_CHECK_ARG(pb && gb && pairs && count && P >= 0 && G >= 0 && gstride >= 4 && cap >= 0, "kg_host_match_boxes: bad arguments");
-    int n = 0;
-    for (int j = 0; j < P; ++j) {
+    // ground-truth boxes as structure of arrays: the overlap pre-test below is a branch-free loop the host compiler vectorises, and
+    // almost every pair is disjoint (IoU exactly 0 < thresh); the exact float32 IoU runs only on the overlapping ones
+    float* soa = (float*)malloc(sizeof(float) * 4 * (size_t)(G > 0 ? G : 1));
+    unsigned char* ov = (unsigned char*)malloc((size_t)(G > 0 ? G : 1));
+    if (!soa || !ov) { free(soa); free(ov); kg_set_error("kg_host_match_boxes: out of host memory"); return KG_ERR_ARG; }
+    float *b0 = soa, *b1 = soa + G, *b2 = soa + 2 * (size_t)G, *b3 = soa + 3 * (size_t)G;
+    for (int g = 0; g < G; ++g) {
+        const float* b = gb + (long)g * gstride;
+        b0[g] = b[0]; b1[g] = b[1]; b2[g] = b[2]; b3[g] = b[3];
+    }
+    const bool prefilter = thresh > 0.f;
+    int n = 0, rc = KG_OK;
+    for (int j = 0; j < P && rc == KG_OK; ++j) {
         const float a0 = pb[4 * j], a1 = pb[4 * j + 1], a2 = pb[4 * j + 2], a3 = pb[4 * j + 3];
         const float area_a = (a2 - a0) * (a3 - a1);
         for (int g = 0; g < G; ++g) {
-            const float* b = gb + (long)g * gstride;
-            const float area_b = (b[2] - b[0]) * (b[3] - b[1]);
-            float ih = (a2 < b[2] ? a2 : b[2]) - (a0 > b[0] ? a0 : b[0]);
-            float iw = (a3 < b[3] ? a3 : b[3]) - (a1 > b[1] ? a1 : b[1]);
-            if (thresh > 0.f && (!(ih > 0.f) || !(iw > 0.f))) continue;      // disjoint boxes: inter = 0 -> IoU 0 (most pairs)
+            const float ih = (a2 < b2[g] ? a2 : b2[g]) - (a0 > b0[g] ? a0 : b0[g]);
+            const float iw = (a3 < b3[g] ? a3 : b3[g]) - (a1 > b1[g] ? a1 : b1[g]);
+            ov[g] = (unsigned char)((ih > 0.f) & (iw > 0.f));
+        }
+        for (int g = 0; g < G; ++g) {
+            if (prefilter && !ov[g]) continue;
+            const float area_b = (b2[g] - b0[g]) * (b3[g] - b1[g]);
+            float ih = (a2 < b2[g] ? a2 : b2[g]) - (a0 > b0[g] ? a0 : b0[g]);
+            float iw = (a3 < b3[g] ? a3 : b3[g]) - (a1 > b1[g] ? a1 : b1[g]);
             if (!(ih > 0.f)) ih = 0.f;
             if (!(iw > 0.f)) iw = 0.f;
             const float inter = ih * iw;
             const float uni = area_a + area_b - inter;
             const float iou = uni <= 2.f ? 0.f : inter / uni;
             if (iou >= thresh) {
-                if (n >= cap) { kg_set_error("kg_host_match_boxes: more than %d matches", cap); return KG_ERR_ARG; }
+                if (n >= cap) { kg_set_error("kg_host_match_boxes: more than %d matches", cap); rc = KG_ERR_ARG; break; }
                 pairs[2 * n] = j; pairs[2 * n + 1] = g; ++n;
             }
         }
     }
+    free(soa); free(ov);
+    if (rc != KG_OK) return rc;
     *count = n;
     return KG_OK;
 }
 
+// ---- host glue of SEG_loss (seg_loss.py:57-80): crops of the matched ground-truth masks, nearest-resized to the patch size,
+// written as bytes into one (pinned) staging buffer.  Pure host code: 2400 crops per step cost 7 ms as a Python loop.
+// masks[i] = float32 [n_i][H][W] (C order); work = int32 [nwork][9] rows (img, gt index, y1, y2, x1, x2, h1, w1, out offset):
+// out[off + y*w1 + x] = (uint8) masks[img][g][y1 + sy][x1 + sx] with sy = min(floor(y * (y2-y1)/h1), y2-y1-1) (cv2 INTER_NEAREST rule
+// as stated in seg_loss.nearest_resize), identity when the crop already has the patch size.
+#include <math.h>
 extern "C" int kg_host_crop_masks(const float* const* masks, const int* work, int nwork, int H, int W, unsigned char* out) {
     KG_CHECK_ARG(masks && work && out && nwork >= 0 && H > 0 && W > 0, "kg_host_crop_masks: bad arguments");
     for (int k = 0; k < nwork; ++k) {
