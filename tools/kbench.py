@@ -31,6 +31,8 @@ CASES = {
     "wg1_l3": ("wgrad", 8, 32, 256, 1024, 1),
     "wg1_c0": ("wgrad", 8, 512, 128, 64, 1),
     "igemm1_c0": ("igemm", 8, 512, 128, 64, 1),
+    "small3_c0": ("igemm", 8, 512, 8, 64, 3),        # c0_conv.0 (3 -> 64, image rows padded to 8 channels): conv_small_mfma
+    "small7_stem": ("igemm_s2", 8, 512, 8, 64, 7),   # stem conv1 (7x7 stride 2)
     "igemm3_deep": ("igemm", 8, 64, 512, 256, 3),
     "igemm3_deep2": ("igemm", 8, 32, 1024, 512, 3),
 }
@@ -46,11 +48,13 @@ def main():
     rnd = (lambda *sh: torch.full(sh, 1.0, device=dev)) if const else (lambda *sh: torch.randn(*sh, device=dev))
     x = (rnd(M, cin) * 0.5).to(BF16)
     geom = (M, H, H, H, H, k, k, 1, k // 2)
+    if kind == "igemm_s2":
+        kind, geom = "igemm", (N * (H // 2) ** 2, H, H, H // 2, H // 2, k, k, 2, k // 2)
     flops = 2.0 * M * cout * k * k * cin
     if kind in ("fwd", "igemm"):
         pw = PackedWeight(cout, k * k, cin, dev)
         pw.buf.copy_((torch.randn_like(pw.buf.float()) * 0.05).to(BF16))
-        y = torch.empty(M, cout, dtype=BF16, device=dev)
+        y = torch.empty(geom[0], cout, dtype=BF16, device=dev)
         bias = torch.zeros(cout, device=dev)
         if kind == "fwd":
             fn = lambda: ops.conv_halo(x, pw, cout, N, H, H, k, y=y, bias=bias, relu=True)
