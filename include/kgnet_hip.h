@@ -121,6 +121,16 @@ int kg_img_pack(const float* img_nchw, void* out_rows8, int ldout, int N, int C,
 int kg_bn_stats_train(const void* x, int ldx, int M, int C, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float momentum, float eps, float* mean_out, float* invstd_out, float* scale,
                       float* shift, float* scratch, int scratch_floats, const kg_planes_t* planes, void* stream);
+/* BatchNorm statistics from the PRODUCING conv's epilogue (the conv of KGnet.py:82-93 that feeds a train-mode BatchNorm2d):
+ * kg_conv_stats_begin arms the calling host thread's next kg_conv2d_igemm / kg_conv2d_halo launch (bf16 rows output, no ReLU / residual /
+ * mask): that launch also writes per-(pixel tile, channel) {sum, sum of squares} partials of its fp32 accumulators into `part`;
+ * kg_conv_stats_end returns the tile count nb (0: the launch used a kernel without this epilogue -- fall back to kg_bn_stats_train) and
+ * disarms; kg_bn_finalize_train = the second stage of kg_bn_stats_train over those partials [nb][C][2]. */
+int kg_conv_stats_begin(float* part, long cap_floats);
+int kg_conv_stats_end(int* nb);
+int kg_bn_finalize_train(const float* part, int nb, int M, int C, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps, float* mean_out, float* invstd_out, float* scale,
+                         float* shift, void* stream);
 int kg_bn_scale_shift_eval(int C, const float* gamma, const float* beta, const float* running_mean,
                            const float* running_var, float eps, float* scale, float* shift, void* stream);
 int kg_bn_apply(const void* x, int ldx, const float* scale, const float* shift, const void* res, int ldres, void* y,

@@ -40,6 +40,23 @@ extern "C" int kg_tr_probe(void* out, void* stream) {
     return KG_OK;
 }
 
+// ---- BatchNorm statistics from the producing conv's epilogue (conv_args.h): arm -> conv launch -> read back the tile count.
+static thread_local KgConvStats g_conv_stats = {nullptr, 0, 0};
+KgConvStats& kg_conv_stats() { return g_conv_stats; }
+extern "C" int kg_conv_stats_begin(float* part, long cap_floats) {
+    KG_CHECK_ARG(part && cap_floats > 0, "kg_conv_stats_begin: bad buffer");
+    g_conv_stats = KgConvStats{part, cap_floats, 0};
+    return KG_OK;
+}
+// *nb = pixel tiles whose partials [nb][Cout][2] the conv wrote (0: the launch took a kernel without the statistics epilogue, or
+// none ran -- the caller falls back to kg_bn_stats_train); disarms the channel.
+extern "C" int kg_conv_stats_end(int* nb) {
+    KG_CHECK_ARG(nb, "kg_conv_stats_end: null pointer");
+    *nb = g_conv_stats.nb;
+    g_conv_stats = KgConvStats{nullptr, 0, 0};
+    return KG_OK;
+}
+
 // ---- host glue of the per-box seg branch (KGnet.py:258-267, 321-350): box tables of seg.make_plan.  Pure host code, integer
 // arithmetic; 10 tile tables + 5 bin lists per step cost 2.2 ms as NumPy repeat / argsort chains for 2400 boxes.
 // kg_host_tile_table: one {row0, (h << 16) | w, (oy0 << 16) | ox0, 0} entry per th x tw tile of every box, box-major, tile rows

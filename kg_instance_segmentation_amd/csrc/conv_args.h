@@ -12,7 +12,44 @@ struct ConvArgs {
     int relu, f32_C;
     KMap km;                   // split-bf16 planes of x (kg_common.h): X-side offset of virtual channel unit q
     int yP, yps, rP, rps;      // planes / plane strides of the output rows and of the residual
+    float* stat_part;          // != null: BatchNorm statistics of the output (kg_conv_stats_begin): partials [pixel tile][Cout][2]
 };
+
+// ---- BatchNorm statistics in the conv epilogue ---------------------------------------------------------------------------------
+// A conv whose output goes straight into a train-mode BatchNorm (KGnet.py:82-93 after every backbone conv) also needs the
+// per-channel sum and sum of squares of that output; the separate column-reduction pass re-read the whole tensor (43 launches,
+// 0.5 ms per step).  Here every lane sums the rows it is about to store (kg_stat_add), the 16 lanes that share a cout range are
+// combined with wave shuffles, the pixel waves of the workgroup through LDS in wave order, and the workgroup writes ONE partial
+// per channel: part[(tile * Cout + c) * 2 + {0, 1}] -- the layout bn_finalize_train_kernel combines in double, in tile order.
+// Everything is a fixed order: the statistics are reproducible like the two-pass ones (they are taken from the fp32 accumulators,
+// before the split-bf16 rounding of the store).
+__device__ __forceinline__ void kg_stat_add(float (&s)[16], float (&q)[16], const float (&v)[16]) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+}
+// NW pixel waves (index wrow) share a cout tile of NC channels; this lane holds channels cl0 .. cl0+15 of it.  red: LDS, NW * NC * 2
+// floats, no longer read by anybody (the caller has passed a barrier since the last tile access).  part_tile = part + tile * Cout * 2.
+template <int NW, int NC>
+__device__ __forceinline__ void kg_stat_commit(float (&s)[16], float (&q)[16], float* red, int wrow, int cl0, int lm, float* part_tile,
+                                               int c0, int Cout) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s[e] += __shfl_xor(s[e], o, 64); q[e] += __shfl_xor(q[e], o, 64); }
+    }
+    if (lm == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { red[(wrow * NC + cl0 + e) * 2] = s[e]; red[(wrow * NC + cl0 + e) * 2 + 1] = q[e]; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < NC * 2; t += blockDim.x) {
+        const int c = t >> 1;
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) acc += red[(w * NC + c) * 2 + (t & 1)];
+        if (c0 + c < Cout) part_tile[(long)(c0 + c) * 2 + (t & 1)] = acc;
+    }
+}
 
 // Shared tail of every conv kernel: v[NV] = accumulators + bias of output channels cb .. cb+NV-1 of row m.
 // (+ residual planes) -> ReLU -> ReLU mask (plane 0 of the masking tensor carries its sign) -> split-bf16 store.

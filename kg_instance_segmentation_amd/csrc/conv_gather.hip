@@ -165,21 +165,30 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
 
     // ---- epilogue: lane owns pixel row m and couts cb .. cb+15 --------------------------------------------------------------
     const int cb = c0 + wcw * 64 + g * 16;
-    if (cb >= a.Cout) return;
+    const bool stats = a.stat_part != nullptr;                 // (uniform)
+    if (cb >= a.Cout && !stats) return;
     float bv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
     const EpiArgs ep = kg_epi(a);
+    float ss[16], sq[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ss[e] = sq[e] = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const long m = (long)m0 + wp * 64 + j * 16 + lm;
-        if (m >= a.M) continue;
+        if (m >= a.M || cb >= a.Cout) continue;
         float v[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bv[i * 4 + r];
+        if (stats) kg_stat_add(ss, sq, v);
         kg_conv_epilogue<16>(ep, m, cb, v);
+    }
+    if (stats) {
+        __syncthreads();                                       // every wave has left the ring: its LDS becomes the combine buffer
+        kg_stat_commit<4, 128>(ss, sq, reinterpret_cast<float*>(smem), wp, wcw * 64 + g * 16, lm, a.stat_part + (long)blockIdx.x * a.Cout * 2, c0, a.Cout);
     }
 }
 

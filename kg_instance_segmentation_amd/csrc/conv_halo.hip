@@ -37,6 +37,7 @@ struct HaloArgs {
     // split-bf16 planes (kg_common.h): cin_pad counts the VIRTUAL channels of a tap (what the packed weights hold); km maps a
     // virtual 64-channel chunk to its (x plane, channel chunk); GM = 1: grp_chunks virtual chunks and grp_C real channels per head
     KMap km; int grp_C;
+    float* stat_part; // != null (GM = 0, bf16 rows output): BatchNorm statistics of the output, partials [pixel tile][Cout][2] (conv_args.h)
     int kp_raw;       // GM = 1: 1 = export the kp logits without the sigmoid of KGnet.py:300 (parity tests, logit-space consumers)
     int yP, yps, rP, rps;
 };
@@ -449,7 +450,11 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 
     // ---- epilogue: lane owns pixel (oy0 + wp*4 + j, ox0 + lm) and couts cb .. cb+15 ----------------------
     const int cb = c0 + wc * 64 + g * 16;
-    if (cb >= a.Cout) return;
+    const bool stats = GM == 0 && a.stat_part != nullptr;      // (uniform)
+    if (cb >= a.Cout && !stats) return;
+    float ss[16], sq[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ss[e] = sq[e] = 0.f;
     float bv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
@@ -463,13 +468,14 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int oy = oy0 + (wp & 3) * 4 + j;
-        if (oy >= Hd || ox >= Wd) continue;
+        if (oy >= Hd || ox >= Wd || cb >= a.Cout) continue;
         const long m = rowbase + (long)oy * Wd + ox;
         float v[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bv[i * 4 + r];
+        if (stats) kg_stat_add(ss, sq, v);
         if constexpr (GM == 1) {   // fp32 NCHW export to the kp (sigmoid, KGnet.py:300) / short / mid maps
             const long hw = (long)a.H * a.W;
             const long nimg = rowbase / hw, pix = (long)oy * Wd + ox;
@@ -497,6 +503,10 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
         }
         if (a.y) kg_conv_epilogue<16>(ep, m, cb, v);      // (last: the split store consumes v)
     }
+    if (stats) {
+        __syncthreads();                                       // every wave has left the halo and the ring: their LDS becomes the combine buffer
+        kg_stat_commit<WPX, TC>(ss, sq, reinterpret_cast<float*>(smem), wp, wc * 64 + g * 16, lm, a.stat_part + (long)bix * a.Cout * 2, c0, a.Cout);
+    }
 }
 
 template <int KS, int WC, int WPX, int GM = 0>
@@ -510,6 +520,7 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y, GM == 1 ? (a.head_split ? 3 : 1) : kg_cdiv(a.Cout, TC));
+    if (a.stat_part) a.stat_part = (GM == 0 && !a.tiletab) ? kg_conv_stats_claim(grid.x, a.Cout) : nullptr;   // (armed by the caller: BatchNorm statistics)
     static const int use_xcd = getenv("KG_HALO_XCD") ? atoi(getenv("KG_HALO_XCD")) : 1;
     // (not for the widest heads: 24 cout blocks of one tile stream 24 different 3 MB weight slices through the XCD's 4 MB L2: -2 %)
     a.xcd_map = use_xcd && !a.tiletab && grid.x % 8 == 0 && (grid.y > 1 || use_xcd > 1) && (long)a.Cout * a.K * 2 <= (24L << 20);
@@ -546,6 +557,8 @@ extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, v
     a.N = N; a.H = H; a.W = W; a.tiles_x = kg_cdiv(W, 16); a.tiles_y = kg_cdiv(H, 16);
     a.cin_pad = cin_pad * vplanes; a.ldx = ldx; a.Cout = Cout; a.ldy = ldy; a.ldres = ldres; a.ldmask = ldmask; a.K = K;
     a.flip = flip; a.relu = relu; a.f32_C = f32_C; a.tiletab = (const int4*)tiletab; a.ntiles = ntiles; a.f32_hw = total_rows;
+    if (y && !y_f32 && !res && !mask && !relu && !flip && kg_conv_stats().part && kg_conv_stats().nb == 0)
+        a.stat_part = kg_conv_stats().part;      // provisional: launch_halo claims it with the tile count of the variant it launches
     const int k1skip = wc >> 8; wc &= 255;   // bit 8: the weights are zero for channels 32..63 of every chunk -> k-step 1 is skipped
     if (wc == 0) wc = 1;   // measured on MI355X: the 16x32-pixel x 64-cout tile (8 waves) beats the 16x16 x 128/192-cout tiles at every KGnet shape
     hipStream_t st = (hipStream_t)stream;

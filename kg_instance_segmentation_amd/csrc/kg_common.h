@@ -72,6 +72,17 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {   // LDS byte addr
 
 static inline int kg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Side channel of kg_conv_stats_begin / kg_conv_stats_end (api.hip): the NEXT conv launch of this host thread that supports it
+// writes the BatchNorm statistics partials of its output (conv_args.h) into `part` and records its pixel-tile count.
+struct KgConvStats { float* part; long cap_floats; int nb; };
+KgConvStats& kg_conv_stats();
+static inline float* kg_conv_stats_claim(int tiles, int Cout) {   // launcher side: returns the partial buffer when armed and large enough
+    KgConvStats& st = kg_conv_stats();
+    if (!st.part || st.nb != 0 || (long)tiles * Cout * 2 > st.cap_floats) return nullptr;
+    st.nb = tiles;
+    return st.part;
+}
+
 // ---- split-bf16 storage ("planes") -------------------------------------------------------------------------------------
 // The reference computes in fp32 (KGnet.py:22-29 -> F.conv2d on fp32 tensors).  CDNA4's fast matrix path is bf16 MFMA with
 // fp32 accumulation, so wider-than-bf16 tensors are stored as P planes of bf16 whose sum is the value:

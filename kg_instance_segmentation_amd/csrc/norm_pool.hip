@@ -180,6 +180,17 @@ extern "C" int kg_bn_stats_train(const void* x, int ldx, int M, int C, const flo
     KG_CHECK_LAUNCH("bn_stats_train");
     return KG_OK;
 }
+// The second stage of kg_bn_stats_train alone, over partials [nb][C][2] that the producing conv's epilogue wrote (kg_conv_stats_begin /
+// kg_conv_stats_end, conv_args.h): same fixed-order double combine, same running-statistics update.
+extern "C" int kg_bn_finalize_train(const float* part, int nb, int M, int C, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, float momentum, float eps, float* mean_out, float* invstd_out, float* scale,
+                                    float* shift, void* stream) {
+    KG_CHECK_ARG(part && gamma && beta && mean_out && invstd_out && scale && shift && nb >= 1 && M >= 1 && C >= 1, "kg_bn_finalize_train: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, part, nb, C, (long)M, gamma, beta, running_mean,
+                       running_var, momentum, eps, mean_out, invstd_out, scale, shift);
+    KG_CHECK_LAUNCH("bn_finalize_train");
+    return KG_OK;
+}
 extern "C" int kg_bn_scale_shift_eval(int C, const float* gamma, const float* beta, const float* running_mean,
                                       const float* running_var, float eps, float* scale, float* shift, void* stream) {
     KG_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift, "kg_bn_scale_shift_eval: null pointer");

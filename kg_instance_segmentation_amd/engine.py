@@ -50,7 +50,7 @@ def trunc(t, P):
 
 class Var:
     """Activation (split-bf16 rows, ops.PT) + its gradient slot."""
-    __slots__ = ("t", "C", "relu", "grad", "masked", "pending", "pmasked", "req", "parent", "c0", "gP")
+    __slots__ = ("t", "C", "relu", "grad", "masked", "pending", "pmasked", "req", "parent", "c0", "gP", "bn_part")
 
     def __init__(self, t, C, relu=False, req=True, parent=None, c0=0, gP=None):
         self.t = t if isinstance(t, PT) else PT(t)
@@ -233,9 +233,10 @@ class Engine:
             s.pwT.stale = False
 
     # ---- ops ------------------------------------------------------------------------------------
-    def conv(self, xv, s, N, H, W, relu, out=None, y_f32=None, tile=0, oP=None):
+    def conv(self, xv, s, N, H, W, relu, out=None, y_f32=None, tile=0, oP=None, bn_stats=False):
         """xv: Var over [N*H*W, >=cin_pad]; returns Var over [N*OH*OW, cout] (or fp32 NCHW when y_f32).
-        oP: planes of the output (default: the conv's own precision)."""
+        oP: planes of the output (default: the conv's own precision).  bn_stats: the output feeds a train-mode BatchNorm -- the conv
+        kernel also writes the statistics partials of its output when it can (ops.conv_stats_begin); the Var then carries them."""
         train = self.tape is not None
         self.prepare(s, need_T=train and xv.req)
         OH = (H + 2 * s.pad - s.k) // s.stride + 1
@@ -247,8 +248,13 @@ class Engine:
             out = ops.alloc_pt(M, s.cout, oP, dev)
         geom = (M, H, W, OH, OW, s.k, s.k, s.stride, s.pad)
         xin = trunc(xv.t, s.P)
+        arm = bn_stats and ops.CONV_BN_STATS and self.m.training and y_f32 is None and not relu
+        part = ops.conv_stats_begin(dev) if arm else None
         ops.conv_auto(xin, s.pw, s.cout, geom, N, y=out, y_f32=y_f32, bias=s.bias_cat if s.has_bias else None, relu=relu, tile=tile)
         yv = Var(out, s.cout, relu=relu, gP=s.gP)
+        if arm:
+            nb = ops.conv_stats_end()
+            yv.bn_part = (part, nb) if nb > 0 else None
         if train:
             def bwd():
                 g = yv.take_grad()
@@ -289,7 +295,12 @@ class Engine:
         if out is None:
             out = ops.alloc_pt(xv.rows, C, self.bpt, dev)
         if self.m.training:
-            mean, invstd, scale, shift = ops.bn_stats_train(xv.t, C, gamma.detach(), beta.detach(), rm, rv)
+            bp = getattr(xv, "bn_part", None)
+            if bp is not None:       # the producing conv's epilogue already summed the rows (conv_args.h): second stage only
+                mean, invstd, scale, shift = ops.bn_finalize_train(bp[0], bp[1], xv.rows, C, gamma.detach(), beta.detach(), rm, rv)
+                xv.bn_part = None
+            else:
+                mean, invstd, scale, shift = ops.bn_stats_train(xv.t, C, gamma.detach(), beta.detach(), rm, rv)
             self.nbt.append(self.P(p + ".num_batches_tracked"))      # += 1 for all 43 layers in one launch at the end of forward_dec
             self.stats_written = True
         else:
@@ -374,15 +385,16 @@ class Engine:
 
     # ---- the network ------------------------------------------------------------------------------
     def bottleneck(self, xv, p, N, H, W, inplanes, planes, stride, has_ds, out=None):
-        a, _, _ = self.conv(xv, self.spec(p + ".conv1", inplanes, planes, 1, bias=False), N, H, W, False)
+        # (every conv here feeds a BatchNorm directly: bn_stats -- one shared partial buffer, so each conv is followed by ITS bn)
+        a, _, _ = self.conv(xv, self.spec(p + ".conv1", inplanes, planes, 1, bias=False), N, H, W, False, bn_stats=True)
         a = self.bn(a, p + ".bn1", True)
-        b, OH, OW = self.conv(a, self.spec(p + ".conv2", planes, planes, 3, stride, 1, bias=False), N, H, W, False)
+        b, OH, OW = self.conv(a, self.spec(p + ".conv2", planes, planes, 3, stride, 1, bias=False), N, H, W, False, bn_stats=True)
         b = self.bn(b, p + ".bn2", True)
-        c, _, _ = self.conv(b, self.spec(p + ".conv3", planes, planes * 4, 1, bias=False), N, OH, OW, False)
         if has_ds:
-            d, _, _ = self.conv(xv, self.spec(p + ".downsample.0", inplanes, planes * 4, 1, stride, 0, bias=False), N, H, W, False)
+            d, _, _ = self.conv(xv, self.spec(p + ".downsample.0", inplanes, planes * 4, 1, stride, 0, bias=False), N, H, W, False, bn_stats=True)
             idt = self.bn(d, p + ".downsample.1", False)
-        else:
+        c, _, _ = self.conv(b, self.spec(p + ".conv3", planes, planes * 4, 1, bias=False), N, OH, OW, False, bn_stats=True)
+        if not has_ds:
             idt = xv
         y = self.bn(c, p + ".bn3", True, res=idt, out=out)
         return y, OH, OW

@@ -476,6 +476,32 @@ def bn_stats_train(x, C, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5):
     return st[0], st[1], st[2], st[3]
 
 
+CONV_BN_STATS = __import__("os").environ.get("KG_CONV_BN_STATS", "1") == "1"   # BatchNorm statistics in the producing conv's epilogue
+
+
+def conv_stats_begin(dev):
+    """Arms the next conv launch of this thread to also write the BatchNorm statistics partials of its output (kg_conv_stats_begin)."""
+    part = scratch_f32(1 << 21, dev, "bnpart")
+    _lib.call("kg_conv_stats_begin", ptr(part), c_long(part.numel()))
+    return part
+
+
+def conv_stats_end():
+    """Pixel tiles the armed conv wrote partials for (0: its kernel has no statistics epilogue); disarms."""
+    import ctypes
+    nb = ctypes.c_int(0)
+    _lib.call("kg_conv_stats_end", ctypes.byref(nb))
+    return nb.value
+
+
+def bn_finalize_train(part, nb, M, C, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5):
+    """(mean, invstd, scale, shift) from the partials a conv epilogue wrote; updates running stats in place like bn_stats_train."""
+    st = torch.empty(4, C, dtype=torch.float32, device=part.device)
+    _lib.call("kg_bn_finalize_train", ptr(part), nb, M, C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), c_float(momentum), c_float(eps),
+              ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream_ptr())
+    return st[0], st[1], st[2], st[3]
+
+
 def bn_scale_shift_eval(C, gamma, beta, rmean, rvar, eps=1e-5):
     st = torch.empty(2, C, dtype=torch.float32, device=gamma.device)
     _lib.call("kg_bn_scale_shift_eval", C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), c_float(eps), ptr(st[0]), ptr(st[1]), stream_ptr())

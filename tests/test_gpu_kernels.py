@@ -484,3 +484,44 @@ def test_wgrad_reduce_multi(cin, taps, S, counts):
         got = torch.cat(outs, 0).double()
         want = ref * (acc + 1)
         assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(64, 256, 1, 1, 2, 40, 36), (256, 512, 1, 1, 3, 17, 23), (128, 128, 3, 1, 2, 33, 50), (256, 512, 1, 2, 2, 20, 24),
+                                  (128, 128, 3, 2, 2, 26, 30), (128, 64, 3, 1, 1, 16, 32), (1024, 256, 1, 1, 2, 9, 11)])
+def test_conv_epilogue_bn_statistics(case):
+    """BatchNorm statistics from the producing conv's epilogue (kg_conv_stats_begin / _end + kg_bn_finalize_train, conv_args.h): mean /
+    invstd / scale / shift and the running-statistics update against float64 statistics of the float64 conv output (the epilogue sums
+    the fp32 accumulators), and against the two-pass kg_bn_stats_train over the stored bf16 rows (which sees the rounded values)."""
+    cin, cout, k, stride, N, H, W = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = bfr(torch.randn(N, cin, H, W, generator=g))
+    w = bfr(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k))
+    ref = F.conv2d(x.double(), w.double(), None, stride, k // 2)
+    OH, OW = ref.shape[2:]
+    M = N * OH * OW
+    pw = PackedWeight(cout, k * k, cin, DEV); pw.pack(w.to(DEV))
+    y = torch.empty(M, cout, dtype=BF16, device=DEV)
+    geom = (M, H, W, OH, OW, k, k, stride, k // 2)
+    gamma = (torch.rand(cout, generator=g) + 0.5).to(DEV); beta = torch.randn(cout, generator=g).to(DEV)
+    part = ops.conv_stats_begin(torch.device(DEV))
+    kind = ops.conv_auto(rows_of(x).to(DEV), pw, cout, geom, N, y=y)
+    nb = ops.conv_stats_end()
+    if kind == "1x1":        # the streaming 1x1 kernels (single-plane operands, K <= 128 or Cout <= 64) have no statistics epilogue:
+        assert nb == 0      # the channel reports it and the caller runs the two-pass kg_bn_stats_train
+        return
+    assert nb > 0, (kind, "this conv shape must take a kernel with the statistics epilogue")
+    rm1, rv1 = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+    mean, invstd, scale, shift = ops.bn_finalize_train(part, nb, M, cout, gamma, beta, rm1, rv1)
+    r = ref.permute(1, 0, 2, 3).reshape(cout, -1)
+    mu, var = r.mean(1), r.var(1, unbiased=False)
+    report(f"bnstats{case}.mean", mean.cpu(), mu, atol=1e-5, rtol=1e-4)
+    report(f"bnstats{case}.invstd", invstd.cpu(), 1.0 / torch.sqrt(var + 1e-5), atol=1e-5, rtol=2e-4)
+    report(f"bnstats{case}.running_var", rv1.cpu(), 0.9 + 0.1 * r.var(1, unbiased=True), atol=1e-5, rtol=2e-4)
+    report(f"bnstats{case}.shift", shift.cpu(), beta.cpu().double() - mu * gamma.cpu().double() / torch.sqrt(var + 1e-5), atol=2e-4, rtol=2e-4)
+    rm2, rv2 = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+    mean2, invstd2, _, _ = ops.bn_stats_train(y, cout, gamma, beta, rm2, rv2)
+    report(f"bnstats{case}.mean_vs_two_pass", mean.cpu(), mean2.cpu(), atol=2e-3, rtol=1e-2)      # (the two-pass version sees bf16-rounded rows)
+    report(f"bnstats{case}.invstd_vs_two_pass", invstd.cpu(), invstd2.cpu(), atol=1e-3, rtol=1e-2)
+    # disarmed again: a second conv leaves the buffer alone
+    ops.conv_auto(rows_of(x).to(DEV), pw, cout, geom, N, y=y)
+    assert ops.conv_stats_end() == 0
