@@ -9,9 +9,9 @@ with autograd (`loss.backward()` fills `.grad` of all parameters).  There is no 
 for the arithmetic: a missing libkgnet_hip.so or a non-GPU tensor raises.
 
 Numerics: the reference computes in fp32.  Here convolutions run on bf16 MFMA with fp32 accumulation over split-bf16
-storage (engine.py): `precision="mixed"` (default; env KG_PRECISION) keeps the trunk (stem, layer1-3, decoder) in
-hi + lo bf16 planes (16 significant bits, 3 MFMA products) and the two-layer 7x7 heads / seg branch in bf16;
-"fp32" stores hi + mid + lo (the fp32 value exactly, 6 products) everywhere; "bf16" is single-plane.
+storage (engine.py, PRECISIONS): `precision="fp32"` (default; env KG_PRECISION) stores every forward tensor as hi + mid + lo
+bf16 planes == the fp32 value exactly (6 MFMA products per multiply; results within rtol 1e-4 / atol 1e-5 of the reference) and
+runs the backward pass on hi + lo planes; "mixed" / "trunk2" / "bf16" are bf16 mixed-precision policies (opt-in).
 Head maps and the feature maps c0..c4 are returned as fp32 tensors like the reference's (KGnet.py:318;
 the feature maps are NCHW-shaped with channels-last memory).
 """
@@ -171,7 +171,7 @@ class ResNet(nn.Module):
         return self._engine.precision
 
     def set_precision(self, precision):
-        """"mixed" (default), "fp32" or "bf16" -- see the module docstring."""
+        """one of engine.PRECISIONS ("fp32" = default) -- see the module docstring."""
         self._engine.set_precision(precision)
         self._seg.invalidate_caches()
         return self

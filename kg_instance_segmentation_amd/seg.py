@@ -124,6 +124,11 @@ class SegBranch:
         """planes of the seg branch's activations / weights (engine.PRECISIONS)"""
         return self.m._engine.pseg
 
+    @property
+    def Pg(self):
+        """planes of the branch's gradients and of the operands of its backward convolutions (engine.PRECISIONS, last entry)"""
+        return min(self.m._engine.pseg, self.m._engine.pg)
+
     def invalidate_caches(self):
         self.packed = {}
 
@@ -152,7 +157,7 @@ class SegBranch:
             self.packed[key] = e
         if need_T and not e["T_ok"]:
             if e["pwT"] is None:
-                e["pwT"] = PackedWeight(cin, k * k, ops.round_up(cout, 8), w.device, xP=self.P_, wP=self.P_)
+                e["pwT"] = PackedWeight(cin, k * k, ops.round_up(cout, 8), w.device, xP=self.Pg, wP=min(self.Pg, self.m._engine.pdw))
             e["pwT"].pack(w.detach(), transposed=True)
             e["T_ok"] = True
         e["need_T"] = bool(need_T) or e.get("need_T", False)
@@ -323,6 +328,9 @@ class SegBranch:
     def alloc(self, rows, C, dev):
         return ops.alloc_pt(rows, C, self.P_, dev)
 
+    def galloc(self, rows, C, dev):
+        return ops.alloc_pt(rows, C, self.Pg, dev)
+
     def rconv(self, x, pw, cout, rowdesc, M, k, y=None, y_f32=None, bias=None, relu=False, mask=None, mode=2, tiles=None, tiles16=None):
         """Ragged conv (mode 2) or its input gradient (mode 3).  3x3 convs over 64-channel-aligned inputs run on the
         LDS-halo kernel with one (box, 16x32 tile) entry per workgroup; the rest on the gather implicit GEMM.
@@ -403,7 +411,13 @@ class SegBranch:
         gw = eng.new_grad(key + ".weight", w)
         use16 = t16 if (k == 3 and t16 is not None and M >= 0.35 * t16.shape[0] * 256) else None
         db = eng.new_grad(key + ".bias", self.P(key + ".bias"))
-        ops.conv_wgrad(x, g, cin, cout, geom, [(gw, 0, cout)], mode=2, rowdesc=rowdesc, tiletab16=use16, bias_out=db)
+        pw_ = min(self.Pg, self.m._engine.pw)
+        gw_ = g
+        if isinstance(x, PT) and x.P > pw_:
+            x = PT(x.t, pw_, x.ps)          # weight-gradient operands
+        if isinstance(g, PT) and g.P > pw_:
+            gw_ = PT(g.t, pw_, g.ps)
+        ops.conv_wgrad(x, gw_, cin, cout, geom, [(gw, 0, cout)], mode=2, rowdesc=rowdesc, tiletab16=use16, bias_out=db)
         pgrads[key + ".weight"], pgrads[key + ".bias"] = gw, db
         if dx is not None:
             _, pwT, _ = self.packw(key, True)
@@ -415,12 +429,12 @@ class SegBranch:
         CH = arch.FEAT_CH
         pgrads = {}
         rows0 = plan.rows[0]
-        gz = self.alloc(rows0, 8, dev)
+        gz = self.galloc(rows0, 8, dev)
         ops.grad_pack(gflat, flat, gz, 1, 1, rows0, 1, 8)
-        dhid = self.alloc(rows0, 64, dev)
+        dhid = self.galloc(rows0, 64, dev)
         t32_0, t16_0 = self.T32(plan, 0, plan.nb[0]), self.T16(plan, 0, plan.nb[0])
         self.conv_bwd("seg_head.2", hid, gz, plan.rowdesc[0], rows0, 3, pgrads, dx=dhid, mask=hid.hi(), t32=t32_0, t16=t16_0)
-        dpre = self.alloc(rows0, 64, dev)
+        dpre = self.galloc(rows0, 64, dev)
         self.conv_bwd("seg_head.0", pre[0], dhid, plan.rowdesc[0], rows0, 3, pgrads, dx=dpre, mask=pre[0].hi(), t32=t32_0, t16=t16_0)
         # Gradient w.r.t. the feature maps: per level the crop-gradient rows of the combine boxes (columns 0..C of the concat
         # gradient, rows [0, rowsC)) and of the boxes that end at this level (dpre rows [rowsC, rows)); reduced per feature
@@ -450,12 +464,12 @@ class SegBranch:
             nxt, dcat = None, None
             if nc:
                 cat, uin = cats[l], uins[l]
-                dcat = self.alloc(rowsC, ccat, dev)
+                dcat = self.galloc(rowsC, ccat, dev)
                 self.conv_bwd(f"skip_combine.{l}.cat_conv.0", cat, dpre.rows(0, rowsC), plan.rowdesc[l], rowsC, 1, pgrads, dx=dcat, mask=cat.hi())
-                duin = self.alloc(rowsC, CH[l + 1], dev)
+                duin = self.galloc(rowsC, CH[l + 1], dev)
                 self.conv_bwd(f"skip_combine.{l}.up.0", uin, dcat.cols(CH[l], CH[l] + cout), plan.rowdesc[l], rowsC, 3, pgrads, dx=duin,
                               t32=self.T32(plan, l, nc), t16=self.T16(plan, l, nc))
-                nxt = self.alloc(plan.rows[l + 1], CH[l + 1], dev)
+                nxt = self.galloc(plan.rows[l + 1], CH[l + 1], dev)
                 ops.bilinear_bwd(duin, nxt, 0, 0, 0, 0, 0, CH[l + 1], boxdesc=plan.bil_d[l], row2box=plan.row2box[l + 1], mask=pre[l + 1].hi())
             reduce_level(l, dcat.cols(0, CH[l]) if dcat is not None else None, rowsC if dcat is not None else 0,
                          dpre.rows(rowsC) if rows > rowsC else None)

@@ -34,6 +34,8 @@ DEV = "cuda"
 EVAL_TOL = {"fp32": (1e-4, 1e-5, 0.0), "trunk2": (2e-2, 0.0, 3e-2), "mixed": (2e-2, 0.0, 7e-2), "bf16": (2e-2, 0.0, 1e-1)}     # rtol, atol, atol as a fraction of rms
 TRAIN_TOL = {"fp32": (1e-3, 1e-4, 0.0), "trunk2": (2e-2, 0.0, 3e-2), "mixed": (2e-2, 0.0, 5e-2), "bf16": (2e-2, 0.0, 1.5e-1)}
 GRAD_COS = {"fp32": 0.9999, "trunk2": 0.99, "mixed": 0.99, "bf16": 0.85}
+for _d in (EVAL_TOL, TRAIN_TOL, GRAD_COS):
+    _d["fp32full"] = _d["fp32"]          # (6 products in the backward pass too: held to the same bounds as the default policy)
 
 
 def sha(a):
@@ -107,7 +109,7 @@ def test_eval_logits_vs_reference(golden, cal_sd, precision, name):
     assert worst[0][0] <= 1.0, worst[:5]
 
 
-@pytest.mark.parametrize("precision", ["fp32", "trunk2", "mixed", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32full", "trunk2", "mixed", "bf16"])
 def test_train_step_vs_reference(golden, cal_sd, precision):
     """Losses, train-mode maps and EVERY parameter gradient (seeded 1024-element subset) against the reference's train step."""
     g = golden("net_cal.npz")
@@ -120,7 +122,7 @@ def test_train_step_vs_reference(golden, cal_sd, precision):
     d0, d1, d2, d3, pred = m(x.to(DEV), gt_boxes)
     l1 = [ldec(p, t.to(DEV)) for p, t in zip((d0, d1, d2, d3), gt_lv)]
     l2 = lseg(pred, gt_masks, gt_boxes)
-    ltol = {"fp32": 2e-5, "trunk2": 2e-3, "mixed": 3e-3, "bf16": 2e-2}[precision]
+    ltol = {"fp32": 2e-5, "fp32full": 2e-5, "trunk2": 2e-3, "mixed": 3e-3, "bf16": 2e-2}[precision]
     print("loss_dec", [float(v) for v in l1], "ref", g["train.loss_dec"], "loss_seg", float(l2), float(g["train.loss_seg"]))
     np.testing.assert_allclose([float(v) for v in l1], g["train.loss_dec"], rtol=ltol)
     assert abs(float(l2) - float(g["train.loss_seg"])) <= ltol * abs(float(g["train.loss_seg"]))
@@ -153,11 +155,11 @@ def test_train_step_vs_reference(golden, cal_sd, precision):
     ratios = np.array([r for _, _, r in rows])
     print("   norm ratio: min %.4f max %.4f" % (ratios.min(), ratios.max()))
     assert rows[0][0] >= GRAD_COS[precision], rows[:5]
-    assert np.all(np.abs(ratios - 1) <= {"fp32": 2e-3, "trunk2": 5e-2, "mixed": 5e-2, "bf16": 0.3}[precision])
+    assert np.all(np.abs(ratios - 1) <= {"fp32": 2e-3, "fp32full": 2e-3, "trunk2": 5e-2, "mixed": 5e-2, "bf16": 0.3}[precision])
     sd = m.state_dict()
     for k in ("bn1.running_mean", "bn1.running_var", "layer3.5.bn3.running_mean", "layer3.5.bn3.running_var"):
-        np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"train.stat.{k}"], rtol={"fp32": 1e-4, "trunk2": 1e-3, "mixed": 1e-3, "bf16": 3e-2}[precision],
-                                   atol={"fp32": 1e-6, "trunk2": 1e-5, "mixed": 1e-5, "bf16": 3e-3}[precision])
+        np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"train.stat.{k}"], rtol={"fp32": 1e-4, "fp32full": 1e-4, "trunk2": 1e-3, "mixed": 1e-3, "bf16": 3e-2}[precision],
+                                   atol={"fp32": 1e-6, "fp32full": 1e-6, "trunk2": 1e-5, "mixed": 1e-5, "bf16": 3e-3}[precision])
 
 
 @pytest.mark.parametrize("precision", ["mixed", "fp32"])
