@@ -78,8 +78,7 @@ class KernelTimer:
         orig_conv, orig_wgrad = ops.conv_igemm, ops.conv_wgrad
 
         def flushq():      # the batched weight (re)pack rides in front of a step's first conv launch: keep it out of that launch's bracket
-            if ops.PACKQ.jobs:
-                ops.PACKQ.flush()
+            ops.flush_packs()
 
         def conv(x, pw, cout, geom, *a, **k):
             if not timer.on or timer.only_dominant:

@@ -30,7 +30,19 @@ typedef struct kg_planes {
     int c_planes, c_pstride;   /* third bf16 rows operand */
     int y_planes, y_pstride;   /* output rows */
     int w_planes;              /* planes of the packed weights (virtual-channel layout, see kg_pack_weight) */
+    int reserved_;
+    const float* scale;        /* device scalar or NULL: kg_grad_pack / kg_f32_to_planes multiply by *scale (kg_grad_scale) */
 } kg_planes_t;
+
+/* The same C ABI is built for two 16-bit storage formats of the rows / packed-weight operands ("bf16 rows" above):
+ *   libkgnet_hip.so      bfloat16 (kg_rows_format() == 0);
+ *   libkgnet_hip_f16.so  IEEE half (kg_rows_format() == 1): 11 significant bits per plane, so hi + lo planes (22 bits, 3 MFMA
+ *                        products per multiply) carry the reference's fp32 tensors where bf16 needs three planes (6 products).
+ *                        Packed weights are stored times 2^12 and every conv epilogue scales its fp32 accumulators back; the
+ *                        gradients of a backward pass are stored times a power of two chosen on the device (kg_grad_scale).
+ * Entry points without rows operands (losses, post-processing, NMS, optimizer, ...) are format-independent and live in
+ * libkgnet_hip.so only. */
+int kg_rows_format(void);
 
 const char* kg_last_error(void);
 int kg_version(void);
@@ -205,8 +217,6 @@ int kg_mask_inter_pairs(const void* a, const void* b, const int* pairs, int npai
 /* ---- per-box segmentation branch (KGnet.py:246-267, 321-350): ragged row bookkeeping ---- */
 int kg_seg_build_rows(const int* boxtab8, int nb, int* rowdesc, int* row2box, int* srcrow, void* stream);
 int kg_rows_gather(const void* src, int ldsrc, const int* srcrow, void* dst, int lddst, long nrows, int C, void* stream);
-int kg_rows_scatter_add(const void* g, int ld, const int* srcrow, float* acc, int C, long nrows, int accld, void* stream);
-int kg_rows_scatter_add_bf16(const void* g, int ld, const int* srcrow, void* acc_bf16, int C, long nrows, int accld, void* stream);
 int kg_f32_to_bf16_rows(const float* acc, void* out, int C, long rows, int ldout, const void* addto, int ldadd,
                         void* stream);
 /* crops of the fp32 feature maps forward_dec returns (KGnet.py:318 -> get_patches :246-256): dst (planes y) = src_f32[srcrow[r]] */
@@ -234,6 +244,16 @@ int kg_crop_grad_reduce(const void* ga, int lda, const void* gb, int ldb, long r
  * is OpenCV's published generic INTER_LINEAR float path (oracle/paste.py) ---- */
 int kg_mask_paste(const float* flat, const int* dets, int nd, int input_h, int input_w, int image_h, int image_w,
                   float seg_thresh, void* out, int out_is_u8, void* stream);
+
+/* ---- gradient scale of the half-precision backward pass (csrc/gradscale.hip) ----
+ * kg_grad_scale: out[0] = S = 2^(target_log2 - e), out[1] = 1 / S, where max |v| over the n <= 24 fp32 device tensors
+ * ptrs[i][0 .. counts[i]) (host arrays of device pointers / counts) = f * 2^e, f in [0.5, 1); S = 1 when the maximum is 0 or not
+ * finite.  scratch: 2 zero-initialised unsigned on the device (left zeroed).  The tensors are the gradients of the loss w.r.t.
+ * the network outputs (12 head maps + the seg probabilities: what `loss.backward()` hands to KGnet.forward's node, train.py:153).
+ * kg_scale_tensors: multiplies njobs fp32 tensors by *scale in ONE launch: jobs = device array of 24-byte records
+ * {float* p; long n; int blk0; int pad;} (blk0 = first workgroup of the job, 4096 elements per workgroup). */
+int kg_grad_scale(const void* const* ptrs, const long* counts, int n, int target_log2, void* scratch, float* out, void* stream);
+int kg_scale_tensors(const void* jobs, int njobs, int total_blocks, const float* scale, void* stream);
 
 #ifdef __cplusplus
 }

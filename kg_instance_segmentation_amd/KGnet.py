@@ -34,6 +34,30 @@ class _Node(nn.Module):
     """Pure container so that parameter keys match the reference's dotted names."""
 
 
+def _begin_scaled_backward(eng, top_grads):
+    """Half-precision build (engine.HALF_POLICIES): the power-of-two scale of this backward pass, computed on the device from the
+    gradients of the loss w.r.t. the network outputs (ops.grad_scale).  Returns the device pair {S, 1 / S} or None (bf16 build)."""
+    if not eng.fmt:
+        return None
+    from . import ops
+    gs = ops.grad_scale(top_grads)
+    if eng.grad_store is not None:
+        eng.grad_store.unscale = gs[1:2]      # data parallel: a bucket is divided by S right before its all-reduce
+    return gs
+
+
+def _end_scaled_backward(eng, gs, pgrads):
+    """divides S out of every parameter gradient the backward pass produced outside the data-parallel flat buffer (one launch)"""
+    if gs is None:
+        return
+    from . import ops
+    store = eng.grad_store
+    ops.scale_tensors([g for k, g in pgrads.items() if g is not None and not (store is not None and store.owns(k, g))], gs[1:2])
+    if store is not None:
+        store.unscale_pending()
+        store.unscale = None
+
+
 class _DecFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, record, x, *params):
@@ -59,10 +83,13 @@ class _DecFunction(torch.autograd.Function):
             else:
                 n, c, h, w = g.shape
                 fg.append(g.float().permute(0, 2, 3, 1).contiguous().view(n * h * w, c))
-        with torch.cuda.device(next(g for g in grads if g is not None).device):
-            pg = eng.backward_dec(list(grads[:12]), fg)
-        out = [None, None, None]
         store = eng.grad_store
+        with torch.cuda.device(next(g for g in grads if g is not None).device):
+            mg = [None if g is None else g.contiguous().float() for g in grads[:12]]
+            gs = _begin_scaled_backward(eng, mg + fg)
+            pg = eng.backward_dec(mg, fg, gscale=gs)
+            _end_scaled_backward(eng, gs, pg)
+        out = [None, None, None]
         for k in ctx.keys:
             g = pg.get(k)
             if store is not None and g is not None and store.owns(k, g):
@@ -101,11 +128,16 @@ class _NetFunction(torch.autograd.Function):
         dev = next(g for g in grads if g is not None).device
         with torch.cuda.device(dev):
             gflat = grads[12]
+            if gflat is not None:
+                gflat = gflat.contiguous().float()
+            mg = [None if g is None else g.contiguous().float() for g in grads[:12]]
+            gs = _begin_scaled_backward(eng, mg + [gflat])
             fg, spg = [None] * 5, {}
             if gflat is not None and ctx.saved is not None:
-                fg, spg = seg.run_backward(ctx.plan, ctx.saved, gflat.contiguous().float(), ctx.feat_shapes)
-            pg = eng.backward_dec(list(grads[:12]), fg)
-        pg.update(spg)
+                fg, spg = seg.run_backward(ctx.plan, ctx.saved, gflat, ctx.feat_shapes, gscale=gs)
+            pg = eng.backward_dec(mg, fg, gscale=gs)
+            pg.update(spg)
+            _end_scaled_backward(eng, gs, pg)
         out = [None, None, None, None]
         store = eng.grad_store
         for k in model._all_param_keys:

@@ -9,6 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # KG_LIB_PATH: another build of the SAME library (kernel A/B tuning on one GPU box); it must export the whole C ABI like the default
 LIB_PATH = os.environ.get("KG_LIB_PATH") or os.path.join(_HERE, "libkgnet_hip.so")
+# the same C ABI built for IEEE-half rows (include/kgnet_hip.h, kg_rows_format() == 1): entry points with rows / packed-weight operands only
+LIB_F16_PATH = os.environ.get("KG_LIB_F16_PATH") or os.path.join(os.path.dirname(LIB_PATH), "libkgnet_hip_f16.so")
 
 c_int, c_long, c_float, c_double, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 P = c_void_p
@@ -16,6 +18,9 @@ P = c_void_p
 # name -> argtypes (restype is int status unless listed in _RESTYPE)
 _SIGS = {
     "kg_version": [],
+    "kg_rows_format": [],
+    "kg_grad_scale": [P, P, c_int, c_int, P, P, P],
+    "kg_scale_tensors": [P, c_int, c_int, P, P],
     "kg_device_arch": [ctypes.c_char_p, c_int],
     "kg_tr_probe": [P, P],
     "kg_conv2d_igemm": [P, P, P, P, P, P, P, P] + [c_int] * 21 + [P, P],
@@ -68,8 +73,6 @@ _SIGS = {
     "kg_f64_probe": [P, P, P, c_int, P],
     "kg_seg_build_rows": [P, c_int, P, P, P, P],
     "kg_rows_gather": [P, c_int, P, P, c_int, c_long, c_int, P],
-    "kg_rows_scatter_add": [P, c_int, P, P, c_int, c_long, c_int, P],
-    "kg_rows_scatter_add_bf16": [P, c_int, P, P, c_int, c_long, c_int, P],
     "kg_f32_to_bf16_rows": [P, P, c_int, c_long, c_int, P, c_int, P],
     "kg_rows_gather_f32": [P, c_int, P, P, c_int, c_long, c_int, P, P],
     "kg_planes_to_f32": [P, c_int, P, c_int, c_long, c_int, P, P],
@@ -81,35 +84,51 @@ _RESTYPE = {"kg_postproc_workspace_bytes": c_long}
 SYMBOLS = tuple(_SIGS) + ("kg_last_error",)
 
 _lib = None
+_lib_f16 = None
 
 
 class KGLibraryError(RuntimeError):
     pass
 
 
-def load():
-    """Loads the HIP library; raises KGLibraryError (never falls back) when it is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path, must_have_all):
+    if not os.path.exists(path):
         raise KGLibraryError(
-            f"{LIB_PATH} is missing: build it with `python -m kg_instance_segmentation_amd.build` "
+            f"{path} is missing: build it with `python -m kg_instance_segmentation_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the KGnet hot path.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     lib.kg_last_error.restype = ctypes.c_char_p
     lib.kg_last_error.argtypes = []
     for name, args in _SIGS.items():
-        fn = getattr(lib, name)  # AttributeError => ABI drift, surface it
+        if must_have_all:
+            fn = getattr(lib, name)  # AttributeError => ABI drift, surface it
+        else:
+            fn = getattr(lib, name, None)
+            if fn is None:
+                continue
         fn.argtypes = args
         fn.restype = _RESTYPE.get(name, c_int)
-    _lib = lib
     return lib
 
 
-def call(name, *args):
-    """Calls a status-returning entry point and raises on a non-zero status."""
-    lib = load()
+def load(fmt=0):
+    """Loads the HIP library (fmt 1: its IEEE-half build); raises KGLibraryError (never falls back) when it is absent."""
+    global _lib, _lib_f16
+    if fmt:
+        if _lib_f16 is None:
+            lib = _open(LIB_F16_PATH, False)
+            if lib.kg_rows_format() != 1:
+                raise KGLibraryError(f"{LIB_F16_PATH} is not the half-precision build (kg_rows_format() != 1)")
+            _lib_f16 = lib
+        return _lib_f16
+    if _lib is None:
+        _lib = _open(LIB_PATH, True)
+    return _lib
+
+
+def call(name, *args, fmt=0):
+    """Calls a status-returning entry point (of the library built for rows format `fmt`) and raises on a non-zero status."""
+    lib = load(fmt)
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise KGLibraryError(f"{name} failed ({rc}): {lib.kg_last_error().decode()}")

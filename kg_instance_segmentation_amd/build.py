@@ -14,6 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libkgnet_hip.so")
+LIB_F16 = os.path.join(HERE, "libkgnet_hip_f16.so")      # the same sources with IEEE-half rows (-DKG_F16, csrc/kg_common.h)
+# sources with rows / packed-weight operands: built once per 16-bit format
+ROWS_SOURCES = ("api.hip", "conv_igemm.hip", "conv_gather.hip", "conv_small.hip", "conv_halo.hip", "conv3_c64.hip", "conv1x1.hip",
+                "conv_wgrad.hip", "wgrad_halo.hip", "norm_pool.hip", "loss.hip", "seg.hip")
 SOURCES = {
     "api.hip": [],
     "conv_igemm.hip": [],
@@ -32,6 +36,7 @@ SOURCES = {
     "optim.hip": ["-ffp-contract=off"],
     "seg.hip": [],
     "paste.hip": ["-ffp-contract=off"],
+    "gradscale.hip": [],
 }
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -45,13 +50,16 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]
     jobs = []
-    for src, extra in SOURCES.items():
-        s = os.path.join(CSRC, src)
-        if not os.path.exists(s):
-            continue
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        if force or _stale(o, [s, __file__] + hdrs):
-            jobs.append((s, o, [HIPCC] + FLAGS + extra + ["-c", s, "-o", o]))
+    variants = [("", [], list(SOURCES)), ("_f16", ["-DKG_F16"], [s for s in SOURCES if s in ROWS_SOURCES])]
+    for suffix, defs, srcs in variants:
+        for src in srcs:
+            extra = SOURCES[src]
+            s = os.path.join(CSRC, src)
+            if not os.path.exists(s):
+                continue
+            o = os.path.join(OBJ, src.replace(".hip", suffix + ".o"))
+            if force or _stale(o, [s, __file__] + hdrs):
+                jobs.append((s, o, [HIPCC] + FLAGS + defs + extra + ["-c", s, "-o", o]))
 
     def run(job):
         s, o, cmd = job
@@ -62,16 +70,18 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr}")
         return r.stderr
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=max(4, (os.cpu_count() or 4))) as ex:
         for warn in ex.map(run, jobs):
             if warn and verbose:
                 print(warn)
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    if force or jobs or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stderr}")
+    for (suffix, _, srcs), lib in zip(variants, (LIB, LIB_F16)):
+        objs = [os.path.join(OBJ, s.replace(".hip", suffix + ".o")) for s in srcs if os.path.exists(os.path.join(CSRC, s))]
+        if force or jobs or _stale(lib, objs):
+            # -Bsymbolic: both libraries export the same C ABI; each must bind its own internal references
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", lib] + objs
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stderr}")
     return LIB
 
 

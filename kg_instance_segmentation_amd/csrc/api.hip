@@ -12,7 +12,8 @@ void kg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* kg_last_error(void) { return g_err; }
-extern "C" int kg_version(void) { return 100; }
+extern "C" int kg_version(void) { return 101; }
+extern "C" int kg_rows_format(void) { return KG_ROWS_FORMAT; }    // 0: bfloat16 rows (libkgnet_hip.so), 1: IEEE half rows (libkgnet_hip_f16.so)
 
 // Name of the GPU architecture the process sees (e.g. "gfx950:sramecc+:xnack-"); KG_ERR_HIP when no device.
 extern "C" int kg_device_arch(char* out, int cap) {
@@ -31,7 +32,7 @@ __global__ void tr_probe_kernel(unsigned short* out) {
     const int l = threadIdx.x;
     for (int j = 0; j < 4; ++j) lds[l * 4 + j] = (unsigned short)(l * 4 + j);  // element id, lane-linear 8-byte pieces
     __syncthreads();
-    bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(&lds[l * 4]));
+    bf16x4 v = KG_DS_READ_TR16((lds_bf16x4*)(&lds[l * 4]));
     *reinterpret_cast<uint2*>(&out[l * 4]) = __builtin_bit_cast(uint2, v);
 }
 extern "C" int kg_tr_probe(void* out, void* stream) {

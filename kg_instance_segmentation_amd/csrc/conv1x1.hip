@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bcur[u][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = KG_MFMA16(af[i], bcur[u][j], acc[i][j]);
             }
 #pragma unroll
             for (int u = 0; u < KU; ++u)
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bv[i * 4 + r];
+                    for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(acc[i][j][r]) + bv[i * 4 + r];
                 if (a.res) {
                     const bf16_t* rq = a.res + m * a.ldres + cb;
                     if (full && ((reinterpret_cast<uintptr_t>(rq) & 15) == 0)) {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const C1Args a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{bv[nb][i * 4 + 0], bv[nb][i * 4 + 1], bv[nb][i * 4 + 2], bv[nb][i * 4 + 3]};
+                for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{KG_BIAS_ACC(bv[nb][i * 4 + 0]), KG_BIAS_ACC(bv[nb][i * 4 + 1]), KG_BIAS_ACC(bv[nb][i * 4 + 2]), KG_BIAS_ACC(bv[nb][i * 4 + 3])};
 #pragma unroll
             for (int ks = 0; ks < 2 * KC; ++ks) {
                 bf16x8 af[4], bf[2];
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const C1Args a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = KG_MFMA16(af[i], bf[j], acc[i][j]);
             }
             if (NB == 1 || nb > 0) __syncthreads();   // NB == 1: all B fragments read, xl becomes the output tile; else: the previous block's output reads are done
 #pragma unroll
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const C1Args a) {
                     if (m >= a.M) continue;
                     const f32x4 v0 = *reinterpret_cast<const f32x4*>(ol + r * 256 + (((2 * e_c8) ^ (r & 15)) * 16));
                     const f32x4 v1 = *reinterpret_cast<const f32x4*>(ol + r * 256 + (((2 * e_c8 + 1) ^ (r & 15)) * 16));
-                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    float v[8] = {KG_ACC(v0[0]), KG_ACC(v0[1]), KG_ACC(v0[2]), KG_ACC(v0[3]), KG_ACC(v1[0]), KG_ACC(v1[1]), KG_ACC(v1[2]), KG_ACC(v1[3])};
                     if (a.res) {
                         const uint4 rv = *reinterpret_cast<const uint4*>(a.res + m * a.ldres + cpiece);
                         const bf16_t* rs = reinterpret_cast<const bf16_t*>(&rv);

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512) void conv3_c64_kernel(const C3Args a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = KG_MFMA16(af[i], bf[j], acc[i][j]);
         };
         ld(a0, b0, 0);
 #pragma unroll
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512) void conv3_c64_kernel(const C3Args a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bv[i * 4 + r];
+                for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(acc[i][j][r]) + bv[i * 4 + r];
             if (a.res) {
                 const bf16_t* rq = a.res + m * a.ldres + cb;
 #pragma unroll

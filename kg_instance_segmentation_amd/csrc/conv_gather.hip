@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k][i], bfr[k][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = KG_MFMA16(af[k][i], bfr[k][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);   // the MFMAs of k-step 0 stay in front of the wait for k-step 1
             if (k == 0 && s + 2 < nstage && wave >= 4) { issue(); __builtin_amdgcn_sched_barrier(0); }
         }
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bv[i * 4 + r];
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(acc[i][j][r]) + bv[i * 4 + r];
         if (stats) kg_stat_add(ss, sq, v);
         kg_conv_epilogue<16>(ep, m, cb, v);
     }

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
             if ((MK >> i) & 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = KG_MFMA16(af[i], bfr[j], acc[i][j]);
             }
         if (KG_HALO_SETPRIO) __builtin_amdgcn_s_setprio(0);
     };
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                             asm volatile("" : "+v"(fa[B]), "+v"(fb[B][0]), "+v"(fb[B][1]), "+v"(fb[B][2]), "+v"(fb[B][3]));
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[HD][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[B], fb[B][j], acc[HD][j], 0, 0, 0);
+                            for (int j = 0; j < 4; ++j) acc[HD][j] = KG_MFMA16(fa[B], fb[B][j], acc[HD][j]);
                             __builtin_amdgcn_sched_barrier(0);
                         };
                         rd(std::integral_constant<int, 0>{});
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bv[i * 4 + r];
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(acc[i][j][r]) + bv[i * 4 + r];
         if (stats) kg_stat_add(ss, sq, v);
         if constexpr (GM == 1) {   // fp32 NCHW export to the kp (sigmoid, KGnet.py:300) / short / mid maps
             const long hw = (long)a.H * a.W;

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(WC* WP * 64) void conv_igemm_kernel(const ConvArgs 
             for (int i = 0; i < CF; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = KG_MFMA16(af[i], bfr[j], acc[i][j]);
         }
     }
 
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(WC* WP * 64) void conv_igemm_kernel(const ConvArgs 
 #pragma unroll
         for (int i = 0; i < CF; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[i * 4 + r] = acc[i][j][r] + bv[i * 4 + r];
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(acc[i][j][r]) + bv[i * 4 + r];
         if (a.y_f32) {       // fp32 exports carry no residual / mask in KGnet (head maps)
             if (a.relu) {
 #pragma unroll
@@ -307,6 +307,7 @@ static inline PackPlanes make_pack_planes(int xP, int wP, int cin_pad) {
 __device__ __forceinline__ void pack_store_planes(bf16_t* __restrict__ rowp, float v, const PackPlanes& q, int cin_pad) {
     // rowp = &dst[row * K + tap * cin_virt + c0 + channel] of virtual plane 0
     bf16_t pl[3];
+    v *= KG_WSCALE;       // (half build: packed weights are stored times 2^12, the conv epilogues scale the accumulators back: KG_ACC)
     for (int j = 0; j < 3; ++j) { pl[j] = f2bf(v); v -= bf2f(pl[j]); }
     for (int k = 0; k < q.nv; ++k) {
         const int j = (q.wtab >> (2 * k)) & 3;

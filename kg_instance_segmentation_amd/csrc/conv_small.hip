@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[q][e] = bv[e];
+            for (int e = 0; e < 8; ++e) acc[q][e] = KG_BIAS_ACC(bv[e]);
         for (int tap = 0; tap < a.ntaps; ++tap) {
             const int dy = tap / a.KW, dx = tap - dy * a.KW;
             const int dyo = dy - a.pad, dxo = dx - a.pad;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
             if (m >= a.M) continue;
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = acc[q][e];
+            for (int e = 0; e < 8; ++e) v[e] = KG_ACC(acc[q][e]);
             if (a.res) {
                 const uint4 rv = *reinterpret_cast<const uint4*>(a.res + m * a.ldres + cb);
                 const bf16_t* rs = reinterpret_cast<const bf16_t*>(&rv);
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_small_mfma_kernel(const ConvArgs a) 
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = KG_MFMA16(af[i], bfr[j], acc[i][j]);
         }
     }
     // ---- epilogue: lane owns pixel row m and couts cb .. cb+15 (Cout % 8 == 0, 16-byte aligned rows: checked by the caller) ----
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_small_mfma_kernel(const ConvArgs a) 
         if (m >= a.M) continue;
         float v[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = acc[e >> 2][j][e & 3] + bv[e];
+        for (int e = 0; e < 16; ++e) v[e] = KG_ACC(acc[e >> 2][j][e & 3]) + bv[e];
         kg_conv_epilogue<16>(ep, m, cb, v);
     }
 }

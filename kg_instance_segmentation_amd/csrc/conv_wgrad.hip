@@ -39,7 +39,7 @@ __device__ __forceinline__ bf16x8 load_tr_frag(const unsigned char* tile, int p0
         for (int h = 0; h < 2; ++h) {
             int r = p0 + G * 8 + h * 4 + (i >> 2);
             int off = r * 128 + ((cf0 ^ tr_f(r)) * 32) + (i & 3) * 8;
-            bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + off));
+            bf16x4 v = KG_DS_READ_TR16((lds_bf16x4*)(tile + off));
             out[h * 4 + 0] = v[0]; out[h * 4 + 1] = v[1]; out[h * 4 + 2] = v[2]; out[h * 4 + 3] = v[3];
         }
     } else {
@@ -47,7 +47,7 @@ __device__ __forceinline__ bf16x8 load_tr_frag(const unsigned char* tile, int p0
         for (int j = 0; j < 8; ++j) {
             int r = p0 + G * 8 + j;
             int off = r * 128 + ((cf0 ^ tr_f(r)) * 32) + i * 2;
-            out[j] = *reinterpret_cast<const __bf16*>(tile + off);
+            out[j] = *reinterpret_cast<const kg_h16*>(tile + off);
         }
     }
     return out;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = KG_MFMA16(af[i], bfr[j], acc[i][j]);
         }
     }
 
@@ -181,7 +181,7 @@ __device__ __forceinline__ bf16x8 load_tr_frag128(const unsigned char* tile, int
     for (int h = 0; h < 2; ++h) {
         const int r = p0 + G * 8 + h * 4 + (i >> 2);
         const int off = r * 256 + ((cf ^ tr_f8(r)) * 32) + (i & 3) * 8;
-        bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + off));
+        bf16x4 v = KG_DS_READ_TR16((lds_bf16x4*)(tile + off));
         out[h * 4 + 0] = v[0]; out[h * 4 + 1] = v[1]; out[h * 4 + 2] = v[2]; out[h * 4 + 3] = v[3];
     }
     return out;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void conv_wgrad128_kernel(const WgradArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = KG_MFMA16(af[i], bfr[j], acc[i][j]);
         }
     }
     float* out = a.dwp + (long)split * a.split_stride;

@@ -5,9 +5,41 @@
 #include <stdio.h>
 #include <string.h>
 
-typedef uint16_t bf16_t;  // raw bfloat16 bits
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// ---- 16-bit operand format of the build ---------------------------------------------------------------------------------------
+// The library is built twice from the same sources (build.py): libkgnet_hip.so with bfloat16 rows / packed weights and
+// libkgnet_hip_f16.so (-DKG_F16) with IEEE half rows.  Both run at the same MFMA rate (v_mfma_f32_16x16x32_{bf16,f16}); half keeps
+// 11 significant bits per plane instead of 8, so hi + lo half planes carry 22 bits (bf16: three planes for 24) and a product of two
+// such tensors needs 3 MFMA products instead of 6 -- at the price of half's 5-bit exponent, which the build pays for with
+//   * packed weights stored as w * 2^12 (KG_WSCALE; |w| < 16 representable, the lo plane of any |w| > 3e-5 is a NORMAL half) and
+//     every conv epilogue scaling its fp32 accumulators by 2^-12 (KG_ACC),
+//   * activations stored as they are (|x| <= 65504; the lo plane of small values is a subnormal half, which the f16 MFMA keeps:
+//     tools/micro/f16_mfma.hip -- absolute error <= 2^-25),
+//   * gradients stored times a per-step power of two chosen on the device from the loss gradients (kg_grad_scale).
+// `bf16_t` / `bf16x8` / bf2f / f2bf keep their names in both builds: "the 16-bit storage element" and its conversions.
+typedef uint16_t bf16_t;  // raw bits of the 16-bit storage element (bfloat16, or IEEE half under KG_F16)
+#ifdef KG_F16
+typedef _Float16 kg_h16;
+#define KG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define KG_WSCALE 4096.0f
+#define KG_OSCALE (1.0f / 4096.0f)
+#define KG_ACC(v) ((v) * KG_OSCALE)          // fp32 accumulator of x * (w * KG_WSCALE) -> value
+#define KG_BIAS_ACC(b) ((b) * KG_WSCALE)     // a bias preloaded into such an accumulator
+#define KG_ROWS_FORMAT 1
+typedef __attribute__((ext_vector_type(4))) __fp16 kg_fp16x4_;        // (the builtin's own element type; same bits as _Float16)
+#define KG_DS_READ_TR16(p) __builtin_bit_cast(bf16x4_fwd_, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) kg_fp16x4_*)(p)))
+#else
+typedef __bf16 kg_h16;
+#define KG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define KG_WSCALE 1.0f
+#define KG_OSCALE 1.0f
+#define KG_ACC(v) (v)
+#define KG_BIAS_ACC(b) (b)
+#define KG_ROWS_FORMAT 0
+#define KG_DS_READ_TR16(p) __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p)
+#endif
+typedef __attribute__((ext_vector_type(8))) kg_h16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) kg_h16 bf16x4;
+typedef bf16x4 bf16x4_fwd_;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define KG_OK 0
@@ -42,13 +74,18 @@ void kg_set_error(const char* fmt, ...);
         }                                                                             \
     } while (0)
 
+#ifdef KG_F16
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+#else
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even f32 -> bf16 through the hardware convert: the casts below compile to ONE v_cvt_pk_bf16_f32 per pair on
-// gfx950 (the integer add-and-shift formulation costs ~8 VALU per value: 1 us per 16x16-pixel tile in the conv epilogues)
-typedef __attribute__((ext_vector_type(2))) __bf16 kg_bf16x2_t;
-__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+#endif
+// round-to-nearest-even f32 -> 16 bit through the hardware convert: the casts below compile to ONE v_cvt_pk_bf16_f32 per pair on
+// gfx950 (the integer add-and-shift formulation costs ~8 VALU per value: 1 us per 16x16-pixel tile in the conv epilogues); half:
+// v_cvt_f16_f32 (overflow -> inf: an activation beyond +-65504 surfaces as inf / NaN downstream, it is never clamped silently)
+typedef __attribute__((ext_vector_type(2))) kg_h16 kg_bf16x2_t;
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (kg_h16)f); }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    const kg_bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    const kg_bf16x2_t v = {(kg_h16)lo, (kg_h16)hi};
     return __builtin_bit_cast(uint32_t, v);
 }
 
@@ -97,9 +134,11 @@ struct kg_planes_t {
     int c_planes, c_pstride;   // third bf16 rows operand
     int y_planes, y_pstride;   // output rows
     int w_planes;              // planes of the packed weights (virtual-channel layout of kg_pack_weight*)
+    int reserved_;
+    const float* scale;        // device scalar or null: fp32 -> rows conversions (kg_grad_pack, kg_f32_to_planes) multiply by *scale
 };
 static inline kg_planes_t kg_planes_or_default(const kg_planes_t* p) {
-    kg_planes_t d = {1, 0, 1, 0, 1, 0, 1, 0, 1};
+    kg_planes_t d = {1, 0, 1, 0, 1, 0, 1, 0, 1, 0, nullptr};
     if (p) {
         d = *p;
         if (d.a_planes < 1) d.a_planes = 1;

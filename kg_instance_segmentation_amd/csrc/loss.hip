@@ -214,8 +214,9 @@ extern "C" int kg_sigmoid_inplace(float* x, long n, void* stream) {
 // Pack an fp32 NCHW gradient [N][C][HW] into bf16 rows [N*HW][ld] (channels >= C zero-filled up to
 // cpad).  If prob != null the gradient is w.r.t. sigmoid output and is multiplied by p*(1-p).
 __global__ void grad_pack_kernel(const float* __restrict__ g, const float* __restrict__ prob, bf16_t* __restrict__ out,
-                                 int N, int C, long HW, int ld, int cpad, int P, int ps) {
+                                 int N, int C, long HW, int ld, int cpad, int P, int ps, const float* __restrict__ scale) {
     long total = (long)N * HW;
+    const float S = scale ? *scale : 1.f;       // (half build: the power-of-two gradient scale of this step, gradscale.hip)
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long n = i / HW, p = i - n * HW;
         for (int c0 = 0; c0 < cpad; c0 += 8) {
@@ -229,7 +230,7 @@ __global__ void grad_pack_kernel(const float* __restrict__ g, const float* __res
                     t = g[o];
                     if (prob) { float q = prob[o]; t *= q * (1.f - q); }
                 }
-                v[e] = t;
+                v[e] = t * S;
             }
             kg_store_planes<8>(out + i * ld + c0, P, ps, v, true);
         }
@@ -244,7 +245,7 @@ extern "C" int kg_grad_pack(const float* g, const float* prob, void* out, int N,
     long total = (long)N * H * W;
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(grad_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, prob, (bf16_t*)out, N, C,
-                       (long)H * W, ld, cpad, pp.y_planes, pp.y_pstride);
+                       (long)H * W, ld, cpad, pp.y_planes, pp.y_pstride, pp.scale);
     KG_CHECK_LAUNCH("grad_pack");
     return KG_OK;
 }

@@ -46,62 +46,6 @@ extern "C" int kg_rows_gather(const void* src, int ldsrc, const int* srcrow, voi
     return KG_OK;
 }
 
-// acc[srcrow[r]][c] += g[r][c]   (fp32 atomics: boxes may overlap on the feature map)
-__global__ void rows_scatter_add_kernel(const bf16_t* __restrict__ g, int ld, const int* __restrict__ srcrow,
-                                        float* __restrict__ acc, int C8, long nrows, int accld) {
-    long total = nrows * C8;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / C8; int c = (int)(i - r * C8) * 8;
-        uint4 v = *reinterpret_cast<const uint4*>(g + r * ld + c);
-        const bf16_t* s = reinterpret_cast<const bf16_t*>(&v);
-        float* a = acc + (long)srcrow[r] * accld + c;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(a + e, bf2f(s[e]));
-    }
-}
-extern "C" int kg_rows_scatter_add(const void* g, int ld, const int* srcrow, float* acc, int C, long nrows, int accld,
-                                   void* stream) {
-    KG_CHECK_ARG(g && srcrow && acc && C % 8 == 0 && ld % 8 == 0, "kg_rows_scatter_add: bad args");
-    if (nrows == 0) return KG_OK;
-    long total = nrows * (C / 8);
-    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, ld, srcrow, acc,
-                       C / 8, nrows, accld);
-    KG_CHECK_LAUNCH("rows_scatter_add");
-    return KG_OK;
-}
-
-// acc[srcrow[r]][c] += g[r][c] with packed bf16 atomics (global_atomic_pk_add_bf16): half the atomic count of the
-// fp32 variant, no conversion pass; the accumulator is the bf16 gradient tensor itself (boxes rarely overlap more
-// than a few times, so bf16 accumulation rounding stays below the bf16 storage noise of the gradient).
-typedef __attribute__((ext_vector_type(2))) short s16x2;
-__global__ void rows_scatter_add_bf16_kernel(const bf16_t* __restrict__ g, int ld, const int* __restrict__ srcrow,
-                                             bf16_t* __restrict__ acc, int C8, long nrows, int accld) {
-    long total = nrows * C8;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / C8; int c = (int)(i - r * C8) * 8;
-        uint4 v = *reinterpret_cast<const uint4*>(g + r * ld + c);
-        bf16_t* a = acc + (long)srcrow[r] * accld + c;
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (w[e] & 0x7fff7fffu)   // skip +-0 pairs (ReLU-masked gradients are mostly zero)
-                __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) s16x2*)(a + 2 * e),
-                                                           __builtin_bit_cast(s16x2, w[e]));
-    }
-}
-extern "C" int kg_rows_scatter_add_bf16(const void* g, int ld, const int* srcrow, void* acc, int C, long nrows, int accld,
-                                        void* stream) {
-    KG_CHECK_ARG(g && srcrow && acc && C % 8 == 0 && ld % 8 == 0 && accld % 8 == 0, "kg_rows_scatter_add_bf16: bad args");
-    if (nrows == 0) return KG_OK;
-    long total = nrows * (C / 8);
-    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(rows_scatter_add_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, ld, srcrow,
-                       (bf16_t*)acc, C / 8, nrows, accld);
-    KG_CHECK_LAUNCH("rows_scatter_add_bf16");
-    return KG_OK;
-}
-
 // out[r][c] = bf16( acc[r][c] (+ addto[r][c]) )
 __global__ void f32_to_bf16_rows_kernel(const float* __restrict__ acc, bf16_t* __restrict__ out, int C8, long rows,
                                         int ldout, const bf16_t* __restrict__ addto, int ldadd) {
@@ -190,13 +134,15 @@ extern "C" int kg_planes_to_f32(const void* x, int ldx, float* out, int ldout, l
 
 // out[row][0:C] (P planes) = acc[row][0:C] (fp32) (+ addto planes)
 __global__ void f32_to_planes_kernel(const float* __restrict__ acc, int ldacc, bf16_t* __restrict__ out, int ldout, int P, int ps,
-                                     const bf16_t* __restrict__ addto, int ldadd, int aP, int aps, long rows, int C8) {
+                                     const bf16_t* __restrict__ addto, int ldadd, int aP, int aps, long rows, int C8,
+                                     const float* __restrict__ scale) {
     long total = rows * C8;
+    const float S = scale ? *scale : 1.f;       // (gradients entering the half build's backward pass: gradscale.hip; addto is already scaled)
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i / C8; int c = (int)(i - r * C8) * 8;
         const float4* sp = reinterpret_cast<const float4*>(acc + r * ldacc + c);
         const float4 a = sp[0], b = sp[1];
-        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        float v[8] = {a.x * S, a.y * S, a.z * S, a.w * S, b.x * S, b.y * S, b.z * S, b.w * S};
         if (addto) {
             float t[8];
             kg_load_planes8(addto + r * ldadd + c, aP, aps, t);
@@ -216,7 +162,7 @@ extern "C" int kg_f32_to_planes(const float* acc, int ldacc, void* out, int ldou
     long total = rows * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(f32_to_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, acc, ldacc, (bf16_t*)out, ldout, pp.y_planes,
-                       pp.y_pstride, (const bf16_t*)addto, ldadd, pp.b_planes, pp.b_pstride, rows, C / 8);
+                       pp.y_pstride, (const bf16_t*)addto, ldadd, pp.b_planes, pp.b_pstride, rows, C / 8, pp.scale);
     KG_CHECK_LAUNCH("f32_to_planes");
     return KG_OK;
 }

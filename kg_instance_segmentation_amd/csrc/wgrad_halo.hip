@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
     for (int c = 0; c < (BIAS ? NCF : 1); ++c) accb[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 ones;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    for (int e = 0; e < 8; ++e) ones[e] = (kg_h16)1.0f;
 
     // lane-constant fragment addresses of buffer 0 (absolute LDS byte addresses; k-step s adds an immediate, buffer 1 adds BUF)
     const unsigned lds0 = lds_addr(smem);
@@ -246,14 +246,14 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
                 for (int c = 0; c < NCF; ++c) { tie(fa[S & 1][c][0]); tie(fa[S & 1][c][1]); }
                 if (BIAS && do_bias) {               // wave-uniform
 #pragma unroll
-                    for (int c = 0; c < (BIAS ? NCF : 1); ++c) accb[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat(fa[S & 1][c]), ones, accb[c], 0, 0, 0);
+                    for (int c = 0; c < (BIAS ? NCF : 1); ++c) accb[c] = KG_MFMA16(cat(fa[S & 1][c]), ones, accb[c]);
                 }
             }
             tie(fb[I % (LA + 1)][0]); tie(fb[I % (LA + 1)][1]);
             if (Q < UNITS / 8 || wave + 8 * Q < UNITS) {   // (wave-uniform; only the last slot can be idle)
                 const bf16x8 bfr = cat(fb[I % (LA + 1)]);
 #pragma unroll
-                for (int c = 0; c < NCF; ++c) acc[Q][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat(fa[S & 1][c]), bfr, acc[Q][c], 0, 0, 0);
+                for (int c = 0; c < NCF; ++c) acc[Q][c] = KG_MFMA16(cat(fa[S & 1][c]), bfr, acc[Q][c]);
             }
             __builtin_amdgcn_sched_barrier(0);       // keep the unit's MFMAs between its wait and the next unit's reads
             if constexpr (I == 3 * UPW) {

@@ -6,20 +6,26 @@ pixel-major rows; channel concatenations (torch.cat at KGnet.py:289-298) never h
 write straight into column slices of the concat buffer.  ReLU backward is folded into the
 data-gradient kernels' epilogue (mask operand) whenever every contribution passes through one.
 
-Precision (ops.PT, csrc/kg_common.h "planes"): the reference is fp32 (KGnet.py:22-29).  A tensor is stored as P planes of
-bf16 whose sum is the value and multiplied with bf16 MFMA products accumulated in fp32.  A policy (PRECISIONS) names the planes
-of (backbone = stem conv1 + layer1-3 with their 43 BatchNorm layers | c0_conv + top-down decoder | the two 7x7 head layers | seg
-branch | gradients):
-  "fp32" (default) (3, 3, 3, 3 | 2): forward on hi + mid + lo planes == the fp32 values exactly, 6 products per multiply: passes
-           SURVEY 8d's fp32 tolerance (rtol 1e-4 / atol 1e-5) element-wise on pre-sigmoid logits.  The backward pass is LINEAR in the
-           incoming gradient -- its rounding does not compound through the batch statistics the way the forward's does -- and runs on
-           hi + lo planes (16 significant bits, 3 products): every parameter gradient keeps the cosine (>= 0.9999) and norm (2e-3)
-           of the all-three-plane policy to 4 digits (tools/pareto.py, profiles/r03_pareto.json) at 2/3 of its cost;
-  "fp32full" (3, 3, 3, 3 | 3): 6 products in the backward pass as well;
-  "fp32w1d1" / "fp32b1": cheaper backward operands (single-plane W / x / dY): gradient norms drift to 2.5e-3 / 1e-2;
-  "trunk2" (2, 2, 1, 1 | 1), "mixed" (2, 1, 1, 1 | 1), "bf16" (1, 1, 1, 1 | 1): bf16-MFMA mixed precision -- only the BatchNorm backbone,
-           whose train-mode batch statistics amplify a storage error ~x1.2 per layer (x3600 over the 45 layers at random init), in
-           hi + lo planes; held to the blueprint's bf16 clause (rtol 2e-2) plus a stated atol, not to the fp32 tolerance.
+Precision (ops.PT, csrc/kg_common.h): the reference is fp32 (KGnet.py:22-29); gfx950's fast matrix path is the 16-bit MFMA with fp32
+accumulation (2.5 PFLOP/s for bf16 and half alike, against 157 TFLOP/s for fp32 operands).  A tensor is therefore stored as P
+16-bit "planes" whose sum is the value, and a product of two such tensors is evaluated as the MFMA products x_i * w_j with
+i + j < max(xP, wP), accumulated in fp32.  A policy (PRECISIONS) names the 16-bit format and the planes of (backbone = stem conv1 +
+layer1-3 with their 43 BatchNorm layers | c0_conv + top-down decoder | the two 7x7 head layers | seg branch | gradients):
+  "fp32" (default), IEEE half, (2, 2, 2, 2 | 1): hi + lo half planes carry 22 significant bits, 3 products per multiply: the forward
+           pass is within SURVEY 8d's fp32 tolerance (rtol 1e-4 / atol 1e-5, element-wise on pre-sigmoid logits; worst measured
+           |d| / bound 0.44 eval, 0.87 train).  Half's 5-bit exponent is paid for with a constant weight scale (kg_common.h KG_WSCALE)
+           and, in the backward pass -- which is LINEAR in the loss gradients, so its rounding does not compound through the batch
+           statistics the way the forward's does and single half planes (11 bits, 1 product) suffice: every parameter gradient
+           cosine >= 0.99998, norm within 6e-4 of the reference -- with one power-of-two gradient scale per step chosen on the device
+           (csrc/gradscale.hip, ops.grad_scale);
+  "fp32b2": hi + lo half planes in the backward pass as well (3 products);
+  "half" / "halfmix": half mixed precision (single planes; the BatchNorm backbone on two): within rtol 2e-2 / atol 2e-2 rms;
+  "fp32bf" (bfloat16, (3, 3, 3, 3 | 2)): hi + mid + lo bf16 planes == the fp32 value exactly, 6 products per multiply, backward on
+           hi + lo planes (3 products): the same tolerance as "fp32" at 2.1x its cost; "fp32bf_full": 6 products in the backward too;
+  "trunk2", "mixed", "bf16" (bfloat16): bf16 mixed precision -- only the BatchNorm backbone, whose train-mode batch statistics
+           amplify a storage error ~x1.2 per layer (x3600 over the 45 layers at random init), in hi + lo planes.
+(tools/pareto.py -> profiles/r03_pareto.json lists, per policy, the worst deviation at both tolerances of SURVEY 8d and the train-step
+throughput.)
 """
 import os
 
@@ -28,16 +34,22 @@ import torch
 from . import arch, ops
 from .ops import BF16, PT, PackedWeight
 
-# planes of (backbone, c0 + decoder, heads, seg branch, GRADIENTS flowing through backbone / decoder = operands of the backward convs)
 # planes of (backbone, c0 + decoder, heads, seg branch, GRADIENTS flowing through the network = dY operand of the input gradients
 # [, x and dY of the WEIGHT gradients (their rounding does not propagate) [, W of the input gradients]])
 PRECISIONS = {
-    "fp32": (3, 3, 3, 3, 2),          # default: fp32-faithful forward (6 products), backward on hi + lo operands (3 products)
-    "fp32full": (3, 3, 3, 3, 3),      # three planes in the backward pass as well (6 products everywhere)
-    "fp32w1d1": (3, 3, 3, 3, 2, 1, 1),  # gradients stored in two planes, single-plane W / x / dY operands in the backward convolutions
-    "fp32b1": (3, 3, 3, 3, 1),        # single-plane backward
+    # IEEE-half rows (libkgnet_hip_f16.so): hi + lo half planes = 22 significant bits, 3 MFMA products per multiply
+    "fp32": (2, 2, 2, 2, 1),          # DEFAULT: fp32-faithful forward on hi + lo half planes, backward on single half planes
+    "fp32b2": (2, 2, 2, 2, 2),        # hi + lo half planes in the backward pass as well
+    "half": (1, 1, 1, 1, 1),          # half mixed precision: single half planes everywhere (11 significant bits)
+    "halfmix": (2, 1, 1, 1, 1),       # ... with the BatchNorm backbone (the amplifier of storage errors in train mode) on hi + lo planes
+    # bfloat16 rows (libkgnet_hip.so)
+    "fp32bf": (3, 3, 3, 3, 2),        # fp32 values as hi + mid + lo bf16 planes (exact), 6 products; backward on hi + lo planes (3 products)
+    "fp32bf_full": (3, 3, 3, 3, 3),   # three bf16 planes in the backward pass as well (6 products everywhere: round 2's "fp32")
+    "fp32bf_w1d1": (3, 3, 3, 3, 2, 1, 1),  # gradients stored in two planes, single-plane W / x / dY operands in the backward convolutions
+    "fp32bf_b1": (3, 3, 3, 3, 1),     # single-plane bf16 backward
     "trunk2": (2, 2, 1, 1, 1), "mixed": (2, 1, 1, 1, 1), "bf16": (1, 1, 1, 1, 1),
 }
+HALF_POLICIES = ("fp32", "fp32b2", "half", "halfmix")
 DEFAULT_PRECISION = "fp32"
 
 
@@ -80,10 +92,10 @@ class Var:
         if self.parent is not None:
             p = self.parent
             if p.grad is None:
-                p.grad = ops.alloc_pt(p.rows, p.C, p.gP, p.t.device)
+                p.grad = ops.alloc_pt(p.rows, p.C, p.gP, p.t.device, dtype=p.t.t.dtype)
                 p.masked = True
             return p.grad.cols(self.c0, self.c0 + self.C)
-        return ops.alloc_pt(self.rows, self.C, self.gP, self.t.device)
+        return ops.alloc_pt(self.rows, self.C, self.gP, self.t.device, dtype=self.t.t.dtype)
 
     def add_grad(self, g, masked):
         if self.parent is not None:      # written in place into the parent's buffer
@@ -153,6 +165,9 @@ class Engine:
         self.pt, self.pd, self.ph, self.pseg, self.pg = pol[:5]
         self.pw = pol[5] if len(pol) > 5 else self.pg        # planes of x and dY in the weight gradients (their error does not propagate)
         self.pdw = pol[6] if len(pol) > 6 else self.pg       # planes of W in the input gradients
+        self.dt = ops.F16 if precision in HALF_POLICIES else ops.BF16      # 16-bit format of every rows tensor / packed weight (ops.fmt_of)
+        self.fmt = 1 if self.dt == ops.F16 else 0
+        self.gscale = None         # half build: device {S, 1 / S} of the running backward pass (ops.grad_scale)
         self.bpt = self.pt         # backbone planes of the CURRENT forward (see forward_dec)
         self.invalidate_caches()
 
@@ -220,7 +235,7 @@ class Engine:
         taps = s.k * s.k
         if s.pw is None or s.versions != ver or s.pw.buf.device != dev:
             if s.pw is None or s.pw.buf.device != dev:
-                s.pw = PackedWeight(s.cout, taps, s.cin_pad, dev, xP=s.P, wP=s.P)
+                s.pw = PackedWeight(s.cout, taps, s.cin_pad, dev, xP=s.P, wP=s.P, dtype=self.dt)
                 s.pw.cin_real = s.cin          # (FLOP accounting of bench.py: real channels, not the padding / plane copies)
                 s.pwT = None
             r = 0
@@ -235,7 +250,7 @@ class Engine:
                 s.pwT.stale = True
         if need_T and (s.pwT is None or getattr(s.pwT, "stale", True)):
             if s.pwT is None:
-                s.pwT = PackedWeight(s.cin, taps, ops.round_up(s.cout, 8), dev, xP=s.gP, wP=min(s.P, s.gP, self.pdw))    # backward operands: gP planes
+                s.pwT = PackedWeight(s.cin, taps, ops.round_up(s.cout, 8), dev, xP=s.gP, wP=min(s.P, s.gP, self.pdw), dtype=self.dt)    # backward operands: gP planes
                 s.pwT.cin_real = s.cout
             r = 0
             for w, co in zip(ws, s.couts):
@@ -256,15 +271,15 @@ class Engine:
         dev = xv.t.device
         oP = s.P if oP is None else oP
         if y_f32 is None and out is None:
-            out = ops.alloc_pt(M, s.cout, oP, dev)
+            out = ops.alloc_pt(M, s.cout, oP, dev, dtype=self.dt)
         geom = (M, H, W, OH, OW, s.k, s.k, s.stride, s.pad)
         xin = trunc(xv.t, s.P)
         arm = bn_stats and ops.CONV_BN_STATS and self.m.training and y_f32 is None and not relu
-        part = ops.conv_stats_begin(dev) if arm else None
+        part = ops.conv_stats_begin(dev, self.fmt) if arm else None
         ops.conv_auto(xin, s.pw, s.cout, geom, N, y=out, y_f32=y_f32, bias=s.bias_cat if s.has_bias else None, relu=relu, tile=tile)
         yv = Var(out, s.cout, relu=relu, gP=s.gP)
         if arm:
-            nb = ops.conv_stats_end()
+            nb = ops.conv_stats_end(self.fmt)
             yv.bn_part = (part, nb) if nb > 0 else None
         if train:
             def bwd():
@@ -304,7 +319,7 @@ class Engine:
         gamma, beta = self.P(p + ".weight"), self.P(p + ".bias")
         rm, rv = self.P(p + ".running_mean"), self.P(p + ".running_var")
         if out is None:
-            out = ops.alloc_pt(xv.rows, C, self.bpt, dev)
+            out = ops.alloc_pt(xv.rows, C, self.bpt, dev, dtype=self.dt)
         if self.m.training:
             bp = getattr(xv, "bn_part", None)
             if bp is not None:       # the producing conv's epilogue already summed the rows (conv_args.h): second stage only
@@ -335,7 +350,7 @@ class Engine:
                     return
                 dg = self.new_grad(p + ".weight", gamma)
                 db = self.new_grad(p + ".bias", beta)
-                dx = ops.alloc_pt(xv.rows, C, xv.gP, dev)
+                dx = ops.alloc_pt(xv.rows, C, xv.gP, dev, dtype=self.dt)
                 ops.bn_bwd(xv.t, g, C, gamma.detach(), mean, invstd, dg, db, dx)
                 self.param_grads[p + ".weight"] = dg
                 self.param_grads[p + ".bias"] = db
@@ -348,7 +363,7 @@ class Engine:
     def maxpool(self, xv, N, H, W):
         C = xv.C
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        out = ops.alloc_pt(N * OH * OW, C, xv.P, xv.t.device)
+        out = ops.alloc_pt(N * OH * OW, C, xv.P, xv.t.device, dtype=self.dt)
         arg = torch.empty(N * OH * OW, C, dtype=torch.uint8, device=xv.t.device) if self.tape is not None else None
         ops.maxpool_fwd(xv.t, out, N, H, W, C, argmax=arg)
         yv = Var(out, C, relu=False, gP=xv.gP)
@@ -357,7 +372,7 @@ class Engine:
                 g = yv.take_grad()
                 if g is None:
                     return
-                dx = ops.alloc_pt(xv.rows, C, xv.gP, xv.t.device)
+                dx = ops.alloc_pt(xv.rows, C, xv.gP, xv.t.device, dtype=self.dt)
                 ops.maxpool_bwd(xv.t, g, dx, N, H, W, C, argmax=arg)
                 xv.add_grad(dx, masked=False)
             self.tape.append(bwd)
@@ -365,7 +380,7 @@ class Engine:
 
     def upsample(self, xv, N, IH, IW, OH, OW, P=None):
         C = xv.C
-        out = ops.alloc_pt(N * OH * OW, C, xv.P if P is None else P, xv.t.device)
+        out = ops.alloc_pt(N * OH * OW, C, xv.P if P is None else P, xv.t.device, dtype=self.dt)
         ops.bilinear_fwd(xv.t, out, N, IH, IW, OH, OW, C)
         yv = Var(out, C, relu=False, gP=min(out.P, self.pg))
         if self.tape is not None:
@@ -373,7 +388,7 @@ class Engine:
                 g = yv.take_grad()
                 if g is None:
                     return
-                dx = ops.alloc_pt(xv.rows, C, xv.gP, xv.t.device)
+                dx = ops.alloc_pt(xv.rows, C, xv.gP, xv.t.device, dtype=self.dt)
                 ops.bilinear_bwd(g, dx, N, IH, IW, OH, OW, C)
                 xv.add_grad(dx, masked=False)
             self.tape.append(bwd)
@@ -432,15 +447,15 @@ class Engine:
         # BatchNorm amplifier of storage errors is gone, and "mixed" batch-1 inference is 25 % faster in plain bf16.)
         self.bpt = self.pt if (self.m.training or not self.eval_downgrade) else min(self.pt, max(self.pd, 1))
         pt, pd = self.bpt, self.pd
-        x8 = Var(ops.img_pack(img, max(pt, pd)), 8, relu=False, req=False)
+        x8 = Var(ops.img_pack(img, max(pt, pd), dtype=self.dt), 8, relu=False, req=False)
         dims = [(H, W)]
         # c0 branch (KGnet.py:276): both convs at full resolution; c0 lands in cat0[:, 64:128]
-        cat0 = ops.alloc_pt(N * H * W, 128, pd, dev)
+        cat0 = ops.alloc_pt(N * H * W, 128, pd, dev, dtype=self.dt)
         c0a, _, _ = self.conv(x8, self.spec("c0_conv.0", 3, 64, 3, 1, 1, P=pd), N, H, W, True)
         c0, _, _ = self.conv(c0a, self.spec("c0_conv.2", 64, 64, 3, 1, 1, P=pd), N, H, W, True, out=cat0.cols(64, 128))
         # stem (KGnet.py:278-282)
         s1, H1, W1 = self.conv(x8, self.spec("conv1", 3, 64, 7, 2, 3, bias=False), N, H, W, False)
-        cat1 = ops.alloc_pt(N * H1 * W1, 128, pt, dev)
+        cat1 = ops.alloc_pt(N * H1 * W1, 128, pt, dev, dtype=self.dt)
         c1 = self.bn(s1, "bn1", True, out=cat1.cols(64, 128))
         f, Hc, Wc = self.maxpool(c1, N, H1, W1)
         dims.append((H1, W1))
@@ -452,7 +467,7 @@ class Engine:
                 Ho, Wo = (Hc - 1) // st + 1, (Wc - 1) // st + 1
                 out = None
                 if b == blocks - 1 and li < 2:  # c2 / c3 land in their concat buffers
-                    catb = ops.alloc_pt(N * Ho * Wo, planes * 8, pt, dev)
+                    catb = ops.alloc_pt(N * Ho * Wo, planes * 8, pt, dev, dtype=self.dt)
                     cats.append(catb)
                     out = catb.cols(planes * 4, planes * 8)
                 f, Hc, Wc = self.bottleneck(f, f"{name}.{b}", N, Hc, Wc, inplanes if b == 0 else planes * 4, planes, st, b == 0, out=out)
@@ -517,7 +532,7 @@ class Engine:
         ent = self.fusedT.get(key)
         if ent is None or ent[0] != ver or ent[1].buf.device != dev:
             lay = self.heads2_tables(dev)
-            pwF = ent[1] if ent is not None and ent[1].buf.device == dev else PackedWeight(64, 49, C, dev, xP=ph, wP=ph, groups=3)
+            pwF = ent[1] if ent is not None and ent[1].buf.device == dev else PackedWeight(64, 49, C, dev, xP=ph, wP=ph, groups=3, dtype=self.dt)
             for k, w in enumerate(ws):
                 pwF.pack_rows(w.detach(), lay["rows"][k], group=k)
             bias64 = torch.cat([b.detach() for b in bs] + [lay["zero1"]])[lay["bias_idx"]]
@@ -530,7 +545,7 @@ class Engine:
             ver = self.stamp + tuple(w._version for w in ws) + tuple(w.data_ptr() for w in ws)
             if ent is None or ent[0] != ver or ent[1].buf.device != dev:
                 gph = min(ph, self.pg)
-                pwT = ent[1] if ent is not None and ent[1].buf.device == dev else PackedWeight(3 * C, 49, 64, dev, xP=gph, wP=min(gph, self.pdw))
+                pwT = ent[1] if ent is not None and ent[1].buf.device == dev else PackedWeight(3 * C, 49, 64, dev, xP=gph, wP=min(gph, self.pdw), dtype=self.dt)
                 for k, w in enumerate(ws):
                     pwT.pack(w.detach(), row0=k * C, c0=self.HEAD_OFF[k], transposed=True)
                 self.fusedT[key] = (ver, pwT)
@@ -567,7 +582,7 @@ class Engine:
                     ops.conv_wgrad(trunc(hid.t, min(hid.gP, self.pw)).cols(k * C, (k + 1) * C), trunc(gk, self.pw), C, co, geom, [(gw, 0, co)], N=N, bias_out=db)
                     self.param_grads[s.names[0] + ".weight"] = gw
                     self.param_grads[s.names[0] + ".bias"] = db
-                dh = ops.alloc_pt(hid.rows, 3 * C, hid.gP, dev)
+                dh = ops.alloc_pt(hid.rows, 3 * C, hid.gP, dev, dtype=self.dt)
                 # kp / short cout blocks only see dY channels 0..23 (k-step 1 of the chunk skipped); mid sees 24..63
                 ops.conv_halo(g, pwT, 2 * C, N, H, W, 7, y=dh.cols(0, 2 * C), mask=hid.t.hi()[:, :2 * C], flip=True, k1skip=True, algo_cin=7.5)
                 ops.conv_halo(g, pwT.rows_from(2 * C), C, N, H, W, 7, y=dh.cols(2 * C, 3 * C), mask=hid.t.hi()[:, 2 * C:], flip=True, algo_cin=40)
@@ -584,8 +599,11 @@ class Engine:
             outs.append(o.view(self.N, h, w, fv.C).permute(0, 3, 1, 2))
         return outs
 
-    def backward_dec(self, map_grads, feat_grads):
-        """map_grads: 12 fp32 NCHW (or None); feat_grads: 5 fp32 [rows, C] tensors (or None)."""
+    def backward_dec(self, map_grads, feat_grads, gscale=None):
+        """map_grads: 12 fp32 NCHW (or None); feat_grads: 5 fp32 [rows, C] tensors (or None) or split rows (ops.PT) already in the
+        backward pass's own scale.  gscale (half build): device {S, 1 / S} of this backward pass (ops.grad_scale) -- the fp32 gradients
+        enter times S, the parameter gradients come back times S (the caller divides them: ops.scale_tensors)."""
+        gsc = gscale[0:1] if gscale is not None else None
         if self.grad_store is not None:
             self.grad_store.dense_backward_started()
         for (slot, lvl, N, Hh, Wh) in self.head_slots:
@@ -593,7 +611,7 @@ class Engine:
             if all(g is None for g in gs):
                 continue
             dev = self.maps[3 * lvl].device
-            packed = ops.alloc_pt(N * Hh * Wh, 64, min(self.ph, self.pg), dev)
+            packed = ops.alloc_pt(N * Hh * Wh, 64, min(self.ph, self.pg), dev, dtype=self.dt)
             for k, g in enumerate(gs):
                 co = arch.HEADS[k][1]
                 view = packed.cols(self.HEAD_OFF[k], self.HEAD_OFF[k] + self.HEAD_PAD[k])
@@ -602,7 +620,7 @@ class Engine:
                         view.plane(p).zero_()
                 else:
                     prob = self.maps[3 * lvl] if k == 0 else None
-                    ops.grad_pack(g.contiguous().float(), prob, view, N, co, Hh, Wh, self.HEAD_PAD[k])
+                    ops.grad_pack(g.contiguous().float(), prob, view, N, co, Hh, Wh, self.HEAD_PAD[k], scale=gsc)
             slot["grad"] = packed
         for fv, g in zip(self.feats, feat_grads):
             if g is None:
@@ -610,8 +628,8 @@ class Engine:
             if isinstance(g, PT):              # the fused forward's seg backward already wrote split-bf16 rows
                 fv.add_grad(g, masked=False)
                 continue
-            gp = ops.alloc_pt(fv.rows, fv.C, fv.gP, g.device)
-            ops.f32_to_planes(g, gp, fv.C)
+            gp = ops.alloc_pt(fv.rows, fv.C, fv.gP, g.device, dtype=self.dt)
+            ops.f32_to_planes(g, gp, fv.C, scale=gsc)
             fv.add_grad(gp, masked=False)
         hook = self.grad_hook
         tape, self.tape = self.tape, None

@@ -13,6 +13,7 @@ from . import _lib
 from ._lib import c_int, c_long, c_float, c_double, ptr, stream_ptr
 
 BF16 = torch.bfloat16
+F16 = torch.float16      # rows of the half-precision build (libkgnet_hip_f16.so, csrc/kg_common.h): 11 significant bits per plane
 _scratch = {}
 PARAM_EPOCH = [0]      # bumped whenever parameters / running statistics are written behind PyTorch's version counters (engine.prepare)
 
@@ -68,14 +69,29 @@ class PT:
         return self.t.as_strided(self.t.shape, self.t.stride(), self.t.storage_offset() + p * self.ps)
 
 
-def alloc_pt(rows, C, P, dev, zero=False):
-    """[rows, C] in P planes: one [rows, P*C] buffer, plane p = columns p*C .. (p+1)*C."""
-    buf = (torch.zeros if zero else torch.empty)(rows, P * C, dtype=BF16, device=dev)
+def alloc_pt(rows, C, P, dev, zero=False, dtype=BF16):
+    """[rows, C] in P planes: one [rows, P*C] buffer, plane p = columns p*C .. (p+1)*C.  dtype: BF16 or F16 (the 16-bit format)."""
+    buf = (torch.zeros if zero else torch.empty)(rows, P * C, dtype=dtype, device=dev)
     return PT(buf[:, :C], P, C)
 
 
 def base(x):
     return x.t if isinstance(x, PT) else x
+
+
+def fmt_of(x):
+    """rows format of a tensor / PT / PackedWeight: 0 = bfloat16 (libkgnet_hip.so), 1 = IEEE half (libkgnet_hip_f16.so)"""
+    if isinstance(x, PackedWeight):
+        x = x.buf
+    dt = base(x).dtype
+    if dt == F16:
+        return 1
+    assert dt == BF16, dt
+    return 0
+
+
+def dtype_of(x):
+    return base(x).dtype
 
 
 def nplanes(x):
@@ -84,20 +100,24 @@ def nplanes(x):
 
 class _Planes(_lib.ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("a_planes", "a_pstride", "b_planes", "b_pstride", "c_planes", "c_pstride",
-                                     "y_planes", "y_pstride", "w_planes")]
+                                     "y_planes", "y_pstride", "w_planes", "reserved_")] + [("scale", _lib.c_void_p)]
 
 
 _PL_CACHE = {}
 
 
-def pl(a=None, b=None, c=None, y=None, w=1):
-    """kg_planes_t* for a call (None when every operand is single-plane bf16).  a / b / c / y: rows operands (tensor, PT or None)."""
-    key = nplanes(a) + nplanes(b) + nplanes(c) + nplanes(y) + (w,)
-    if key == (1, 0, 1, 0, 1, 0, 1, 0, 1):
+def pl(a=None, b=None, c=None, y=None, w=1, scale=None):
+    """kg_planes_t* for a call (None when every operand is single-plane and there is no scale).  a / b / c / y: rows operands
+    (tensor, PT or None); scale: device fp32 scalar the fp32 -> rows conversions multiply by (kg_grad_scale)."""
+    sp = scale.data_ptr() if scale is not None else 0
+    key = nplanes(a) + nplanes(b) + nplanes(c) + nplanes(y) + (w, 0, sp)
+    if key == (1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 0):
         return None
     st = _PL_CACHE.get(key)
     if st is None:
-        st = _lib.ctypes.pointer(_Planes(*key))
+        if len(_PL_CACHE) > 4096:
+            _PL_CACHE.clear()
+        st = _lib.ctypes.pointer(_Planes(*key[:10], sp or None))
         _PL_CACHE[key] = st
     return st
 
@@ -110,7 +130,7 @@ def vplanes(xP, wP):
 
 def _rows(t):
     t = base(t)
-    assert t.dim() == 2 and t.dtype == BF16 and (t.shape[1] == 1 or t.stride(1) == 1), (t.shape, t.stride(), t.dtype)
+    assert t.dim() == 2 and t.dtype in (BF16, F16) and (t.shape[1] == 1 or t.stride(1) == 1), (t.shape, t.stride(), t.dtype)
     return t
 
 
@@ -127,10 +147,20 @@ class PackQueue:
     every conv wrapper) packs all recorded tensors with ONE kg_pack_weight_batch launch.  The job table is uploaded only
     when it differs from the previous step's (same tensors -> same pointers)."""
 
-    def __init__(self):
-        self.defer = False
+    DEFER = [False]      # (one switch for the queues of both formats)
+
+    def __init__(self, fmt=0):
+        self.fmt = fmt
         self.jobs, self.keep = [], []
         self.sig, self.table = None, None
+
+    @property
+    def defer(self):
+        return PackQueue.DEFER[0]
+
+    @defer.setter
+    def defer(self, v):
+        PackQueue.DEFER[0] = v
 
     def add(self, w, pw, row0, c0, transposed, rowmap, tap_stride=0):
         Cout, Cin, KH, KW = w.shape
@@ -156,11 +186,20 @@ class PackQueue:
         if sig != self.sig or self.table is None or self.table.device != dev:
             self.table = h2d(arr.view(np.uint8).reshape(-1), dev)
             self.sig = sig
-        _lib.call("kg_pack_weight_batch", ptr(self.table), len(self.jobs), blk, stream_ptr())
+        _lib.call("kg_pack_weight_batch", ptr(self.table), len(self.jobs), blk, stream_ptr(), fmt=self.fmt)
         self.jobs, self.keep = [], []
 
 
-PACKQ = PackQueue()
+PACKQ = PackQueue(0)
+PACKQ16 = PackQueue(1)
+
+
+def flush_packs():
+    """packs every weight queued since the last conv launch (one kg_pack_weight_batch launch per 16-bit format)"""
+    if PACKQ.jobs:
+        PACKQ.flush()
+    if PACKQ16.jobs:
+        PACKQ16.flush()
 
 
 class PackedWeight:
@@ -169,13 +208,13 @@ class PackedWeight:
     of the kept products x_i * w_j (smallest first), a copy of w plane j of cin_pad channels each; groups > 1: that many such blocks side by side
     (the fused second-layer heads), tap stride = groups * vplanes * cin_pad."""
 
-    def __init__(self, rows, taps, cin_pad, dev, xP=1, wP=1, groups=1):
+    def __init__(self, rows, taps, cin_pad, dev, xP=1, wP=1, groups=1, dtype=BF16):
         self.rows, self.taps, self.cin_pad, self.xP, self.wP, self.groups = rows, taps, cin_pad, xP, wP, groups
         self.vp = vplanes(xP, wP)
         self.tap_stride = groups * self.vp * cin_pad
         # (8-channel inputs: conv_small.hip reads whole tap quads)
         self.K = round_up((round_up(taps, 4) if cin_pad == 8 else taps) * self.tap_stride, 64)
-        self.buf = torch.zeros(round_up(rows, 384), self.K, dtype=BF16, device=dev)   # rows cover any 64/128/192 cout tile
+        self.buf = torch.zeros(round_up(rows, 384), self.K, dtype=dtype, device=dev)   # rows cover any 64/128/192 cout tile
 
     def pack(self, w, row0=0, c0=0, transposed=False):
         """w: fp32 OIHW parameter.  forward: rows=Cout, channels=Cin; transposed (dgrad): rows=Cin, channels=Cout."""
@@ -183,10 +222,10 @@ class PackedWeight:
         assert w.dtype == torch.float32 and w.is_contiguous()
         assert self.groups == 1
         if PACKQ.defer:
-            PACKQ.add(w, self, row0, c0, transposed, None)
+            (PACKQ16 if fmt_of(self) else PACKQ).add(w, self, row0, c0, transposed, None)
             return
         _lib.call("kg_pack_weight", ptr(w), ptr(self.buf), Cout, Cin, KH, KW, self.K, self.cin_pad, row0, c0,
-                  1 if transposed else 0, self.xP, self.wP, stream_ptr())
+                  1 if transposed else 0, self.xP, self.wP, stream_ptr(), fmt=fmt_of(self))
 
 
     def rows_from(self, r0):
@@ -202,10 +241,10 @@ class PackedWeight:
         assert w.dtype == torch.float32 and w.is_contiguous() and rowmap.dtype == torch.int32 and rowmap.numel() == Cout
         c0 = group * self.vp * self.cin_pad
         if PACKQ.defer:
-            PACKQ.add(w, self, 0, c0, False, rowmap, self.tap_stride)
+            (PACKQ16 if fmt_of(self) else PACKQ).add(w, self, 0, c0, False, rowmap, self.tap_stride)
             return
         _lib.call("kg_pack_weight_rows", ptr(w), ptr(self.buf), Cout, Cin, KH, KW, self.K, self.cin_pad, ptr(rowmap), c0,
-                  self.xP, self.wP, self.tap_stride, stream_ptr())
+                  self.xP, self.wP, self.tap_stride, stream_ptr(), fmt=fmt_of(self))
 
 
 def heads2_layout():
@@ -224,19 +263,17 @@ def heads2_layout():
 
 def conv_halo_heads2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C, kp_sigmoid=True):
     """kg_conv2d_halo_heads2: x = fused hidden rows [N*H*W, >=3C]; kp/sh/md fp32 NCHW outputs (kp gets the sigmoid)."""
-    if PACKQ.jobs:
-        PACKQ.flush()
+    flush_packs()
     assert kp.is_contiguous() and sh.is_contiguous() and md.is_contiguous() and vmap.dtype == torch.int32
     assert nplanes(x)[0] == pw.xP and pw.groups == 3
     _lib.call("kg_conv2d_halo_heads2", ptr(_rows(x)), ptr(pw.buf), ptr(bias64), ptr(vmap), ptr(kp), ptr(sh), ptr(md), N, H, W, C,
-              ld(x), pw.K, 1 if kp_sigmoid else 0, pl(a=x, w=pw.wP), stream_ptr())
+              ld(x), pw.K, 1 if kp_sigmoid else 0, pl(a=x, w=pw.wP), stream_ptr(), fmt=fmt_of(x))
 
 
 def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, mode=0,
                rowdesc=None, tile=0):
     """geom = (M, H, W, OH, OW, KH, KW, stride, pad): H, W = gathered tensor's dims, OH, OW = output dims."""
-    if PACKQ.jobs:
-        PACKQ.flush()
+    flush_packs()
     M, H, W, OH, OW, KH, KW, stride, pad = geom
     assert nplanes(x)[0] == pw.xP, (nplanes(x), pw.xP)
     f32_C = 0
@@ -246,7 +283,7 @@ def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=
     _lib.call("kg_conv2d_igemm", ptr(_rows(x)), ptr(pw.buf), ptr(bias), ptr(base(y)), ptr(y_f32), ptr(base(res)), ptr(base(mask)), ptr(rowdesc),
               M, H, W, OH, OW, pw.cin_pad, ld(x), cout, ld(y) if y is not None else 0,
               ld(res) if res is not None else 0, ld(mask) if mask is not None else 0, pw.K, KH, KW, stride, pad, 1,
-              mode, 1 if relu else 0, f32_C, tile, pl(a=x, b=res, y=y, w=pw.wP), stream_ptr())
+              mode, 1 if relu else 0, f32_C, tile, pl(a=x, b=res, y=y, w=pw.wP), stream_ptr(), fmt=fmt_of(x))
 
 
 USE_HALO = True
@@ -264,19 +301,17 @@ def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None,
     tiletab (int32 [ntiles,4] device tensor): ragged boxes instead of N images of HxW.
     k1skip (7x7 only): the packed weights are zero for channels 32..63 of every 64-channel chunk.
     algo_cin: number of input channels that carry data (FLOP accounting of bench.py's timer; unused here)."""
-    if PACKQ.jobs:
-        PACKQ.flush()
+    flush_packs()
     assert nplanes(x)[0] == pw.xP, (nplanes(x), pw.xP)
     planes = pl(a=x, b=res, y=y, w=pw.wP)
     x, y, res, mask = base(x), base(y), base(res), base(mask)
     if (USE_C3 and planes is None and KS == 3 and pw.cin_pad == 64 and y is not None and y_f32 is None and wc == 0 and HALO_WC == 0
             and (tiletab is None or tiletab16 is not None)):
         # 64 input channels: persistent kernel with resident weights and double-buffered halos (conv3_c64.hip)
-        if PACKQ.jobs:
-            PACKQ.flush()
+        flush_packs()
         _lib.call("kg_conv3x3_c64", ptr(_rows(x)), ptr(pw.buf), ptr(bias), ptr(y), ptr(res), ptr(mask), N, H, W, ld(x), cout, ld(y),
                   ld(res) if res is not None else 0, ld(mask) if mask is not None else 0, pw.K, 1 if flip else 0, 1 if relu else 0,
-                  ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, stream_ptr())
+                  ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, stream_ptr(), fmt=fmt_of(x))
         return
     wc = wc or HALO_WC
     if k1skip:
@@ -288,7 +323,7 @@ def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None,
     _lib.call("kg_conv2d_halo", ptr(_rows(x)), ptr(pw.buf), ptr(bias), ptr(y), ptr(y_f32), ptr(res), ptr(mask), N, H, W,
               pw.cin_pad, ld(x), cout, ld(y) if y is not None else 0, ld(res) if res is not None else 0,
               ld(mask) if mask is not None else 0, pw.K, KS, 1 if flip else 0, 1 if relu else 0, f32_C, wc, ptr(tiletab),
-              tiletab.shape[0] if tiletab is not None else 0, total_rows, planes, stream_ptr())
+              tiletab.shape[0] if tiletab is not None else 0, total_rows, planes, stream_ptr(), fmt=fmt_of(x))
 
 
 USE_1X1 = True
@@ -297,13 +332,12 @@ GATHER_1X1 = __import__("os").environ.get("KG_GATHER_1X1", "1") == "1"
 
 def conv1x1(x, pw, cout, y, bias=None, res=None, mask=None, relu=False):
     """1x1 stride-1 conv / input gradient as a streaming GEMM over the rows of x (kg_conv1x1); single-plane bf16 only."""
-    if PACKQ.jobs:
-        PACKQ.flush()
+    flush_packs()
     assert pw.vp == 1 and all(nplanes(t)[0] == 1 for t in (x, y, res))
     x, y, res, mask = base(x), base(y), base(res), base(mask)
     _lib.call("kg_conv1x1", ptr(_rows(x)), ptr(pw.buf), ptr(bias), ptr(_rows(y)), ptr(res), ptr(mask), c_long(x.shape[0]),
               pw.cin_pad, pw.K, ld(x), cout, ld(y), ld(res) if res is not None else 0, ld(mask) if mask is not None else 0,
-              1 if relu else 0, stream_ptr())
+              1 if relu else 0, stream_ptr(), fmt=fmt_of(x))
 
 
 def can_1x1(x, pw, KH, stride, pad, y, y_f32, res=None):
@@ -383,10 +417,10 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
         Kc = KH * KW * cin
         Kpad = round_up(Kc, 8)
         xP = nplanes(x)[0]
-        col = alloc_pt(M, Kpad, xP, xb.device, zero=Kpad != Kc)
+        col = alloc_pt(M, Kpad, xP, xb.device, zero=Kpad != Kc, dtype=xb.dtype)
         for p_ in range(xP):
             _lib.call("kg_im2col_small", ctypes_offset(xb, p_ * xps), ctypes_offset(col.t, p_ * col.ps), N, H, W, OH, OW, KH, KW, stride, pad, cin,
-                      ld(xb), ld(col), stream_ptr())
+                      ld(xb), ld(col), stream_ptr(), fmt=fmt_of(xb))
         g, off, cnt = grads[0]
         tmp = torch.empty(cout, Kc, 1, 1, dtype=torch.float32, device=xb.device)
         conv_wgrad(col if xP > 1 else col.t, dy, Kc, cout, (M, OH, OW, OH, OW, 1, 1, 1, 0), [(tmp, off, cnt)])
@@ -410,7 +444,7 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
         fused_bias = bias_out is not None and not planed
         dbp = scratch_f32(S * cout, xb.device, "wgrad_bias") if fused_bias else None
         _lib.call("kg_conv2d_wgrad_halo", ptr(xb), ptr(dyb), ptr(part), N or 0, H, W, ld(xb), ld(dyb), cin, cout, cin_lim, cout_lim, KH, S,
-                  c_long(nelem), ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, ptr(dbp), planes, stream_ptr())
+                  c_long(nelem), ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, ptr(dbp), planes, stream_ptr(), fmt=fmt_of(x))
         if dbp is None and bias_out is not None:       # planed operands: the all-ones unit would count every plane product
             bias_grad(dy, cout, bias_out, accumulate=accumulate)
     else:
@@ -418,7 +452,7 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
         S = wgrad_splits(M * np_, cin_lim, cout_lim, KH * KW, nelem)
         part = scratch_f32(S * nelem, xb.device, "wgrad")
         _lib.call("kg_conv2d_wgrad", ptr(xb), ptr(dyb), ptr(part), ptr(rowdesc), M, H, W, OH, OW, ld(xb), ld(dyb), cin, cout, cin_lim, cout_lim,
-                  KH, KW, stride, pad, 1, mode, S, c_long(nelem), planes, stream_ptr())
+                  KH, KW, stride, pad, 1, mode, S, c_long(nelem), planes, stream_ptr(), fmt=fmt_of(xb))
         if bias_out is not None:
             bias_grad(dy, cout, bias_out, accumulate=accumulate)
     contiguous = all(grads[i][1] + grads[i][2] == grads[i + 1][1] for i in range(len(grads) - 1))
@@ -439,7 +473,7 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
 
 def wgrad_halo(x, dy, part, N, H, W, cin, cout, cin_lim, cout_lim, KS, S, nelem, tiletab16=None, dbp=None):
     _lib.call("kg_conv2d_wgrad_halo", ptr(x), ptr(dy), ptr(part), N, H, W, ld(x), ld(dy), cin, cout, cin_lim, cout_lim, KS, S,
-              c_long(nelem), ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, ptr(dbp), None, stream_ptr())
+              c_long(nelem), ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, ptr(dbp), None, stream_ptr(), fmt=fmt_of(x))
 
 
 def ctypes_offset(t, elem_off):
@@ -453,15 +487,15 @@ def bias_grad(dy, C, db, accumulate=False):
     sc = scratch_f32(2048 * max(C, 1), dyb.device, "bias")
     for p in range(P):
         _lib.call("kg_bias_grad", ctypes_offset(dyb, p * ps), ptr(db), ptr(sc), sc.numel(), dyb.shape[0], C, ld(dyb),
-                  1 if (accumulate or p > 0) else 0, stream_ptr())
+                  1 if (accumulate or p > 0) else 0, stream_ptr(), fmt=fmt_of(dyb))
 
 
-def img_pack(img, P=1):
+def img_pack(img, P=1, dtype=BF16):
     """fp32 NCHW image -> [N*H*W, 8] rows (3 real channels + zero padding) in P planes."""
     N, C, H, W = img.shape
     img = img.contiguous().float()
-    out = alloc_pt(N * H * W, 8, P, img.device)
-    _lib.call("kg_img_pack", ptr(img), ptr(out.t), ld(out), N, C, H, W, pl(y=out), stream_ptr())
+    out = alloc_pt(N * H * W, 8, P, img.device, dtype=dtype)
+    _lib.call("kg_img_pack", ptr(img), ptr(out.t), ld(out), N, C, H, W, pl(y=out), stream_ptr(), fmt=fmt_of(out))
     return out if P > 1 else out.t
 
 
@@ -472,25 +506,26 @@ def bn_stats_train(x, C, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5):
     st = torch.empty(4, C, dtype=torch.float32, device=dev)
     sc = scratch_f32(2 * C * 512, dev, "bn")
     _lib.call("kg_bn_stats_train", ptr(xb), ld(xb), xb.shape[0], C, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
-              c_float(momentum), c_float(eps), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), ptr(sc), sc.numel(), pl(a=x), stream_ptr())
+              c_float(momentum), c_float(eps), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), ptr(sc), sc.numel(), pl(a=x), stream_ptr(), fmt=fmt_of(xb))
     return st[0], st[1], st[2], st[3]
 
 
 CONV_BN_STATS = __import__("os").environ.get("KG_CONV_BN_STATS", "1") == "1"   # BatchNorm statistics in the producing conv's epilogue
 
 
-def conv_stats_begin(dev):
-    """Arms the next conv launch of this thread to also write the BatchNorm statistics partials of its output (kg_conv_stats_begin)."""
+def conv_stats_begin(dev, fmt=0):
+    """Arms the next conv launch of this thread (in the library of rows format `fmt`) to also write the BatchNorm statistics
+    partials of its output (kg_conv_stats_begin)."""
     part = scratch_f32(1 << 21, dev, "bnpart")
-    _lib.call("kg_conv_stats_begin", ptr(part), c_long(part.numel()))
+    _lib.call("kg_conv_stats_begin", ptr(part), c_long(part.numel()), fmt=fmt)
     return part
 
 
-def conv_stats_end():
+def conv_stats_end(fmt=0):
     """Pixel tiles the armed conv wrote partials for (0: its kernel has no statistics epilogue); disarms."""
     import ctypes
     nb = ctypes.c_int(0)
-    _lib.call("kg_conv_stats_end", ctypes.byref(nb))
+    _lib.call("kg_conv_stats_end", ctypes.byref(nb), fmt=fmt)
     return nb.value
 
 
@@ -510,52 +545,52 @@ def bn_scale_shift_eval(C, gamma, beta, rmean, rvar, eps=1e-5):
 
 def bn_apply(x, C, scale, shift, y, res=None, relu=False):
     _lib.call("kg_bn_apply", ptr(_rows(x)), ld(x), ptr(scale), ptr(shift), ptr(base(res)), ld(res) if res is not None else 0, ptr(_rows(y)), ld(y),
-              base(x).shape[0], C, 1 if relu else 0, pl(a=x, b=res, y=y), stream_ptr())
+              base(x).shape[0], C, 1 if relu else 0, pl(a=x, b=res, y=y), stream_ptr(), fmt=fmt_of(x))
 
 
 def bn_bwd(x, dy, C, gamma, mean, invstd, dgamma, dbeta, dx, accumulate=False):
     sc = scratch_f32(2 * C * 512 + 3 * C, base(x).device, "bn")
     _lib.call("kg_bn_bwd", ptr(_rows(x)), ld(x), ptr(_rows(dy)), ld(dy), ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
-              1 if accumulate else 0, ptr(_rows(dx)), ld(dx), base(x).shape[0], C, ptr(sc), sc.numel(), pl(a=x, b=dy, y=dx), stream_ptr())
+              1 if accumulate else 0, ptr(_rows(dx)), ld(dx), base(x).shape[0], C, ptr(sc), sc.numel(), pl(a=x, b=dy, y=dx), stream_ptr(), fmt=fmt_of(x))
 
 
 def maxpool_fwd(x, y, N, H, W, C, argmax=None):
     """argmax (optional uint8 [N*OH*OW, C]): receives the winning tap of every output element for maxpool_bwd."""
-    _lib.call("kg_maxpool3s2_fwd", ptr(_rows(x)), ld(x), ptr(_rows(y)), ld(y), ptr(argmax), N, H, W, C, pl(a=x, y=y), stream_ptr())
+    _lib.call("kg_maxpool3s2_fwd", ptr(_rows(x)), ld(x), ptr(_rows(y)), ld(y), ptr(argmax), N, H, W, C, pl(a=x, y=y), stream_ptr(), fmt=fmt_of(x))
 
 
 def maxpool_bwd(x, dy, dx, N, H, W, C, argmax=None):
     _lib.call("kg_maxpool3s2_bwd", ptr(_rows(x)), ld(x), ptr(_rows(dy)), ld(dy), ptr(_rows(dx)), ld(dx), ptr(argmax), N, H, W, C,
-              pl(a=x, b=dy, y=dx), stream_ptr())
+              pl(a=x, b=dy, y=dx), stream_ptr(), fmt=fmt_of(dy))
 
 
 def bilinear_fwd(x, y, N, IH, IW, OH, OW, C, boxdesc=None, row2box=None):
     rows = base(y).shape[0] if boxdesc is not None else 0
     _lib.call("kg_bilinear_fwd", ptr(_rows(x)), ld(x), ptr(_rows(y)), ld(y), N, IH, IW, OH, OW, C, ptr(boxdesc), ptr(row2box),
-              c_long(rows), pl(a=x, y=y), stream_ptr())
+              c_long(rows), pl(a=x, y=y), stream_ptr(), fmt=fmt_of(x))
 
 
 def bilinear_bwd(dy, dx, N, IH, IW, OH, OW, C, boxdesc=None, row2box=None, mask=None):
     rows = base(dx).shape[0] if boxdesc is not None else 0
     _lib.call("kg_bilinear_bwd", ptr(_rows(dy)), ld(dy), ptr(_rows(dx)), ld(dx), N, IH, IW, OH, OW, C, ptr(boxdesc), ptr(row2box),
-              c_long(rows), ptr(base(mask)), ld(mask) if mask is not None else 0, pl(a=dy, y=dx), stream_ptr())
+              c_long(rows), ptr(base(mask)), ld(mask) if mask is not None else 0, pl(a=dy, y=dx), stream_ptr(), fmt=fmt_of(dy))
 
 
 def add_rows(a, b, y, C, mask=None):
     """y = (a + b) [masked by mask > 0]; b may be None."""
     _lib.call("kg_add_rows", ptr(_rows(a)), ld(a), ptr(base(b)), ld(b) if b is not None else 0, ptr(base(mask)),
-              ld(mask) if mask is not None else 0, ptr(_rows(y)), ld(y), c_long(base(a).shape[0]), C, pl(a=a, b=b, y=y), stream_ptr())
+              ld(mask) if mask is not None else 0, ptr(_rows(y)), ld(y), c_long(base(a).shape[0]), C, pl(a=a, b=b, y=y), stream_ptr(), fmt=fmt_of(a))
 
 
 def planes_to_f32(x, C, out):
     """out [rows, C] fp32 (row stride out.stride(0)) = sum of the planes of x."""
-    _lib.call("kg_planes_to_f32", ptr(_rows(x)), ld(x), ptr(out), out.stride(0), c_long(base(x).shape[0]), C, pl(a=x), stream_ptr())
+    _lib.call("kg_planes_to_f32", ptr(_rows(x)), ld(x), ptr(out), out.stride(0), c_long(base(x).shape[0]), C, pl(a=x), stream_ptr(), fmt=fmt_of(x))
 
 
-def f32_to_planes(acc, y, C, addto=None):
-    """y (planes) = acc [rows, C] fp32 (+ addto planes)."""
+def f32_to_planes(acc, y, C, addto=None, scale=None):
+    """y (planes) = acc [rows, C] fp32 (* the device scalar `scale`) (+ addto planes)."""
     _lib.call("kg_f32_to_planes", ptr(acc), acc.stride(0), ptr(_rows(y)), ld(y), ptr(base(addto)), ld(addto) if addto is not None else 0,
-              c_long(acc.shape[0]), C, pl(b=addto, y=y), stream_ptr())
+              c_long(acc.shape[0]), C, pl(b=addto, y=y, scale=scale), stream_ptr(), fmt=fmt_of(y))
 
 
 def sigmoid_(x):
@@ -563,5 +598,45 @@ def sigmoid_(x):
     return x
 
 
-def grad_pack(g, prob, out, N, C, H, W, cpad):
-    _lib.call("kg_grad_pack", ptr(g), ptr(prob), ptr(_rows(out)), N, C, H, W, ld(out), cpad, pl(y=out), stream_ptr())
+def grad_pack(g, prob, out, N, C, H, W, cpad, scale=None):
+    _lib.call("kg_grad_pack", ptr(g), ptr(prob), ptr(_rows(out)), N, C, H, W, ld(out), cpad, pl(y=out, scale=scale), stream_ptr(), fmt=fmt_of(out))
+
+
+# ---- gradient scale of the half-precision backward pass (csrc/gradscale.hip) ------------------------------------------------------
+GRAD_TARGET_LOG2 = int(__import__("os").environ.get("KG_GRAD_TARGET_LOG2", "10"))   # the largest loss gradient of a step lands in [512, 1024): 64x headroom to 65504, normal halves down to 2^-24 of it
+_gs_state = {}
+
+
+def grad_scale(tensors):
+    """Device pair {S, 1 / S} (fp32 [2]) for this backward pass: S = the power of two that brings max |t| over the given fp32
+    tensors (the gradients of the loss w.r.t. the network outputs) into [2^(T-1), 2^T), T = GRAD_TARGET_LOG2.  No host sync."""
+    import ctypes
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    assert 1 <= len(ts) <= 24 and all(t.dtype == torch.float32 and t.is_contiguous() for t in ts)
+    dev = ts[0].device
+    scr = _gs_state.get(str(dev))
+    if scr is None:
+        scr = torch.zeros(2, dtype=torch.int32, device=dev)
+        _gs_state[str(dev)] = scr
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    cnts = (ctypes.c_long * len(ts))(*[t.numel() for t in ts])
+    _lib.call("kg_grad_scale", ptrs, cnts, len(ts), GRAD_TARGET_LOG2, ptr(scr), ptr(out), stream_ptr())
+    return out
+
+
+def scale_tensors(tensors, scale):
+    """every fp32 tensor *= the device scalar `scale`, one launch (kg_scale_tensors)"""
+    import numpy as np
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    if not ts:
+        return
+    dt = np.dtype([("p", "<u8"), ("n", "<i8"), ("blk0", "<i4"), ("pad", "<i4")])
+    arr = np.zeros(len(ts), dt)
+    blk = 0
+    for i, t in enumerate(ts):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        arr[i] = (t.data_ptr(), t.numel(), blk, 0)
+        blk += (t.numel() + 4095) // 4096
+    tab = h2d(arr.view(np.uint8).reshape(-1), ts[0].device)
+    _lib.call("kg_scale_tensors", ptr(tab), len(ts), blk, ptr(scale), stream_ptr())

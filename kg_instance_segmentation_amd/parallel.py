@@ -195,6 +195,7 @@ class FlatGradReducer:
         self.bucket_of = {k: i for i, (_, _, ks) in enumerate(self.buckets) for k in ks}
         self.missing = [set(ks) for _, _, ks in self.buckets]
         self.inflight, self.seg_launched = [], False
+        self.unscale, self.seg_unscaled = None, False      # half-precision backward (ops.grad_scale): device 1 / S of the running backward pass
         eng.grad_store = self
         eng.grad_hook = self._on_grads
         return self
@@ -234,21 +235,28 @@ class FlatGradReducer:
     def begin_step(self):
         """Call before the forward of every step: re-arms the buckets and zeroes the seg-branch slots."""
         self.missing = [set(ks) for _, _, ks in self.buckets]
-        self.seg_launched = False
+        self.seg_launched, self.seg_unscaled = False, False
+        self._pend_done = set()
         a, b, _ = self.seg_bucket
         if b > a:
             self.flat[a:b].zero_()
 
-    def seg_done(self):
-        """(the seg branch's backward has enqueued all its gradient kernels on this rank)"""
+    def seg_done(self, unscale=None):
+        """(the seg branch's backward has enqueued all its gradient kernels on this rank).  unscale: forward_seg ran as its own
+        autograd node in the half-precision build -- its gradients carry ITS power-of-two scale, divided out here."""
+        a, b, _ = self.seg_bucket
+        if unscale is not None and b > a and not self.seg_unscaled:
+            from . import ops
+            ops.scale_tensors([self.flat[a:b]], unscale)
+            self.seg_unscaled = True
 
     def dense_backward_started(self):
         """Start of forward_dec's backward, which EVERY rank runs and which autograd schedules after the seg branch's backward
         (forward_seg consumes forward_dec's outputs): the one point where all ranks can issue the seg bucket's all-reduce in
         the same order -- a rank whose images had no valid box contributes the zeros of begin_step().  The reduction then runs
         underneath the whole dense backward."""
-        if world_size() > 1 and not self.seg_launched and self.seg_bucket[1] > self.seg_bucket[0]:
-            self._launch(self.seg_bucket[0], self.seg_bucket[1])
+        if not self.seg_launched and self.seg_bucket[1] > self.seg_bucket[0]:
+            self._launch(self.seg_bucket[0], self.seg_bucket[1], unscale=not self.seg_unscaled)
         self.seg_launched = True
 
     def _on_grads(self, items, last):
@@ -259,11 +267,33 @@ class FlatGradReducer:
             self.missing[i].discard(name)
             if not self.missing[i]:
                 self.missing[i] = {None}          # launched
-                if world_size() > 1:
-                    self._launch(self.buckets[i][0], self.buckets[i][1])
+                self._launch(self.buckets[i][0], self.buckets[i][1])
 
-    def _launch(self, a, b):
-        self.inflight.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+    def unscale_pending(self):
+        """end of a half-precision backward pass: gradients this rank produced in buckets that did not complete (some parameter of
+        the bucket got no gradient this step) still carry the pass's scale -- divide it out slot by slot (finish() reduces such
+        buckets as they stand)"""
+        if self.unscale is None:
+            return
+        from . import ops
+        todo = []
+        for i, (_, _, ks) in enumerate(self.buckets):
+            if self.missing[i] != {None}:
+                for k in ks:
+                    if k not in self.missing[i] and k not in self._pend_done:
+                        todo.append(self.slot[k])
+                        self._pend_done.add(k)
+        if todo:
+            ops.scale_tensors(todo, self.unscale)
+
+    def _launch(self, a, b, unscale=True):
+        """a bucket is complete on this rank: divide out the backward pass's power-of-two scale (half-precision build; every rank has
+        its own), then SUM-all-reduce it in place"""
+        if unscale and self.unscale is not None:
+            from . import ops
+            ops.scale_tensors([self.flat[a:b]], self.unscale)
+        if world_size() > 1:
+            self.inflight.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
         """After loss.backward(): reduces whatever was not produced on this rank this step (as zeros / stale-free: a bucket whose
@@ -275,7 +305,7 @@ class FlatGradReducer:
                 if self.missing[i] != {None}:
                     for k in self.missing[i]:
                         self.slot[k].zero_()
-                    self._launch(a, b)
+                    self._launch(a, b, unscale=False)      # (no backward pass is running: whatever this bucket holds is unscaled or zero)
                     self.missing[i] = {None}
             for w in self.inflight:
                 w.wait()

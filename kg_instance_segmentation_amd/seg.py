@@ -95,16 +95,21 @@ class _SegFunction(torch.autograd.Function):
     def backward(ctx, gflat):
         if ctx.saved is None:
             raise RuntimeError("forward_seg was run without gradient recording")
-        gfeats, pgrads = ctx.branch.run_backward(ctx.plan, ctx.saved, gflat.contiguous().float(), ctx.feat_shapes)
+        eng = ctx.branch.m._engine
+        gflat = gflat.contiguous().float()
+        gs = ops.grad_scale([gflat]) if eng.fmt else None       # half build: this node's own power-of-two gradient scale
+        gfeats, pgrads = ctx.branch.run_backward(ctx.plan, ctx.saved, gflat, ctx.feat_shapes, gscale=gs)
         out = [None, None, None] + gfeats
-        store = ctx.branch.m._engine.grad_store
+        store = eng.grad_store
+        if gs is not None:
+            ops.scale_tensors([g for k, g in pgrads.items() if g is not None and not (store is not None and store.owns(k, g))], gs[1:2])
         for k in ctx.branch.param_keys:
             g = pgrads.get(k)
             if store is not None and g is not None and store.owns(k, g):
                 g = store.deliver(k, ctx.branch.P(k))
             out.append(g)
         if store is not None:
-            store.seg_done()
+            store.seg_done(unscale=gs[1:2] if gs is not None else None)
         return tuple(out)
 
 
@@ -123,6 +128,11 @@ class SegBranch:
     def P_(self):
         """planes of the seg branch's activations / weights (engine.PRECISIONS)"""
         return self.m._engine.pseg
+
+    @property
+    def dt(self):
+        """16-bit format of the branch's rows / packed weights (engine.HALF_POLICIES)"""
+        return self.m._engine.dt
 
     @property
     def Pg(self):
@@ -151,13 +161,13 @@ class SegBranch:
         e = self.packed.get(key)
         cout, cin, k, _ = w.shape
         if e is None or e["ver"] != ver or e["pw"].buf.device != w.device:
-            pw = e["pw"] if e is not None and e["pw"].buf.device == w.device else PackedWeight(cout, k * k, ops.round_up(cin, 8), w.device, xP=self.P_, wP=self.P_)
+            pw = e["pw"] if e is not None and e["pw"].buf.device == w.device else PackedWeight(cout, k * k, ops.round_up(cin, 8), w.device, xP=self.P_, wP=self.P_, dtype=self.dt)
             pw.pack(w.detach())
             e = {"ver": ver, "pw": pw, "pwT": e["pwT"] if e is not None and e["pw"].buf.device == w.device else None, "T_ok": False}
             self.packed[key] = e
         if need_T and not e["T_ok"]:
             if e["pwT"] is None:
-                e["pwT"] = PackedWeight(cin, k * k, ops.round_up(cout, 8), w.device, xP=self.Pg, wP=min(self.Pg, self.m._engine.pdw))
+                e["pwT"] = PackedWeight(cin, k * k, ops.round_up(cout, 8), w.device, xP=self.Pg, wP=min(self.Pg, self.m._engine.pdw), dtype=self.dt)
             e["pwT"].pack(w.detach(), transposed=True)
             e["T_ok"] = True
         e["need_T"] = bool(need_T) or e.get("need_T", False)
@@ -311,12 +321,12 @@ class SegBranch:
             for p_ in range(dst.P):
                 if p_ < frows.P:
                     _lib.call("kg_rows_gather", ops.ctypes_offset(frows.t, p_ * frows.ps), ops.ld(frows), sr,
-                              ops.ctypes_offset(ops.base(dst), p_ * dst.ps), ops.ld(dst), c_long(nrows), C, stream_ptr())
+                              ops.ctypes_offset(ops.base(dst), p_ * dst.ps), ops.ld(dst), c_long(nrows), C, stream_ptr(), fmt=ops.fmt_of(dst))
                 else:
                     dst.plane(p_)[:nrows].zero_()
             return
         _lib.call("kg_rows_gather_f32", ptr(frows), frows.stride(0), sr, ptr(ops.base(dst)), ops.ld(dst), c_long(nrows), C,
-                  ops.pl(y=dst), stream_ptr())
+                  ops.pl(y=dst), stream_ptr(), fmt=ops.fmt_of(dst))
 
     @staticmethod
     def _head(t, M):
@@ -326,10 +336,10 @@ class SegBranch:
         return t.rows(0, M) if isinstance(t, PT) else t[:M]
 
     def alloc(self, rows, C, dev):
-        return ops.alloc_pt(rows, C, self.P_, dev)
+        return ops.alloc_pt(rows, C, self.P_, dev, dtype=self.dt)
 
     def galloc(self, rows, C, dev):
-        return ops.alloc_pt(rows, C, self.Pg, dev)
+        return ops.alloc_pt(rows, C, self.Pg, dev, dtype=self.dt)
 
     def rconv(self, x, pw, cout, rowdesc, M, k, y=None, y_f32=None, bias=None, relu=False, mask=None, mode=2, tiles=None, tiles16=None):
         """Ragged conv (mode 2) or its input gradient (mode 3).  3x3 convs over 64-channel-aligned inputs run on the
@@ -423,14 +433,16 @@ class SegBranch:
             _, pwT, _ = self.packw(key, True)
             self.rconv(g, pwT, cin, rowdesc, M, k, y=dx, mask=mask, mode=3, tiles=t32, tiles16=t16)
 
-    def run_backward(self, plan, saved, gflat, feat_shapes):
+    def run_backward(self, plan, saved, gflat, feat_shapes, gscale=None):
+        """gscale (half build): device {S, 1 / S} (ops.grad_scale): gflat enters times S; the split-rows feature gradients and the
+        parameter gradients are returned times S (the caller divides the latter), fp32 feature gradients are divided here."""
         pre, cats, uins, hid, flat, top = saved
         dev = gflat.device
         CH = arch.FEAT_CH
         pgrads = {}
         rows0 = plan.rows[0]
         gz = self.galloc(rows0, 8, dev)
-        ops.grad_pack(gflat, flat, gz, 1, 1, rows0, 1, 8)
+        ops.grad_pack(gflat, flat, gz, 1, 1, rows0, 1, 8, scale=gscale[0:1] if gscale is not None else None)
         dhid = self.galloc(rows0, 64, dev)
         t32_0, t16_0 = self.T32(plan, 0, plan.nb[0]), self.T16(plan, 0, plan.nb[0])
         self.conv_bwd("seg_head.2", hid, gz, plan.rowdesc[0], rows0, 3, pgrads, dx=dhid, mask=hid.hi(), t32=t32_0, t16=t16_0)
@@ -442,18 +454,22 @@ class SegBranch:
         gfeats = [None] * 5
 
         out_planes = getattr(plan, "out_planes", None)      # fused training forward: write the engine's split-bf16 gradient rows directly
+        f32_outs = []
 
         def reduce_level(l, ga, rows_a, gb):
             n, c, h, w = feat_shapes[l]
             out = outp = None
             if out_planes is not None:
-                outp = ops.alloc_pt(n * h * w, c, out_planes[l], dev)
+                outp = ops.alloc_pt(n * h * w, c, out_planes[l], dev, dtype=self.dt)
             else:
                 out = torch.empty(n * h * w, c, dtype=torch.float32, device=dev)
             _lib.call("kg_crop_grad_reduce", ptr(ops.base(ga)), ops.ld(ga) if ga is not None else 0, ptr(ops.base(gb)),
                       ops.ld(gb) if gb is not None else 0, c_long(rows_a), ptr(plan.tab_d[l]), ptr(plan.bin_start_d[l]),
                       ptr(plan.bin_boxes_d[l]), BIN_SIZE[l], n, h, w, c, ptr(out), ptr(ops.base(outp)), ops.ld(outp) if outp is not None else 0,
-                      ops.pl(a=ga if ga is not None else gb, b=gb if gb is not None else ga, y=outp), stream_ptr())
+                      ops.pl(a=ga if ga is not None else gb, b=gb if gb is not None else ga, y=outp), stream_ptr(),
+                      fmt=ops.fmt_of(ga if ga is not None else gb))
+            if out is not None and gscale is not None:
+                f32_outs.append(out)
             gfeats[l] = outp if outp is not None else out.view(n, h, w, c).permute(0, 3, 1, 2)
 
         for l in range(0, top):
@@ -476,6 +492,8 @@ class SegBranch:
             dpre = nxt
         if dpre is not None:
             reduce_level(top, None, 0, dpre)
+        if f32_outs:
+            ops.scale_tensors(f32_outs, gscale[1:2])
         # parameters of levels that no box reached get zero gradients (autograd accumulates nothing for None)
         return gfeats, pgrads
 

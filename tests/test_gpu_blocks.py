@@ -17,14 +17,15 @@ from kg_instance_segmentation_amd.ops import BF16, PT  # noqa: E402
 from oracle import net as onet  # noqa: E402
 
 DEV = "cuda"
-THR = {"bf16": 0.985, "mixed": 0.99995, "trunk2": 0.99995, "fp32": 0.9999999}
+THR = {"bf16": 0.985, "mixed": 0.99995, "trunk2": 0.99995, "fp32bf": 0.9999999, "fp32": 0.999999, "half": 0.99995}
+CUR = {"dt": BF16}      # 16-bit format of the policy under test (engine.HALF_POLICIES: IEEE half)
 
 
 def to_pt(x_nchw, P):
     """fp32 NCHW (cpu) -> split-bf16 rows on the device"""
     n, c, h, w = x_nchw.shape
     r = x_nchw.permute(0, 2, 3, 1).reshape(n * h * w, c).contiguous().to(DEV)
-    pt = ops.alloc_pt(n * h * w, c, P, DEV)
+    pt = ops.alloc_pt(n * h * w, c, P, DEV, dtype=CUR["dt"])
     ops.f32_to_planes(r, pt, c)
     return pt
 
@@ -64,10 +65,11 @@ def check(name, got, ref, thr=0.985):
     assert c >= thr, name
 
 
-@pytest.fixture(scope="module", params=["bf16", "mixed", "fp32"])
+@pytest.fixture(scope="module", params=["bf16", "mixed", "fp32bf", "fp32", "half"])
 def model(state_dict0, request):
     m = KGnet.resnet50(pretrained=False, precision=request.param)
     m.load_state_dict(state_dict0)
+    CUR["dt"] = m._engine.dt
     return m.to(DEV).train()
 
 
@@ -118,9 +120,9 @@ def test_stem_and_decoder_level(model, state_dict0):
     eng = model._engine
     thr = THR[eng.precision]
     eng.tape, eng.param_grads = [], {}
-    x8 = Var(ops.img_pack(img.to(DEV), eng.pt), 8, relu=False, req=False)
+    x8 = Var(ops.img_pack(img.to(DEV), eng.pt, dtype=CUR["dt"]), 8, relu=False, req=False)
     s1, H1, W1 = eng.conv(x8, eng.spec("conv1", 3, 64, 7, 2, 3, bias=False), N, H, W, False)
-    cat1 = ops.alloc_pt(N * H1 * W1, 128, eng.pt, DEV)
+    cat1 = ops.alloc_pt(N * H1 * W1, 128, eng.pt, DEV, dtype=CUR["dt"])
     c1 = eng.bn(s1, "bn1", True, out=cat1.cols(64, 128))
     p, Hp, Wp = eng.maxpool(c1, N, H1, W1)
     # decoder level 1 style: upsample p (64 ch) to c1's size, c1_up_conv-like 3x3 (use c1_up_conv: 64->64), concat, c1_cat_refine
@@ -153,7 +155,7 @@ def test_heads_level(model, state_dict0):
     g = torch.Generator().manual_seed(3)
     x = F.relu(bfr(torch.randn(N, C, H, W, generator=g)))
     eng = model._engine
-    thr = THR["bf16" if eng.ph == 1 else eng.precision]      # the two head layers are single-plane bf16 in "mixed"
+    thr = THR[("half" if eng.fmt else "bf16") if eng.ph == 1 else eng.precision]      # the two head layers are single-plane in "mixed" / "half"
     eng.tape, eng.param_grads = [], {}
     from kg_instance_segmentation_amd import arch
     xv = Var(to_pt(x, eng.pt), C, relu=True, req=True)
@@ -163,8 +165,12 @@ def test_heads_level(model, state_dict0):
     outs = eng.heads_second(hid, 0, C, N, H, W)
     gm = [torch.randn(N, co, H, W, generator=g) * 1e-3 for _, co in arch.HEADS]
     eng.maps, eng.feats = outs, []
-    pgrads = eng.backward_dec([t.to(DEV) for t in gm], [])
+    gmd = [t.to(DEV) for t in gm]
+    gs = ops.grad_scale(gmd) if eng.fmt else None        # half build: the backward pass runs on gradients times a power of two
+    pgrads = eng.backward_dec(gmd, [], gscale=gs)
     gx = xv.take_grad()
+    if gs is not None:
+        ops.scale_tensors(list(pgrads.values()), gs[1:2])
     torch.cuda.synchronize()
     sd = oracle_params(state_dict0, [f"{h}_head_c0." for h, _ in arch.HEADS])
     net = onet.Net(sd, training=True)
@@ -177,7 +183,7 @@ def test_heads_level(model, state_dict0):
     torch.autograd.backward(ref, gm)
     for (h, _), o, r in zip(arch.HEADS, outs, ref):
         check(f"head.{h}.out", o.cpu(), r, thr)
-    check("head.dx", val(gx, N, H, W), xd.grad, thr)
+    check("head.dx", val(gx, N, H, W) * (float(gs[1]) if gs is not None else 1.0), xd.grad, thr)
     assert len(pgrads) == 12
     for k, gg in pgrads.items():
         check(k, gg, sd[k].grad, thr)
@@ -192,7 +198,7 @@ def test_seg_branch_forward_backward(model, state_dict0):
     boxes = [np.array([[10.2, 12.7, 40.5, 50.5, 1.0], [0.0, 0.0, 95.0, 127.0, 0.9], [30.5, 60.5, 37.5, 71.5, 0.8],
                        [50, 20, 52, 90, 0.7], [64.4, 100.6, 90.2, 126.9, 0.6], [2.5, 3.5, 14.5, 17.5, 0.5]], np.float32),
              np.array([[20, 30, 60, 80, 1.0], [5, 100, 25, 120, 1.0], [70.5, 8.5, 93.5, 40.5, 1.0], [1, 1, 3, 3, 1.0]], np.float32)]
-    thr = THR["bf16" if model._engine.pseg == 1 else model._engine.precision]
+    thr = THR[("half" if model._engine.fmt else "bf16") if model._engine.pseg == 1 else model._engine.precision]
     fd = [f.to(DEV).requires_grad_(True) for f in feats]       # fp32 NCHW feature maps, as the reference passes them (KGnet.py:321)
     patches, dets = model.forward_seg(fd, boxes)
     wts = [[torch.randn(p.shape, generator=g) for p in pp] for pp in patches]

@@ -4,19 +4,19 @@ Fixture: the calibrated weights (oracle/weightgen.py variant "cal": logits O(1),
 generated from the reference (tests/golden/net_cal.npz, tools/gen_goldens.py:gen_net_cal) -- the raw random-init fixture has
 logits of +-500 (saturated sigmoids) and is chaotic in train mode, see test_gpu_net.py.
 
-Stated tolerances |got - ref| <= atol + rtol * |ref|  (rms = root mean square of the reference map):
-  precision "fp32"  (hi+mid+lo planes, 6 MFMA products): rtol 1e-4, atol 1e-5 * max(1, rms) -- SURVEY 8d's fp32 tolerance for the
-            O(1) kp / seg logits, scaled with the map for the offset maps (rms 1-6 pixels); measured worst |d| / bound: 0.98;
-            train-mode tensors (batch-statistics BN amplifies reduction-order differences): rtol 1e-3, atol 1e-4, the same
-            bound the CPU oracle is held to against the reference (tests/test_oracle_net.py);
-  precision "trunk2" (whole trunk in hi+lo planes, heads bf16): rtol 2e-2, atol 3e-2 * rms (two bf16 head layers:
-            ~0.5 % of rms per element, 5-6 sigma over the 1.4 M elements of a 512 x 512 map);
-  precision "mixed" (default: BatchNorm backbone in hi+lo planes while it normalises with batch statistics; c0_conv, decoder and
-            heads bf16 = 8 bf16 layers): train-mode maps rtol 2e-2, atol 5e-2 * rms; eval mode (running statistics: the backbone
-            runs in bf16 too) atol 7e-2 * rms;
-  precision "bf16":  rtol 2e-2, atol 1e-1 * rms (60 layers of bf16 storage).
-Parameter gradients (train step 2 x 128 x 128): cosine against the reference per parameter >= 0.9999 / 0.99 / 0.85
-(measured on MI355X: 0.99999 / 0.9992 / 0.856 minimum over the 217 parameters)."""
+Stated tolerances |got - ref| <= atol + rtol * |ref|  (rms = root mean square of the reference map), per policy (engine.PRECISIONS):
+  "fp32" (DEFAULT: hi + lo IEEE-half planes, 3 MFMA products) and "fp32bf" (hi + mid + lo bf16 planes, 6 products):
+            rtol 1e-4, atol 1e-5 * max(1, rms) -- SURVEY 8d's fp32 tolerance for the O(1) kp / seg logits, scaled with the map for the
+            offset maps (rms 1-6 pixels) -- in eval AND train mode (measured worst |d| / bound on MI355X: 0.44 / 0.87 for "fp32",
+            0.45 / 0.78 for "fp32bf"); every parameter gradient: cosine >= 0.9999, norm within 2e-3 (measured 0.999987 / 6e-4);
+  "half"    (single IEEE-half planes, 11 significant bits): SURVEY 8d's reduced-precision clause, rtol 2e-2, with atol 2e-2 * rms
+            (measured max |d| = 1.6e-2 rms in train mode, 5e-3 rms in eval mode);
+  "trunk2"  (bf16; whole trunk in hi + lo planes, heads bf16): rtol 2e-2, atol 3e-2 * rms;
+  "mixed"   (bf16; BatchNorm backbone in hi + lo planes, c0_conv / decoder / heads plain bf16 = 8 bf16 layers): rtol 2e-2,
+            atol 5e-2 * rms -- NOT the blueprint's clause (a plain-bf16 multiply carries 8 bits), kept as an opt-in speed policy;
+  "bf16":   rtol 2e-2, atol 1e-1 * rms (train 1.5e-1) -- 60 layers of bf16 storage.
+Parameter gradients (train step 2 x 128 x 128): cosine against the reference per parameter >= 0.9999 ("fp32", "fp32bf") / 0.97
+("half") / 0.99 ("trunk2", "mixed") / 0.85 ("bf16")."""
 import hashlib
 
 import numpy as np
@@ -31,11 +31,15 @@ from kg_instance_segmentation_amd.seg_loss import SEG_loss  # noqa: E402
 from oracle import synth, weightgen  # noqa: E402
 
 DEV = "cuda"
-EVAL_TOL = {"fp32": (1e-4, 1e-5, 0.0), "trunk2": (2e-2, 0.0, 3e-2), "mixed": (2e-2, 0.0, 7e-2), "bf16": (2e-2, 0.0, 1e-1)}     # rtol, atol, atol as a fraction of rms
-TRAIN_TOL = {"fp32": (1e-3, 1e-4, 0.0), "trunk2": (2e-2, 0.0, 3e-2), "mixed": (2e-2, 0.0, 5e-2), "bf16": (2e-2, 0.0, 1.5e-1)}
-GRAD_COS = {"fp32": 0.9999, "trunk2": 0.99, "mixed": 0.99, "bf16": 0.85}
-for _d in (EVAL_TOL, TRAIN_TOL, GRAD_COS):
-    _d["fp32full"] = _d["fp32"]          # (6 products in the backward pass too: held to the same bounds as the default policy)
+# rtol, atol, atol as a fraction of rms
+EVAL_TOL = {"fp32": (1e-4, 1e-5, 0.0), "fp32bf": (1e-4, 1e-5, 0.0), "half": (2e-2, 0.0, 2e-2), "trunk2": (2e-2, 0.0, 3e-2), "mixed": (2e-2, 0.0, 6e-2),
+            "bf16": (2e-2, 0.0, 1e-1)}
+TRAIN_TOL = dict(EVAL_TOL, mixed=(2e-2, 0.0, 5e-2), bf16=(2e-2, 0.0, 1.5e-1))
+GRAD_COS = {"fp32": 0.9999, "fp32bf": 0.9999, "half": 0.97, "trunk2": 0.99, "mixed": 0.99, "bf16": 0.85}
+GRAD_NORM = {"fp32": 2e-3, "fp32bf": 2e-3, "half": 5e-2, "trunk2": 5e-2, "mixed": 5e-2, "bf16": 0.3}
+LOSS_TOL = {"fp32": 2e-5, "fp32bf": 2e-5, "half": 2e-3, "trunk2": 2e-3, "mixed": 3e-3, "bf16": 2e-2}
+STAT_TOL = {"fp32": (1e-4, 1e-6), "fp32bf": (1e-4, 1e-6), "half": (1e-3, 1e-5), "trunk2": (1e-3, 1e-5), "mixed": (1e-3, 1e-5), "bf16": (3e-2, 3e-3)}
+POLICIES = ["fp32", "fp32bf", "half", "trunk2", "mixed", "bf16"]
 
 
 def sha(a):
@@ -77,7 +81,7 @@ def _x(g, name):
     return x.to(DEV)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "trunk2", "mixed", "bf16"])
+@pytest.mark.parametrize("precision", POLICIES)
 @pytest.mark.parametrize("name", ["a", "b"])
 def test_eval_logits_vs_reference(golden, cal_sd, precision, name):
     g = golden("net_cal.npz")
@@ -109,7 +113,7 @@ def test_eval_logits_vs_reference(golden, cal_sd, precision, name):
     assert worst[0][0] <= 1.0, worst[:5]
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp32full", "trunk2", "mixed", "bf16"])
+@pytest.mark.parametrize("precision", POLICIES)
 def test_train_step_vs_reference(golden, cal_sd, precision):
     """Losses, train-mode maps and EVERY parameter gradient (seeded 1024-element subset) against the reference's train step."""
     g = golden("net_cal.npz")
@@ -122,7 +126,7 @@ def test_train_step_vs_reference(golden, cal_sd, precision):
     d0, d1, d2, d3, pred = m(x.to(DEV), gt_boxes)
     l1 = [ldec(p, t.to(DEV)) for p, t in zip((d0, d1, d2, d3), gt_lv)]
     l2 = lseg(pred, gt_masks, gt_boxes)
-    ltol = {"fp32": 2e-5, "fp32full": 2e-5, "trunk2": 2e-3, "mixed": 3e-3, "bf16": 2e-2}[precision]
+    ltol = LOSS_TOL[precision]
     print("loss_dec", [float(v) for v in l1], "ref", g["train.loss_dec"], "loss_seg", float(l2), float(g["train.loss_seg"]))
     np.testing.assert_allclose([float(v) for v in l1], g["train.loss_dec"], rtol=ltol)
     assert abs(float(l2) - float(g["train.loss_seg"])) <= ltol * abs(float(g["train.loss_seg"]))
@@ -155,14 +159,13 @@ def test_train_step_vs_reference(golden, cal_sd, precision):
     ratios = np.array([r for _, _, r in rows])
     print("   norm ratio: min %.4f max %.4f" % (ratios.min(), ratios.max()))
     assert rows[0][0] >= GRAD_COS[precision], rows[:5]
-    assert np.all(np.abs(ratios - 1) <= {"fp32": 2e-3, "fp32full": 2e-3, "trunk2": 5e-2, "mixed": 5e-2, "bf16": 0.3}[precision])
+    assert np.all(np.abs(ratios - 1) <= GRAD_NORM[precision])
     sd = m.state_dict()
     for k in ("bn1.running_mean", "bn1.running_var", "layer3.5.bn3.running_mean", "layer3.5.bn3.running_var"):
-        np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"train.stat.{k}"], rtol={"fp32": 1e-4, "fp32full": 1e-4, "trunk2": 1e-3, "mixed": 1e-3, "bf16": 3e-2}[precision],
-                                   atol={"fp32": 1e-6, "fp32full": 1e-6, "trunk2": 1e-5, "mixed": 1e-5, "bf16": 3e-3}[precision])
+        np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"train.stat.{k}"], rtol=STAT_TOL[precision][0], atol=STAT_TOL[precision][1])
 
 
-@pytest.mark.parametrize("precision", ["mixed", "fp32"])
+@pytest.mark.parametrize("precision", ["fp32", "half", "mixed"])
 def test_full_size_forward_vs_oracle(cal_sd, precision):
     """512 x 512 (BASELINE's size), batch 1: forward_dec + forward_seg against the reference-pinned CPU oracle (oracle/net.py),
     element-wise on kp logits / offsets / seg logits."""
@@ -199,7 +202,7 @@ def test_training_step_with_boxes_is_deterministic(cal_sd):
     N, H, W = 2, 512, 512
     x, gt_boxes, gt_masks, gt_lv = synth.train_batch(N, H, W, 3, n_boxes=300, smin=14, smax=40)
     ldec, lseg = DetectionLossAll(kp_radius=5), SEG_loss(height=H, width=W)
-    m = make_model(cal_sd, "mixed").train()
+    m = make_model(cal_sd, "fp32").train()
     runs = []
     for _ in range(2):
         m.load_state_dict(cal_sd)
@@ -217,7 +220,7 @@ def test_training_step_with_boxes_is_deterministic(cal_sd):
 def test_backward_of_a_stale_forward_is_refused(cal_sd):
     """The engine keeps the activations of the latest forward_dec only: backward through an older forward must raise, not
     silently use the newer activations."""
-    m = make_model(cal_sd, "mixed").train()
+    m = make_model(cal_sd, "fp32").train()
     x = torch.rand(1, 3, 64, 64, device=DEV) - 0.5
     a = m.forward_dec(x)[0][1].sum()
     b = m.forward_dec(x)[0][1].sum()
@@ -235,7 +238,7 @@ def test_config3_batch16_full_path(cal_sd):
     from kg_instance_segmentation_amd import postprocessing as kpp
     from oracle import postproc as op
     N, S = 16, 512
-    m = make_model(cal_sd, "mixed").eval()
+    m = make_model(cal_sd, "fp32").eval()
     x = (torch.rand(N, 3, S, S, generator=torch.Generator().manual_seed(16)) - 0.5).to(DEV)
     with torch.no_grad():
         dec = m.forward_dec(x)[:4]

@@ -14,20 +14,41 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from kg_instance_segmentation_amd import _lib, ops  # noqa: E402
-from kg_instance_segmentation_amd.ops import BF16, PT, PackedWeight  # noqa: E402
+from kg_instance_segmentation_amd.ops import BF16, F16, PT  # noqa: E402
 
 DEV = "cuda"
-TOL = {1: 6e-3, 2: 1.5e-4, 3: 3e-6}
+DT = [BF16]          # 16-bit format under test: BF16 (libkgnet_hip.so) or F16 (IEEE half rows, libkgnet_hip_f16.so)
+TOLS = {BF16: {1: 6e-3, 2: 1.5e-4, 3: 3e-6}, F16: {1: 1e-3, 2: 5e-6, 3: 3e-6}}      # (half: 11 bits per plane, hi + lo = 22 bits)
+# (P, format): bf16 hi + lo / hi + mid + lo, half single / hi + lo
+VARIANTS = [(2, BF16), (3, BF16), (1, F16), (2, F16)]
+VIDS = ["bf16x2", "bf16x3", "f16x1", "f16x2"]
+
+
+class _Tol:
+    def __getitem__(self, P):
+        return TOLS[DT[0]][P]
+
+
+TOL = _Tol()
+
+
+def PackedWeight(*a, **k):
+    k.setdefault("dtype", DT[0])
+    return ops.PackedWeight(*a, **k)
+
+
+def alloc_pt(rows, C, P, dev):
+    return ops.alloc_pt(rows, C, P, dev, dtype=DT[0])
 
 
 def to_pt(rows_f32, P, ctot=None, c0=0):
     """fp32 [rows, C] (device) -> PT with P planes (optionally a column slice c0.. of a wider [rows, ctot] plane)."""
     rows, C = rows_f32.shape
     ctot = ctot or C
-    buf = torch.zeros(rows, P * ctot, dtype=BF16, device=rows_f32.device)
+    buf = torch.zeros(rows, P * ctot, dtype=DT[0], device=rows_f32.device)
     r = rows_f32.clone()
     for p in range(P):
-        h = r.to(BF16)
+        h = r.to(DT[0])
         buf[:, p * ctot + c0:p * ctot + c0 + C] = h
         r = r - h.float()
     return PT(buf[:, c0:c0 + C], P, ctot)
@@ -58,6 +79,7 @@ def check(name, got, ref, rel):
 
 
 def test_split_roundtrip_exact():
+    DT[0] = BF16
     """P = 3 planes written by the kernels hold fp32 values exactly (kg_f32_to_planes -> kg_planes_to_f32), including tiny and huge
     magnitudes; P = 2 keeps 16 bits."""
     g = torch.Generator().manual_seed(0)
@@ -65,7 +87,7 @@ def test_split_roundtrip_exact():
     x = torch.where(x.abs() < 1e-30, torch.full_like(x, 1e-30), x)       # (residual planes of values near FLT_MIN are denormal: flushed)
     x[0, :6] = torch.tensor([0.0, -0.0, 1.0, -1.0, 1.0e38, 1.0 + 2.0 ** -23], device=DEV)
     for P in (1, 2, 3):
-        pt = ops.alloc_pt(1000, 64, P, DEV)
+        pt = alloc_pt(1000, 64, P, DEV)
         ops.f32_to_planes(x, pt, 64)
         back = torch.empty_like(x)
         ops.planes_to_f32(pt, 64, back)
@@ -90,9 +112,10 @@ PLANE_CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("P", [2, 3])
+@pytest.mark.parametrize("P,dt", VARIANTS, ids=VIDS)
 @pytest.mark.parametrize("case", PLANE_CONV_CASES)
-def test_conv_forward_dgrad_wgrad_planes(case, P):
+def test_conv_forward_dgrad_wgrad_planes(case, P, dt):
+    DT[0] = dt
     cin, cout, k, stride, pad, N, H, W, relu, bias = case
     g = torch.Generator().manual_seed(abs(hash(case)) % 1000 + P)
     x = torch.randn(N, cin, H, W, generator=g)
@@ -112,7 +135,7 @@ def test_conv_forward_dgrad_wgrad_planes(case, P):
     xp = to_pt(xr.to(DEV), P, ctot=cin_pad + 16, c0=8)                 # a column slice of a wider buffer: ld != C, ps != C
     pw = PackedWeight(cout, k * k, cin_pad, DEV, xP=P, wP=P)
     pw.pack(w.to(DEV))
-    y = ops.alloc_pt(N * OH * OW, cout, P, DEV)
+    y = alloc_pt(N * OH * OW, cout, P, DEV)
     geom = (N * OH * OW, H, W, OH, OW, k, k, stride, pad)
     route = ops.conv_auto(xp, pw, cout, geom, N, y=y, bias=b.to(DEV) if bias else None, relu=relu)
     torch.cuda.synchronize()
@@ -140,6 +163,7 @@ def test_conv_forward_dgrad_wgrad_planes(case, P):
 
 @pytest.mark.parametrize("P", [2, 3])
 def test_mixed_plane_counts(P):
+    DT[0] = BF16
     """The head convs of the "mixed" policy: a single-plane conv reads plane 0 of a P-plane trunk tensor, and its input gradient
     (single-plane dY and weights) is written back as P planes straight from the fp32 accumulators."""
     g = torch.Generator().manual_seed(5)
@@ -158,14 +182,15 @@ def test_mixed_plane_counts(P):
     dy = torch.randn(N, C, H, W, generator=g).to(BF16)
     pwT = PackedWeight(C, k * k, C, DEV)
     pwT.pack(w.to(DEV), transposed=True)
-    dx = ops.alloc_pt(N * H * W, C, P, DEV)
+    dx = alloc_pt(N * H * W, C, P, DEV)
     ops.conv_auto(rows_f32(dy).to(DEV), pwT, C, geom, N, y=dx, transposed=True)
     refd = torch.nn.grad.conv2d_input((N, C, H, W), w.to(BF16).double(), dy.double(), 1, 3)
     check("P-plane store of a bf16 dgrad", nchw(from_pt(dx), N, H, W), refd, TOL[P])
 
 
-@pytest.mark.parametrize("P", [2, 3])
-def test_elementwise_planes(P):
+@pytest.mark.parametrize("P,dt", VARIANTS, ids=VIDS)
+def test_elementwise_planes(P, dt):
+    DT[0] = dt
     g = torch.Generator().manual_seed(9)
     N, C, H, W = 2, 64, 18, 22
     x = torch.randn(N, C, H, W, generator=g) * 3 + 1
@@ -176,7 +201,7 @@ def test_elementwise_planes(P):
     gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
     rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     mean, invstd, scale, shift = ops.bn_stats_train(xp, C, gamma.to(DEV), beta.to(DEV), rm, rv)
-    y = ops.alloc_pt(M, C, P, DEV)
+    y = alloc_pt(M, C, P, DEV)
     ops.bn_apply(xp, C, scale, shift, y, res=rp, relu=True)
     xd = x.double().requires_grad_(True)
     gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
@@ -188,13 +213,13 @@ def test_elementwise_planes(P):
     dyu = dy * (pre.detach() > 0)
     ref.backward(dy.double())
     dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
-    dx = ops.alloc_pt(M, C, P, DEV)
+    dx = alloc_pt(M, C, P, DEV)
     ops.bn_bwd(xp, to_pt(rows_f32(dyu.float()).to(DEV), P), C, gamma.to(DEV), mean, invstd, dg, db, dx)
     check(f"bn bwd dx P={P}", nchw(from_pt(dx), N, H, W), xd.grad, TOL[P] * 4)
     check(f"bn bwd dgamma P={P}", dg, gd.grad, TOL[P] * 4)
     # max pool
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    yp = ops.alloc_pt(N * OH * OW, C, P, DEV)
+    yp = alloc_pt(N * OH * OW, C, P, DEV)
     arg = torch.empty(N * OH * OW, C, dtype=torch.uint8, device=DEV)
     ops.maxpool_fwd(xp, yp, N, H, W, C, argmax=arg)
     xq = from_pt(xp).cpu()                                        # the value the planes hold (P = 2: 16-bit rounding of x)
@@ -203,35 +228,38 @@ def test_elementwise_planes(P):
     check(f"maxpool fwd P={P}", nchw(from_pt(yp), N, OH, OW), refp, 1e-7 if P == 3 else TOL[P])
     dyp = torch.randn(N, C, OH, OW, generator=g)
     refp.backward(dyp.double())
-    dxp = ops.alloc_pt(M, C, P, DEV)
+    dxp = alloc_pt(M, C, P, DEV)
     ops.maxpool_bwd(xp, to_pt(rows_f32(dyp).to(DEV), P), dxp, N, H, W, C)
     check(f"maxpool bwd P={P}", nchw(from_pt(dxp), N, H, W), xq4.grad, TOL[P])
-    dxa = ops.alloc_pt(M, C, P, DEV)
+    dxa = alloc_pt(M, C, P, DEV)
     ops.maxpool_bwd(xp, to_pt(rows_f32(dyp).to(DEV), P), dxa, N, H, W, C, argmax=arg)      # the stored winning taps give the same gradient
     assert torch.equal(from_pt(dxa), from_pt(dxp))
     # bilinear 2x up + backward
-    up = ops.alloc_pt(N * 4 * H * W, C, P, DEV)
+    up = alloc_pt(N * 4 * H * W, C, P, DEV)
     ops.bilinear_fwd(xp, up, N, H, W, 2 * H, 2 * W, C)
     xu = x.double().requires_grad_(True)
     refu = F.interpolate(xu, (2 * H, 2 * W), mode="bilinear", align_corners=False)
     check(f"bilinear fwd P={P}", nchw(from_pt(up), N, 2 * H, 2 * W), refu, TOL[P])
     dyu2 = torch.randn(N, C, 2 * H, 2 * W, generator=g)
     refu.backward(dyu2.double())
-    dxu = ops.alloc_pt(M, C, P, DEV)
+    dxu = alloc_pt(M, C, P, DEV)
     ops.bilinear_bwd(to_pt(rows_f32(dyu2).to(DEV), P), dxu, N, H, W, 2 * H, 2 * W, C)
     check(f"bilinear bwd P={P}", nchw(from_pt(dxu), N, H, W), xu.grad, TOL[P])
     # gradient join with ReLU mask
-    out = ops.alloc_pt(M, C, P, DEV)
+    out = alloc_pt(M, C, P, DEV)
     ops.add_rows(xp, rp, out, C, mask=rp.hi())
-    check(f"add_rows P={P}", nchw(from_pt(out), N, H, W), (x.double() + r.double()) * (r.to(BF16).double() > 0), TOL[P])
+    check(f"add_rows P={P}", nchw(from_pt(out), N, H, W), (x.double() + r.double()) * (r.to(DT[0]).double() > 0), TOL[P])
     # image pack
     img = torch.rand(2, 3, 16, 24, generator=g) - 0.5
-    ip = ops.img_pack(img.to(DEV), P)
+    ip = ops.img_pack(img.to(DEV), P, dtype=DT[0])
+    if P == 1:
+        ip = PT(ip)
     check(f"img_pack P={P}", from_pt(ip)[:, :3], rows_f32(img), TOL[P] / 4)
     assert float(from_pt(ip)[:, 3:].abs().max()) == 0.0
 
 
 def test_crop_grad_reduce_matches_index_add_and_is_deterministic():
+    DT[0] = BF16
     """kg_crop_grad_reduce (gradient of get_patches' slicing, KGnet.py:246-256) against index_add_ in fp64 on heavily overlapping
     boxes, twice bit-identically; built through SegBranch.make_plan so that the host-side bin tables are covered too."""
     from kg_instance_segmentation_amd import KGnet
@@ -270,7 +298,7 @@ def test_crop_grad_reduce_matches_index_add_and_is_deterministic():
             ref = torch.zeros(N * h * w, C, dtype=torch.float64, device=DEV).index_add_(0, plan.srcrow[l][:rows].long(), vals.double())
             check(f"crop_grad_reduce level {l} P={P}", outs[0], ref, 2e-6)
             if P == 3:      # the split-bf16 output mode writes the same sums as planes
-                outp = ops.alloc_pt(N * h * w, C, 3, DEV)
+                outp = alloc_pt(N * h * w, C, 3, DEV)
                 L.call("kg_crop_grad_reduce", L.ptr(ops.base(ga)), ops.ld(ga) if ga is not None else 0, L.ptr(ops.base(gb)), ops.ld(gb),
                        L.c_long(rows_a), L.ptr(plan.tab_d[l]), L.ptr(plan.bin_start_d[l]), L.ptr(plan.bin_boxes_d[l]),
                        __import__("kg_instance_segmentation_amd.seg", fromlist=["BIN_SIZE"]).BIN_SIZE[l], N, h, w, C, None, L.ptr(outp.t), ops.ld(outp),
