@@ -508,15 +508,15 @@ def main():
         timer.on = False
     prof_rec, timer.rec = timer.rec, []
     companion = None
-    if world == 1 and not args.no_companion and args.precision != "mixed":
+    if world == 1 and not args.no_companion and args.precision != "half":
         main_run = None
         torch.cuda.empty_cache()
         ksteps = max(2, min(args.steps, 10))
-        comp = run_train("mixed", ksteps, 3, STEP_SYNC, False)
-        companion = {"precision": "mixed", "dtype": "bf16 (single-plane bf16 MFMA operands; BatchNorm backbone hi + lo planes)",
+        comp = run_train("half", ksteps, 3, STEP_SYNC, False)
+        companion = {"precision": "half", "dtype": "f16 (single IEEE-half planes: half mixed precision)",
                      "value": args.batch * ksteps / comp["dt"], "unit": "imgs/s", "ms_per_step": 1e3 * comp["dt"] / ksteps, "steps": ksteps, "warmup": 3,
                      "last_loss": comp["losses"][-1],
-                     "parity": "NOT the reference's arithmetic: bf16 mixed precision, tests/test_gpu_parity.py holds it to rtol 2e-2 + atol 5e-2 rms"}
+                     "parity": "NOT the reference's arithmetic: half mixed precision, tests/test_gpu_parity.py holds it to rtol 2e-2 + atol 2e-2 rms"}
         comp = None
     if rank != 0:
         return
@@ -526,18 +526,26 @@ def main():
     imgs = args.batch * world * args.steps
     from kg_instance_segmentation_amd import engine as kengine
     pol = kengine.PRECISIONS[args.precision]
-    PDESC = {"fp32": "fp32-faithful: every forward tensor = hi + mid + lo bf16 planes == the fp32 value exactly, 6 bf16 MFMA products per multiply, fp32 "
-                     "accumulation (within rtol 1e-4 / atol 1e-5 of the reference on pre-sigmoid logits); backward on hi + lo planes (3 products; "
-                     "every parameter gradient: cosine >= 0.9999, norm within 2e-3 of the reference)",
-             "fp32full": "as fp32 with three planes (6 products) in the backward pass as well",
+    PDESC = {"fp32": "fp32-faithful: every forward tensor = hi + lo IEEE-half planes (22 significant bits), 3 f16 MFMA products per multiply, fp32 "
+                     "accumulation (within rtol 1e-4 / atol 1e-5 of the reference on pre-sigmoid logits, eval and train mode); backward on single half "
+                     "planes with a per-step power-of-two gradient scale chosen on the device (every parameter gradient: cosine >= 0.9999, norm "
+                     "within 2e-3 of the reference)",
+             "fp32b2": "as fp32 with hi + lo half planes (3 products) in the backward pass as well",
+             "half": "half mixed precision: single IEEE-half planes everywhere (f16 MFMA, fp32 accumulation)",
+             "halfmix": "as half, with the BatchNorm backbone (stem conv1, layer1-3) on hi + lo half planes",
+             "fp32bf": "fp32 values as hi + mid + lo bf16 planes (exact), 6 bf16 MFMA products per multiply; backward on hi + lo planes (3 products)",
+             "fp32bf_full": "as fp32bf with three planes (6 products) in the backward pass as well",
              "mixed": "bf16 MFMA, fp32 accumulation; the BatchNorm backbone (stem conv1, layer1-3) stored and multiplied as hi + lo bf16 planes "
                       "(3 products), c0_conv / decoder / 7x7 heads / seg branch single-plane bf16",
              "trunk2": "as mixed, with c0_conv and the decoder in hi + lo planes as well",
              "bf16": "bf16 MFMA, fp32 accumulation, single-plane bf16 storage everywhere"}
+    half = args.precision in kengine.HALF_POLICIES
+    faithful = (pol[0] >= 2 and pol[2] >= 2) if half else (pol[0] >= 3 and pol[2] >= 3)
     out = {"metric": "imgs/s (train fwd+bwd) at 512x512", "value": imgs / dt, "unit": "imgs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32 (as split-bf16 planes on bf16 MFMA, fp32 accumulate)" if pol[0] >= 3 and pol[2] >= 3 else "bf16", "data": "synthetic",
+           "dtype": (("f32 (as hi + lo IEEE-half planes on f16 MFMA, fp32 accumulate)" if half else "f32 (as hi + mid + lo bf16 planes on bf16 MFMA, fp32 accumulate)")
+                     if faithful else ("f16" if half else "bf16")), "data": "synthetic",
            "config": {"workload": f"KGnet train step (forward_dec+forward_seg, 4x DetectionLossAll + SEG_loss, backward, Adam), "
                                   f"batch {args.batch}/GPU, 3x{args.size}x{args.size}, {args.boxes} GT boxes/img, full HIP path",
                       "precision_policy": args.precision, "planes": list(pol), "precision": PDESC.get(args.precision, args.precision),
@@ -546,7 +554,7 @@ def main():
                       "other_readback_policy_imgs_per_s": imgs / other_dt,
                       "step_ms": [round(1e3 * (b - a), 2) for a, b in zip([t0] + marks[:-1], marks)]}}
     if companion is not None:
-        out["bf16_companion"] = companion
+        out["half_companion"] = companion
     if not args.no_kernel_timer:
         if os.environ.get("KG_BENCH_DUMP"):
             timer.rec = prof_rec
@@ -566,9 +574,10 @@ def main():
                                                   note="committed rocprofv3 PMC pass: MFMA-pipe busy / active cycles of this kernel; clock = profiled "
                                                        "active cycles per launch / this run's launch time (DVFS: below 2.4 GHz under MFMA load)") if args.batch == 8 else pm,
                                "note": "achieved = algorithmic fp32 conv FLOPs (2*N*H*W*Cout*49*Cin) of the launches / their HIP-event time, measured inside "
-                                       "the timed region; every fp32 multiply is evaluated as `products_per_multiply` bf16 MFMA products (launch-weighted: 6 in "
-                                       "the forward, 3 in the input gradients), so peak = 2500 TFLOP/s dense bf16 MFMA / products and frac = MFMA-issued "
-                                       "FLOP/s / 2500; traffic = HBM bytes per launch from the committed PMC pass"}
+                                       "the timed region; every multiply of the policy is evaluated as `products_per_multiply` 16-bit MFMA products (launch-weighted over "
+                                       "the forward and input-gradient launches of this kernel; `fp32`: 3 in the forward, 1 in the input gradients), so "
+                                       "peak = 2500 TFLOP/s dense f16 / bf16 MFMA / products and frac = MFMA-issued FLOP/s / 2500; traffic = HBM bytes per launch "
+                                       "from the committed PMC pass"}
         summ = timer.summary(prof_rec)
         if summ:
             out["kernels"] = {k: {"ms_per_step": 1e3 * v["seconds"] / prof_steps, "tflops": v["flops"] / max(v["seconds"], 1e-12) / 1e12,

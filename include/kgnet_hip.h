@@ -248,12 +248,19 @@ int kg_mask_paste(const float* flat, const int* dets, int nd, int input_h, int i
 /* ---- gradient scale of the half-precision backward pass (csrc/gradscale.hip) ----
  * kg_grad_scale: out[0] = S = 2^(target_log2 - e), out[1] = 1 / S, where max |v| over the n <= 24 fp32 device tensors
  * ptrs[i][0 .. counts[i]) (host arrays of device pointers / counts) = f * 2^e, f in [0.5, 1); S = 1 when the maximum is 0 or not
- * finite.  scratch: 2 zero-initialised unsigned on the device (left zeroed).  The tensors are the gradients of the loss w.r.t.
+ * finite.  probs (optional host array, entries may be NULL): sigmoid outputs -- the value taken is then v * q * (1 - q), the gradient
+ * w.r.t. the logit (what kg_grad_pack stores).  scratch: 2 zero-initialised unsigned on the device (left zeroed).  The tensors are the gradients of the loss w.r.t.
  * the network outputs (12 head maps + the seg probabilities: what `loss.backward()` hands to KGnet.forward's node, train.py:153).
- * kg_scale_tensors: multiplies njobs fp32 tensors by *scale in ONE launch: jobs = device array of 24-byte records
- * {float* p; long n; int blk0; int pad;} (blk0 = first workgroup of the job, 4096 elements per workgroup). */
-int kg_grad_scale(const void* const* ptrs, const long* counts, int n, int target_log2, void* scratch, float* out, void* stream);
-int kg_scale_tensors(const void* jobs, int njobs, int total_blocks, const float* scale, void* stream);
+ * kg_scale_tensors: multiplies njobs fp32 tensors by a device scalar each in ONE launch: jobs = device array of 32-byte records
+ * {float* p; long n; const float* scale; int blk0; int pad;} (blk0 = first workgroup of the job, 4096 elements per workgroup).
+ * kg_rows_rescale (stage boundary of the backward pass: the complete gradient of c4 / c3 / c2 / c1, csrc/norm_pool.hip): r = the power of
+ * two that brings max |g| of the rows tensor into [2^(t-1), 2^t); g *= r in place; cum_out = {cum_in[0] * r, 1 / (cum_in[0] * r)},
+ * r_out[0] = r (all on the device).  kg_rows_scale: rows *= *r in place (pending gradients of upstream tensors).  planes: a = g. */
+int kg_grad_scale(const void* const* ptrs, const void* const* probs, const long* counts, int n, int target_log2, void* scratch, float* out, void* stream);
+int kg_scale_tensors(const void* jobs, int njobs, int total_blocks, void* stream);
+int kg_rows_rescale(void* g, int ld, long M, int C, int target_log2, const float* cum_in, float* cum_out, float* r_out, void* scratch,
+                    const kg_planes_t* planes, void* stream);
+int kg_rows_scale(void* g, int ld, long M, int C, const float* r, const kg_planes_t* planes, void* stream);
 
 #ifdef __cplusplus
 }

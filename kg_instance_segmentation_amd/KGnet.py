@@ -34,28 +34,38 @@ class _Node(nn.Module):
     """Pure container so that parameter keys match the reference's dotted names."""
 
 
-def _begin_scaled_backward(eng, top_grads):
+def _begin_scaled_backward(eng, top_grads, probs=None):
     """Half-precision build (engine.HALF_POLICIES): the power-of-two scale of this backward pass, computed on the device from the
     gradients of the loss w.r.t. the network outputs (ops.grad_scale).  Returns the device pair {S, 1 / S} or None (bf16 build)."""
     if not eng.fmt:
+        eng.gscale = None
         return None
     from . import ops
-    gs = ops.grad_scale(top_grads)
+    gs = ops.grad_scale(top_grads, probs)
+    eng.gscale, eng.cur_gsc, eng.param_gsc = gs, None, {}
     if eng.grad_store is not None:
-        eng.grad_store.unscale = gs[1:2]      # data parallel: a bucket is divided by S right before its all-reduce
+        eng.grad_store.unscale_of = eng.param_gsc      # data parallel: a bucket's gradients are divided by their scales right before its all-reduce
     return gs
 
 
+def _kp_probs(eng, map_grads):
+    """the kp maps are sigmoid outputs (KGnet.py:300): their gradients enter the network times p * (1 - p) (engine.backward_dec)"""
+    return [eng.maps[i] if (i % 3 == 0 and g is not None) else None for i, g in enumerate(map_grads)]
+
+
 def _end_scaled_backward(eng, gs, pgrads):
-    """divides S out of every parameter gradient the backward pass produced outside the data-parallel flat buffer (one launch)"""
+    """divides the scale out of every parameter gradient the backward pass produced outside the data-parallel flat buffer (one launch):
+    S for the heads / decoder / seg branch / c0_conv, the cumulative scale of its backbone stage for the rest (engine.stage_boundary)"""
     if gs is None:
         return
     from . import ops
     store = eng.grad_store
-    ops.scale_tensors([g for k, g in pgrads.items() if g is not None and not (store is not None and store.owns(k, g))], gs[1:2])
+    items = [(k, g) for k, g in pgrads.items() if g is not None and not (store is not None and store.owns(k, g))]
+    ops.scale_tensors([g for _, g in items], [eng.param_gsc[k][1:2] for k, _ in items])
     if store is not None:
         store.unscale_pending()
-        store.unscale = None
+        store.unscale_of = None
+    eng.gscale, eng.cur_gsc = None, None
 
 
 class _DecFunction(torch.autograd.Function):
@@ -86,7 +96,7 @@ class _DecFunction(torch.autograd.Function):
         store = eng.grad_store
         with torch.cuda.device(next(g for g in grads if g is not None).device):
             mg = [None if g is None else g.contiguous().float() for g in grads[:12]]
-            gs = _begin_scaled_backward(eng, mg + fg)
+            gs = _begin_scaled_backward(eng, mg + fg, _kp_probs(eng, mg) + [None] * len(fg))
             pg = eng.backward_dec(mg, fg, gscale=gs)
             _end_scaled_backward(eng, gs, pg)
         out = [None, None, None]
@@ -131,7 +141,7 @@ class _NetFunction(torch.autograd.Function):
             if gflat is not None:
                 gflat = gflat.contiguous().float()
             mg = [None if g is None else g.contiguous().float() for g in grads[:12]]
-            gs = _begin_scaled_backward(eng, mg + [gflat])
+            gs = _begin_scaled_backward(eng, mg + [gflat], _kp_probs(eng, mg) + [ctx.saved[4] if (ctx.saved is not None and gflat is not None) else None])
             fg, spg = [None] * 5, {}
             if gflat is not None and ctx.saved is not None:
                 fg, spg = seg.run_backward(ctx.plan, ctx.saved, gflat, ctx.feat_shapes, gscale=gs)

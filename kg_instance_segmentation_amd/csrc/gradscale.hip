@@ -11,6 +11,7 @@
 
 struct GradScaleArgs {
     const float* p[24];
+    const float* q[24];     // optional probabilities: the gradient that enters the network is p * q * (1 - q) (sigmoid outputs: kg_grad_pack)
     long n[24];
     int count, target_log2;
 };
@@ -20,9 +21,12 @@ __global__ __launch_bounds__(256) void grad_scale_kernel(GradScaleArgs a, unsign
     unsigned best = 0;
     for (int t = 0; t < a.count; ++t) {
         const float* p = a.p[t];
+        const float* q = a.q[t];
         const long n = a.n[t];
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-            const unsigned b = __float_as_uint(p[i]) & 0x7fffffffu;      // |v| as ordered bits (NaN sorts above inf: handled below)
+            float v = p[i];
+            if (q) { const float s = q[i]; v *= s * (1.f - s); }          // (exactly kg_grad_pack's expression)
+            const unsigned b = __float_as_uint(v) & 0x7fffffffu;         // |v| as ordered bits (NaN sorts above inf: handled below)
             best = b > best ? b : best;
         }
     }
@@ -57,14 +61,20 @@ __global__ __launch_bounds__(256) void grad_scale_kernel(GradScaleArgs a, unsign
     }
 }
 
-// ptrs / counts: n <= 24 fp32 device tensors (the gradients of the loss w.r.t. the network outputs of this step); out: 2 floats
+// ptrs / counts: n <= 24 fp32 device tensors (the gradients of the loss w.r.t. the network outputs of this step); probs (optional host
+// array, entries may be null): the sigmoid output the gradient refers to -- the value that counts is then g * q * (1 - q), the gradient
+// w.r.t. the LOGIT that kg_grad_pack hands to the network (with saturated sigmoids dL/dq reaches 1e12 while that product is 0); out: 2 floats
 // {S, 1 / S}; scratch: 2 zeroed unsigned (left zeroed).  target_log2: the largest gradient lands in [2^(t-1), 2^t).
-extern "C" int kg_grad_scale(const void* const* ptrs, const long* counts, int n, int target_log2, void* scratch, float* out, void* stream) {
+extern "C" int kg_grad_scale(const void* const* ptrs, const void* const* probs, const long* counts, int n, int target_log2, void* scratch, float* out,
+                             void* stream) {
     KG_CHECK_ARG(ptrs && counts && scratch && out && n >= 1 && n <= 24, "kg_grad_scale: 1..24 tensors, scratch and out required");
     GradScaleArgs a;
     long total = 0;
     a.count = n; a.target_log2 = target_log2;
-    for (int i = 0; i < 24; ++i) { a.p[i] = i < n ? (const float*)ptrs[i] : nullptr; a.n[i] = i < n ? counts[i] : 0; total += a.n[i]; }
+    for (int i = 0; i < 24; ++i) {
+        a.p[i] = i < n ? (const float*)ptrs[i] : nullptr; a.q[i] = (i < n && probs) ? (const float*)probs[i] : nullptr;
+        a.n[i] = i < n ? counts[i] : 0; total += a.n[i];
+    }
     for (int i = 0; i < n; ++i) KG_CHECK_ARG(a.p[i] && a.n[i] >= 0, "kg_grad_scale: null tensor");
     int blocks = (int)((total + 256 * 16 - 1) / (256 * 16));
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
@@ -73,17 +83,17 @@ extern "C" int kg_grad_scale(const void* const* ptrs, const long* counts, int n,
     return KG_OK;
 }
 
-struct ScaleJob {   // 16 bytes + blk0, mirrored by ops.scale_tensors
-    float* p; long n; int blk0; int pad;
+struct ScaleJob {   // 32 bytes, mirrored by ops.scale_tensors
+    float* p; long n; const float* scale; int blk0; int pad;
 };
-__global__ __launch_bounds__(256) void scale_tensors_kernel(const ScaleJob* __restrict__ jobs, int njobs, const float* __restrict__ scale) {
+__global__ __launch_bounds__(256) void scale_tensors_kernel(const ScaleJob* __restrict__ jobs, int njobs) {
     int lo = 0, hi = njobs - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const ScaleJob j = jobs[lo];
-    const float s = *scale;
+    const float s = *j.scale;
     const long base = ((long)blockIdx.x - j.blk0) * 4096;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -98,11 +108,12 @@ __global__ __launch_bounds__(256) void scale_tensors_kernel(const ScaleJob* __re
         }
     }
 }
-// jobs: device array of njobs 24-byte records {float* p; long n; int blk0; int pad;} (a workgroup scales 4096 elements;
-// total_blocks = sum of ceil(n / 4096)); every element is multiplied by *scale (device scalar: out[1] of kg_grad_scale).
-extern "C" int kg_scale_tensors(const void* jobs, int njobs, int total_blocks, const float* scale, void* stream) {
-    KG_CHECK_ARG(jobs && scale && njobs > 0 && total_blocks > 0, "kg_scale_tensors: empty job list");
-    hipLaunchKernelGGL(scale_tensors_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const ScaleJob*)jobs, njobs, scale);
+// jobs: device array of njobs 32-byte records {float* p; long n; const float* scale; int blk0; int pad;} (a workgroup scales 4096
+// elements; total_blocks = sum of ceil(n / 4096)); every element of job j is multiplied by *jobs[j].scale (a device scalar: the
+// 1 / S of kg_grad_scale or the 1 / cum of the backbone stage the parameter belongs to, kg_rows_rescale).
+extern "C" int kg_scale_tensors(const void* jobs, int njobs, int total_blocks, void* stream) {
+    KG_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "kg_scale_tensors: empty job list");
+    hipLaunchKernelGGL(scale_tensors_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const ScaleJob*)jobs, njobs);
     KG_CHECK_LAUNCH("scale_tensors");
     return KG_OK;
 }

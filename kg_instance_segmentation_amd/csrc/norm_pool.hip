@@ -545,3 +545,99 @@ extern "C" int kg_add_rows(const void* a, int lda, const void* b, int ldb, const
     KG_CHECK_LAUNCH("add_rows");
     return KG_OK;
 }
+
+// ---- stage boundaries of the half-precision backward pass ------------------------------------------------------------------------
+// The BatchNorm backbone multiplies the gradient by gamma / sigma layer after layer: at random init it grows ~2^12 from c4 to the
+// stem (tools/gradmax_probe.py), more than one global power-of-two scale can place inside IEEE half's range together with the
+// 1e-7-sized loss gradients of the heads.  The backward pass therefore re-normalises the gradient where it enters a backbone stage
+// (the complete gradient of c4, c3, c2, c1): kg_rows_rescale measures max |g| of that rows tensor on the device, multiplies the tensor
+// in place by the power of two r that brings the maximum into [2^(T-1), 2^T), and chains the running scale: cum_out = cum_in * r.
+// Everything downstream of the boundary (the stage's backward convs and BatchNorms) is linear in g, so its parameter gradients come
+// out times cum_out and are divided by it where they leave (kg_scale_tensors, one device scalar per parameter); gradient contributions
+// that were produced at the old scale for tensors further upstream (decoder skip / seg crop gradients of c3, c2, c1) are multiplied by
+// the same r (kg_rows_scale).  All factors are powers of two: exact.  No host round trip.
+__global__ __launch_bounds__(256) void rows_absmax_kernel(const RowsR g, long M, int C8, int target_log2, const float* __restrict__ cum_in,
+                                                          float* __restrict__ cum_out, float* __restrict__ r_out, unsigned* scratch) {
+    const long total = M * C8;
+    unsigned best = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C8; const int c = (int)(i - r * C8) * 8;
+        float v[8];
+        rd8(g, r, c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const unsigned b = __float_as_uint(v[e]) & 0x7fffffffu; best = b > best ? b : best; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned q = __shfl_xor(best, o, 64); best = q > best ? q : best; }
+    __shared__ unsigned wmax[4];
+    __shared__ bool last;
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned m = wmax[0];
+        for (int w = 1; w < 4; ++w) m = wmax[w] > m ? wmax[w] : m;
+        atomicMax(&scratch[0], m);
+        __threadfence();
+        last = atomicAdd(&scratch[1], 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        const unsigned m = atomicMax(&scratch[0], 0u);
+        float r = 1.f;
+        if (m != 0 && m < 0x7f800000u) {      // (an all-zero or already overflowed tensor is left as it is)
+            int e;
+            frexpf(__uint_as_float(m), &e);
+            int k = target_log2 - e;
+            k = k > 60 ? 60 : (k < -60 ? -60 : k);
+            r = ldexpf(1.f, k);
+        }
+        const float c = cum_in[0] * r;
+        r_out[0] = r; cum_out[0] = c; cum_out[1] = 1.f / c;
+        scratch[0] = 0; scratch[1] = 0;
+        __threadfence();
+    }
+}
+__global__ void rows_scale_kernel(bf16_t* __restrict__ p, int ld, int P, int ps, long M, int C8, const float* __restrict__ r) {
+    const float s = *r;
+    if (s == 1.f) return;
+    const long total = M * C8 * P;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long q = i / P; const int pl = (int)(i - q * P);
+        const long row = q / C8; const int c = (int)(q - row * C8) * 8;
+        uint4* a = reinterpret_cast<uint4*>(p + row * ld + (long)pl * ps + c);
+        uint4 v = *a;
+        bf16_t* h = reinterpret_cast<bf16_t*>(&v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = f2bf(bf2f(h[e]) * s);       // (a power of two: exact in every plane, barring the format's range)
+        *a = v;
+    }
+}
+// planes: a = g.  cum_in: device {scale, 1 / scale} the tensor is expressed in; cum_out (2 floats), r_out (1 float): see above;
+// scratch: 2 zero-initialised unsigned (left zeroed).  In place.
+extern "C" int kg_rows_rescale(void* g, int ld, long M, int C, int target_log2, const float* cum_in, float* cum_out, float* r_out,
+                               void* scratch, const kg_planes_t* planes, void* stream) {
+    KG_PLANES(planes);
+    KG_CHECK_ARG(g && cum_in && cum_out && r_out && scratch && C % 8 == 0 && ld % 8 == 0, "kg_rows_rescale: bad args");
+    if (M == 0) return KG_OK;
+    const long total = M * (C / 8);
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(rows_absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, RowsR{(const bf16_t*)g, ld, pp.a_planes, pp.a_pstride}, M, C / 8,
+                       target_log2, cum_in, cum_out, r_out, (unsigned*)scratch);
+    KG_CHECK_LAUNCH("rows_absmax");
+    int b2 = (int)((total * pp.a_planes + 255) / 256); if (b2 > 16384) b2 = 16384;
+    hipLaunchKernelGGL(rows_scale_kernel, dim3(b2), dim3(256), 0, (hipStream_t)stream, (bf16_t*)g, ld, pp.a_planes, pp.a_pstride, M, C / 8, (const float*)r_out);
+    KG_CHECK_LAUNCH("rows_scale");
+    return KG_OK;
+}
+// rows *= *r (device scalar, a power of two), every plane, in place.  planes: a = g
+extern "C" int kg_rows_scale(void* g, int ld, long M, int C, const float* r, const kg_planes_t* planes, void* stream) {
+    KG_PLANES(planes);
+    KG_CHECK_ARG(g && r && C % 8 == 0 && ld % 8 == 0, "kg_rows_scale: bad args");
+    if (M == 0) return KG_OK;
+    const long total = M * (C / 8) * pp.a_planes;
+    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(rows_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)g, ld, pp.a_planes, pp.a_pstride, M, C / 8, r);
+    KG_CHECK_LAUNCH("rows_scale");
+    return KG_OK;
+}

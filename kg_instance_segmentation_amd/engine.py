@@ -69,7 +69,7 @@ def trunc(t, P):
 
 class Var:
     """Activation (split-bf16 rows, ops.PT) + its gradient slot."""
-    __slots__ = ("t", "C", "relu", "grad", "masked", "pending", "pmasked", "req", "parent", "c0", "gP", "bn_part")
+    __slots__ = ("t", "C", "relu", "grad", "masked", "pending", "pmasked", "req", "parent", "c0", "gP", "bn_part", "gsc", "boundary")
 
     def __init__(self, t, C, relu=False, req=True, parent=None, c0=0, gP=None):
         self.t = t if isinstance(t, PT) else PT(t)
@@ -78,6 +78,8 @@ class Var:
         self.grad, self.masked = None, True
         self.pending, self.pmasked = None, True     # one more contribution whose addition is deferred to take_grad (fused with the mask)
         self.parent, self.c0 = parent, c0
+        self.gsc = None            # half build: device {scale, 1 / scale} this tensor's gradient is expressed in (None: the pass's S)
+        self.boundary = False      # half build: the gradient is re-normalised when complete (Engine.stage_boundary)
 
     @property
     def rows(self):
@@ -97,7 +99,11 @@ class Var:
             return p.grad.cols(self.c0, self.c0 + self.C)
         return ops.alloc_pt(self.rows, self.C, self.gP, self.t.device, dtype=self.t.t.dtype)
 
-    def add_grad(self, g, masked):
+    def add_grad(self, g, masked, gsc=None):
+        if gsc is not self.gsc:
+            if self.grad is not None or self.pending is not None:
+                raise RuntimeError("gradient contributions of one tensor carry different scales (engine stage boundaries)")
+            self.gsc = gsc
         if self.parent is not None:      # written in place into the parent's buffer
             self.parent.masked = self.parent.masked and masked
             return
@@ -155,7 +161,7 @@ class Engine:
         self.eval_downgrade = os.environ.get("KG_EVAL_DOWNGRADE", "0") == "1"     # opt-in: eval-mode backbone on the decoder's planes ("mixed": plain bf16 inference)
         self.raw_kp_logits = False   # test hook: inference-only export of the kp LOGITS instead of sigmoid(logits) (KGnet.py:300)
         self.grad_store = None     # parallel.FlatGradReducer: key -> persistent fp32 view the gradient kernels write into directly
-        self.grad_hook = None      # parallel.GradReducer.attach: called with [(key, grad)] as backward produces them
+        self.grad_hook = None      # parallel.FlatGradReducer.attach: called with [(key, grad)] as backward produces them
 
     def set_precision(self, precision):
         if precision not in PRECISIONS:
@@ -168,6 +174,7 @@ class Engine:
         self.dt = ops.F16 if precision in HALF_POLICIES else ops.BF16      # 16-bit format of every rows tensor / packed weight (ops.fmt_of)
         self.fmt = 1 if self.dt == ops.F16 else 0
         self.gscale = None         # half build: device {S, 1 / S} of the running backward pass (ops.grad_scale)
+        self.cur_gsc, self.param_gsc = None, {}      # ... and the (stage) scale each parameter gradient was produced in
         self.bpt = self.pt         # backbone planes of the CURRENT forward (see forward_dec)
         self.invalidate_caches()
 
@@ -183,14 +190,39 @@ class Engine:
     def new_grad(self, key, like):
         """Destination of a parameter gradient: a fresh tensor, or -- data parallel -- the parameter's slot in the persistent flat
         gradient buffer (parallel.FlatGradReducer), which RCCL reduces in place and the optimizer reads in place."""
+        if self.gscale is not None:
+            self.param_gsc[key] = self.cur_gsc if self.cur_gsc is not None else self.gscale
         if self.grad_store is not None:
             v = self.grad_store.get(key)
             if v is not None:
                 return v
         return torch.empty_like(like)
 
+    def stage_boundary(self, yv, g):
+        """Half build: the gradient g of a backbone stage output (c4, c3, c2 or c1) is complete -- re-normalise it to the target magnitude
+        on the device (ops.rows_rescale: the BatchNorm backbone multiplies the gradient by gamma / sigma layer after layer, ~2^12 from c4
+        to the stem at random init), and bring the contributions the decoder / seg branch already left on the stage outputs further
+        upstream to the same scale."""
+        if self.gscale is None:
+            return
+        cum_in = yv.gsc if yv.gsc is not None else self.gscale
+        r, cum = ops.rows_rescale(g, yv.C, cum_in)
+        yv.gsc = cum
+        for fv in self.feats[1:]:
+            if fv is yv:
+                break
+            if fv.gsc is not cum_in and not (fv.gsc is None and cum_in is self.gscale):
+                if fv.grad is not None or fv.pending is not None:
+                    raise RuntimeError("stage boundary: an upstream gradient carries an unexpected scale")
+            for t in (fv.grad, fv.pending):
+                if t is not None:
+                    ops.rows_scale(t, fv.C, r)
+            fv.gsc = cum
+
     def place_grad(self, key, g):
         """a small (bias / BatchNorm) gradient vector produced as a slice of a shared buffer: copied into its flat slot if there is one"""
+        if self.gscale is not None:
+            self.param_gsc[key] = self.cur_gsc if self.cur_gsc is not None else self.gscale
         if self.grad_store is not None:
             v = self.grad_store.get(key)
             if v is not None:
@@ -276,10 +308,14 @@ class Engine:
         xin = trunc(xv.t, s.P)
         arm = bn_stats and ops.CONV_BN_STATS and self.m.training and y_f32 is None and not relu
         part = ops.conv_stats_begin(dev, self.fmt) if arm else None
-        ops.conv_auto(xin, s.pw, s.cout, geom, N, y=out, y_f32=y_f32, bias=s.bias_cat if s.has_bias else None, relu=relu, tile=tile)
+        nb = 0
+        try:
+            ops.conv_auto(xin, s.pw, s.cout, geom, N, y=out, y_f32=y_f32, bias=s.bias_cat if s.has_bias else None, relu=relu, tile=tile)
+        finally:
+            if arm:          # (always disarm: an exception in the launch must not leave the side channel armed for the next conv)
+                nb = ops.conv_stats_end(self.fmt)
         yv = Var(out, s.cout, relu=relu, gP=s.gP)
         if arm:
-            nb = ops.conv_stats_end(self.fmt)
             yv.bn_part = (part, nb) if nb > 0 else None
         if train:
             def bwd():
@@ -288,6 +324,7 @@ class Engine:
                     return
                 g = trunc(g, s.gP)       # (an output stored in more planes than this conv computes in: its gradient is rounded alike)
                 grads, off = [], 0
+                self.cur_gsc = yv.gsc     # (half build: the scale the parameter gradients produced here come out in)
                 for n, co in zip(s.names, s.couts):
                     w = self.P(n + ".weight")
                     gw = self.new_grad(n + ".weight", w)
@@ -303,11 +340,13 @@ class Engine:
                         off += co
                 if xv.req:
                     existing = xv.grad if xv.parent is None else None
+                    if existing is not None and xv.gsc is not yv.gsc:
+                        raise RuntimeError("gradient contributions of one tensor carry different scales (engine stage boundaries)")
                     dx = existing if existing is not None else xv.alloc_grad()
                     gin = (N * H * W, OH, OW, H, W, s.k, s.k, s.stride, s.pad)
                     ops.conv_auto(g, s.pwT, s.cin, gin, N, y=dx, res=existing, mask=xv.t.hi() if xv.relu else None, transposed=True)
                     if existing is None:
-                        xv.add_grad(dx, masked=xv.relu)
+                        xv.add_grad(dx, masked=xv.relu, gsc=yv.gsc)
                     else:
                         xv.masked = xv.masked or xv.relu
             self.tape.append(bwd)
@@ -348,15 +387,18 @@ class Engine:
                 g = yv.take_grad()
                 if g is None:
                     return
+                if yv.boundary:
+                    self.stage_boundary(yv, g)
+                self.cur_gsc = yv.gsc
                 dg = self.new_grad(p + ".weight", gamma)
                 db = self.new_grad(p + ".bias", beta)
                 dx = ops.alloc_pt(xv.rows, C, xv.gP, dev, dtype=self.dt)
                 ops.bn_bwd(xv.t, g, C, gamma.detach(), mean, invstd, dg, db, dx)
                 self.param_grads[p + ".weight"] = dg
                 self.param_grads[p + ".bias"] = db
-                xv.add_grad(dx, masked=True)
+                xv.add_grad(dx, masked=True, gsc=yv.gsc)
                 if res is not None:
-                    res.add_grad(g, masked=False)
+                    res.add_grad(g, masked=False, gsc=yv.gsc)
             self.tape.append(bwd)
         return yv
 
@@ -374,7 +416,7 @@ class Engine:
                     return
                 dx = ops.alloc_pt(xv.rows, C, xv.gP, xv.t.device, dtype=self.dt)
                 ops.maxpool_bwd(xv.t, g, dx, N, H, W, C, argmax=arg)
-                xv.add_grad(dx, masked=False)
+                xv.add_grad(dx, masked=False, gsc=yv.gsc)
             self.tape.append(bwd)
         return yv, OH, OW
 
@@ -390,7 +432,7 @@ class Engine:
                     return
                 dx = ops.alloc_pt(xv.rows, C, xv.gP, xv.t.device, dtype=self.dt)
                 ops.bilinear_bwd(g, dx, N, IH, IW, OH, OW, C)
-                xv.add_grad(dx, masked=False)
+                xv.add_grad(dx, masked=False, gsc=yv.gsc)
             self.tape.append(bwd)
         return yv
 
@@ -404,7 +446,7 @@ class Engine:
                     return
                 c = 0
                 for p in parts:
-                    p.add_grad(g.cols(c, c + p.C), masked=cv.relu)
+                    p.add_grad(g.cols(c, c + p.C), masked=cv.relu, gsc=cv.gsc)
                     c += p.C
             self.tape.append(bwd)
         return cv
@@ -502,6 +544,8 @@ class Engine:
         if self.stats_written:
             ops.PARAM_EPOCH[0] += 1      # the running statistics moved: folded eval-mode scale / shift copies are stale
         self.feats, self.dims, self.N, self.maps = feats, dims, N, maps
+        for fv in feats[1:]:
+            fv.boundary = True       # (half build: stage boundaries of the backward pass, stage_boundary)
         return maps, feats, dims
 
     HEAD_OFF = (0, 8, 24)      # channel offsets of the kp / short / mid gradients in the fused [rows, 64] dY buffer
@@ -604,6 +648,7 @@ class Engine:
         backward pass's own scale.  gscale (half build): device {S, 1 / S} of this backward pass (ops.grad_scale) -- the fp32 gradients
         enter times S, the parameter gradients come back times S (the caller divides them: ops.scale_tensors)."""
         gsc = gscale[0:1] if gscale is not None else None
+        self.gscale, self.cur_gsc = gscale, None
         if self.grad_store is not None:
             self.grad_store.dense_backward_started()
         for (slot, lvl, N, Hh, Wh) in self.head_slots:

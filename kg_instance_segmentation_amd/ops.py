@@ -607,12 +607,17 @@ GRAD_TARGET_LOG2 = int(__import__("os").environ.get("KG_GRAD_TARGET_LOG2", "10")
 _gs_state = {}
 
 
-def grad_scale(tensors):
+def grad_scale(tensors, probs=None):
     """Device pair {S, 1 / S} (fp32 [2]) for this backward pass: S = the power of two that brings max |t| over the given fp32
-    tensors (the gradients of the loss w.r.t. the network outputs) into [2^(T-1), 2^T), T = GRAD_TARGET_LOG2.  No host sync."""
+    tensors (the gradients of the loss w.r.t. the network outputs) into [2^(T-1), 2^T), T = GRAD_TARGET_LOG2.  probs[i] (optional):
+    the sigmoid output tensors[i] refers to -- its values count as t * q * (1 - q), what grad_pack hands to the network.  No host sync."""
     import ctypes
-    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    probs = probs or [None] * len(tensors)
+    pairs = [(t, q) for t, q in zip(tensors, probs) if t is not None and t.numel() > 0]
+    ts = [t for t, _ in pairs]
+    qs = [q for _, q in pairs]
     assert 1 <= len(ts) <= 24 and all(t.dtype == torch.float32 and t.is_contiguous() for t in ts)
+    assert all(q is None or (q.dtype == torch.float32 and q.is_contiguous() and q.numel() == t.numel()) for t, q in pairs)
     dev = ts[0].device
     scr = _gs_state.get(str(dev))
     if scr is None:
@@ -620,23 +625,45 @@ def grad_scale(tensors):
         _gs_state[str(dev)] = scr
     out = torch.empty(2, dtype=torch.float32, device=dev)
     ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    prbs = (ctypes.c_void_p * len(ts))(*[q.data_ptr() if q is not None else None for q in qs])
     cnts = (ctypes.c_long * len(ts))(*[t.numel() for t in ts])
-    _lib.call("kg_grad_scale", ptrs, cnts, len(ts), GRAD_TARGET_LOG2, ptr(scr), ptr(out), stream_ptr())
+    _lib.call("kg_grad_scale", ptrs, prbs, cnts, len(ts), GRAD_TARGET_LOG2, ptr(scr), ptr(out), stream_ptr())
     return out
 
 
 def scale_tensors(tensors, scale):
-    """every fp32 tensor *= the device scalar `scale`, one launch (kg_scale_tensors)"""
+    """every fp32 tensor *= a device scalar, one launch (kg_scale_tensors).  scale: one device scalar tensor for all, or a list with
+    one per tensor (parameters of different backbone stages carry different cumulative scales, rows_rescale)."""
     import numpy as np
-    ts = [t for t in tensors if t is not None and t.numel() > 0]
-    if not ts:
+    scales = scale if isinstance(scale, (list, tuple)) else [scale] * len(tensors)
+    pairs = [(t, sc) for t, sc in zip(tensors, scales) if t is not None and t.numel() > 0]
+    if not pairs:
         return
-    dt = np.dtype([("p", "<u8"), ("n", "<i8"), ("blk0", "<i4"), ("pad", "<i4")])
-    arr = np.zeros(len(ts), dt)
+    dt = np.dtype([("p", "<u8"), ("n", "<i8"), ("scale", "<u8"), ("blk0", "<i4"), ("pad", "<i4")])
+    arr = np.zeros(len(pairs), dt)
     blk = 0
-    for i, t in enumerate(ts):
-        assert t.dtype == torch.float32 and t.is_contiguous()
-        arr[i] = (t.data_ptr(), t.numel(), blk, 0)
+    for i, (t, sc) in enumerate(pairs):
+        assert t.dtype == torch.float32 and t.is_contiguous() and sc.dtype == torch.float32
+        arr[i] = (t.data_ptr(), t.numel(), sc.data_ptr(), blk, 0)
         blk += (t.numel() + 4095) // 4096
-    tab = h2d(arr.view(np.uint8).reshape(-1), ts[0].device)
-    _lib.call("kg_scale_tensors", ptr(tab), len(ts), blk, ptr(scale), stream_ptr())
+    tab = h2d(arr.view(np.uint8).reshape(-1), pairs[0][0].device)
+    _lib.call("kg_scale_tensors", ptr(tab), len(pairs), blk, stream_ptr())
+
+
+def rows_rescale(g, C, cum_in, target_log2=None):
+    """Stage boundary of the half-precision backward pass (csrc/norm_pool.hip): g (rows / PT, in place) *= r, the power of two that
+    brings max |g| into [2^(T-1), 2^T).  cum_in: device {scale, 1 / scale} g is expressed in.  Returns (r [1], cum_out [2]) device tensors."""
+    dev = base(g).device
+    scr = _gs_state.get(str(dev))
+    if scr is None:
+        scr = torch.zeros(2, dtype=torch.int32, device=dev)
+        _gs_state[str(dev)] = scr
+    out = torch.empty(3, dtype=torch.float32, device=dev)
+    _lib.call("kg_rows_rescale", ptr(_rows(g)), ld(g), c_long(base(g).shape[0]), C, GRAD_TARGET_LOG2 if target_log2 is None else target_log2,
+              ptr(cum_in), ptr(out[0:2]), ptr(out[2:3]), ptr(scr), pl(a=g), stream_ptr(), fmt=fmt_of(g))
+    return out[2:3], out[0:2]
+
+
+def rows_scale(g, C, r):
+    """g (rows / PT) *= the device scalar r (a power of two), in place, every plane"""
+    _lib.call("kg_rows_scale", ptr(_rows(g)), ld(g), c_long(base(g).shape[0]), C, ptr(r), pl(a=g), stream_ptr(), fmt=fmt_of(g))

@@ -54,96 +54,6 @@ def detection_denominators(gt_levels):
     return den
 
 
-class GradReducer:
-    """Bucketed gradient SUM all-reduce over RCCL.
-
-    attach(model): overlapped mode -- the decoder/heads backward (one explicit tape, engine.backward_dec) hands over
-    parameter gradients as soon as their kernels are enqueued, in backward order: the 7x7 head weights (64 M of the
-    73.9 M parameters) are complete after the first quarter of the backward pass, so their all-reduce runs on RCCL's
-    stream underneath the remaining backward kernels.  Buckets are large (few messages over the point-to-point xGMI
-    links).  reduce() after loss.backward() handles whatever was not covered (the seg-branch parameters, whose backward
-    may not run on a rank without valid boxes; a missing gradient counts as zero), or everything when not attached."""
-
-    def __init__(self, params, bucket_mb=64):
-        self.params = [p for p in params if p.requires_grad]
-        self.cap = bucket_mb << 20
-        self.pending, self.pending_bytes, self.inflight = [], 0, []
-        self.covered = set()
-        self.by_name = None
-
-    # ---- overlapped mode -------------------------------------------------------------------------
-    def attach(self, model):
-        self.by_name = dict(model.named_parameters())
-        model._engine.grad_hook = self._on_grads
-        return self
-
-    def _on_grads(self, items, last):
-        if world_size() == 1:
-            return
-        for name, g in items:
-            if name not in self.by_name or g is None:
-                continue
-            self.pending.append(g); self.pending_bytes += g.numel() * 4
-            self.covered.add(name)
-            if self.pending_bytes >= self.cap:
-                self._launch()
-        if last:
-            self._launch()
-            self._drain()
-
-    def _launch(self):
-        if not self.pending:
-            return
-        flat = torch.cat([g.reshape(-1) for g in self.pending])
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-        self.inflight.append((work, flat, self.pending))
-        self.pending, self.pending_bytes = [], 0
-
-    def _drain(self):
-        for work, flat, gs in self.inflight:
-            work.wait()
-            off = 0
-            for g in gs:
-                n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g))
-                off += n
-        self.inflight = []
-
-    # ---- after backward --------------------------------------------------------------------------
-    def reduce(self):
-        """All-reduces .grad (SUM over ranks, in place) of every parameter the overlapped mode did not cover this step."""
-        if world_size() == 1:
-            return
-        if self.by_name is not None:
-            todo = [p for n, p in self.by_name.items() if p.requires_grad and n not in self.covered]
-        else:
-            todo = self.params
-        self.covered = set()
-        buckets, cur, size = [], [], 0
-        for p in reversed(todo):
-            cur.append(p); size += p.numel() * 4
-            if size >= self.cap:
-                buckets.append(cur); cur, size = [], 0
-        if cur:
-            buckets.append(cur)
-        works = []
-        for b in buckets:
-            gs = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b]
-            flat = torch.cat([g.reshape(-1) for g in gs])
-            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, b))
-        for w, flat, b in works:
-            w.wait()
-            off = 0
-            for p in b:
-                n = p.numel()
-                g = flat[off:off + n].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-                off += n
-
-
 class FlatGradReducer:
     """Data-parallel gradient exchange over ONE persistent flat fp32 buffer.
 
@@ -158,7 +68,14 @@ class FlatGradReducer:
     The seg-branch bucket is zeroed at the start of a step (a rank whose images have no valid box runs no seg backward and must
     contribute zeros) and reduced when the dense backward starts (the same point of the collective sequence on every rank).
     finish() (after loss.backward()) waits for the outstanding reductions; `grad_scale` (e.g. 1 / world for a mean) is not applied:
-    the losses are normalised globally instead (detection_denominators)."""
+    the losses are normalised globally instead (detection_denominators).
+
+    Contract (asserted): ONE backward pass per forward and `optimizer.zero_grad(set_to_none=True)` (PyTorch's default) before every
+    forward -- the slot IS `param.grad` and the gradient kernels overwrite it, so gradient accumulation over several backward passes
+    cannot be expressed (begin_step raises if a parameter still carries a gradient; deliver raises on a foreign `.grad` tensor).
+    Known divergence from the single-device step: a parameter NO rank produced a gradient for (a skip_combine level no box of the
+    global batch reaches) gets its zero slot as `.grad` here -- Adam then applies a momentum-only update -- where one process
+    leaves `.grad` None and skips it; telling the two apart would need one more collective per step."""
 
     def __init__(self, bucket_mb=64):
         self.cap = bucket_mb << 20
@@ -168,6 +85,7 @@ class FlatGradReducer:
         self.model = model
         eng = model._engine
         params = dict(model.named_parameters())
+        self._params = {k: p for k, p in params.items() if p.requires_grad}
         seg_keys = [k for k in model._seg.param_keys if params[k].requires_grad]
         dec_keys = [k for k in reversed(model._param_keys) if k not in set(seg_keys) and params[k].requires_grad]
         # backward completes the heads first (they are last in the forward), the stem last; state_dict order is forward order
@@ -195,7 +113,7 @@ class FlatGradReducer:
         self.bucket_of = {k: i for i, (_, _, ks) in enumerate(self.buckets) for k in ks}
         self.missing = [set(ks) for _, _, ks in self.buckets]
         self.inflight, self.seg_launched = [], False
-        self.unscale, self.seg_unscaled = None, False      # half-precision backward (ops.grad_scale): device 1 / S of the running backward pass
+        self.unscale_of, self.seg_unscaled = None, False   # half-precision backward: key -> device {scale, 1 / scale} of the gradients the running backward pass produced (engine.param_gsc)
         eng.grad_store = self
         eng.grad_hook = self._on_grads
         return self
@@ -226,14 +144,19 @@ class FlatGradReducer:
     def deliver(self, key, param):
         """The slot IS the gradient: install it as param.grad (adding to a gradient accumulated earlier) and give autograd nothing."""
         v = self.slot[key]
-        if param.grad is None or param.grad.data_ptr() == v.data_ptr():
-            param.grad = v
-        else:
-            param.grad.add_(v)
+        if param.grad is not None and param.grad.data_ptr() != v.data_ptr():
+            raise RuntimeError(f"FlatGradReducer: {key}.grad is a tensor this reducer does not own (zero_grad(set_to_none=False) or a gradient "
+                               "accumulated before attach()): call optimizer.zero_grad(set_to_none=True) before every forward")
+        param.grad = v
         return None
 
     def begin_step(self):
         """Call before the forward of every step: re-arms the buckets and zeroes the seg-branch slots."""
+        stale = [k for k, p in self._params.items() if p.grad is not None]
+        if stale:
+            raise RuntimeError(f"FlatGradReducer: {len(stale)} parameters (e.g. {stale[0]}) still carry a gradient at the start of a forward: the "
+                               "gradient kernels overwrite the flat slots, so accumulation over several backward passes is not supported -- "
+                               "call optimizer.zero_grad(set_to_none=True) before every forward")
         self.missing = [set(ks) for _, _, ks in self.buckets]
         self.seg_launched, self.seg_unscaled = False, False
         self._pend_done = set()
@@ -244,11 +167,12 @@ class FlatGradReducer:
     def seg_done(self, unscale=None):
         """(the seg branch's backward has enqueued all its gradient kernels on this rank).  unscale: forward_seg ran as its own
         autograd node in the half-precision build -- its gradients carry ITS power-of-two scale, divided out here."""
-        a, b, _ = self.seg_bucket
+        a, b, ks = self.seg_bucket
         if unscale is not None and b > a and not self.seg_unscaled:
             from . import ops
             ops.scale_tensors([self.flat[a:b]], unscale)
             self.seg_unscaled = True
+            self._pend_done.update(ks)
 
     def dense_backward_started(self):
         """Start of forward_dec's backward, which EVERY rank runs and which autograd schedules after the seg branch's backward
@@ -256,7 +180,7 @@ class FlatGradReducer:
         the same order -- a rank whose images had no valid box contributes the zeros of begin_step().  The reduction then runs
         underneath the whole dense backward."""
         if not self.seg_launched and self.seg_bucket[1] > self.seg_bucket[0]:
-            self._launch(self.seg_bucket[0], self.seg_bucket[1], unscale=not self.seg_unscaled)
+            self._launch(self.seg_bucket[0], self.seg_bucket[1], self.seg_bucket[2], unscale=not self.seg_unscaled)
         self.seg_launched = True
 
     def _on_grads(self, items, last):
@@ -267,31 +191,32 @@ class FlatGradReducer:
             self.missing[i].discard(name)
             if not self.missing[i]:
                 self.missing[i] = {None}          # launched
-                self._launch(self.buckets[i][0], self.buckets[i][1])
+                self._launch(*self.buckets[i])
+
+    def _unscale(self, keys):
+        """divides the scale out of the slots of `keys` that the running backward pass produced (half-precision build: every rank has its own
+        scales, so this happens BEFORE the all-reduce)"""
+        if not self.unscale_of:
+            return
+        from . import ops
+        ks = [k for k in keys if k in self.unscale_of and k not in self._pend_done]
+        if ks:
+            ops.scale_tensors([self.slot[k] for k in ks], [self.unscale_of[k][1:2] for k in ks])
+            self._pend_done.update(ks)
 
     def unscale_pending(self):
         """end of a half-precision backward pass: gradients this rank produced in buckets that did not complete (some parameter of
         the bucket got no gradient this step) still carry the pass's scale -- divide it out slot by slot (finish() reduces such
         buckets as they stand)"""
-        if self.unscale is None:
-            return
-        from . import ops
-        todo = []
         for i, (_, _, ks) in enumerate(self.buckets):
             if self.missing[i] != {None}:
-                for k in ks:
-                    if k not in self.missing[i] and k not in self._pend_done:
-                        todo.append(self.slot[k])
-                        self._pend_done.add(k)
-        if todo:
-            ops.scale_tensors(todo, self.unscale)
+                self._unscale([k for k in ks if k not in self.missing[i]])
 
-    def _launch(self, a, b, unscale=True):
-        """a bucket is complete on this rank: divide out the backward pass's power-of-two scale (half-precision build; every rank has
-        its own), then SUM-all-reduce it in place"""
-        if unscale and self.unscale is not None:
-            from . import ops
-            ops.scale_tensors([self.flat[a:b]], self.unscale)
+    def _launch(self, a, b, keys, unscale=True):
+        """a bucket is complete on this rank: divide out the backward pass's power-of-two scales (half-precision build), then
+        SUM-all-reduce it in place"""
+        if unscale:
+            self._unscale(keys)
         if world_size() > 1:
             self.inflight.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
@@ -305,7 +230,7 @@ class FlatGradReducer:
                 if self.missing[i] != {None}:
                     for k in self.missing[i]:
                         self.slot[k].zero_()
-                    self._launch(a, b, unscale=False)      # (no backward pass is running: whatever this bucket holds is unscaled or zero)
+                    self._launch(a, b, ks, unscale=False)      # (no backward pass is running: whatever this bucket holds is unscaled or zero)
                     self.missing[i] = {None}
             for w in self.inflight:
                 w.wait()

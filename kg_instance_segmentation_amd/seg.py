@@ -97,8 +97,12 @@ class _SegFunction(torch.autograd.Function):
             raise RuntimeError("forward_seg was run without gradient recording")
         eng = ctx.branch.m._engine
         gflat = gflat.contiguous().float()
-        gs = ops.grad_scale([gflat]) if eng.fmt else None       # half build: this node's own power-of-two gradient scale
+        gs = ops.grad_scale([gflat], [ctx.saved[4]]) if eng.fmt else None       # half build: this node's own power-of-two gradient scale
+        eng.gscale, eng.cur_gsc = gs, None
+        if gs is not None:
+            eng.param_gsc = {}
         gfeats, pgrads = ctx.branch.run_backward(ctx.plan, ctx.saved, gflat, ctx.feat_shapes, gscale=gs)
+        eng.gscale = None
         out = [None, None, None] + gfeats
         store = eng.grad_store
         if gs is not None:
@@ -235,7 +239,8 @@ class SegBranch:
             out = np.empty((cnt, 4), np.int32)
             if cnt:
                 r0 = np.ascontiguousarray(p.row0[l][:-1], np.int64)
-                got = lib.kg_host_tile_table(vp(np.ascontiguousarray(h, np.int32)), vp(np.ascontiguousarray(w, np.int32)), vp(r0), nb, th, tw, vp(out), cnt)
+                hc, wc = np.ascontiguousarray(h, np.int32), np.ascontiguousarray(w, np.int32)      # (named: the arrays must outlive the call)
+                got = lib.kg_host_tile_table(vp(hc), vp(wc), vp(r0), nb, th, tw, vp(out), cnt)
                 if got != cnt:
                     raise _lib.KGLibraryError(f"kg_host_tile_table: {got} entries, expected {cnt}")
             return out

@@ -208,7 +208,7 @@ def test_elementwise_planes(P, dt):
     pre = F.batch_norm(xd, None, None, gd, bd, True, 0.1, 1e-5) + r.double()
     ref = F.relu(pre)
     check(f"bn fwd P={P}", nchw(from_pt(y), N, H, W), ref, TOL[P])
-    check("bn running_var", rv, 0.9 + 0.1 * x.double().var((0, 2, 3), unbiased=True), 1e-5)
+    check("bn running_var", rv, 0.9 + 0.1 * x.double().var((0, 2, 3), unbiased=True), max(1e-5, TOL[P] / 10))
     dy = torch.randn(N, C, H, W, generator=g)
     dyu = dy * (pre.detach() > 0)
     ref.backward(dy.double())

@@ -1,5 +1,5 @@
 """CPU (gloo, world size 2): the data-parallel helpers reproduce the single-process global-batch step:
-global loss normalisers and bucketed gradient SUM all-reduce (kg_instance_segmentation_amd/parallel.py)."""
+global loss normalisers and the flat in-place gradient SUM all-reduce (kg_instance_segmentation_amd/parallel.py)."""
 import os
 import socket
 
@@ -57,8 +57,8 @@ def _worker(rank, world, port, out):
     for q in (a, b):
         q.grad = None
     l_local.backward()
-    red = parallel.GradReducer([a, b], bucket_mb=1)
-    red.reduce()
+    for q in (a, b):                       # gradient SUM over the ranks (what FlatGradReducer does bucket by bucket)
+        dist.all_reduce(q.grad, op=dist.ReduceOp.SUM)
     tot = l_local.detach().clone(); dist.all_reduce(tot)
     out[rank] = (float(tot), float(lg), float((a.grad - ga).abs().max()), float((b.grad - gb).abs().max()), float(gb.abs().max()))
     dist.destroy_process_group()
@@ -73,59 +73,6 @@ def test_global_batch_equivalence_gloo_world2():
         tot, lg, ea, eb, scale = out[r]
         assert abs(tot - lg) <= 1e-5 * abs(lg)
         assert ea <= 1e-5 and eb <= 1e-5 * max(scale, 1.0)
-
-
-def _overlap_worker(rank, world, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
-    from kg_instance_segmentation_amd import parallel
-    parallel.init_from_env(backend="gloo")
-
-    class Eng:
-        grad_hook = None
-
-    class Model(torch.nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.heads = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(n)) for n in (1 << 18, 5, 1 << 17, 40)])
-            self.seg = torch.nn.Parameter(torch.zeros(33))       # "seg branch": its backward does not run on rank 1
-            self.rest = torch.nn.Parameter(torch.zeros(7, 3))
-            self._engine = Eng()
-
-    m = Model()
-    red = parallel.GradReducer(m.parameters(), bucket_mb=1).attach(m)
-    names = dict(m.named_parameters())
-    expect = {}
-    for step in range(2):                   # two steps: the covered set must reset
-        produced = {}
-        order = ["heads.0", "heads.1", "heads.2", "heads.3", "rest"]
-        items = []
-        for k, n in enumerate(order):
-            g = torch.full_like(names[n], float((rank + 1) * (k + 1) * (step + 1)))
-            produced[n] = g
-            expect[n] = float(3 * (k + 1) * (step + 1))     # sum over ranks 1 + 2
-            items.append((n, g))
-        # engine.backward_dec hands the gradients over in groups, then signals the end of the tape
-        m._engine.grad_hook(items[:2], False)
-        m._engine.grad_hook(items[2:], False)
-        m._engine.grad_hook([], True)
-        for n, g in produced.items():
-            names[n].grad = g
-        names["seg"].grad = torch.full((33,), 10.0 * (step + 1)) if rank == 0 else None
-        red.reduce()
-        ok = all(float((names[n].grad - expect[n]).abs().max()) == 0.0 for n in order)
-        ok = ok and float((names["seg"].grad - 10.0 * (step + 1)).abs().max()) == 0.0
-        out[(rank, step)] = ok
-    dist.destroy_process_group()
-
-
-def test_overlapped_reducer_gloo_world2():
-    """GradReducer.attach: gradients handed over during backward are all-reduced in buckets and written back in place;
-    reduce() afterwards covers the rest, with a missing gradient (no seg backward on one rank) counted as zero."""
-    world = 2
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_overlap_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    assert all(out[(r, s)] for r in range(world) for s in range(2))
 
 
 def _flat_worker(rank, world, port, out):
@@ -197,6 +144,18 @@ def _flat_worker(rank, world, port, out):
             ok = ok and names[k].grad is not None and float((names[k].grad - 7.0 * (step + 1)).abs().max()) == 0.0
         for p in m.parameters():
             p.grad = None                                  # optimizer.zero_grad(set_to_none=True)
+    # the contract is asserted: a forward that starts while a parameter still carries a gradient (no zero_grad: accumulation over
+    # several backward passes) is refused, and so is a foreign .grad tensor at delivery
+    names["conv1.weight"].grad = red.get("conv1.weight")
+    try:
+        red.begin_step(); ok = False
+    except RuntimeError:
+        pass
+    names["conv1.weight"].grad = torch.zeros_like(names["conv1.weight"])
+    try:
+        red.deliver("conv1.weight", names["conv1.weight"]); ok = False
+    except RuntimeError:
+        pass
     out[rank] = ok
     dist.destroy_process_group()
 

@@ -1,0 +1,36 @@
+"""debug (GPU box): per-tensor max |gradient| of one train step in a half policy, relative to the scaled top-level maximum --
+how much headroom the gradient scale needs (ops.GRAD_TARGET_LOG2).  usage: python tools/gradmax_probe.py [cal|raw] [size] [batch] [boxes]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from kg_instance_segmentation_amd import KGnet, engine, ops
+from kg_instance_segmentation_amd.loss import DetectionLossAll
+from kg_instance_segmentation_amd.seg_loss import SEG_loss
+from oracle import synth, weightgen
+variant = sys.argv[1] if len(sys.argv) > 1 else "cal"
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+NB = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+sd = weightgen.gen_state_dict(0, variant=variant) if variant == "cal" else weightgen.gen_state_dict(0)
+m = KGnet.resnet50(pretrained=False, precision="fp32"); m.load_state_dict(sd); m = m.to("cuda").train()
+rec = []
+orig = engine.Var.add_grad
+def add_grad(self, g, masked, gsc=None):
+    if isinstance(g, ops.PT):
+        t = g.t.float().abs()
+        rec.append((float(t.max()), float(t[t > 0].median()) if (t > 0).any() else 0.0, self.C, self.rows))
+    return orig(self, g, masked, gsc)
+engine.Var.add_grad = add_grad
+x, gt_boxes, gt_masks, gt_lv = synth.train_batch(N, S, S, 3, n_boxes=NB, smin=14, smax=40) if S >= 256 else synth.train_batch(N, S, S, 3, n_boxes=NB)
+ldec, lseg = DetectionLossAll(kp_radius=5), SEG_loss(height=S, width=S)
+d0, d1, d2, d3, pred = m(x.to("cuda"), gt_boxes)
+loss = sum(ldec(p, t.to("cuda")) for p, t in zip((d0, d1, d2, d3), gt_lv)) + lseg(pred, gt_masks, gt_boxes)
+loss.backward(); torch.cuda.synchronize()
+mx = np.array([r[0] for r in rec]); md = np.array([r[1] for r in rec])
+print("target 2^%d; gradient tensors %d; max over tensors of max|g| = 2^%.1f; min of max = 2^%.1f; median element: min over tensors 2^%.1f, median 2^%.1f" %
+      (ops.GRAD_TARGET_LOG2, len(rec), np.log2(mx.max()), np.log2(mx[mx > 0].min()), np.log2(md[md > 0].min()), np.log2(np.median(md[md > 0]))))
+for r in sorted(rec, key=lambda r: -r[0])[:6]:
+    print("  max 2^%.1f median 2^%.1f  C=%d rows=%d" % (np.log2(r[0]), np.log2(max(r[1], 1e-30)), r[2], r[3]))
+bad = [n for n, p in m.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+print("non-finite parameter gradients:", bad[:5])

@@ -3,7 +3,7 @@
 #   bash tools/profile_round.sh r01
 # Writes gpurun_out/<tag>_*: bench JSON (with cpu_baseline), rocprofv3 kernel-trace summary of the same command,
 # per-launch dump, and two separate PMC passes (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md prescribes.
-tag=${1:-r02}
+tag=${1:-r03}
 R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
@@ -21,7 +21,7 @@ tail -3 $O/${tag}_prof.log; cat $O/${tag}_bench_n1.json | cut -c1-600
 cd /tmp
 # MFMA-pipe utilisation / LDS conflicts: two more counter passes (SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs)
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/${tag}_pmc_a -o p -- python $R/bench.py --steps 1 --warmup 1 --profile-run > $O/${tag}_pmc_a.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $O/${tag}_pmc_b -o p -- python $R/bench.py --steps 1 --warmup 1 --profile-run > $O/${tag}_pmc_b.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $O/${tag}_pmc_b -o p -- python $R/bench.py --steps 1 --warmup 1 --profile-run > $O/${tag}_pmc_b.log 2>&1
 python $R/tools/pmc_summary.py $O/${tag}_pmc_mfma_lds.json $(find $O/${tag}_pmc_a $O/${tag}_pmc_b -name "*counter_collection.csv") > /dev/null 2>&1
 rm -rf $O/${tag}_pmc_a $O/${tag}_pmc_b
 rocprofv3 --kernel-trace --output-format csv -d $O/${tag}_shp -o p -- python $R/bench.py --steps 4 --warmup 1 --profile-run > $O/${tag}_shp.log 2>&1
