@@ -175,6 +175,10 @@ int kg_detection_loss_bwd(const float* kp, const float* sh, const float* md, con
 int kg_seg_loss(const float* prob, const void* tgt_u8, const int* patches, const void* pairs, int npatches, float* part,
                 float* out1, const float* grad_out, float* gprob, void* stream);
 
+/* measurement hook (bench.py --mode eval): begin arms this host thread -- every kg_postproc_scale call then records HIP events at its
+ * phase boundaries on its own stream; end waits and returns the summed milliseconds {Hough vote, Gaussian, peaks + ranking, grouping} */
+int kg_postproc_timing_begin(void);
+int kg_postproc_timing_end(float* ms4);
 /* ---- post-processing in float64, bit-identical to postprocessing.py:16-261 and nms.py:4-53 ---- */
 long kg_postproc_workspace_bytes(int H, int W, int peak_cap, int skel_cap);
 int kg_postproc_scale(const float* kp, const float* soff, const float* mid, int H, int W, double thresh, void* ws,

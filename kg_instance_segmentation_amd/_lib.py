@@ -62,6 +62,8 @@ _SIGS = {
     "kg_grad_pack": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "kg_postproc_workspace_bytes": [c_int, c_int, c_int, c_int],
     "kg_postproc_scale": [P, P, P, c_int, c_int, c_double, P, c_long, c_int, c_int, P, P, P, P, P, P, P, P],
+    "kg_postproc_timing_begin": [],
+    "kg_postproc_timing_end": [P],
     "kg_skeleton_boxes": [P, P, c_int, c_double, c_int, P, P, c_int, P],
     "kg_nms": [P, P, c_int, c_double, P, c_long, P, P, P],
     "kg_gt_maps": [P, c_int, c_int, c_int, P, P],

@@ -714,6 +714,46 @@ static void carve(void* ws, int H, int W, int peak_cap, int skel_cap, PPWs* p) {
     p->scanpart = (int*)take(5 * SCAN_NB * 4);
 }
 
+// ---- phase timing (measurement hook of bench.py --mode eval: the roofline of the HBM-bound phases) ------------------------------------
+// kg_postproc_timing_begin() arms this host thread: every kg_postproc_scale call then records HIP events on ITS stream at the phase
+// boundaries (Hough vote | Gaussian | peaks + ranking | grouping).  kg_postproc_timing_end(ms) waits for them and returns the
+// summed durations of the calls since begin: ms[0..3] = Hough, Gaussian, peaks, grouping.  Not armed: no events, no cost.
+#include <vector>
+struct PPTiming { bool on = false; std::vector<hipEvent_t> ev; };
+static PPTiming& pp_timing() { static thread_local PPTiming t; return t; }
+static inline void pp_mark(hipStream_t st) {
+    PPTiming& t = pp_timing();
+    if (!t.on) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    t.ev.push_back(e);
+}
+extern "C" int kg_postproc_timing_begin(void) {
+    PPTiming& t = pp_timing();
+    for (hipEvent_t e : t.ev) (void)hipEventDestroy(e);
+    t.ev.clear();
+    t.on = true;
+    return KG_OK;
+}
+extern "C" int kg_postproc_timing_end(float* ms4) {
+    PPTiming& t = pp_timing();
+    KG_CHECK_ARG(ms4 && t.on, "kg_postproc_timing_end: not armed");
+    t.on = false;
+    for (int k = 0; k < 4; ++k) ms4[k] = 0.f;
+    for (size_t c = 0; c + 5 <= t.ev.size(); c += 5) {
+        KG_HIP(hipEventSynchronize(t.ev[c + 4]));
+        for (int k = 0; k < 4; ++k) {
+            float ms = 0.f;
+            KG_HIP(hipEventElapsedTime(&ms, t.ev[c + k], t.ev[c + k + 1]));
+            ms4[k] += ms;
+        }
+    }
+    for (hipEvent_t e : t.ev) (void)hipEventDestroy(e);
+    t.ev.clear();
+    return KG_OK;
+}
+
 // P1..P4 for one scale (batch element 0 of the maps).  kp [5][H][W], soff [10][H][W], mid [40][H][W] fp32
 // device pointers.  Outputs (device): skel [skel_cap][5][3] f64, nskel, and optionally copies of the
 // intermediate stages (heat_out/blur_out [5][H][W] f64, peaks) for parity tests.
@@ -729,6 +769,7 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
     PPWs p; carve(ws, H, W, peak_cap, skel_cap, &p);
     const int HW = H * W;
     const double norm = 3.141592653589793 * 25.0;  // np.pi * KP_RADIUS**2 (postprocessing.py:51)
+    pp_mark(st);
     KG_HIP(hipMemsetAsync(p.count, 0, (size_t)5 * HW * 4, st));
     KG_HIP(hipMemsetAsync(p.cursor, 0, (size_t)5 * HW * 4, st));
     KG_HIP(hipMemsetAsync(p.heavy_n, 0, 4, st));
@@ -748,8 +789,10 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
     hipLaunchKernelGGL(hough_sum_heavy_kernel, dim3(2048), dim3(64), 0, st, HW, p.count, p.offs, p.keys, p.vals, p.sorted, norm,
                        p.heat, p.heavy_n, p.heavy_list);
     int gg = (5 * HW + 255) / 256; if (gg > 8192) gg = 8192;
+    pp_mark(st);
     hipLaunchKernelGGL(gauss_kernel<0>, dim3(gg), dim3(256), 0, st, p.heat, p.tmp, 5, H, W);
     hipLaunchKernelGGL(gauss_kernel<1>, dim3(gg), dim3(256), 0, st, p.tmp, p.blur, 5, H, W);
+    pp_mark(st);
     hipLaunchKernelGGL(peaks_kernel<0>, dim3(p.nblk), dim3(256), 0, st, p.blur, H, W, thresh, p.blkcount, (const int*)nullptr, 0,
                        (int*)nullptr, (int*)nullptr, (int*)nullptr, (double*)nullptr);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, p.blkcount, p.blkbase, p.nblk);
@@ -758,6 +801,7 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
                        p.ids, p.xs, p.ys, p.conf);
     hipLaunchKernelGGL(kp_rank_kernel, dim3(256), dim3(256), 0, st, p.npk, peak_cap, p.ids, p.xs, p.ys, p.conf, p.sid, p.sx, p.sy,
                        p.sconf);
+    pp_mark(st);
     static bool group_attr = false;
     if (!group_attr) {
         KG_HIP(hipFuncSetAttribute((const void*)group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GroupLds)));
@@ -765,6 +809,7 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
     }
     hipLaunchKernelGGL(group_kernel, dim3(1), dim3(256), sizeof(GroupLds), st, p.npk, peak_cap, p.sid, p.sx, p.sy, p.sconf, mid, H, W, p.alive,
                        skel_cap, p.skxy, skel, nskel);
+    pp_mark(st);
     if (heat_out) KG_HIP(hipMemcpyAsync(heat_out, p.heat, (size_t)5 * HW * 8, hipMemcpyDeviceToDevice, st));
     if (blur_out) KG_HIP(hipMemcpyAsync(blur_out, p.blur, (size_t)5 * HW * 8, hipMemcpyDeviceToDevice, st));
     if (npeaks_out) KG_HIP(hipMemcpyAsync(npeaks_out, p.npk, 4, hipMemcpyDeviceToDevice, st));
