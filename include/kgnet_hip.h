@@ -203,6 +203,9 @@ int kg_adam_step(const void* jobs, int njobs, int total_blocks, float beta1, flo
 /* ---- host glue of SEG_loss (seg_loss.py:57-80), pure host code: crops of the matched ground-truth masks (float32 [n][H][W] per
  * image), nearest-resized to the patch size, as bytes.  work = int32 [nwork][9]: (img, gt, y1, y2, x1, x2, h1, w1, out offset) ---- */
 int kg_host_crop_masks(const float* const* masks, const int* work, int nwork, int H, int W, unsigned char* out);
+/* the same crops for DEVICE-resident masks (seg_loss.py:57-80 on the GPU): masks = device array of device pointers
+ * (float32 [n_i][H][W]), work = device int32 [nwork][9] (the rows of kg_host_crop_masks), out = device bytes */
+int kg_crop_masks(const void* masks, const int* work, int nwork, int H, int W, void* out, void* stream);
 /* box tables of the per-box seg branch (host glue of KGnet.py:258-267,321-350; pure host code, integer arithmetic).
  * kg_host_tile_table: one {row0, (h << 16) | w, (oy0 << 16) | ox0, 0} entry per th x tw tile of every box (box-major); returns the count.
  * kg_host_bin_csr: per BS x BS bin of each image the ascending list of boxes touching it (tab = int32 [nb][8] rows {img, y1, x1, h, w, ..});

@@ -69,6 +69,7 @@ _SIGS = {
     "kg_gt_maps": [P, c_int, c_int, c_int, P, P],
     "kg_adam_step": [P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, P],
     "kg_host_crop_masks": [P, P, c_int, c_int, c_int, P],
+    "kg_crop_masks": [P, P, c_int, c_int, c_int, P, P],
     "kg_host_match_boxes": [P, c_int, P, c_int, c_int, c_float, P, c_int, P],
     "kg_host_tile_table": [P, P, P, c_int, c_int, c_int, P, c_int],                       # (these two return a COUNT, -1 on overflow:
     "kg_host_bin_csr": [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int],               #  call them through load(), not call())

@@ -99,3 +99,44 @@ extern "C" int kg_mask_paste(const float* flat, const int* dets, int nd, int inp
     KG_CHECK_LAUNCH("mask_paste");
     return KG_OK;
 }
+
+// ---- SEG_loss target preparation on the device (second half: seg_loss.py:57-80) ---------------------------------------
+// For callers whose ground-truth masks are device-resident (float32 [n_i][H][W] tensors on the GPU): the crop of the matched mask
+// [y1:y2, x1:x2] nearest-resized to the predicted patch (h1, w1) -- cv2.resize(..., INTER_NEAREST) as restated by kg_host_crop_masks:
+// src = min(floor(dst * src_size / dst_size), src_size - 1), identity when the sizes agree -- written as bytes at the pair's offset of
+// the target buffer kg_seg_loss reads.  One workgroup per (pair, 1024-pixel slab); the same work rows as the host function.
+__global__ __launch_bounds__(256) void crop_masks_kernel(const float* const* __restrict__ masks, const int* __restrict__ work, int nwork,
+                                                         int H, int W, unsigned char* __restrict__ out) {
+    const int k = blockIdx.x;
+    const int* w = work + 9 * k;
+    const float* m = masks[w[0]] + (long)w[1] * H * W;
+    const int ya = w[2], xa = w[4];
+    int yb = w[3], xb = w[5];
+    const int h1 = w[6], w1 = w[7];
+    if (yb > H) yb = H;
+    if (xb > W) xb = W;
+    const int h0 = yb - ya, w0 = xb - xa;
+    if (h0 <= 0 || w0 <= 0) return;          // (rejected on the host before the launch)
+    const bool same = h0 == h1 && w0 == w1;
+    const double fy = (double)h0 / h1, fx = (double)w0 / w1;
+    unsigned char* o = out + w[8];
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < h1 * w1; i += gridDim.y * 256) {
+        const int y = i / w1, x = i - y * w1;
+        int sy = y, sx = x;
+        if (!same) {
+            sy = (int)floor(y * fy); if (sy > h0 - 1) sy = h0 - 1;
+            sx = (int)floor(x * fx); if (sx > w0 - 1) sx = w0 - 1;
+        }
+        o[i] = (unsigned char)m[(long)(ya + sy) * W + xa + sx];
+    }
+}
+// masks: DEVICE array of nimg device pointers (float32 [n_i][H][W]); work: device int32 [nwork][9] rows (img, gt index, y1, y2, x1, x2,
+// h1, w1, out offset) -- the rows kg_host_crop_masks takes; out: device bytes.
+extern "C" int kg_crop_masks(const void* masks, const int* work, int nwork, int H, int W, void* out, void* stream) {
+    KG_CHECK_ARG(masks && work && out && nwork >= 0 && H > 0 && W > 0, "kg_crop_masks: bad arguments");
+    if (nwork == 0) return KG_OK;
+    hipLaunchKernelGGL(crop_masks_kernel, dim3(nwork, 4), dim3(256), 0, (hipStream_t)stream, (const float* const*)masks, work, nwork, H, W,
+                       (unsigned char*)out);
+    KG_CHECK_LAUNCH("crop_masks");
+    return KG_OK;
+}

@@ -113,9 +113,10 @@ def gather_skeleton_single(skeleton0, skeleton1, skeleton2, skeleton3):
             np.asarray(skeleton_to_box(skeleton2, 4)), np.asarray(skeleton_to_box(skeleton3, 8)))
 
 
-def detect(dec, nms_thresh=0.5):
+def detect(dec, nms_thresh=0.5, timing=None):
     """Fused test.py:105-116: four scales -> refine -> boxes -> NMS with a single device->host copy.
-    dec = ([kp,short,mid] x 4).  Returns N x 5 float64 ndarray or None."""
+    dec = ([kp,short,mid] x 4).  Returns N x 5 float64 ndarray or None.  timing (dict, measurement hook of bench.py): receives
+    "boxes_nms_ms", the GPU time of the box assembly + NMS launches."""
     from . import nms as _nms
     dev = dec[0][0].device
     # the scales are independent and the greedy grouping of a scale is ONE workgroup: run them on separate streams -- the caller's
@@ -147,11 +148,18 @@ def detect(dec, nms_thresh=0.5):
     cap = min(cap, 1 << 15)
     boxes = torch.empty(cap, 5, dtype=torch.float64, device=dev)
     nbox = torch.zeros(1, dtype=torch.int32, device=dev)
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     for (skel, nsk), scale in zip(sks, (1, 2, 4, 8)):
         with torch.cuda.device(dev):
             _lib.call("kg_skeleton_boxes", ptr(skel), ptr(nsk), skel.shape[0], c_double(scale), 1, ptr(boxes), ptr(nbox), cap, stream_ptr())
     out, nk = _nms.nms_device(boxes, nbox, cap, float(nms_thresh))
+    if timing is not None:
+        e1.record()
     k = int(nk.item())
+    if timing is not None:
+        timing["boxes_nms_ms"] = e0.elapsed_time(e1)
     if k == 0:
         return None
     return out[:k].cpu().numpy()

@@ -144,9 +144,28 @@ class SEG_loss(nn.Module):
             return None                      # seg_loss.py:93-96
         rec_img, rec_j, rec_npx, rec_p0, rec_cnt = (np.concatenate(v) for v in (rec_img, rec_j, rec_npx, rec_p0, rec_cnt))
         work = np.ascontiguousarray(np.concatenate(work), np.int32)
-        tgt_host = torch.empty(toff, dtype=torch.uint8, pin_memory=True)
-        marr = [np.asarray(m) for m in gt_masks]
-        if all(m.dtype == np.float32 and m.flags.c_contiguous and m.ndim == 3 and m.shape[1:] == marr[0].shape[1:] for m in marr if m.size):
+        tgt = None
+        if all(torch.is_tensor(m) and m.is_cuda for m in gt_masks):
+            # device-resident ground-truth masks: crop + nearest-resize on the GPU, nothing crosses PCIe (kg_crop_masks);
+            # the reference's collater hands host arrays (collater.py), which take the host path below
+            ms = [m.contiguous().float() for m in gt_masks]
+            sized = [m for m in ms if m.numel()]
+            H0, W0 = sized[0].shape[1:]
+            if any(m.dim() != 3 or tuple(m.shape[1:]) != (H0, W0) for m in sized):
+                raise ValueError("SEG_loss: device masks must be [n, H, W] tensors of one size")
+            if (np.minimum(work[:, 3], H0) <= work[:, 2]).any() or (np.minimum(work[:, 5], W0) <= work[:, 4]).any():
+                raise _lib.KGLibraryError("SEG_loss: empty ground-truth crop")
+            dev = sized[0].device
+            ptrs = ops.h2d(np.array([m.data_ptr() for m in ms], np.int64), dev)
+            tgt = torch.empty(toff, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.call("kg_crop_masks", _lib.ptr(ptrs), _lib.ptr(ops.h2d(work.reshape(-1), dev)), len(work), int(H0), int(W0), _lib.ptr(tgt), _lib.stream_ptr())
+            self._keep = ms       # (the crops are read asynchronously: keep the converted masks alive until the next call)
+        tgt_host = torch.empty(0 if tgt is not None else toff, dtype=torch.uint8, pin_memory=True)
+        marr = [] if tgt is not None else [np.asarray(m) for m in gt_masks]
+        if tgt is not None:
+            pass
+        elif all(m.dtype == np.float32 and m.flags.c_contiguous and m.ndim == 3 and m.shape[1:] == marr[0].shape[1:] for m in marr if m.size):
             import ctypes
             H0, W0 = next(m.shape[1:] for m in marr if m.size)
             ptrs = (ctypes.c_void_p * len(marr))(*[m.ctypes.data for m in marr])
@@ -173,7 +192,8 @@ class SEG_loss(nn.Module):
         pair_t = np.zeros(npairs, dtype=[("off", np.int32), ("w", np.float32)])
         pair_t["off"] = np.concatenate(pair_off); pair_t["w"] = np.concatenate(pair_w)
         nrec = len(rec_img)
-        tgt = tgt_host.to(dev, non_blocking=True)
+        if tgt is None:
+            tgt = tgt_host.to(dev, non_blocking=True)
         ptab_d = ops.h2d(ptab, dev)
         pairs_d = ops.h2d(pair_t.view(np.uint8), dev)
         return _SegLossFn.apply(flat, tgt, ptab_d, pairs_d, nrec)
