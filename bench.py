@@ -476,7 +476,9 @@ def main():
             opt.step()
             return loss.item() if sync else loss.detach()      # train.py:156 reads the loss back every step
 
-        def timed(K, sync):
+        def timed(K, sync, park_gc=True):
+            if not park_gc:       # (what the drop-in train.py does: the cyclic collector stays on -- reported beside the headline)
+                return timed_(K, sync)
             # the K timed steps run with Python's cyclic collector parked (gc.freeze + disable, as training loops at scale do: a gen-2
             # pass over the model's ~10^5 objects is a multi-ms host stall at a random step); the step itself leaves no cycles behind
             # (tools/cycle_probe.py), so memory does not grow meanwhile
@@ -510,7 +512,8 @@ def main():
         timer.on, timer.only_dominant, timer.rec = kernel_timer, True, []
         dt_, ls, mk = timed(steps, sync_each_step)
         timer.on = False
-        res = {"dt": dt_, "losses": ls, "marks": mk, "dom_rec": timer.rec, "step": step, "timed": timed}
+        res = {"dt": dt_, "losses": ls, "marks": mk, "dom_rec": timer.rec, "step": step, "timed": timed,
+               "overflow": (lambda: model.grad_overflowed(reset=False))}
         timer.rec = []
         return res
 
@@ -523,8 +526,11 @@ def main():
     last = losses[-1]
     dom_rec = main_run["dom_rec"]
     other_dt = dt
+    gc_on_dt = None
     if not args.profile_run:
         other_dt, _, _ = main_run["timed"](args.steps, not STEP_SYNC)      # the other loss-read-back policy, reported as a note
+        gc_on_dt, _, _ = main_run["timed"](args.steps, STEP_SYNC, park_gc=False)   # the same steps with Python's cyclic GC left enabled
+    overflowed = bool(main_run["overflow"]())
     prof_steps = 0
     if not args.no_kernel_timer:      # per-kernel breakdown: extra, untimed steps with events around every conv launch
         timer.on, timer.only_dominant, prof_steps = True, False, 2
@@ -578,6 +584,8 @@ def main():
                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "last_loss": last,
                       "loss_readback": "every step (train.py:156)" if STEP_SYNC else "after the timed region",
                       "other_readback_policy_imgs_per_s": imgs / other_dt,
+                      "gc_enabled_imgs_per_s": (imgs / gc_on_dt) if gc_on_dt else None,
+                      "grad_overflow": overflowed,      # sticky device flag of the half-precision backward (KGnet.grad_overflowed): must be false
                       "step_ms": [round(1e3 * (b - a), 2) for a, b in zip([t0] + marks[:-1], marks)]}}
     if companion is not None:
         out["half_companion"] = companion

@@ -264,7 +264,7 @@ int kg_mask_paste(const float* flat, const int* dets, int nd, int input_h, int i
  * two that brings max |g| of the rows tensor into [2^(t-1), 2^t); g *= r in place; cum_out = {cum_in[0] * r, 1 / (cum_in[0] * r)},
  * r_out[0] = r (all on the device).  kg_rows_scale: rows *= *r in place (pending gradients of upstream tensors).  planes: a = g. */
 int kg_grad_scale(const void* const* ptrs, const void* const* probs, const long* counts, int n, int target_log2, void* scratch, float* out, void* stream);
-int kg_scale_tensors(const void* jobs, int njobs, int total_blocks, void* stream);
+int kg_scale_tensors(const void* jobs, int njobs, int total_blocks, int* nonfinite, void* stream);   /* nonfinite: optional device int, set to 1 on an inf / NaN result */
 int kg_rows_rescale(void* g, int ld, long M, int C, int target_log2, const float* cum_in, float* cum_out, float* r_out, void* scratch,
                     const kg_planes_t* planes, void* stream);
 int kg_rows_scale(void* g, int ld, long M, int C, const float* r, const kg_planes_t* planes, void* stream);

@@ -43,6 +43,8 @@ def _begin_scaled_backward(eng, top_grads, probs=None):
     from . import ops
     gs = ops.grad_scale(top_grads, probs)
     eng.gscale, eng.cur_gsc, eng.param_gsc = gs, None, {}
+    if eng.overflow_flag is None or eng.overflow_flag.device != gs.device:
+        eng.overflow_flag = torch.zeros(1, dtype=torch.int32, device=gs.device)
     if eng.grad_store is not None:
         eng.grad_store.unscale_of = eng.param_gsc      # data parallel: a bucket's gradients are divided by their scales right before its all-reduce
     return gs
@@ -61,7 +63,7 @@ def _end_scaled_backward(eng, gs, pgrads):
     from . import ops
     store = eng.grad_store
     items = [(k, g) for k, g in pgrads.items() if g is not None and not (store is not None and store.owns(k, g))]
-    ops.scale_tensors([g for _, g in items], [eng.param_gsc[k][1:2] for k, _ in items])
+    ops.scale_tensors([g for _, g in items], [eng.param_gsc[k][1:2] for k, _ in items], flag=eng.overflow_flag)
     if store is not None:
         store.unscale_pending()
         store.unscale_of = None
@@ -217,6 +219,18 @@ class ResNet(nn.Module):
         self._engine.set_precision(precision)
         self._seg.invalidate_caches()
         return self
+
+    def grad_overflowed(self, reset=True):
+        """Half-precision policies: True if a backward pass since the last call produced a non-finite parameter gradient -- the
+        half-precision backward left IEEE half's range (or the forward did: an activation beyond +-65504, a weight >= 16).  Nothing is
+        clamped silently: such a step's gradients are inf / NaN and the flag is sticky.  Reads one device int (synchronises)."""
+        f = self._engine.overflow_flag
+        if f is None:
+            return False
+        v = bool(int(f.item()))
+        if reset and v:
+            f.zero_()
+        return v
 
     def invalidate_caches(self):
         """Drop the packed bf16 weight copies and folded BatchNorm constants: call after writing parameters or running

@@ -20,7 +20,7 @@ _SIGS = {
     "kg_version": [],
     "kg_rows_format": [],
     "kg_grad_scale": [P, P, P, c_int, c_int, P, P, P],
-    "kg_scale_tensors": [P, c_int, c_int, P],
+    "kg_scale_tensors": [P, c_int, c_int, P, P],
     "kg_rows_rescale": [P, c_int, c_long, c_int, c_int, P, P, P, P, P, P],
     "kg_rows_scale": [P, c_int, c_long, c_int, P, P, P],
     "kg_device_arch": [ctypes.c_char_p, c_int],

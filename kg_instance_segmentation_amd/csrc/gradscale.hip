@@ -86,7 +86,7 @@ extern "C" int kg_grad_scale(const void* const* ptrs, const void* const* probs, 
 struct ScaleJob {   // 32 bytes, mirrored by ops.scale_tensors
     float* p; long n; const float* scale; int blk0; int pad;
 };
-__global__ __launch_bounds__(256) void scale_tensors_kernel(const ScaleJob* __restrict__ jobs, int njobs) {
+__global__ __launch_bounds__(256) void scale_tensors_kernel(const ScaleJob* __restrict__ jobs, int njobs, int* __restrict__ nonfinite) {
     int lo = 0, hi = njobs - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void scale_tensors_kernel(const ScaleJob* __re
     const ScaleJob j = jobs[lo];
     const float s = *j.scale;
     const long base = ((long)blockIdx.x - j.blk0) * 4096;
+    bool bad = false;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const long i = base + (u * 256 + threadIdx.x) * 4L;
@@ -102,18 +103,23 @@ __global__ __launch_bounds__(256) void scale_tensors_kernel(const ScaleJob* __re
         if (i + 4 <= j.n && (reinterpret_cast<uintptr_t>(j.p + i) & 15) == 0) {
             f32x4 v = *reinterpret_cast<const f32x4*>(j.p + i);
             v[0] *= s; v[1] *= s; v[2] *= s; v[3] *= s;
+            bad = bad || !(fabsf(v[0]) <= 3.4e38f) || !(fabsf(v[1]) <= 3.4e38f) || !(fabsf(v[2]) <= 3.4e38f) || !(fabsf(v[3]) <= 3.4e38f);
             *reinterpret_cast<f32x4*>(j.p + i) = v;
         } else {
-            for (long k = i; k < i + 4 && k < j.n; ++k) j.p[k] *= s;
+            for (long k = i; k < i + 4 && k < j.n; ++k) { const float v = j.p[k] * s; bad = bad || !(fabsf(v) <= 3.4e38f); j.p[k] = v; }
         }
     }
+    // a half-precision backward pass that left IEEE half's range (more than 64x growth inside one stage, or an inf / NaN activation)
+    // shows up HERE as a non-finite parameter gradient: raise the sticky flag (KGnet.grad_overflowed() reads it; nothing is clamped)
+    if (nonfinite && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(nonfinite, 1);
 }
 // jobs: device array of njobs 32-byte records {float* p; long n; const float* scale; int blk0; int pad;} (a workgroup scales 4096
 // elements; total_blocks = sum of ceil(n / 4096)); every element of job j is multiplied by *jobs[j].scale (a device scalar: the
-// 1 / S of kg_grad_scale or the 1 / cum of the backbone stage the parameter belongs to, kg_rows_rescale).
-extern "C" int kg_scale_tensors(const void* jobs, int njobs, int total_blocks, void* stream) {
+// 1 / S of kg_grad_scale or the 1 / cum of the backbone stage the parameter belongs to, kg_rows_rescale).  nonfinite (optional device
+// int): set to 1 when a scaled element is inf / NaN.
+extern "C" int kg_scale_tensors(const void* jobs, int njobs, int total_blocks, int* nonfinite, void* stream) {
     KG_CHECK_ARG(jobs && njobs > 0 && total_blocks > 0, "kg_scale_tensors: empty job list");
-    hipLaunchKernelGGL(scale_tensors_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const ScaleJob*)jobs, njobs);
+    hipLaunchKernelGGL(scale_tensors_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const ScaleJob*)jobs, njobs, nonfinite);
     KG_CHECK_LAUNCH("scale_tensors");
     return KG_OK;
 }

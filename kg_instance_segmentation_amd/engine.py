@@ -175,6 +175,7 @@ class Engine:
         self.fmt = 1 if self.dt == ops.F16 else 0
         self.gscale = None         # half build: device {S, 1 / S} of the running backward pass (ops.grad_scale)
         self.cur_gsc, self.param_gsc = None, {}      # ... and the (stage) scale each parameter gradient was produced in
+        self.overflow_flag = getattr(self, "overflow_flag", None)     # device int32[1]: a backward pass produced a non-finite gradient (KGnet.grad_overflowed)
         self.bpt = self.pt         # backbone planes of the CURRENT forward (see forward_dec)
         self.invalidate_caches()
 

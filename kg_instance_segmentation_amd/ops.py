@@ -631,9 +631,10 @@ def grad_scale(tensors, probs=None):
     return out
 
 
-def scale_tensors(tensors, scale):
+def scale_tensors(tensors, scale, flag=None):
     """every fp32 tensor *= a device scalar, one launch (kg_scale_tensors).  scale: one device scalar tensor for all, or a list with
-    one per tensor (parameters of different backbone stages carry different cumulative scales, rows_rescale)."""
+    one per tensor (parameters of different backbone stages carry different cumulative scales, rows_rescale).  flag (optional device
+    int32[1]): set to 1 when a result is inf / NaN."""
     import numpy as np
     scales = scale if isinstance(scale, (list, tuple)) else [scale] * len(tensors)
     pairs = [(t, sc) for t, sc in zip(tensors, scales) if t is not None and t.numel() > 0]
@@ -647,7 +648,7 @@ def scale_tensors(tensors, scale):
         arr[i] = (t.data_ptr(), t.numel(), sc.data_ptr(), blk, 0)
         blk += (t.numel() + 4095) // 4096
     tab = h2d(arr.view(np.uint8).reshape(-1), pairs[0][0].device)
-    _lib.call("kg_scale_tensors", ptr(tab), len(pairs), blk, stream_ptr())
+    _lib.call("kg_scale_tensors", ptr(tab), len(pairs), blk, ptr(flag), stream_ptr())
 
 
 def rows_rescale(g, C, cum_in, target_log2=None):

@@ -201,7 +201,7 @@ class FlatGradReducer:
         from . import ops
         ks = [k for k in keys if k in self.unscale_of and k not in self._pend_done]
         if ks:
-            ops.scale_tensors([self.slot[k] for k in ks], [self.unscale_of[k][1:2] for k in ks])
+            ops.scale_tensors([self.slot[k] for k in ks], [self.unscale_of[k][1:2] for k in ks], flag=self.model._engine.overflow_flag)
             self._pend_done.update(ks)
 
     def unscale_pending(self):

@@ -284,3 +284,24 @@ def test_pretrained_loads_a_torchvision_keyed_checkpoint(tmp_path, monkeypatch):
         warnings.simplefilter("always")
         KGnet.resnet50(pretrained=True)
     assert any("KG_RESNET50_PTH" in str(x.message) for x in w)
+
+
+def test_half_build_loads_and_exports_the_rows_entry_points(lib):
+    """libkgnet_hip_f16.so: the same C ABI built for IEEE-half rows (include/kgnet_hip.h): loads, identifies itself, and exports
+    every entry point that takes rows / packed-weight operands; the format-independent ones live in libkgnet_hip.so only."""
+    from kg_instance_segmentation_amd import _lib, build, ops
+    build.build()
+    half = _lib.load(1)
+    assert half.kg_rows_format() == 1 and lib.kg_rows_format() == 0
+    rows_entries = ["kg_conv2d_igemm", "kg_conv2d_halo", "kg_conv2d_halo_heads2", "kg_conv3x3_c64", "kg_conv1x1", "kg_pack_weight",
+                    "kg_pack_weight_rows", "kg_pack_weight_batch", "kg_im2col_small", "kg_conv2d_wgrad", "kg_conv2d_wgrad_halo", "kg_bias_grad",
+                    "kg_img_pack", "kg_bn_stats_train", "kg_bn_apply", "kg_bn_bwd", "kg_maxpool3s2_fwd", "kg_maxpool3s2_bwd", "kg_bilinear_fwd",
+                    "kg_bilinear_bwd", "kg_add_rows", "kg_grad_pack", "kg_rows_gather", "kg_rows_gather_f32", "kg_planes_to_f32", "kg_f32_to_planes",
+                    "kg_crop_grad_reduce", "kg_rows_rescale", "kg_rows_scale", "kg_conv_stats_begin", "kg_conv_stats_end", "kg_last_error"]
+    missing = [n for n in rows_entries if not hasattr(half, n)]
+    assert not missing, missing
+    assert not hasattr(half, "kg_postproc_scale") and not hasattr(half, "kg_adam_step")
+    # kg_planes_t: 10 ints + a device pointer (header, csrc/kg_common.h and the ctypes mirror agree on the layout)
+    assert ctypes.sizeof(ops._Planes) == 48 and ops._Planes.scale.offset == 40
+    hdr = open(os.path.join(ROOT, "include", "kgnet_hip.h")).read()
+    assert "int reserved_;" in hdr and "const float* scale;" in hdr

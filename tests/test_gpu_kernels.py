@@ -525,3 +525,63 @@ def test_conv_epilogue_bn_statistics(case):
     # disarmed again: a second conv leaves the buffer alone
     ops.conv_auto(rows_of(x).to(DEV), pw, cout, geom, N, y=y)
     assert ops.conv_stats_end() == 0
+
+
+# ---- gradient scale of the half-precision backward pass (csrc/gradscale.hip, norm_pool.hip) --------------------------------------------
+def test_grad_scale_and_scale_tensors():
+    """kg_grad_scale: S = the power of two that brings max |g| (kp maps: |g * p * (1 - p)|) into [2^(T-1), 2^T); zero / non-finite input ->
+    S = 1; kg_scale_tensors: per-tensor device scalars, exact for powers of two, sticky non-finite flag."""
+    T = ops.GRAD_TARGET_LOG2
+    g = torch.Generator().manual_seed(0)
+    a = (torch.randn(3, 5, 17, 19, generator=g) * 1e-6).to(DEV)
+    b = (torch.randn(1000, generator=g) * 3e-4).to(DEV)
+    gs = ops.grad_scale([a, None, b])
+    S, inv = float(gs[0]), float(gs[1])
+    m = max(float(a.abs().max()), float(b.abs().max()))
+    assert S * inv == 1.0 and math.log2(S) == round(math.log2(S)) and 2.0 ** (T - 1) <= m * S < 2.0 ** T
+    # sigmoid outputs: the logit gradient g * p * (1 - p) counts (saturated p -> 0), not dL/dp
+    p = torch.rand(3, 5, 17, 19, generator=g).to(DEV)
+    p[0, 0, 0, 0] = 1.0
+    big = a.clone(); big[0, 0, 0, 0] = 1e12                       # dL/dp of a saturated pixel (loss.py:13 clamps log at -100)
+    gs2 = ops.grad_scale([big], [p])
+    m2 = float((big * p * (1 - p)).abs().max())
+    assert 2.0 ** (T - 1) <= m2 * float(gs2[0]) < 2.0 ** T
+    assert float(ops.grad_scale([torch.zeros(10, device=DEV)])[0]) == 1.0
+    assert float(ops.grad_scale([torch.full((4,), float("nan"), device=DEV)])[0]) == 1.0
+    # scale_tensors: different scalars per tensor, unaligned views, flag
+    x, y = torch.randn(4097, device=DEV), torch.randn(33, device=DEV)[1:]
+    x0, y0 = x.clone(), y.clone()
+    s1, s2 = torch.tensor([0.25], device=DEV), torch.tensor([8.0], device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.scale_tensors([x, y.contiguous() if not y.is_contiguous() else y], [s1, s2], flag=flag)
+    assert torch.equal(x, x0 * 0.25) and torch.equal(y, y0 * 8.0) and int(flag) == 0
+    z = torch.tensor([1.0, float("inf"), 2.0], device=DEV)
+    ops.scale_tensors([z], s1, flag=flag)
+    assert int(flag) == 1
+
+
+@pytest.mark.parametrize("dt", [BF16, ops.F16])
+def test_rows_rescale_stage_boundary(dt):
+    """kg_rows_rescale / kg_rows_scale: in-place power-of-two re-normalisation of a gradient rows tensor (all planes), chained scale."""
+    T = ops.GRAD_TARGET_LOG2
+    g = torch.Generator().manual_seed(1)
+    v = (torch.randn(777, 64, generator=g) * 37.0).to(DEV)
+    for P in (1, 2):
+        pt = ops.alloc_pt(777, 64, P, DEV, dtype=dt)
+        ops.f32_to_planes(v, pt, 64)
+        before = torch.empty(777, 64, device=DEV); ops.planes_to_f32(pt, 64, before)
+        cum_in = torch.tensor([4.0, 0.25], device=DEV)
+        r, cum = ops.rows_rescale(pt, 64, cum_in)
+        after = torch.empty(777, 64, device=DEV); ops.planes_to_f32(pt, 64, after)
+        rr = float(r)
+        assert math.log2(rr) == round(math.log2(rr)) and 2.0 ** (T - 1) <= float(before.abs().max()) * rr < 2.0 ** T
+        assert torch.equal(after, before * rr) and float(cum[0]) == 4.0 * rr and float(cum[0]) * float(cum[1]) == 1.0
+        other = ops.alloc_pt(100, 64, P, DEV, dtype=dt)
+        ops.f32_to_planes(v[:100].contiguous(), other, 64)
+        o0 = torch.empty(100, 64, device=DEV); ops.planes_to_f32(other, 64, o0)
+        ops.rows_scale(other, 64, r)
+        o1 = torch.empty(100, 64, device=DEV); ops.planes_to_f32(other, 64, o1)
+        assert torch.equal(o1, o0 * rr)
+    zero = ops.alloc_pt(8, 64, 1, DEV, zero=True, dtype=dt)
+    r0, c0 = ops.rows_rescale(zero, 64, torch.tensor([2.0, 0.5], device=DEV))
+    assert float(r0) == 1.0 and float(c0[0]) == 2.0
