@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const C1Args a) {
                 }
                 if (a.relu) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    for (int e = 0; e < 16; ++e) v[e] = kg_relu(v[e]);
                 }
                 if (a.mask) {
                     const bf16_t* mp = a.mask + m * a.ldmask + cb;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(const C1Args a) {
                     }
                     if (a.relu) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        for (int e = 0; e < 8; ++e) v[e] = kg_relu(v[e]);
                     }
                     if (a.mask) {
                         const uint4 mv = *reinterpret_cast<const uint4*>(a.mask + m * a.ldmask + cpiece);

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512) void conv3_c64_kernel(const C3Args a) {
             }
             if (a.relu) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                for (int e = 0; e < 16; ++e) v[e] = kg_relu(v[e]);
             }
             if (a.mask) {
                 const bf16_t* mp = a.mask + m * a.ldmask + cb;

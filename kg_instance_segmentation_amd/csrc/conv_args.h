@@ -79,7 +79,7 @@ __device__ __forceinline__ void kg_conv_epilogue(const EpiArgs& e, long m, int c
     }
     if (e.relu) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        for (int k = 0; k < NV; ++k) v[k] = kg_relu(v[k]);
     }
     if (e.mask) {
         const bf16_t* mp = e.mask + m * e.ldmask + cb;

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
         if (a.y_f32) {
             if (a.relu) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                for (int e = 0; e < 16; ++e) v[e] = kg_relu(v[e]);
             }
             // dense: NCHW [N][f32_C][H*W]; ragged: [f32_C][total rows] (f32_hw = total rows, image index 0)
             const long hw = a.tiletab ? (long)a.f32_hw : (long)a.H * a.W;

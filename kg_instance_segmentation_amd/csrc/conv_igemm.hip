@@ -190,7 +190,7 @@ __global__ __launch_bounds__(WC* WP * 64) void conv_igemm_kernel(const ConvArgs 
         if (a.y_f32) {       // fp32 exports carry no residual / mask in KGnet (head maps)
             if (a.relu) {
 #pragma unroll
-                for (int e = 0; e < NV; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                for (int e = 0; e < NV; ++e) v[e] = kg_relu(v[e]);
             }
         }
         if (a.y_f32) {

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
             }
             if (a.relu) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                for (int e = 0; e < 8; ++e) v[e] = kg_relu(v[e]);
             }
             if (a.mask) {
                 const uint4 mv = *reinterpret_cast<const uint4*>(a.mask + m * a.ldmask + cb);

@@ -103,6 +103,10 @@ __device__ __forceinline__ void lgkm_wait(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
 }
 
+// ReLU as torch.relu evaluates it: a NaN stays a NaN (`v > 0 ? v : 0` would turn it into 0 and hide an out-of-range activation of the
+// half build behind the next layer)
+__device__ __forceinline__ float kg_relu(float v) { return v < 0.f ? 0.f : v; }
+
 __device__ __forceinline__ unsigned lds_addr(const void* p) {   // LDS byte address of a pointer into __shared__ memory
     return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const unsigned char*)p;
 }

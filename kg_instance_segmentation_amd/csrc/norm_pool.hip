@@ -219,7 +219,7 @@ __global__ void bn_apply_kernel(const RowsR x, const float* __restrict__ scale,
         }
         if (relu) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            for (int e = 0; e < 8; ++e) v[e] = kg_relu(v[e]);
         }
         wr8(y, r, c, v);
     }

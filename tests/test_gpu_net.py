@@ -461,7 +461,7 @@ def test_train_step_leaves_no_reference_cycles(state_dict0):
 def test_half_range_violation_is_loud(state_dict0):
     """The default policy stores packed weights times 2^12 in IEEE half (|w| < 16) and activations as they are (|x| <= 65504).  A network
     outside that range must not be clamped silently: the outputs / loss turn non-finite and the sticky gradient flag is raised."""
-    from oracle import weightgen
+    from oracle import synth, weightgen
     m = KGnet.resnet50(pretrained=False)
     m.load_state_dict(weightgen.gen_state_dict(0, variant="cal"))
     m = m.to(DEV).train()
