@@ -260,14 +260,17 @@ int kg_mask_paste(const float* flat, const int* dets, int nd, int input_h, int i
  * the network outputs (12 head maps + the seg probabilities: what `loss.backward()` hands to KGnet.forward's node, train.py:153).
  * kg_scale_tensors: multiplies njobs fp32 tensors by a device scalar each in ONE launch: jobs = device array of 32-byte records
  * {float* p; long n; const float* scale; int blk0; int pad;} (blk0 = first workgroup of the job, 4096 elements per workgroup).
- * kg_rows_rescale (stage boundary of the backward pass: the complete gradient of c4 / c3 / c2 / c1, csrc/norm_pool.hip): r = the power of
- * two that brings max |g| of the rows tensor into [2^(t-1), 2^t); g *= r in place; cum_out = {cum_in[0] * r, 1 / (cum_in[0] * r)},
- * r_out[0] = r (all on the device).  kg_rows_scale: rows *= *r in place (pending gradients of upstream tensors).  planes: a = g. */
+ * kg_rows_rescale (re-normalisation point of the backward pass: a complete gradient rows tensor, csrc/norm_pool.hip): r = the power of
+ * two <= 1 that brings max |g| of the rows tensor back into [2^(t-1), 2^t) when it exceeds 2^t (r = 1 otherwise: the scale only ever goes
+ * down); g *= r in place; cum_out = {cum_in[0] * r, 1 / (cum_in[0] * r)}, r_out[0] = r (all on the device).  kg_rows_scale: rows *= *r (* *r2:
+ * a gradient written under an earlier scale is converted with scale_now and 1 / scale_then) in place; kg_rows_scale_multi: the same for
+ * up to 8 rows tensors in one launch: desc = host int64 [n][6] rows {pointer, ld, M, C, planes, plane stride}.  planes: a = g. */
 int kg_grad_scale(const void* const* ptrs, const void* const* probs, const long* counts, int n, int target_log2, void* scratch, float* out, void* stream);
 int kg_scale_tensors(const void* jobs, int njobs, int total_blocks, int* nonfinite, void* stream);   /* nonfinite: optional device int, set to 1 on an inf / NaN result */
 int kg_rows_rescale(void* g, int ld, long M, int C, int target_log2, const float* cum_in, float* cum_out, float* r_out, void* scratch,
                     const kg_planes_t* planes, void* stream);
-int kg_rows_scale(void* g, int ld, long M, int C, const float* r, const kg_planes_t* planes, void* stream);
+int kg_rows_scale(void* g, int ld, long M, int C, const float* r, const float* r2, const kg_planes_t* planes, void* stream);   /* *= *r * (r2 ? *r2 : 1) */
+int kg_rows_scale_multi(const long* desc, int n, const float* r, const float* r2, void* stream);
 
 #ifdef __cplusplus
 }

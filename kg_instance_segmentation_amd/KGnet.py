@@ -42,7 +42,7 @@ def _begin_scaled_backward(eng, top_grads, probs=None):
         return None
     from . import ops
     gs = ops.grad_scale(top_grads, probs)
-    eng.gscale, eng.cur_gsc, eng.param_gsc = gs, None, {}
+    eng.gscale, eng.param_gsc = gs, {}
     if eng.overflow_flag is None or eng.overflow_flag.device != gs.device:
         eng.overflow_flag = torch.zeros(1, dtype=torch.int32, device=gs.device)
     if eng.grad_store is not None:
@@ -57,7 +57,7 @@ def _kp_probs(eng, map_grads):
 
 def _end_scaled_backward(eng, gs, pgrads):
     """divides the scale out of every parameter gradient the backward pass produced outside the data-parallel flat buffer (one launch):
-    S for the heads / decoder / seg branch / c0_conv, the cumulative scale of its backbone stage for the rest (engine.stage_boundary)"""
+    each by the running scale it was produced in (engine.renormalise moves it at the re-normalisation points of the pass)"""
     if gs is None:
         return
     from . import ops
@@ -67,7 +67,7 @@ def _end_scaled_backward(eng, gs, pgrads):
     if store is not None:
         store.unscale_pending()
         store.unscale_of = None
-    eng.gscale, eng.cur_gsc = None, None
+    eng.gscale = None
 
 
 class _DecFunction(torch.autograd.Function):
@@ -99,7 +99,7 @@ class _DecFunction(torch.autograd.Function):
         with torch.cuda.device(next(g for g in grads if g is not None).device):
             mg = [None if g is None else g.contiguous().float() for g in grads[:12]]
             gs = _begin_scaled_backward(eng, mg + fg, _kp_probs(eng, mg) + [None] * len(fg))
-            pg = eng.backward_dec(mg, fg, gscale=gs)
+            pg = eng.backward_dec(mg, fg, gscale=eng.gscale)
             _end_scaled_backward(eng, gs, pg)
         out = [None, None, None]
         for k in ctx.keys:
@@ -147,7 +147,7 @@ class _NetFunction(torch.autograd.Function):
             fg, spg = [None] * 5, {}
             if gflat is not None and ctx.saved is not None:
                 fg, spg = seg.run_backward(ctx.plan, ctx.saved, gflat, ctx.feat_shapes, gscale=gs)
-            pg = eng.backward_dec(mg, fg, gscale=gs)
+            pg = eng.backward_dec(mg, fg, gscale=eng.gscale)      # (the running scale: the seg branch's backward may have moved it)
             pg.update(spg)
             _end_scaled_backward(eng, gs, pg)
         out = [None, None, None, None]

@@ -22,7 +22,8 @@ _SIGS = {
     "kg_grad_scale": [P, P, P, c_int, c_int, P, P, P],
     "kg_scale_tensors": [P, c_int, c_int, P, P],
     "kg_rows_rescale": [P, c_int, c_long, c_int, c_int, P, P, P, P, P, P],
-    "kg_rows_scale": [P, c_int, c_long, c_int, P, P, P],
+    "kg_rows_scale": [P, c_int, c_long, c_int, P, P, P, P],
+    "kg_rows_scale_multi": [P, c_int, P, P, P],
     "kg_device_arch": [ctypes.c_char_p, c_int],
     "kg_tr_probe": [P, P],
     "kg_conv2d_igemm": [P, P, P, P, P, P, P, P] + [c_int] * 21 + [P, P],

@@ -546,16 +546,20 @@ extern "C" int kg_add_rows(const void* a, int lda, const void* b, int ldb, const
     return KG_OK;
 }
 
-// ---- stage boundaries of the half-precision backward pass ------------------------------------------------------------------------
-// The BatchNorm backbone multiplies the gradient by gamma / sigma layer after layer: at random init it grows ~2^12 from c4 to the
-// stem (tools/gradmax_probe.py), more than one global power-of-two scale can place inside IEEE half's range together with the
-// 1e-7-sized loss gradients of the heads.  The backward pass therefore re-normalises the gradient where it enters a backbone stage
-// (the complete gradient of c4, c3, c2, c1): kg_rows_rescale measures max |g| of that rows tensor on the device, multiplies the tensor
-// in place by the power of two r that brings the maximum into [2^(T-1), 2^T), and chains the running scale: cum_out = cum_in * r.
-// Everything downstream of the boundary (the stage's backward convs and BatchNorms) is linear in g, so its parameter gradients come
-// out times cum_out and are divided by it where they leave (kg_scale_tensors, one device scalar per parameter); gradient contributions
-// that were produced at the old scale for tensors further upstream (decoder skip / seg crop gradients of c3, c2, c1) are multiplied by
-// the same r (kg_rows_scale).  All factors are powers of two: exact.  No host round trip.
+// ---- re-normalisation points of the half-precision backward pass ---------------------------------------------------------------
+// Gradients grow ~2^0.9 per bottleneck through the BatchNorm backbone at random init (gamma / sigma), x316 = 1 / sqrt(eps) through
+// the BatchNorm of a (nearly) dead channel, x4 per level through the adjoint of the 2x bilinear upsampling when they are spatially
+// coherent (tools/gradmax_probe.py) -- more than one global power-of-two scale can place inside IEEE half's range together with
+// the 1e-7-sized loss gradients of the heads.  The backward pass therefore re-normalises itself (engine.renormalise) where the
+// gradient of a decoder level output, of c1, of every second bottleneck output or of a seg-branch level is complete:
+// kg_rows_rescale measures max |g| of that rows tensor on the device and, when it has grown beyond 2^T, multiplies the tensor in
+// place by the power of two r < 1 that brings the maximum back into [2^(T-1), 2^T) (r = 1 otherwise: the scale only ever goes
+// down), and chains the running scale: cum_out = cum_in * r; every other live gradient tensor is
+// multiplied by the same r (kg_rows_scale), so that all live gradients share one scale.  Everything downstream is linear in g: its
+// parameter gradients come out times the running scale of the moment and are divided by it where they leave (kg_scale_tensors,
+// one device scalar per tensor).  A gradient tensor that was written under an earlier (larger) scale -- contributions waiting on
+// tensors further upstream -- is converted when it is next combined or consumed: *= scale_now * (1 / scale_then) <= 1
+// (kg_rows_scale with two device scalars).  All factors are powers of two: exact.  No host round trip.
 __global__ __launch_bounds__(256) void rows_absmax_kernel(const RowsR g, long M, int C8, int target_log2, const float* __restrict__ cum_in,
                                                           float* __restrict__ cum_out, float* __restrict__ r_out, unsigned* scratch) {
     const long total = M * C8;
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(256) void rows_absmax_kernel(const RowsR g, long M,
             int e;
             frexpf(__uint_as_float(m), &e);
             int k = target_log2 - e;
-            k = k > 60 ? 60 : (k < -60 ? -60 : k);
+            k = k > 0 ? 0 : (k < -60 ? -60 : k);      // only ever DOWN: a factor > 1 could push another live gradient tensor out of range
             r = ldexpf(1.f, k);
         }
         const float c = cum_in[0] * r;
@@ -598,8 +602,9 @@ __global__ __launch_bounds__(256) void rows_absmax_kernel(const RowsR g, long M,
         __threadfence();
     }
 }
-__global__ void rows_scale_kernel(bf16_t* __restrict__ p, int ld, int P, int ps, long M, int C8, const float* __restrict__ r) {
-    const float s = *r;
+__global__ void rows_scale_kernel(bf16_t* __restrict__ p, int ld, int P, int ps, long M, int C8, const float* __restrict__ r,
+                                  const float* __restrict__ r2) {
+    const float s = *r * (r2 ? *r2 : 1.f);
     if (s == 1.f) return;
     const long total = M * C8 * P;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -626,18 +631,57 @@ extern "C" int kg_rows_rescale(void* g, int ld, long M, int C, int target_log2, 
                        target_log2, cum_in, cum_out, r_out, (unsigned*)scratch);
     KG_CHECK_LAUNCH("rows_absmax");
     int b2 = (int)((total * pp.a_planes + 255) / 256); if (b2 > 16384) b2 = 16384;
-    hipLaunchKernelGGL(rows_scale_kernel, dim3(b2), dim3(256), 0, (hipStream_t)stream, (bf16_t*)g, ld, pp.a_planes, pp.a_pstride, M, C / 8, (const float*)r_out);
+    hipLaunchKernelGGL(rows_scale_kernel, dim3(b2), dim3(256), 0, (hipStream_t)stream, (bf16_t*)g, ld, pp.a_planes, pp.a_pstride, M, C / 8, (const float*)r_out,
+                       (const float*)nullptr);
     KG_CHECK_LAUNCH("rows_scale");
     return KG_OK;
 }
-// rows *= *r (device scalar, a power of two), every plane, in place.  planes: a = g
-extern "C" int kg_rows_scale(void* g, int ld, long M, int C, const float* r, const kg_planes_t* planes, void* stream) {
+// rows *= *r (* *r2 when given) (device scalars, powers of two), every plane, in place.  planes: a = g
+extern "C" int kg_rows_scale(void* g, int ld, long M, int C, const float* r, const float* r2, const kg_planes_t* planes, void* stream) {
     KG_PLANES(planes);
     KG_CHECK_ARG(g && r && C % 8 == 0 && ld % 8 == 0, "kg_rows_scale: bad args");
     if (M == 0) return KG_OK;
     const long total = M * (C / 8) * pp.a_planes;
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(rows_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)g, ld, pp.a_planes, pp.a_pstride, M, C / 8, r);
+    hipLaunchKernelGGL(rows_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)g, ld, pp.a_planes, pp.a_pstride, M, C / 8, r, r2);
     KG_CHECK_LAUNCH("rows_scale");
+    return KG_OK;
+}
+// up to 8 rows tensors *= *r in ONE launch (engine.renormalise: the other live gradient tensors of the pass); blockIdx.y = tensor
+struct RowsScaleMulti { bf16_t* p[8]; int ld[8]; long M[8]; int C8[8]; int P[8]; int ps[8]; int n; };
+__global__ void rows_scale_multi_kernel(RowsScaleMulti a, const float* __restrict__ r, const float* __restrict__ r2) {
+    const float s = *r * (r2 ? *r2 : 1.f);
+    if (s == 1.f) return;
+    const int t = blockIdx.y;
+    const int P = a.P[t], C8 = a.C8[t], ps = a.ps[t], ld = a.ld[t];
+    bf16_t* p = a.p[t];
+    const long total = a.M[t] * C8 * P;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long q = i / P; const int pl = (int)(i - q * P);
+        const long row = q / C8; const int c = (int)(q - row * C8) * 8;
+        uint4* ad = reinterpret_cast<uint4*>(p + row * ld + (long)pl * ps + c);
+        uint4 v = *ad;
+        bf16_t* h = reinterpret_cast<bf16_t*>(&v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = f2bf(bf2f(h[e]) * s);
+        *ad = v;
+    }
+}
+extern "C" int kg_rows_scale_multi(const long* desc, int n, const float* r, const float* r2, void* stream) {
+    KG_CHECK_ARG(desc && r && n >= 1 && n <= 8, "kg_rows_scale_multi: 1..8 tensors");
+    RowsScaleMulti a;
+    long most = 0;
+    for (int t = 0; t < 8; ++t) {
+        const long* d = desc + 6 * (t < n ? t : 0);
+        a.p[t] = (bf16_t*)d[0]; a.ld[t] = (int)d[1]; a.M[t] = t < n ? d[2] : 0; a.C8[t] = (int)d[3] / 8; a.P[t] = (int)d[4]; a.ps[t] = (int)d[5];
+        KG_CHECK_ARG(t >= n || (a.p[t] && d[3] % 8 == 0 && d[1] % 8 == 0 && d[4] >= 1 && d[4] <= 3 && d[5] % 8 == 0), "kg_rows_scale_multi: bad descriptor");
+        const long tot = a.M[t] * a.C8[t] * a.P[t];
+        most = tot > most ? tot : most;
+    }
+    a.n = n;
+    if (most == 0) return KG_OK;
+    int blocks = (int)((most + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rows_scale_multi_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a, r, r2);
+    KG_CHECK_LAUNCH("rows_scale_multi");
     return KG_OK;
 }

@@ -69,7 +69,8 @@ def trunc(t, P):
 
 class Var:
     """Activation (split-bf16 rows, ops.PT) + its gradient slot."""
-    __slots__ = ("t", "C", "relu", "grad", "masked", "pending", "pmasked", "req", "parent", "c0", "gP", "bn_part", "gsc", "boundary")
+    __slots__ = ("t", "C", "relu", "grad", "masked", "pending", "pmasked", "req", "parent", "c0", "gP", "bn_part", "boundary", "gsc")
+    ENG = None       # half build, during a backward pass: the engine whose running gradient scale this pass's tensors are written in
 
     def __init__(self, t, C, relu=False, req=True, parent=None, c0=0, gP=None):
         self.t = t if isinstance(t, PT) else PT(t)
@@ -78,8 +79,8 @@ class Var:
         self.grad, self.masked = None, True
         self.pending, self.pmasked = None, True     # one more contribution whose addition is deferred to take_grad (fused with the mask)
         self.parent, self.c0 = parent, c0
-        self.gsc = None            # half build: device {scale, 1 / scale} this tensor's gradient is expressed in (None: the pass's S)
-        self.boundary = False      # half build: the gradient is re-normalised when complete (Engine.stage_boundary)
+        self.boundary = False      # half build: the backward pass re-normalises itself when this gradient is complete (Engine.renormalise)
+        self.gsc = None            # half build: the scale object (device {scale, 1 / scale}) this tensor's gradient was last written in
 
     @property
     def rows(self):
@@ -99,11 +100,20 @@ class Var:
             return p.grad.cols(self.c0, self.c0 + self.C)
         return ops.alloc_pt(self.rows, self.C, self.gP, self.t.device, dtype=self.t.t.dtype)
 
-    def add_grad(self, g, masked, gsc=None):
-        if gsc is not self.gsc:
+    def to_current_scale(self):
+        """half build: a gradient written under an earlier (larger) running scale is converted before it is combined or consumed"""
+        eng = Var.ENG
+        if eng is not None and eng.gscale is not None and self.gsc is not None and self.gsc is not eng.gscale:
+            ts = [(t, self.C) for t in (self.grad, self.pending) if t is not None]
+            if ts:
+                ops.rows_scale_multi(ts, eng.gscale[0:1], self.gsc[1:2])      # * scale_now / scale_then <= 1: never out of range
+            self.gsc = eng.gscale
+
+    def add_grad(self, g, masked):
+        if Var.ENG is not None:
             if self.grad is not None or self.pending is not None:
-                raise RuntimeError("gradient contributions of one tensor carry different scales (engine stage boundaries)")
-            self.gsc = gsc
+                self.to_current_scale()
+            self.gsc = Var.ENG.gscale
         if self.parent is not None:      # written in place into the parent's buffer
             self.parent.masked = self.parent.masked and masked
             return
@@ -120,6 +130,7 @@ class Var:
         g = self.grad
         if g is None:
             return None
+        self.to_current_scale()
         need_mask = self.relu and not (self.masked and self.pmasked)
         if self.pending is not None:       # sum of the two contributions and the ReLU mask in ONE pass
             ops.add_rows(g, self.pending, g, self.C, mask=self.t.hi() if need_mask else None)
@@ -173,8 +184,8 @@ class Engine:
         self.pdw = pol[6] if len(pol) > 6 else self.pg       # planes of W in the input gradients
         self.dt = ops.F16 if precision in HALF_POLICIES else ops.BF16      # 16-bit format of every rows tensor / packed weight (ops.fmt_of)
         self.fmt = 1 if self.dt == ops.F16 else 0
-        self.gscale = None         # half build: device {S, 1 / S} of the running backward pass (ops.grad_scale)
-        self.cur_gsc, self.param_gsc = None, {}      # ... and the (stage) scale each parameter gradient was produced in
+        self.gscale = None         # half build: device {scale, 1 / scale} ALL live gradients of the running backward pass are expressed in
+        self.param_gsc = {}        # ... and the scale each parameter gradient was produced in (divided out where it leaves)
         self.overflow_flag = getattr(self, "overflow_flag", None)     # device int32[1]: a backward pass produced a non-finite gradient (KGnet.grad_overflowed)
         self.bpt = self.pt         # backbone planes of the CURRENT forward (see forward_dec)
         self.invalidate_caches()
@@ -192,38 +203,33 @@ class Engine:
         """Destination of a parameter gradient: a fresh tensor, or -- data parallel -- the parameter's slot in the persistent flat
         gradient buffer (parallel.FlatGradReducer), which RCCL reduces in place and the optimizer reads in place."""
         if self.gscale is not None:
-            self.param_gsc[key] = self.cur_gsc if self.cur_gsc is not None else self.gscale
+            self.param_gsc[key] = self.gscale
         if self.grad_store is not None:
             v = self.grad_store.get(key)
             if v is not None:
                 return v
         return torch.empty_like(like)
 
-    def stage_boundary(self, yv, g):
-        """Half build: the gradient g of a backbone stage output (c4, c3, c2 or c1) is complete -- re-normalise it to the target magnitude
-        on the device (ops.rows_rescale: the BatchNorm backbone multiplies the gradient by gamma / sigma layer after layer, ~2^12 from c4
-        to the stem at random init), and bring the contributions the decoder / seg branch already left on the stage outputs further
-        upstream to the same scale."""
+    def renormalise(self, g, C):
+        """Half build: re-normalise the backward pass.  The gradient tensor g (rows / PT, complete, in the running scale) is measured on
+        the device and, if its largest element has grown beyond the target magnitude, multiplied in place by the power of two r < 1
+        that brings it back (ops.rows_rescale); the running scale becomes scale * r (never larger: the scale only ever goes DOWN).
+        Gradient tensors written earlier under a larger scale (contributions waiting on tensors further upstream: the decoder's skip
+        gradients, the seg branch's crop gradients, the identity path of a bottleneck) are converted when they are next combined or
+        consumed (Var.to_current_scale: * scale_now / scale_then <= 1, so a conversion can never leave the format's range);
+        parameter gradients remember the scale they were produced in (new_grad) and are divided by it where they leave.
+        Why: gradients grow ~2^0.9 per bottleneck through the BatchNorm backbone at random init (gamma / sigma: 2^12 from c4 to the
+        stem; a 23-block layer3 of resnet101 alone would leave IEEE half's range), x316 through the BatchNorm of a dead channel, and
+        x4 per level through the adjoint of the 2x bilinear upsampling when they are spatially coherent (tools/gradmax_probe.py); the
+        call sites are the outputs of every second bottleneck, c1, the decoder's level outputs and the seg branch's levels."""
         if self.gscale is None:
             return
-        cum_in = yv.gsc if yv.gsc is not None else self.gscale
-        r, cum = ops.rows_rescale(g, yv.C, cum_in)
-        yv.gsc = cum
-        for fv in self.feats[1:]:
-            if fv is yv:
-                break
-            if fv.gsc is not cum_in and not (fv.gsc is None and cum_in is self.gscale):
-                if fv.grad is not None or fv.pending is not None:
-                    raise RuntimeError("stage boundary: an upstream gradient carries an unexpected scale")
-            for t in (fv.grad, fv.pending):
-                if t is not None:
-                    ops.rows_scale(t, fv.C, r)
-            fv.gsc = cum
+        _, self.gscale = ops.rows_rescale(g, C, self.gscale)
 
     def place_grad(self, key, g):
         """a small (bias / BatchNorm) gradient vector produced as a slice of a shared buffer: copied into its flat slot if there is one"""
         if self.gscale is not None:
-            self.param_gsc[key] = self.cur_gsc if self.cur_gsc is not None else self.gscale
+            self.param_gsc[key] = self.gscale
         if self.grad_store is not None:
             v = self.grad_store.get(key)
             if v is not None:
@@ -323,9 +329,10 @@ class Engine:
                 g = yv.take_grad()
                 if g is None:
                     return
+                if yv.boundary:
+                    self.renormalise(g, yv.C)
                 g = trunc(g, s.gP)       # (an output stored in more planes than this conv computes in: its gradient is rounded alike)
                 grads, off = [], 0
-                self.cur_gsc = yv.gsc     # (half build: the scale the parameter gradients produced here come out in)
                 for n, co in zip(s.names, s.couts):
                     w = self.P(n + ".weight")
                     gw = self.new_grad(n + ".weight", w)
@@ -341,13 +348,13 @@ class Engine:
                         off += co
                 if xv.req:
                     existing = xv.grad if xv.parent is None else None
-                    if existing is not None and xv.gsc is not yv.gsc:
-                        raise RuntimeError("gradient contributions of one tensor carry different scales (engine stage boundaries)")
+                    if existing is not None:
+                        xv.to_current_scale()       # (half build: the dgrad epilogue adds onto it in the running scale)
                     dx = existing if existing is not None else xv.alloc_grad()
                     gin = (N * H * W, OH, OW, H, W, s.k, s.k, s.stride, s.pad)
                     ops.conv_auto(g, s.pwT, s.cin, gin, N, y=dx, res=existing, mask=xv.t.hi() if xv.relu else None, transposed=True)
                     if existing is None:
-                        xv.add_grad(dx, masked=xv.relu, gsc=yv.gsc)
+                        xv.add_grad(dx, masked=xv.relu)
                     else:
                         xv.masked = xv.masked or xv.relu
             self.tape.append(bwd)
@@ -389,17 +396,16 @@ class Engine:
                 if g is None:
                     return
                 if yv.boundary:
-                    self.stage_boundary(yv, g)
-                self.cur_gsc = yv.gsc
+                    self.renormalise(g, yv.C)
                 dg = self.new_grad(p + ".weight", gamma)
                 db = self.new_grad(p + ".bias", beta)
                 dx = ops.alloc_pt(xv.rows, C, xv.gP, dev, dtype=self.dt)
                 ops.bn_bwd(xv.t, g, C, gamma.detach(), mean, invstd, dg, db, dx)
                 self.param_grads[p + ".weight"] = dg
                 self.param_grads[p + ".bias"] = db
-                xv.add_grad(dx, masked=True, gsc=yv.gsc)
+                xv.add_grad(dx, masked=True)
                 if res is not None:
-                    res.add_grad(g, masked=False, gsc=yv.gsc)
+                    res.add_grad(g, masked=False)
             self.tape.append(bwd)
         return yv
 
@@ -417,7 +423,7 @@ class Engine:
                     return
                 dx = ops.alloc_pt(xv.rows, C, xv.gP, xv.t.device, dtype=self.dt)
                 ops.maxpool_bwd(xv.t, g, dx, N, H, W, C, argmax=arg)
-                xv.add_grad(dx, masked=False, gsc=yv.gsc)
+                xv.add_grad(dx, masked=False)
             self.tape.append(bwd)
         return yv, OH, OW
 
@@ -433,7 +439,7 @@ class Engine:
                     return
                 dx = ops.alloc_pt(xv.rows, C, xv.gP, xv.t.device, dtype=self.dt)
                 ops.bilinear_bwd(g, dx, N, IH, IW, OH, OW, C)
-                xv.add_grad(dx, masked=False, gsc=yv.gsc)
+                xv.add_grad(dx, masked=False)
             self.tape.append(bwd)
         return yv
 
@@ -447,7 +453,7 @@ class Engine:
                     return
                 c = 0
                 for p in parts:
-                    p.add_grad(g.cols(c, c + p.C), masked=cv.relu, gsc=cv.gsc)
+                    p.add_grad(g.cols(c, c + p.C), masked=cv.relu)
                     c += p.C
             self.tape.append(bwd)
         return cv
@@ -514,6 +520,7 @@ class Engine:
                     cats.append(catb)
                     out = catb.cols(planes * 4, planes * 8)
                 f, Hc, Wc = self.bottleneck(f, f"{name}.{b}", N, Hc, Wc, inplanes if b == 0 else planes * 4, planes, st, b == 0, out=out)
+                f.boundary = (blocks - 1 - b) % 2 == 0      # (half build: re-normalisation points of the backward pass, renormalise)
             feats.append(f)
             dims.append((Hc, Wc))
         # top-down decoder (KGnet.py:288-298)
@@ -528,6 +535,7 @@ class Engine:
             u, _, _ = self.conv(u_in, self.spec(f"c{lvl + 1}_up_conv.0", cin, cu, 3, 1, 1, P=pd), N, OH, OW, True, out=buf.cols(0, cu), oP=buf.P)
             cv = self.concat(buf, [u, feats[lvl]])
             cur, _, _ = self.conv(cv, self.spec(f"c{lvl}_cat_refine.0", buf.shape[1], cu, 1, P=pd), N, OH, OW, True)
+            cur.boundary = lvl > 0           # (the adjoint of the 2x upsampling below this level multiplies coherent gradients by 4)
             catv[lvl] = cur
         # heads (KGnet.py:300-316): three first 7x7 convs fused along Cout, three second convs
         maps = []
@@ -545,8 +553,7 @@ class Engine:
         if self.stats_written:
             ops.PARAM_EPOCH[0] += 1      # the running statistics moved: folded eval-mode scale / shift copies are stale
         self.feats, self.dims, self.N, self.maps = feats, dims, N, maps
-        for fv in feats[1:]:
-            fv.boundary = True       # (half build: stage boundaries of the backward pass, stage_boundary)
+        feats[1].boundary = True         # (c1; the bottleneck and decoder level outputs were marked where they were made)
         return maps, feats, dims
 
     HEAD_OFF = (0, 8, 24)      # channel offsets of the kp / short / mid gradients in the fused [rows, 64] dY buffer
@@ -648,8 +655,10 @@ class Engine:
         """map_grads: 12 fp32 NCHW (or None); feat_grads: 5 fp32 [rows, C] tensors (or None) or split rows (ops.PT) already in the
         backward pass's own scale.  gscale (half build): device {S, 1 / S} of this backward pass (ops.grad_scale) -- the fp32 gradients
         enter times S, the parameter gradients come back times S (the caller divides them: ops.scale_tensors)."""
-        gsc = gscale[0:1] if gscale is not None else None
-        self.gscale, self.cur_gsc = gscale, None
+        if gscale is not None:
+            self.gscale = gscale           # (the scale the seg branch's backward left: its feature gradients are expressed in it)
+            Var.ENG = self
+        gsc = self.gscale[0:1] if self.gscale is not None else None
         if self.grad_store is not None:
             self.grad_store.dense_backward_started()
         for (slot, lvl, N, Hh, Wh) in self.head_slots:
@@ -688,6 +697,7 @@ class Engine:
                 hook(list(self.param_grads.items())[n0:], False)    # enqueued go to the bucketed all-reduce right away
         if hook is not None:
             hook([], True)
+        Var.ENG = None
         grads = self.param_grads
         self.param_grads = {}
         return grads

@@ -603,7 +603,14 @@ def grad_pack(g, prob, out, N, C, H, W, cpad, scale=None):
 
 
 # ---- gradient scale of the half-precision backward pass (csrc/gradscale.hip) ------------------------------------------------------
-GRAD_TARGET_LOG2 = int(__import__("os").environ.get("KG_GRAD_TARGET_LOG2", "10"))   # the largest loss gradient of a step lands in [512, 1024): 64x headroom to 65504, normal halves down to 2^-24 of it
+# Magnitude target of the gradient scale: ops.grad_scale places the largest loss gradient of a step in [8, 16); the re-normalisation
+# points of the backward pass (engine.renormalise) bring a gradient tensor that has grown beyond it back there -- only ever DOWN: a
+# factor > 1 would also multiply the other live gradient tensors and could push one of them out of range (measured: with up-scaling 4 of 14
+# random-init seeds overflowed).  IEEE half then has 2^12 of headroom up to 65504 between two re-normalisation points -- one BatchNorm
+# layer multiplies the gradient of a (nearly) dead channel by 1 / sqrt(eps) = 316 -- and normal numbers down to 2^-18 of the target.
+# Measured: targets 2^2 .. 2^8 give the same gradient cosines (0.999987) and norms on the calibrated fixture and no overflow on 24
+# random-init seeds at 64^2 (tiny BatchNorm populations: the worst case); tools/dbg_f16.py, tools/gradmax_probe.py.
+GRAD_TARGET_LOG2 = int(__import__("os").environ.get("KG_GRAD_TARGET_LOG2", "4"))
 _gs_state = {}
 
 
@@ -665,6 +672,19 @@ def rows_rescale(g, C, cum_in, target_log2=None):
     return out[2:3], out[0:2]
 
 
-def rows_scale(g, C, r):
-    """g (rows / PT) *= the device scalar r (a power of two), in place, every plane"""
-    _lib.call("kg_rows_scale", ptr(_rows(g)), ld(g), c_long(base(g).shape[0]), C, ptr(r), pl(a=g), stream_ptr(), fmt=fmt_of(g))
+def rows_scale_multi(items, r, r2=None):
+    """every (rows / PT, C) of `items` *= the device scalar r (* r2), eight tensors per launch (kg_rows_scale_multi)"""
+    import ctypes
+    items = [(g, C) for g, C in items if base(g).shape[0] > 0]
+    for i in range(0, len(items), 8):
+        chunk = items[i:i + 8]
+        desc = (ctypes.c_long * (6 * len(chunk)))()
+        for k, (g, C) in enumerate(chunk):
+            P, ps = nplanes(g)
+            desc[6 * k:6 * k + 6] = [_rows(g).data_ptr(), ld(g), base(g).shape[0], C, P, ps]
+        _lib.call("kg_rows_scale_multi", desc, len(chunk), ptr(r), ptr(r2), stream_ptr(), fmt=fmt_of(chunk[0][0]))
+
+
+def rows_scale(g, C, r, r2=None):
+    """g (rows / PT) *= the device scalar r (* r2) (powers of two), in place, every plane"""
+    _lib.call("kg_rows_scale", ptr(_rows(g)), ld(g), c_long(base(g).shape[0]), C, ptr(r), ptr(r2), pl(a=g), stream_ptr(), fmt=fmt_of(g))

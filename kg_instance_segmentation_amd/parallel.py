@@ -164,15 +164,16 @@ class FlatGradReducer:
         if b > a:
             self.flat[a:b].zero_()
 
-    def seg_done(self, unscale=None):
-        """(the seg branch's backward has enqueued all its gradient kernels on this rank).  unscale: forward_seg ran as its own
-        autograd node in the half-precision build -- its gradients carry ITS power-of-two scale, divided out here."""
+    def seg_done(self, unscale_of=None):
+        """(the seg branch's backward has enqueued all its gradient kernels on this rank).  unscale_of: forward_seg ran as its own
+        autograd node in the half-precision build -- its gradients carry ITS power-of-two scales (key -> device {scale, 1 / scale}),
+        divided out here."""
         a, b, ks = self.seg_bucket
-        if unscale is not None and b > a and not self.seg_unscaled:
-            from . import ops
-            ops.scale_tensors([self.flat[a:b]], unscale)
+        if unscale_of is not None and b > a and not self.seg_unscaled:
+            saved, self.unscale_of = self.unscale_of, unscale_of
+            self._unscale(ks)
+            self.unscale_of = saved
             self.seg_unscaled = True
-            self._pend_done.update(ks)
 
     def dense_backward_started(self):
         """Start of forward_dec's backward, which EVERY rank runs and which autograd schedules after the seg branch's backward

@@ -98,7 +98,7 @@ class _SegFunction(torch.autograd.Function):
         eng = ctx.branch.m._engine
         gflat = gflat.contiguous().float()
         gs = ops.grad_scale([gflat], [ctx.saved[4]]) if eng.fmt else None       # half build: this node's own power-of-two gradient scale
-        eng.gscale, eng.cur_gsc = gs, None
+        eng.gscale = gs
         if gs is not None:
             eng.param_gsc = {}
         gfeats, pgrads = ctx.branch.run_backward(ctx.plan, ctx.saved, gflat, ctx.feat_shapes, gscale=gs)
@@ -106,14 +106,15 @@ class _SegFunction(torch.autograd.Function):
         out = [None, None, None] + gfeats
         store = eng.grad_store
         if gs is not None:
-            ops.scale_tensors([g for k, g in pgrads.items() if g is not None and not (store is not None and store.owns(k, g))], gs[1:2])
+            items = [(k, g) for k, g in pgrads.items() if g is not None and not (store is not None and store.owns(k, g))]
+            ops.scale_tensors([g for _, g in items], [eng.param_gsc[k][1:2] for k, _ in items], flag=eng.overflow_flag)
         for k in ctx.branch.param_keys:
             g = pgrads.get(k)
             if store is not None and g is not None and store.owns(k, g):
                 g = store.deliver(k, ctx.branch.P(k))
             out.append(g)
         if store is not None:
-            store.seg_done(unscale=gs[1:2] if gs is not None else None)
+            store.seg_done(unscale_of=eng.param_gsc if gs is not None else None)
         return tuple(out)
 
 
@@ -439,15 +440,21 @@ class SegBranch:
             self.rconv(g, pwT, cin, rowdesc, M, k, y=dx, mask=mask, mode=3, tiles=t32, tiles16=t16)
 
     def run_backward(self, plan, saved, gflat, feat_shapes, gscale=None):
-        """gscale (half build): device {S, 1 / S} (ops.grad_scale): gflat enters times S; the split-rows feature gradients and the
-        parameter gradients are returned times S (the caller divides the latter), fp32 feature gradients are divided here."""
+        """gscale (half build): truthy when the engine carries a running gradient scale (engine.gscale, set by the caller from
+        ops.grad_scale): gflat enters times that scale; after every level the gradient that moves on to the next coarser level is
+        re-normalised on the device together with the feature gradients already produced (the adjoint of the 2x bilinear upsampling
+        multiplies spatially coherent gradients by 4 per level; engine.renormalise); split-rows feature gradients are returned in
+        the engine's scale at return, parameter gradients in the scale they were produced in (the caller divides them), fp32
+        feature gradients are divided here."""
+        eng = self.m._engine
+        scaled = gscale is not None
         pre, cats, uins, hid, flat, top = saved
         dev = gflat.device
         CH = arch.FEAT_CH
         pgrads = {}
         rows0 = plan.rows[0]
         gz = self.galloc(rows0, 8, dev)
-        ops.grad_pack(gflat, flat, gz, 1, 1, rows0, 1, 8, scale=gscale[0:1] if gscale is not None else None)
+        ops.grad_pack(gflat, flat, gz, 1, 1, rows0, 1, 8, scale=eng.gscale[0:1] if scaled else None)
         dhid = self.galloc(rows0, 64, dev)
         t32_0, t16_0 = self.T32(plan, 0, plan.nb[0]), self.T16(plan, 0, plan.nb[0])
         self.conv_bwd("seg_head.2", hid, gz, plan.rowdesc[0], rows0, 3, pgrads, dx=dhid, mask=hid.hi(), t32=t32_0, t16=t16_0)
@@ -459,7 +466,7 @@ class SegBranch:
         gfeats = [None] * 5
 
         out_planes = getattr(plan, "out_planes", None)      # fused training forward: write the engine's split-bf16 gradient rows directly
-        f32_outs = []
+        f32_outs, pt_outs = [], []
 
         def reduce_level(l, ga, rows_a, gb):
             n, c, h, w = feat_shapes[l]
@@ -473,8 +480,8 @@ class SegBranch:
                       ptr(plan.bin_boxes_d[l]), BIN_SIZE[l], n, h, w, c, ptr(out), ptr(ops.base(outp)), ops.ld(outp) if outp is not None else 0,
                       ops.pl(a=ga if ga is not None else gb, b=gb if gb is not None else ga, y=outp), stream_ptr(),
                       fmt=ops.fmt_of(ga if ga is not None else gb))
-            if out is not None and gscale is not None:
-                f32_outs.append(out)
+            if scaled:      # (the scale this level's feature gradient was written in: converted to the final one below)
+                (f32_outs if out is not None else pt_outs).append((out if out is not None else outp, c, eng.gscale))
             gfeats[l] = outp if outp is not None else out.view(n, h, w, c).permute(0, 3, 1, 2)
 
         for l in range(0, top):
@@ -495,10 +502,15 @@ class SegBranch:
             reduce_level(l, dcat.cols(0, CH[l]) if dcat is not None else None, rowsC if dcat is not None else 0,
                          dpre.rows(rowsC) if rows > rowsC else None)
             dpre = nxt
+            if scaled and nxt is not None:
+                eng.renormalise(nxt, CH[l + 1])
         if dpre is not None:
             reduce_level(top, None, 0, dpre)
-        if f32_outs:
-            ops.scale_tensors(f32_outs, gscale[1:2])
+        for t, c, sc in pt_outs:                        # split-rows outputs: into the running scale the dense backward continues in
+            if sc is not eng.gscale:
+                ops.rows_scale(t, c, eng.gscale[0:1], sc[1:2])
+        if f32_outs:                                    # fp32 outputs leave unscaled: each divided by the scale it was written in
+            ops.scale_tensors([t for t, _, _ in f32_outs], [sc[1:2] for _, _, sc in f32_outs])
         # parameters of levels that no box reached get zero gradients (autograd accumulates nothing for None)
         return gfeats, pgrads
 

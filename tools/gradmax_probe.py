@@ -16,11 +16,11 @@ sd = weightgen.gen_state_dict(0, variant=variant) if variant == "cal" else weigh
 m = KGnet.resnet50(pretrained=False, precision="fp32"); m.load_state_dict(sd); m = m.to("cuda").train()
 rec = []
 orig = engine.Var.add_grad
-def add_grad(self, g, masked, gsc=None):
+def add_grad(self, g, masked):
     if isinstance(g, ops.PT):
         t = g.t.float().abs()
         rec.append((float(t.max()), float(t[t > 0].median()) if (t > 0).any() else 0.0, self.C, self.rows))
-    return orig(self, g, masked, gsc)
+    return orig(self, g, masked)
 engine.Var.add_grad = add_grad
 x, gt_boxes, gt_masks, gt_lv = synth.train_batch(N, S, S, 3, n_boxes=NB, smin=14, smax=40) if S >= 256 else synth.train_batch(N, S, S, 3, n_boxes=NB)
 ldec, lseg = DetectionLossAll(kp_radius=5), SEG_loss(height=S, width=S)
