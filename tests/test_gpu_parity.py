@@ -272,3 +272,40 @@ def test_config3_batch16_full_path(cal_sd):
         assert len(grads) == 217 and all(g is not None and torch.isfinite(g).all() for g in grads)
     print("bs16 losses (two image orders):", losses)
     assert abs(losses[0] - losses[1]) <= 1e-4 * abs(losses[0])
+
+
+def test_train_step_256_vs_oracle_full_gradients(cal_sd):
+    """Default policy, 2 x 256 x 256 with 40 boxes per image (the golden train step is 2 x 128 x 128 with sampled gradients): losses and
+    the FULL gradient of every parameter against the reference-pinned CPU oracle's autograd (oracle/net.py) -- cosine >= 0.9999 and norm
+    within 2e-3 per tensor."""
+    from oracle import net as onet
+    torch.set_num_threads(min(torch.get_num_threads(), 32))
+    N, S = 2, 256
+    x, gt_boxes, gt_masks, gt_lv = synth.train_batch(N, S, S, 17, n_boxes=40, smin=14, smax=40)
+    m = make_model(cal_sd, "fp32").train()
+    m.zero_grad()
+    ldec, lseg = DetectionLossAll(kp_radius=5), SEG_loss(height=S, width=S)
+    d0, d1, d2, d3, pred = m(x.to(DEV), gt_boxes)
+    loss = sum(ldec(p, t.to(DEV)) for p, t in zip((d0, d1, d2, d3), gt_lv)) + lseg(pred, gt_masks, gt_boxes)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert not m.grad_overflowed()
+    sd = {k: v.clone() for k, v in cal_sd.items()}
+    names = [k for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    for n in names:
+        sd[n].requires_grad_(True)
+    net = onet.Net(sd, training=True)
+    o0, o1, o2, o3, opred = net.forward(x, gt_boxes)
+    oloss = sum(onet.detection_loss(p, t) for p, t in zip((o0, o1, o2, o3), gt_lv)) + onet.seg_loss(opred, gt_masks, gt_boxes, S, S)
+    oloss.backward()
+    assert abs(float(loss) - float(oloss)) <= 2e-5 * abs(float(oloss))
+    rows = []
+    for n, p in m.named_parameters():
+        if p.grad is None:
+            assert sd[n].grad is None or float(sd[n].grad.abs().max()) == 0.0, n
+            continue
+        a, b = p.grad.detach().double().cpu().flatten(), sd[n].grad.double().flatten()
+        rows.append((float(a @ b / (a.norm() * b.norm() + 1e-300)), n, float(a.norm() / (b.norm() + 1e-300))))
+    rows.sort()
+    print("min cosine %.7f (%s); norm ratio in [%.5f, %.5f]" % (rows[0][0], rows[0][1], min(r for _, _, r in rows), max(r for _, _, r in rows)))
+    assert rows[0][0] >= 0.9999 and all(abs(r - 1) <= 2e-3 for _, _, r in rows), rows[:4]
