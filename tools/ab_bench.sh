@@ -1,11 +1,14 @@
 #!/bin/bash
-# Same-box A/B of two builds of libkgnet_hip.so (box-to-box variance of the train step is ~1.5 %, larger than most kernel changes):
-#   cp kg_instance_segmentation_amd/libkgnet_hip.so kg_instance_segmentation_amd/libkgnet_hip_old.so   # baseline build
-#   ... edit, rebuild ...;  gpurun -- 'bash tools/ab_bench.sh'
+# Same-box A/B of two builds (box-to-box variance of the train step is ~1.5 %, larger than most kernel changes).  The default policy runs on
+# libkgnet_hip_f16.so (IEEE-half rows), the bf16 policies on libkgnet_hip.so:
+#   cp kg_instance_segmentation_amd/libkgnet_hip_f16.so kg_instance_segmentation_amd/libkgnet_hip_f16_old.so   # baseline build
+#   ... edit, rebuild ...;  gpurun -- 'bash tools/ab_bench.sh'            (bf16 policies: LIBVAR=KG_LIB_PATH BASE=libkgnet_hip bash tools/ab_bench.sh --precision mixed)
+LIBVAR=${LIBVAR:-KG_LIB_F16_PATH}
+BASE=${BASE:-libkgnet_hip_f16}
 for i in 1 2 3; do
-  for L in libkgnet_hip_old.so libkgnet_hip.so; do
+  for L in ${BASE}_old.so ${BASE}.so; do
     echo -n "$L "
-    KG_LIB_PATH=$PWD/kg_instance_segmentation_amd/$L python bench.py --steps 10 --warmup 3 --no-companion --no-cpu-baseline "$@" 2>&1 | tail -1 |
+    env $LIBVAR=$PWD/kg_instance_segmentation_amd/$L python bench.py --steps 10 --warmup 3 --no-companion --no-cpu-baseline "$@" 2>&1 | tail -1 |
       python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"
   done
 done
