@@ -551,7 +551,7 @@ extern "C" int kg_add_rows(const void* a, int lda, const void* b, int ldb, const
 // the BatchNorm of a (nearly) dead channel, x4 per level through the adjoint of the 2x bilinear upsampling when they are spatially
 // coherent (tools/gradmax_probe.py) -- more than one global power-of-two scale can place inside IEEE half's range together with
 // the 1e-7-sized loss gradients of the heads.  The backward pass therefore re-normalises itself (engine.renormalise) where the
-// gradient of a decoder level output, of c1, of every second bottleneck output or of a seg-branch level is complete:
+// gradient of a decoder level output, of c1, of every bottleneck output or of a seg-branch level is complete:
 // kg_rows_rescale measures max |g| of that rows tensor on the device and, when it has grown beyond 2^T, multiplies the tensor in
 // place by the power of two r < 1 that brings the maximum back into [2^(T-1), 2^T) (r = 1 otherwise: the scale only ever goes
 // down), and chains the running scale: cum_out = cum_in * r; every other live gradient tensor is

@@ -221,7 +221,7 @@ class Engine:
         Why: gradients grow ~2^0.9 per bottleneck through the BatchNorm backbone at random init (gamma / sigma: 2^12 from c4 to the
         stem; a 23-block layer3 of resnet101 alone would leave IEEE half's range), x316 through the BatchNorm of a dead channel, and
         x4 per level through the adjoint of the 2x bilinear upsampling when they are spatially coherent (tools/gradmax_probe.py); the
-        call sites are the outputs of every second bottleneck, c1, the decoder's level outputs and the seg branch's levels."""
+        call sites are the outputs of every bottleneck, c1, the decoder's level outputs and the seg branch's levels."""
         if self.gscale is None:
             return
         _, self.gscale = ops.rows_rescale(g, C, self.gscale)
@@ -520,7 +520,7 @@ class Engine:
                     cats.append(catb)
                     out = catb.cols(planes * 4, planes * 8)
                 f, Hc, Wc = self.bottleneck(f, f"{name}.{b}", N, Hc, Wc, inplanes if b == 0 else planes * 4, planes, st, b == 0, out=out)
-                f.boundary = (blocks - 1 - b) % 2 == 0      # (half build: re-normalisation points of the backward pass, renormalise)
+                f.boundary = True            # (half build: every bottleneck output is a re-normalisation point of the backward pass, renormalise)
             feats.append(f)
             dims.append((Hc, Wc))
         # top-down decoder (KGnet.py:288-298)

@@ -484,7 +484,7 @@ def test_half_range_violation_is_loud(state_dict0):
 
 def test_resnet101_random_init_gradients_stay_in_half_range():
     """[3, 4, 23] blocks (KGnet.resnet101): at random init the gradient grows ~2^0.9 per bottleneck through the 23-block layer3; the
-    backward pass re-normalises it at every second block output (engine.stage_boundary), so all 366 parameter gradients are finite and
+    backward pass re-normalises it at every block output (engine.renormalise), so all 366 parameter gradients are finite and
     the overflow flag stays down."""
     torch.manual_seed(3)
     m = KGnet.resnet101(pretrained=False).to(DEV).train()
