@@ -11,6 +11,7 @@ Stated tolerances |got - ref| <= atol + rtol * |ref|  (rms = root mean square of
             0.45 / 0.78 for "fp32bf"); every parameter gradient: cosine >= 0.9999, norm within 2e-3 (measured 0.999987 / 6e-4);
   "half"    (single IEEE-half planes, 11 significant bits): SURVEY 8d's reduced-precision clause, rtol 2e-2, with atol 2e-2 * rms
             (measured max |d| = 1.6e-2 rms in train mode, 5e-3 rms in eval mode);
+  "halfmix" (as "half", the BatchNorm backbone on hi + lo half planes): rtol 2e-2, atol 1e-2 * rms (measured 5.6e-3 rms);
   "trunk2"  (bf16; whole trunk in hi + lo planes, heads bf16): rtol 2e-2, atol 3e-2 * rms;
   "mixed"   (bf16; BatchNorm backbone in hi + lo planes, c0_conv / decoder / heads plain bf16 = 8 bf16 layers): rtol 2e-2,
             atol 5e-2 * rms -- NOT the blueprint's clause (a plain-bf16 multiply carries 8 bits), kept as an opt-in speed policy;
@@ -32,14 +33,14 @@ from oracle import synth, weightgen  # noqa: E402
 
 DEV = "cuda"
 # rtol, atol, atol as a fraction of rms
-EVAL_TOL = {"fp32": (1e-4, 1e-5, 0.0), "fp32bf": (1e-4, 1e-5, 0.0), "half": (2e-2, 0.0, 2e-2), "trunk2": (2e-2, 0.0, 3e-2), "mixed": (2e-2, 0.0, 6e-2),
+EVAL_TOL = {"fp32": (1e-4, 1e-5, 0.0), "fp32bf": (1e-4, 1e-5, 0.0), "half": (2e-2, 0.0, 2e-2), "halfmix": (2e-2, 0.0, 1e-2), "trunk2": (2e-2, 0.0, 3e-2), "mixed": (2e-2, 0.0, 6e-2),
             "bf16": (2e-2, 0.0, 1e-1)}
 TRAIN_TOL = dict(EVAL_TOL, mixed=(2e-2, 0.0, 5e-2), bf16=(2e-2, 0.0, 1.5e-1))
-GRAD_COS = {"fp32": 0.9999, "fp32bf": 0.9999, "half": 0.97, "trunk2": 0.99, "mixed": 0.99, "bf16": 0.85}
-GRAD_NORM = {"fp32": 2e-3, "fp32bf": 2e-3, "half": 5e-2, "trunk2": 5e-2, "mixed": 5e-2, "bf16": 0.3}
-LOSS_TOL = {"fp32": 2e-5, "fp32bf": 2e-5, "half": 2e-3, "trunk2": 2e-3, "mixed": 3e-3, "bf16": 2e-2}
-STAT_TOL = {"fp32": (1e-4, 1e-6), "fp32bf": (1e-4, 1e-6), "half": (2e-3, 1e-4), "trunk2": (1e-3, 1e-5), "mixed": (1e-3, 1e-5), "bf16": (3e-2, 3e-3)}
-POLICIES = ["fp32", "fp32bf", "half", "trunk2", "mixed", "bf16"]
+GRAD_COS = {"fp32": 0.9999, "fp32bf": 0.9999, "half": 0.97, "halfmix": 0.999, "trunk2": 0.99, "mixed": 0.99, "bf16": 0.85}
+GRAD_NORM = {"fp32": 2e-3, "fp32bf": 2e-3, "half": 5e-2, "halfmix": 1e-2, "trunk2": 5e-2, "mixed": 5e-2, "bf16": 0.3}
+LOSS_TOL = {"fp32": 2e-5, "fp32bf": 2e-5, "half": 2e-3, "halfmix": 1e-3, "trunk2": 2e-3, "mixed": 3e-3, "bf16": 2e-2}
+STAT_TOL = {"fp32": (1e-4, 1e-6), "fp32bf": (1e-4, 1e-6), "half": (2e-3, 1e-4), "halfmix": (1e-3, 1e-5), "trunk2": (1e-3, 1e-5), "mixed": (1e-3, 1e-5), "bf16": (3e-2, 3e-3)}
+POLICIES = ["fp32", "fp32bf", "half", "halfmix", "trunk2", "mixed", "bf16"]
 
 
 def sha(a):
