@@ -40,7 +40,23 @@ struct HaloArgs {
     float* stat_part; // != null (GM = 0, bf16 rows output): BatchNorm statistics of the output, partials [pixel tile][Cout][2] (conv_args.h)
     int kp_raw;       // GM = 1: 1 = export the kp logits without the sigmoid of KGnet.py:300 (parity tests, logit-space consumers)
     int yP, yps, rP, rps;
+    // 3-product input (x_hi * w_lo | x_lo * w_hi | x_hi * w_hi, kg_plane_pairs): walk order of the virtual chunks, see halo_set_walk
+    int walk3;
 };
+
+// Planed input with the three products of the half-plane policies.  The packed weights keep the plane-major virtual-channel layout of
+// kg_plane_pairs (kg_common.h) and the walk stays "every low-order product before the first hi * hi product" (the fp32 accumulator is
+// still small while two thirds of the additions happen: measured, a chunk-major walk that shares every x_hi halo costs 25 % of the
+// train-mode parity margin).  Inside that constraint the walk is arranged so that ONE x_hi halo serves two products:
+//   low-order phase:  chunk 0: x_lo * w_hi, x_hi * w_lo;  chunk 1: ...;  chunk n-1: x_lo * w_hi, x_hi * w_lo
+//   hi * hi phase:    chunk n-1 (its x_hi halo is still in LDS: not staged again), n-2, ..., 0
+// 64-channel layers (the c0 / c1 heads, the grouped second layers, the seg branch's 3x3) have n = 1: 2 stagings instead of 3.
+static void halo_set_walk(HaloArgs& a, int xP, int wP) {
+    int xi[6], wj[6];
+    const int nv = kg_plane_pairs(xP, wP, xi, wj);
+    static const int on = getenv("KG_HALO_SHARE") ? atoi(getenv("KG_HALO_SHARE")) : 1;
+    a.walk3 = on && nv == 3 && xi[0] == 0 && xi[1] == 1 && xi[2] == 0;
+}
 
 // WPX = pixel waves: 4 -> 16x16 output tile, 8 -> 16 rows x 32 columns (two 16x16 halves side by side)
 // GM = 1: the three second-layer head convs (KGnet.py:161-209 `.2`: C -> 5 / 10 / 40) as ONE launch over the fused hidden
@@ -150,13 +166,22 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     };
 
     const int nchunks = (GM == 1 && a.head_split) ? (biy + 1) * a.grp_chunks : a.cin_pad / 64;
-    for (int cc = (GM == 1 && a.head_split) ? biy * a.grp_chunks : 0; cc < nchunks; ++cc) {
+    for (int ci = (GM == 1 && a.head_split) ? biy * a.grp_chunks : 0; ci < nchunks; ++ci) {
         __syncthreads();
+        int cc = ci;                               // virtual chunk of this step (weights: channel offset cc * 64 of a tap)
+        bool stage = true;                         // (uniform) false: the halo of the previous step is the one this product multiplies
+        if (a.walk3) {
+            const int n = a.km.n, grp = 3 * n;     // virtual chunks of one group (GM == 1: one head, else the whole tap): [x_hi w_lo | x_lo w_hi | x_hi w_hi]
+            const int base = ci / grp * grp, q = ci - base;
+            if (q < 2 * n) cc = base + ((q & 1) ? (q >> 1) : n + (q >> 1));
+            else { cc = base + 2 * n + (grp - 1 - q); stage = q > 2 * n; }
+        }
         int xo;                                    // X-side element offset of this (virtual) chunk
         if constexpr (GM == 1) { const int hd = cc / a.grp_chunks; xo = hd * a.grp_C + a.km.xoff(cc - hd * a.grp_chunks); }
         else xo = a.km.xoff(cc);
         // ---- stage the halo of this 64-channel chunk ------------------------------------------------
-        if (KS == 3) {   // 3x3 (9 taps per staging): all global loads of the halo are issued before the first LDS store
+        if (!stage) {
+        } else if (KS == 3) {   // 3x3 (9 taps per staging): all global loads of the halo are issued before the first LDS store
             constexpr int HPT = (HPIX * 8 + NT - 1) / NT;
             uint4 hreg[HPT];
 #pragma unroll
@@ -545,6 +570,7 @@ extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, v
     int segs_[3];
     const int vplanes = kg_kmap_segs(pp.a_planes, pp.w_planes, segs_);
     a.km = kg_make_kmap(cin_pad, 64, pp.a_planes, pp.a_pstride, pp.w_planes);
+    halo_set_walk(a, pp.a_planes, pp.w_planes);
     a.yP = pp.y_planes; a.yps = pp.y_pstride; a.rP = pp.b_planes; a.rps = pp.b_pstride;
     KG_CHECK_ARG(!(y_f32 && (res || mask)), "kg_conv2d_halo: fp32 exports take no residual / mask");
     KG_CHECK_ARG(x && w && (y || y_f32), "kg_conv2d_halo: null pointer");
@@ -594,6 +620,7 @@ extern "C" int kg_conv2d_halo_heads2(const void* x, const void* w, const float* 
     int segs_[3];
     const int vplanes = kg_kmap_segs(pp.a_planes, pp.w_planes, segs_);
     a.km = kg_make_kmap(C, 64, pp.a_planes, pp.a_pstride, pp.w_planes);
+    halo_set_walk(a, pp.a_planes, pp.w_planes);
     a.yP = 1; a.rP = 1; a.grp_C = C; a.kp_raw = kp_sigmoid ? 0 : 1;
     KG_CHECK_ARG(x && w && vmap && kp && sh && md, "kg_conv2d_halo_heads2: null pointer");
     KG_CHECK_ARG(C % 64 == 0 && C > 0 && ldx % 8 == 0 && ldx >= 3 * C, "kg_conv2d_halo_heads2: C must be a multiple of 64 (got %d)", C);

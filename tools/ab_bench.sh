@@ -9,6 +9,6 @@ for i in 1 2 3; do
   for L in ${BASE}_old.so ${BASE}.so; do
     echo -n "$L "
     env $LIBVAR=$PWD/kg_instance_segmentation_amd/$L python bench.py --steps 10 --warmup 3 --no-companion --no-cpu-baseline "$@" 2>&1 | tail -1 |
-      python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"
+      python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms/step; dominant kernel', d['roofline']['achieved'], d['roofline']['unit'])"
   done
 done
