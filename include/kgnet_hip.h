@@ -32,6 +32,9 @@ typedef struct kg_planes {
     int w_planes;              /* planes of the packed weights (virtual-channel layout, see kg_pack_weight) */
     int reserved_;
     const float* scale;        /* device scalar or NULL: kg_grad_pack / kg_f32_to_planes multiply by *scale (kg_grad_scale) */
+    const float* oscale;       /* device fp32 [Cout] or NULL: kg_conv2d_igemm / kg_conv2d_halo compute act(acc * oscale[co] + bias[co] (+ res)):
+                                  an inference-mode BatchNorm folded into the conv (KGnet.py:82-97 conv -> bn -> relu as one launch;
+                                  oscale = gamma / sqrt(running_var + eps), bias = beta - running_mean * oscale), applied to the fp32 accumulator */
 } kg_planes_t;
 
 /* The same C ABI is built for two 16-bit storage formats of the rows / packed-weight operands ("bf16 rows" above):

@@ -13,6 +13,7 @@ struct ConvArgs {
     KMap km;                   // split-bf16 planes of x (kg_common.h): X-side offset of virtual channel unit q
     int yP, yps, rP, rps;      // planes / plane strides of the output rows and of the residual
     float* stat_part;          // != null: BatchNorm statistics of the output (kg_conv_stats_begin): partials [pixel tile][Cout][2]
+    const float* oscale;       // != null: per-cout factor of the accumulator (kg_planes_t.oscale: folded inference BatchNorm)
 };
 
 // ---- BatchNorm statistics in the conv epilogue ---------------------------------------------------------------------------------
@@ -108,6 +109,7 @@ __device__ __forceinline__ void kg_conv_epilogue(const EpiArgs& e, long m, int c
 static inline void kg_fill_planes(ConvArgs& a, const kg_planes_t& pp, int cin_pad_plane, int unit) {
     a.km = kg_make_kmap(cin_pad_plane, unit, pp.a_planes, pp.a_pstride, pp.w_planes);
     a.yP = pp.y_planes; a.yps = pp.y_pstride; a.rP = pp.b_planes; a.rps = pp.b_pstride;
+    a.oscale = pp.oscale;
 }
 __device__ __forceinline__ EpiArgs kg_epi(const ConvArgs& a) {
     return EpiArgs{a.y, a.res, a.mask, a.ldy, a.ldres, a.ldmask, a.Cout, a.relu, a.yP, a.yps, a.rP, a.rps};

@@ -170,6 +170,9 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
     float bv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+    float sv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sv[e] = (a.oscale && cb + e < a.Cout) ? a.oscale[cb + e] : 1.f;
     const EpiArgs ep = kg_epi(a);
     float ss[16], sq[16];
 #pragma unroll
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(acc[i][j][r]) + bv[i * 4 + r];
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(acc[i][j][r]) * sv[i * 4 + r] + bv[i * 4 + r];
         if (stats) kg_stat_add(ss, sq, v);
         kg_conv_epilogue<16>(ep, m, cb, v);
     }

@@ -42,6 +42,7 @@ struct HaloArgs {
     int yP, yps, rP, rps;
     // 3-product input (x_hi * w_lo | x_lo * w_hi | x_hi * w_hi, kg_plane_pairs): walk order of the virtual chunks, see halo_set_walk
     int walk3;
+    const float* oscale;   // != null (GM = 0): per-cout factor of the accumulator (kg_planes_t.oscale: folded inference BatchNorm)
 };
 
 // Planed input with the three products of the half-plane policies.  The packed weights keep the plane-major virtual-channel layout of
@@ -483,6 +484,14 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     float bv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+    if (GM == 0 && a.oscale) {           // (uniform; the accumulators are scaled in place: no second 16-register table next to acc)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float s = cb + e < a.Cout ? a.oscale[cb + e] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[e >> 2][j][e & 3] *= s;
+        }
+    }
     const EpiArgs ep{a.y, a.res, a.mask, a.ldy, a.ldres, a.ldmask, a.Cout, a.relu, a.yP, a.yps, a.rP, a.rps};
     const int ox = ox0 + (wp >> 2) * 16 + lm;
     int vm[16];
@@ -571,7 +580,7 @@ extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, v
     const int vplanes = kg_kmap_segs(pp.a_planes, pp.w_planes, segs_);
     a.km = kg_make_kmap(cin_pad, 64, pp.a_planes, pp.a_pstride, pp.w_planes);
     halo_set_walk(a, pp.a_planes, pp.w_planes);
-    a.yP = pp.y_planes; a.yps = pp.y_pstride; a.rP = pp.b_planes; a.rps = pp.b_pstride;
+    a.yP = pp.y_planes; a.yps = pp.y_pstride; a.rP = pp.b_planes; a.rps = pp.b_pstride; a.oscale = pp.oscale;
     KG_CHECK_ARG(!(y_f32 && (res || mask)), "kg_conv2d_halo: fp32 exports take no residual / mask");
     KG_CHECK_ARG(x && w && (y || y_f32), "kg_conv2d_halo: null pointer");
     KG_CHECK_ARG(KS == 3 || KS == 7, "kg_conv2d_halo: kernel size must be 3 or 7");

@@ -176,6 +176,9 @@ __global__ __launch_bounds__(WC* WP * 64) void conv_igemm_kernel(const ConvArgs 
     float bv[NV];
 #pragma unroll
     for (int e = 0; e < NV; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+    float sv[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) sv[e] = (a.oscale && cb + e < a.Cout) ? a.oscale[cb + e] : 1.f;
     const int ohw = a.OH * a.OW;
     const EpiArgs ep = kg_epi(a);
 #pragma unroll
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(WC* WP * 64) void conv_igemm_kernel(const ConvArgs 
 #pragma unroll
         for (int i = 0; i < CF; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(acc[i][j][r]) + bv[i * 4 + r];
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(acc[i][j][r]) * sv[i * 4 + r] + bv[i * 4 + r];
         if (a.y_f32) {       // fp32 exports carry no residual / mask in KGnet (head maps)
             if (a.relu) {
 #pragma unroll

@@ -220,13 +220,16 @@ __global__ __launch_bounds__(256) void conv_small_mfma_kernel(const ConvArgs a) 
     float bv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+    float sv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sv[e] = (a.oscale && cb + e < a.Cout) ? a.oscale[cb + e] : 1.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const long m = m0 + j * 16 + lm;
         if (m >= a.M) continue;
         float v[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = KG_ACC(acc[e >> 2][j][e & 3]) + bv[e];
+        for (int e = 0; e < 16; ++e) v[e] = KG_ACC(acc[e >> 2][j][e & 3]) * sv[e] + bv[e];
         kg_conv_epilogue<16>(ep, m, cb, v);
     }
 }
@@ -236,7 +239,8 @@ int kg_launch_conv_small(const ConvArgs& a, hipStream_t st) {
     static const int use_mfma = getenv("KG_CONV_SMALL_MFMA") ? atoi(getenv("KG_CONV_SMALL_MFMA")) : 1;
     const bool planed = a.km.total > 1 || a.yP > 1 || a.rP > 1;
     if (planed && !(a.K >= 32 * a.km.total * ((a.ntaps + 3) / 4))) { kg_set_error("conv_small: packed rows too short for the plane layout"); return KG_ERR_ARG; }
-    if ((use_mfma || planed) && a.K >= 32 * a.km.total * ((a.ntaps + 3) / 4)) {
+    if (a.oscale && !(a.K >= 32 * a.km.total * ((a.ntaps + 3) / 4))) { kg_set_error("conv_small: an output scale needs the MFMA variant's packed layout"); return KG_ERR_ARG; }
+    if ((use_mfma || planed || a.oscale) && a.K >= 32 * a.km.total * ((a.ntaps + 3) / 4)) {
         hipLaunchKernelGGL(conv_small_mfma_kernel, dim3((unsigned)((a.M + 255) / 256), kg_cdiv(a.Cout, 64)), dim3(256), 0, st, a);
         KG_CHECK_LAUNCH("conv_small_mfma");
         return KG_OK;

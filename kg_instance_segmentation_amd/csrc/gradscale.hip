@@ -23,12 +23,20 @@ __global__ __launch_bounds__(256) void grad_scale_kernel(GradScaleArgs a, unsign
         const float* p = a.p[t];
         const float* q = a.q[t];
         const long n = a.n[t];
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-            float v = p[i];
-            if (q) { const float s = q[i]; v *= s * (1.f - s); }          // (exactly kg_grad_pack's expression)
+        auto take = [&](float v, float s, bool hasq) {
+            if (hasq) v *= s * (1.f - s);                                // (exactly kg_grad_pack's expression)
             const unsigned b = __float_as_uint(v) & 0x7fffffffu;         // |v| as ordered bits (NaN sorts above inf: handled below)
             best = b > best ? b : best;
+        };
+        const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
+        const long n4 = vec ? n >> 2 : 0;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {   // 16-byte loads: the pass is HBM-bound
+            const f32x4 v = reinterpret_cast<const f32x4*>(p)[i];
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if (q) s = reinterpret_cast<const f32x4*>(q)[i];
+            take(v[0], s[0], q != nullptr); take(v[1], s[1], q != nullptr); take(v[2], s[2], q != nullptr); take(v[3], s[3], q != nullptr);
         }
+        for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) take(p[i], q ? q[i] : 0.f, q != nullptr);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned q = __shfl_xor(best, o, 64); best = q > best ? q : best; }
@@ -77,7 +85,7 @@ extern "C" int kg_grad_scale(const void* const* ptrs, const void* const* probs, 
     }
     for (int i = 0; i < n; ++i) KG_CHECK_ARG(a.p[i] && a.n[i] >= 0, "kg_grad_scale: null tensor");
     int blocks = (int)((total + 256 * 16 - 1) / (256 * 16));
-    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
     hipLaunchKernelGGL(grad_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, (unsigned*)scratch, out);
     KG_CHECK_LAUNCH("grad_scale");
     return KG_OK;

@@ -140,9 +140,11 @@ struct kg_planes_t {
     int w_planes;              // planes of the packed weights (virtual-channel layout of kg_pack_weight*)
     int reserved_;
     const float* scale;        // device scalar or null: fp32 -> rows conversions (kg_grad_pack, kg_f32_to_planes) multiply by *scale
+    const float* oscale;       // device fp32 [Cout] or null: forward convs (kg_conv2d_igemm, kg_conv2d_halo) compute y = act(acc * oscale[c] + bias[c] (+ res))
+                               // -- an inference-mode BatchNorm (KGnet.py:82-97: conv -> bn -> relu) folded into the conv's epilogue, on the fp32 accumulator
 };
 static inline kg_planes_t kg_planes_or_default(const kg_planes_t* p) {
-    kg_planes_t d = {1, 0, 1, 0, 1, 0, 1, 0, 1, 0, nullptr};
+    kg_planes_t d = {1, 0, 1, 0, 1, 0, 1, 0, 1, 0, nullptr, nullptr};
     if (p) {
         d = *p;
         if (d.a_planes < 1) d.a_planes = 1;

@@ -170,6 +170,7 @@ class Engine:
         self.train_steps, self.stamp = 0, ("e", 0, 0)
         self.generation = 0        # bumped by every forward_dec: a backward must belong to the latest recorded forward
         self.eval_downgrade = os.environ.get("KG_EVAL_DOWNGRADE", "0") == "1"     # opt-in: eval-mode backbone on the decoder's planes ("mixed": plain bf16 inference)
+        self.fuse_eval_bn = os.environ.get("KG_FUSE_EVAL_BN", "1") == "1"       # inference: conv -> bn (-> + res) (-> relu) as ONE launch (conv_bn)
         self.raw_kp_logits = False   # test hook: inference-only export of the kp LOGITS instead of sigmoid(logits) (KGnet.py:300)
         self.grad_store = None     # parallel.FlatGradReducer: key -> persistent fp32 view the gradient kernels write into directly
         self.grad_hook = None      # parallel.FlatGradReducer.attach: called with [(key, grad)] as backward produces them
@@ -298,11 +299,13 @@ class Engine:
             s.pwT.stale = False
 
     # ---- ops ------------------------------------------------------------------------------------
-    def conv(self, xv, s, N, H, W, relu, out=None, y_f32=None, tile=0, oP=None, bn_stats=False):
+    def conv(self, xv, s, N, H, W, relu, out=None, y_f32=None, tile=0, oP=None, bn_stats=False, affine=None, res=None):
         """xv: Var over [N*H*W, >=cin_pad]; returns Var over [N*OH*OW, cout] (or fp32 NCHW when y_f32).
         oP: planes of the output (default: the conv's own precision).  bn_stats: the output feeds a train-mode BatchNorm -- the conv
-        kernel also writes the statistics partials of its output when it can (ops.conv_stats_begin); the Var then carries them."""
+        kernel also writes the statistics partials of its output when it can (ops.conv_stats_begin); the Var then carries them.
+        affine = (scale, shift) fp32 [cout] / res (Var): inference only (conv_bn) -- y = act(conv * scale + shift + res) in the conv's epilogue."""
         train = self.tape is not None
+        assert not (train and (affine is not None or res is not None))
         self.prepare(s, need_T=train and xv.req)
         OH = (H + 2 * s.pad - s.k) // s.stride + 1
         OW = (W + 2 * s.pad - s.k) // s.stride + 1
@@ -317,7 +320,11 @@ class Engine:
         part = ops.conv_stats_begin(dev, self.fmt) if arm else None
         nb = 0
         try:
-            ops.conv_auto(xin, s.pw, s.cout, geom, N, y=out, y_f32=y_f32, bias=s.bias_cat if s.has_bias else None, relu=relu, tile=tile)
+            if affine is not None:
+                assert not s.has_bias
+                ops.conv_auto(xin, s.pw, s.cout, geom, N, y=out, bias=affine[1], oscale=affine[0], res=res.t if res is not None else None, relu=relu, tile=tile)
+            else:
+                ops.conv_auto(xin, s.pw, s.cout, geom, N, y=out, y_f32=y_f32, bias=s.bias_cat if s.has_bias else None, relu=relu, tile=tile)
         finally:
             if arm:          # (always disarm: an exception in the launch must not leave the side channel armed for the next conv)
                 nb = ops.conv_stats_end(self.fmt)
@@ -360,6 +367,32 @@ class Engine:
             self.tape.append(bwd)
         return yv, OH, OW
 
+    def bn_eval_affine(self, p, C):
+        """inference-mode BatchNorm as y = x * scale + shift: the pair only changes with the parameters -- cached under the same validity key
+        as the packed weights"""
+        gamma, beta = self.P(p + ".weight"), self.P(p + ".bias")
+        rm, rv = self.P(p + ".running_mean"), self.P(p + ".running_var")
+        ver = self.stamp + tuple(t._version for t in (gamma, beta, rm, rv)) + tuple(t.data_ptr() for t in (gamma, beta, rm, rv))
+        hit = self.bn_eval.get(p)
+        if hit is None or hit[0] != ver:
+            hit = (ver, ops.bn_scale_shift_eval(C, gamma.detach(), beta.detach(), rm, rv))
+            self.bn_eval[p] = hit
+        return hit[1]
+
+    def conv_bn(self, xv, s, bnp, N, H, W, relu, res=None, out=None, bn_stats=True):
+        """conv -> BatchNorm (-> + res) (-> ReLU), KGnet.py:82-97.  Inference (running statistics, nothing recorded): ONE launch -- the
+        BatchNorm is a per-channel affine map of the conv's fp32 accumulators (kg_planes_t.oscale + bias; the conv output is never stored
+        and re-read), residual and ReLU ride in the same epilogue.  Training: conv (+ statistics in its epilogue), then bn()."""
+        if self.tape is None and not self.m.training and self.fuse_eval_bn:
+            if out is None:
+                OH, OW = (H + 2 * s.pad - s.k) // s.stride + 1, (W + 2 * s.pad - s.k) // s.stride + 1
+                out = ops.alloc_pt(N * OH * OW, s.cout, self.bpt, xv.t.device, dtype=self.dt)
+            yv, OH, OW = self.conv(xv, s, N, H, W, relu, out=out, affine=self.bn_eval_affine(bnp, s.cout), res=res)
+            yv.gP = min(self.bpt, self.pg)
+            return yv, OH, OW
+        y, OH, OW = self.conv(xv, s, N, H, W, False, bn_stats=bn_stats)
+        return self.bn(y, bnp, relu, res=res, out=out), OH, OW
+
     def bn(self, xv, p, relu, res=None, out=None):
         C = xv.C
         dev = xv.t.device
@@ -377,13 +410,7 @@ class Engine:
             self.nbt.append(self.P(p + ".num_batches_tracked"))      # += 1 for all 43 layers in one launch at the end of forward_dec
             self.stats_written = True
         else:
-            # inference: scale / shift only change with the parameters -- cached under the same validity key as the packed weights
-            ver = self.stamp + tuple(t._version for t in (gamma, beta, rm, rv)) + tuple(t.data_ptr() for t in (gamma, beta, rm, rv))
-            hit = self.bn_eval.get(p)
-            if hit is None or hit[0] != ver:
-                hit = (ver, ops.bn_scale_shift_eval(C, gamma.detach(), beta.detach(), rm, rv))
-                self.bn_eval[p] = hit
-            scale, shift = hit[1]
+            scale, shift = self.bn_eval_affine(p, C)
             mean = invstd = None
         ops.bn_apply(xv.t, C, scale, shift, out, res=res.t if res is not None else None, relu=relu)
         yv = Var(out, C, relu=relu, gP=min(self.bpt, self.pg))
@@ -461,17 +488,13 @@ class Engine:
     # ---- the network ------------------------------------------------------------------------------
     def bottleneck(self, xv, p, N, H, W, inplanes, planes, stride, has_ds, out=None):
         # (every conv here feeds a BatchNorm directly: bn_stats -- one shared partial buffer, so each conv is followed by ITS bn)
-        a, _, _ = self.conv(xv, self.spec(p + ".conv1", inplanes, planes, 1, bias=False), N, H, W, False, bn_stats=True)
-        a = self.bn(a, p + ".bn1", True)
-        b, OH, OW = self.conv(a, self.spec(p + ".conv2", planes, planes, 3, stride, 1, bias=False), N, H, W, False, bn_stats=True)
-        b = self.bn(b, p + ".bn2", True)
+        a, _, _ = self.conv_bn(xv, self.spec(p + ".conv1", inplanes, planes, 1, bias=False), p + ".bn1", N, H, W, True)
+        b, OH, OW = self.conv_bn(a, self.spec(p + ".conv2", planes, planes, 3, stride, 1, bias=False), p + ".bn2", N, H, W, True)
         if has_ds:
-            d, _, _ = self.conv(xv, self.spec(p + ".downsample.0", inplanes, planes * 4, 1, stride, 0, bias=False), N, H, W, False, bn_stats=True)
-            idt = self.bn(d, p + ".downsample.1", False)
-        c, _, _ = self.conv(b, self.spec(p + ".conv3", planes, planes * 4, 1, bias=False), N, OH, OW, False, bn_stats=True)
-        if not has_ds:
+            idt, _, _ = self.conv_bn(xv, self.spec(p + ".downsample.0", inplanes, planes * 4, 1, stride, 0, bias=False), p + ".downsample.1", N, H, W, False)
+        else:
             idt = xv
-        y = self.bn(c, p + ".bn3", True, res=idt, out=out)
+        y, _, _ = self.conv_bn(b, self.spec(p + ".conv3", planes, planes * 4, 1, bias=False), p + ".bn3", N, OH, OW, True, res=idt, out=out)
         return y, OH, OW
 
     def forward_dec(self, img, record):
@@ -503,9 +526,9 @@ class Engine:
         c0a, _, _ = self.conv(x8, self.spec("c0_conv.0", 3, 64, 3, 1, 1, P=pd), N, H, W, True)
         c0, _, _ = self.conv(c0a, self.spec("c0_conv.2", 64, 64, 3, 1, 1, P=pd), N, H, W, True, out=cat0.cols(64, 128))
         # stem (KGnet.py:278-282)
-        s1, H1, W1 = self.conv(x8, self.spec("conv1", 3, 64, 7, 2, 3, bias=False), N, H, W, False)
+        H1, W1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         cat1 = ops.alloc_pt(N * H1 * W1, 128, pt, dev, dtype=self.dt)
-        c1 = self.bn(s1, "bn1", True, out=cat1.cols(64, 128))
+        c1, _, _ = self.conv_bn(x8, self.spec("conv1", 3, 64, 7, 2, 3, bias=False), "bn1", N, H, W, True, out=cat1.cols(64, 128), bn_stats=False)
         f, Hc, Wc = self.maxpool(c1, N, H1, W1)
         dims.append((H1, W1))
         feats = [c0, c1]

@@ -100,24 +100,26 @@ def nplanes(x):
 
 class _Planes(_lib.ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("a_planes", "a_pstride", "b_planes", "b_pstride", "c_planes", "c_pstride",
-                                     "y_planes", "y_pstride", "w_planes", "reserved_")] + [("scale", _lib.c_void_p)]
+                                     "y_planes", "y_pstride", "w_planes", "reserved_")] + [("scale", _lib.c_void_p), ("oscale", _lib.c_void_p)]
 
 
 _PL_CACHE = {}
 
 
-def pl(a=None, b=None, c=None, y=None, w=1, scale=None):
+def pl(a=None, b=None, c=None, y=None, w=1, scale=None, oscale=None):
     """kg_planes_t* for a call (None when every operand is single-plane and there is no scale).  a / b / c / y: rows operands
-    (tensor, PT or None); scale: device fp32 scalar the fp32 -> rows conversions multiply by (kg_grad_scale)."""
+    (tensor, PT or None); scale: device fp32 scalar the fp32 -> rows conversions multiply by (kg_grad_scale); oscale: device fp32
+    [Cout] factor of a forward conv's accumulator (folded inference BatchNorm)."""
     sp = scale.data_ptr() if scale is not None else 0
-    key = nplanes(a) + nplanes(b) + nplanes(c) + nplanes(y) + (w, 0, sp)
-    if key == (1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 0):
+    op = oscale.data_ptr() if oscale is not None else 0
+    key = nplanes(a) + nplanes(b) + nplanes(c) + nplanes(y) + (w, 0, sp, op)
+    if key == (1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 0, 0):
         return None
     st = _PL_CACHE.get(key)
     if st is None:
         if len(_PL_CACHE) > 4096:
             _PL_CACHE.clear()
-        st = _lib.ctypes.pointer(_Planes(*key[:10], sp or None))
+        st = _lib.ctypes.pointer(_Planes(*key[:10], sp or None, op or None))
         _PL_CACHE[key] = st
     return st
 
@@ -271,7 +273,7 @@ def conv_halo_heads2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C, kp_sigmoid=Tru
 
 
 def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, mode=0,
-               rowdesc=None, tile=0):
+               rowdesc=None, tile=0, oscale=None):
     """geom = (M, H, W, OH, OW, KH, KW, stride, pad): H, W = gathered tensor's dims, OH, OW = output dims."""
     flush_packs()
     M, H, W, OH, OW, KH, KW, stride, pad = geom
@@ -283,7 +285,7 @@ def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=
     _lib.call("kg_conv2d_igemm", ptr(_rows(x)), ptr(pw.buf), ptr(bias), ptr(base(y)), ptr(y_f32), ptr(base(res)), ptr(base(mask)), ptr(rowdesc),
               M, H, W, OH, OW, pw.cin_pad, ld(x), cout, ld(y) if y is not None else 0,
               ld(res) if res is not None else 0, ld(mask) if mask is not None else 0, pw.K, KH, KW, stride, pad, 1,
-              mode, 1 if relu else 0, f32_C, tile, pl(a=x, b=res, y=y, w=pw.wP), stream_ptr(), fmt=fmt_of(x))
+              mode, 1 if relu else 0, f32_C, tile, pl(a=x, b=res, y=y, w=pw.wP, oscale=oscale), stream_ptr(), fmt=fmt_of(x))
 
 
 USE_HALO = True
@@ -296,14 +298,14 @@ HALO_WC = int(__import__("os").environ.get("KG_HALO_WC", "0"))   # tuning overri
 
 
 def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, flip=False, wc=0,
-              tiletab=None, total_rows=0, k1skip=False, algo_cin=None, tiletab16=None):
+              tiletab=None, total_rows=0, k1skip=False, algo_cin=None, tiletab16=None, oscale=None):
     """Stride-1 "same" KSxKS conv (or its input gradient when flip) with the input halo resident in LDS.
     tiletab (int32 [ntiles,4] device tensor): ragged boxes instead of N images of HxW.
     k1skip (7x7 only): the packed weights are zero for channels 32..63 of every 64-channel chunk.
     algo_cin: number of input channels that carry data (FLOP accounting of bench.py's timer; unused here)."""
     flush_packs()
     assert nplanes(x)[0] == pw.xP, (nplanes(x), pw.xP)
-    planes = pl(a=x, b=res, y=y, w=pw.wP)
+    planes = pl(a=x, b=res, y=y, w=pw.wP, oscale=oscale)      # (oscale: folded inference BatchNorm, y = act(acc * oscale + bias + res))
     x, y, res, mask = base(x), base(y), base(res), base(mask)
     if (USE_C3 and planes is None and KS == 3 and pw.cin_pad == 64 and y is not None and y_f32 is None and wc == 0 and HALO_WC == 0
             and (tiletab is None or tiletab16 is not None)):
@@ -349,18 +351,18 @@ def can_1x1(x, pw, KH, stride, pad, y, y_f32, res=None):
             and 64 <= pw.cin_pad <= 1024 and x.shape[1] >= pw.cin_pad and y.shape[0] == x.shape[0])
 
 
-def conv_auto(x, pw, cout, geom, N, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, transposed=False, tile=0):
+def conv_auto(x, pw, cout, geom, N, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, transposed=False, tile=0, oscale=None):
     """Dense conv forward (transposed=False) or input gradient (True): picks the LDS-halo kernel for stride-1
     "same" 3x3/7x7 convs over 64-channel-aligned inputs, else the gather implicit GEMM."""
     M, H, W, OH, OW, KH, KW, stride, pad = geom
     if (USE_HALO and stride == 1 and KH == KW and KH in (3, 7) and pad == KH // 2 and pw.cin_pad % 64 == 0
             and x.shape[1] >= pw.cin_pad and not (y_f32 is not None and (res is not None or mask is not None))):
-        conv_halo(x, pw, cout, N, OH, OW, KH, y=y, y_f32=y_f32, bias=bias, res=res, mask=mask, relu=relu, flip=transposed)
+        conv_halo(x, pw, cout, N, OH, OW, KH, y=y, y_f32=y_f32, bias=bias, res=res, mask=mask, relu=relu, flip=transposed, oscale=oscale)
         return "halo"
-    if KH == KW and can_1x1(x, pw, KH, stride, pad, y, y_f32, res):
+    if KH == KW and oscale is None and can_1x1(x, pw, KH, stride, pad, y, y_f32, res):
         conv1x1(x, pw, cout, y, bias=bias, res=res, mask=mask, relu=relu)
         return "1x1"
-    conv_igemm(x, pw, cout, geom, y=y, y_f32=y_f32, bias=bias, res=res, mask=mask, relu=relu, mode=1 if transposed else 0, tile=tile)
+    conv_igemm(x, pw, cout, geom, y=y, y_f32=y_f32, bias=bias, res=res, mask=mask, relu=relu, mode=1 if transposed else 0, tile=tile, oscale=oscale)
     return "igemm"
 
 

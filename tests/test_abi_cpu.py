@@ -302,6 +302,6 @@ def test_half_build_loads_and_exports_the_rows_entry_points(lib):
     assert not missing, missing
     assert not hasattr(half, "kg_postproc_scale") and not hasattr(half, "kg_adam_step")
     # kg_planes_t: 10 ints + a device pointer (header, csrc/kg_common.h and the ctypes mirror agree on the layout)
-    assert ctypes.sizeof(ops._Planes) == 48 and ops._Planes.scale.offset == 40
+    assert ctypes.sizeof(ops._Planes) == 56 and ops._Planes.scale.offset == 40 and ops._Planes.oscale.offset == 48
     hdr = open(os.path.join(ROOT, "include", "kgnet_hip.h")).read()
     assert "int reserved_;" in hdr and "const float* scale;" in hdr

@@ -161,6 +161,54 @@ def test_conv_forward_dgrad_wgrad_planes(case, P, dt):
     check(f"bias grad P={P} {case}", db, dyu.double().sum((0, 2, 3)), TOL[P] * 2)
 
 
+FOLDED_BN_CASES = [
+    # cin, cout, k, stride, pad, N, H, W, relu, res     (route)
+    (64, 256, 1, 1, 0, 2, 16, 16, True, True),       # bottleneck conv3 + bn3 + identity + relu -> conv_gather
+    (128, 64, 1, 1, 0, 2, 16, 16, True, False),      # conv1 + bn1 + relu -> conv_gather (64 couts)
+    (64, 64, 3, 1, 1, 2, 20, 28, True, False),       # conv2 + bn2 + relu -> conv_halo<3>
+    (128, 128, 3, 2, 1, 2, 18, 22, True, False),     # strided conv2 -> conv_gather
+    (256, 512, 1, 2, 0, 1, 16, 24, False, False),    # downsample.0 + downsample.1 (no relu)
+    (3, 64, 7, 2, 3, 2, 32, 40, True, False),        # stem conv1 + bn1 + relu -> conv_small
+    (40, 24, 3, 1, 1, 1, 12, 12, True, True),        # odd channel counts -> the generic conv_igemm tiles
+]
+
+
+@pytest.mark.parametrize("P,dt", VARIANTS, ids=VIDS)
+@pytest.mark.parametrize("case", FOLDED_BN_CASES)
+def test_conv_with_folded_inference_batchnorm(case, P, dt):
+    """kg_planes_t.oscale: conv -> inference BatchNorm (-> + res) (-> ReLU) of KGnet.py:82-97 as ONE launch, y = act(acc * scale + shift + res)
+    on the fp32 accumulators -- against float64 conv2d + batch_norm(training=False) on the same fp32 inputs."""
+    DT[0] = dt
+    cin, cout, k, stride, pad, N, H, W, relu, use_res = case
+    g = torch.Generator().manual_seed(abs(hash(case)) % 1000 + 7 * P)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    rm, rv = torch.randn(cout, generator=g) * 0.3, torch.rand(cout, generator=g) * 2 + 0.05
+    gamma[0] = 0.0                                                       # a dead channel: scale 0, output = shift
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(N, cout, OH, OW, generator=g) if use_res else None
+    ref = F.batch_norm(F.conv2d(x.double(), w.double(), None, stride, pad), rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.0, 1e-5)
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    cin_pad = ops.round_up(cin, 8)
+    xr = rows_f32(x)
+    if cin_pad != cin:
+        xr = torch.cat([xr, torch.zeros(xr.shape[0], cin_pad - cin)], 1)
+    xp = to_pt(xr.to(DEV), P, ctot=cin_pad + 16, c0=8)
+    pw = PackedWeight(cout, k * k, cin_pad, DEV, xP=P, wP=P)
+    pw.pack(w.to(DEV))
+    scale, shift = ops.bn_scale_shift_eval(cout, gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV))
+    y = alloc_pt(N * OH * OW, cout, P, DEV)
+    rp = to_pt(rows_f32(res).to(DEV), P) if use_res else None
+    geom = (N * OH * OW, H, W, OH, OW, k, k, stride, pad)
+    route = ops.conv_auto(xp, pw, cout, geom, N, y=y, bias=shift, oscale=scale, res=rp, relu=relu)
+    torch.cuda.synchronize()
+    check(f"conv+bn {route} P={P} {case}", nchw(from_pt(y), N, OH, OW), ref, TOL[P])
+
+
 @pytest.mark.parametrize("P", [2, 3])
 def test_mixed_plane_counts(P):
     DT[0] = BF16
