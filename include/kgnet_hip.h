@@ -58,7 +58,9 @@ int kg_f64_probe(const double* a, const double* b, double* out5n, int n, void* s
  * mode 0: dense forward (H,W = input dims, OH,OW = output dims); mode 1: dense transposed = gradient w.r.t.
  * the input of a forward conv (H,W = dY dims, OH,OW = dX dims, weights packed transposed);
  * mode 2/3: the same on a ragged pixel list with per-row descriptors {(y<<16)|x, (h<<16)|w}.
- * y (bf16 rows) and/or y_f32 (fp32 NCHW [N][f32_C][OH*OW]) receive the result.  tile 0 = auto. */
+ * y (bf16 rows) and/or y_f32 (fp32 NCHW [N][f32_C][OH*OW]) receive the result.  tile 0 = auto; 1..5 pin an output tile; 6 = split-K over the
+ * waves of a 64-pixel x 64-cout tile for launches with too few output tiles to fill the chip (single-image inference: cin_pad % 64 == 0,
+ * dense modes, rows output). */
 int kg_conv2d_igemm(const void* x, const void* w, const float* bias, void* y, float* y_f32, const void* res,
                     const void* mask, const int* rowdesc, int M, int H, int W, int OH, int OW, int cin_pad, int ldx,
                     int Cout, int ldy, int ldres, int ldmask, int K, int KH, int KW, int stride, int pad, int dil,

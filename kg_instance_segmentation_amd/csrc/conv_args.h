@@ -117,5 +117,7 @@ __device__ __forceinline__ EpiArgs kg_epi(const ConvArgs& a) {
 
 // conv_gather.hip: the deep-prefetch variant for cin_pad % 64 == 0 and bf16 row outputs
 int kg_launch_conv_gather(const ConvArgs& a, int cin_pad, hipStream_t st);
+// conv_tiny.hip: split-K variant for launches with too few output tiles (tile = 6: cin_pad % 64 == 0, dense modes, rows output)
+int kg_launch_conv_tiny(const ConvArgs& a, int cin_virt, hipStream_t st);
 // conv_small.hip: direct VALU kernel for cin_pad == 8 (image / single-channel inputs)
 int kg_launch_conv_small(const ConvArgs& a, hipStream_t st);

@@ -262,6 +262,11 @@ extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, 
     a.stride_log2 = stride == 2 ? 1 : 0; a.pad = pad; a.dil = dil; a.mode = mode; a.relu = relu; a.f32_C = f32_C;
     KG_CHECK_ARG(magic_for(a.cpt, K / 8, &a.cpt_magic), "kg_conv2d_igemm: no exact magic divisor for cpt=%d", a.cpt);
     hipStream_t st = (hipStream_t)stream;
+    if (tile == 6) {   // split-K over the waves of a 64 x 64 tile: launches whose output offers too few tiles to fill the chip (conv_tiny.hip)
+        KG_CHECK_ARG(cin_pad % 64 == 0 && y && !y_f32 && mode <= 1 && dil == 1, "kg_conv2d_igemm: tile 6 needs cin_pad %% 64 == 0, a rows output and a dense mode");
+        a.km = kg_make_kmap(cin_pad, 64, pp.a_planes, pp.a_pstride, pp.w_planes);
+        return kg_launch_conv_tiny(a, cin_virt, st);
+    }
     static const int use_gather2 = getenv("KG_GATHER2") ? atoi(getenv("KG_GATHER2")) : 2;   // 2: also 64-cout 3x3 convs (half the cout tile idle, still 2x the 64 x 256 tile)
     if (use_gather2 && tile == 0 && cin_pad % 64 == 0 && y && !y_f32 && (Cout > 64 || (use_gather2 >= 2 && Cout == 64 && (KH * KW > 1 || vplanes > 1))) && dil == 1) {
         a.km = kg_make_kmap(cin_pad, 64, pp.a_planes, pp.a_pstride, pp.w_planes);
@@ -273,7 +278,7 @@ extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, 
     if (use_small && tile == 0 && cin_pad == 8 && (vplanes == 1 || K >= 32 * vplanes * ((KH * KW + 3) / 4)) && KH * KW <= use_small * 9 && y && !y_f32 && Cout % 8 == 0 && ldy % 8 == 0 && al16(y) &&
         (!res || (ldres % 8 == 0 && al16(res))) && (!mask || (ldmask % 8 == 0 && al16(mask))) && dil == 1)
         return kg_launch_conv_small(a, st);   // <= 8 input channels: direct VALU kernel (conv_small.hip)
-    // tile: 0 auto; 1 = 16 couts x 256 px; 2 = 32 x 256; 3 = 64 x 256; 4 = 128 x 128; 5 = 64 x 128
+    // tile: 0 auto; 1 = 16 couts x 256 px; 2 = 32 x 256; 3 = 64 x 256; 4 = 128 x 128; 5 = 64 x 128; (6 = split-K 64 x 64, above)
     if (tile == 0) tile = Cout <= 16 ? 1 : (Cout <= 32 ? 2 : (Cout <= 64 ? 3 : 4));
     switch (tile) {
         case 1: return launch_cfg<1, 4, 1, 2>(a, st);

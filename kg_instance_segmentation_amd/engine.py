@@ -324,7 +324,7 @@ class Engine:
                 assert not s.has_bias
                 ops.conv_auto(xin, s.pw, s.cout, geom, N, y=out, bias=affine[1], oscale=affine[0], res=res.t if res is not None else None, relu=relu, tile=tile)
             else:
-                ops.conv_auto(xin, s.pw, s.cout, geom, N, y=out, y_f32=y_f32, bias=s.bias_cat if s.has_bias else None, relu=relu, tile=tile)
+                ops.conv_auto(xin, s.pw, s.cout, geom, N, y=out, y_f32=y_f32, bias=s.bias_cat if s.has_bias else None, relu=relu, tile=tile, tiny=not arm)
         finally:
             if arm:          # (always disarm: an exception in the launch must not leave the side channel armed for the next conv)
                 nb = ops.conv_stats_end(self.fmt)

@@ -351,10 +351,27 @@ def can_1x1(x, pw, KH, stride, pad, y, y_f32, res=None):
             and 64 <= pw.cin_pad <= 1024 and x.shape[1] >= pw.cin_pad and y.shape[0] == x.shape[0])
 
 
-def conv_auto(x, pw, cout, geom, N, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, transposed=False, tile=0, oscale=None):
+CONV_TINY_WGS = int(__import__("os").environ.get("KG_CONV_TINY_WGS", "96"))     # 0 = never
+CONV_TINY_TILES = int(__import__("os").environ.get("KG_CONV_TINY_TILES", "384"))
+
+
+def conv_auto(x, pw, cout, geom, N, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, transposed=False, tile=0, oscale=None,
+              tiny=True):
     """Dense conv forward (transposed=False) or input gradient (True): picks the LDS-halo kernel for stride-1
-    "same" 3x3/7x7 convs over 64-channel-aligned inputs, else the gather implicit GEMM."""
+    "same" 3x3/7x7 convs over 64-channel-aligned inputs, else the gather implicit GEMM.  tiny: launches whose output gives the
+    regular kernels fewer than CONV_TINY_WGS workgroups (single-image inference, the deepest layers of a small batch) may go to
+    the split-K kernel (conv_tiny.hip); False for a conv that is armed for BatchNorm statistics (that epilogue lives in the regular kernels)."""
     M, H, W, OH, OW, KH, KW, stride, pad = geom
+    halo_ok = (USE_HALO and stride == 1 and KH == KW and KH in (3, 7) and pad == KH // 2 and pw.cin_pad % 64 == 0
+               and x.shape[1] >= pw.cin_pad and not (y_f32 is not None and (res is not None or mask is not None)))
+    if tiny and tile == 0 and CONV_TINY_WGS and y is not None and y_f32 is None and pw.cin_pad % 64 == 0 and x.shape[1] >= pw.cin_pad and KH * KW <= 9:
+        wgs = (N * math.ceil(OH / 16) * math.ceil(OW / 32) * math.ceil(cout / 64)) if halo_ok else math.ceil(M / 256) * math.ceil(cout / 128)
+        tiles = math.ceil(M / 64) * math.ceil(cout / 64)
+        # (no operand reuse inside a 64 x 64 tile: measured 1.75 ns per (tile, K unit) against 0.85 us per K unit of a regular workgroup
+        # -- past ~400 tiles the regular kernel's single round is as fast)
+        if wgs < CONV_TINY_WGS and wgs < tiles <= CONV_TINY_TILES:
+            conv_igemm(x, pw, cout, geom, y=y, bias=bias, res=res, mask=mask, relu=relu, mode=1 if transposed else 0, tile=6, oscale=oscale)
+            return "tiny"
     if (USE_HALO and stride == 1 and KH == KW and KH in (3, 7) and pad == KH // 2 and pw.cin_pad % 64 == 0
             and x.shape[1] >= pw.cin_pad and not (y_f32 is not None and (res is not None or mask is not None))):
         conv_halo(x, pw, cout, N, OH, OW, KH, y=y, y_f32=y_f32, bias=bias, res=res, mask=mask, relu=relu, flip=transposed, oscale=oscale)

@@ -365,7 +365,7 @@ def test_conv_halo_forward_and_dgrad(case):
     pw = PackedWeight(cout, k * k, cin, DEV); pw.pack(w.to(DEV))
     geom = (N * H * W, H, W, H, W, k, k, 1, pad)
     y = torch.empty(N * H * W, cout, dtype=BF16, device=DEV)
-    kind = ops.conv_auto(xr, pw, cout, geom, N, y=y, bias=b.to(DEV) if bias else None, relu=relu)
+    kind = ops.conv_auto(xr, pw, cout, geom, N, y=y, bias=b.to(DEV) if bias else None, relu=relu, tiny=False)
     assert kind == "halo"
     report(f"halo_fwd{case}", nchw_of(y.cpu(), N, H, W), ref, atol=2e-2, rtol=1e-2)
     yf = torch.empty(N, cout, H, W, dtype=torch.float32, device=DEV)
@@ -375,7 +375,7 @@ def test_conv_halo_forward_and_dgrad(case):
         pwT = PackedWeight(cin, k * k, cout, DEV); pwT.pack(w.to(DEV), transposed=True)
         dx = torch.empty(N * H * W, cin, dtype=BF16, device=DEV)
         msk = bfr(torch.randn(N, cin, H, W, generator=g))
-        kind = ops.conv_auto(rows_of(dy).to(DEV), pwT, cin, geom, N, y=dx, mask=rows_of(msk).to(DEV), transposed=True)
+        kind = ops.conv_auto(rows_of(dy).to(DEV), pwT, cin, geom, N, y=dx, mask=rows_of(msk).to(DEV), transposed=True, tiny=False)
         assert kind == "halo"
         report(f"halo_dgrad{case}", nchw_of(dx.cpu(), N, H, W), x.grad * (msk > 0), atol=2e-2, rtol=1e-2)
 
@@ -504,7 +504,7 @@ def test_conv_epilogue_bn_statistics(case):
     geom = (M, H, W, OH, OW, k, k, stride, k // 2)
     gamma = (torch.rand(cout, generator=g) + 0.5).to(DEV); beta = torch.randn(cout, generator=g).to(DEV)
     part = ops.conv_stats_begin(torch.device(DEV))
-    kind = ops.conv_auto(rows_of(x).to(DEV), pw, cout, geom, N, y=y)
+    kind = ops.conv_auto(rows_of(x).to(DEV), pw, cout, geom, N, y=y, tiny=False)      # (armed: the regular kernels, as Engine.conv does)
     nb = ops.conv_stats_end()
     if kind == "1x1":        # the streaming 1x1 kernels (single-plane operands, K <= 128 or Cout <= 64) have no statistics epilogue:
         assert nb == 0      # the channel reports it and the caller runs the two-pass kg_bn_stats_train
@@ -523,7 +523,7 @@ def test_conv_epilogue_bn_statistics(case):
     report(f"bnstats{case}.mean_vs_two_pass", mean.cpu(), mean2.cpu(), atol=2e-3, rtol=1e-2)      # (the two-pass version sees bf16-rounded rows)
     report(f"bnstats{case}.invstd_vs_two_pass", invstd.cpu(), invstd2.cpu(), atol=1e-3, rtol=1e-2)
     # disarmed again: a second conv leaves the buffer alone
-    ops.conv_auto(rows_of(x).to(DEV), pw, cout, geom, N, y=y)
+    ops.conv_auto(rows_of(x).to(DEV), pw, cout, geom, N, y=y, tiny=False)
     assert ops.conv_stats_end() == 0
 
 

@@ -109,6 +109,9 @@ PLANE_CONV_CASES = [
     (256, 512, 1, 2, 0, 1, 16, 24, False, False),    # strided 1x1
     (3, 64, 7, 2, 3, 2, 32, 40, False, False),       # image input -> conv_igemm
     (3, 64, 3, 1, 1, 1, 24, 24, True, True),
+    (256, 256, 3, 1, 1, 1, 10, 14, True, True),      # few output tiles -> conv_tiny (split-K over the waves of a 64 x 64 tile)
+    (512, 128, 1, 1, 0, 1, 9, 11, False, True),      # 1x1 -> conv_tiny
+    (128, 192, 3, 2, 1, 1, 17, 13, True, False),     # strided 3x3 -> conv_tiny (forward + stride-2 input gradient)
 ]
 
 
@@ -137,20 +140,23 @@ def test_conv_forward_dgrad_wgrad_planes(case, P, dt):
     pw.pack(w.to(DEV))
     y = alloc_pt(N * OH * OW, cout, P, DEV)
     geom = (N * OH * OW, H, W, OH, OW, k, k, stride, pad)
-    route = ops.conv_auto(xp, pw, cout, geom, N, y=y, bias=b.to(DEV) if bias else None, relu=relu)
-    torch.cuda.synchronize()
-    check(f"fwd {route} P={P} {case}", nchw(from_pt(y), N, OH, OW), ref, TOL[P])
+    for tiny in (False, True):          # the regular kernel of the shape, then (small problems) the split-K kernel conv_auto prefers
+        y.t.zero_()
+        route = ops.conv_auto(xp, pw, cout, geom, N, y=y, bias=b.to(DEV) if bias else None, relu=relu, tiny=tiny)
+        torch.cuda.synchronize()
+        check(f"fwd {route} P={P} {case}", nchw(from_pt(y), N, OH, OW), ref, TOL[P])
     # input gradient (with the residual operand accumulating onto an existing gradient)
     if cin >= 8:
         pwT = PackedWeight(cin, k * k, ops.round_up(cout, 8), DEV, xP=P, wP=P)
         pwT.pack(w.to(DEV), transposed=True)
         gp = to_pt(rows_f32(dyu.float()).to(DEV), P)
         prev = torch.randn(N * H * W, cin, generator=g)
-        dx = to_pt(prev.to(DEV), P)
         gin = (N * H * W, OH, OW, H, W, k, k, stride, pad)
-        ops.conv_auto(gp, pwT, cin, gin, N, y=dx, res=dx, transposed=True)
-        torch.cuda.synchronize()
-        check(f"dgrad P={P} {case}", nchw(from_pt(dx), N, H, W), xd.grad + nchw(prev.double(), N, H, W), TOL[P])
+        for tiny in (False, True):
+            dx = to_pt(prev.to(DEV), P)
+            route = ops.conv_auto(gp, pwT, cin, gin, N, y=dx, res=dx, transposed=True, tiny=tiny)
+            torch.cuda.synchronize()
+            check(f"dgrad {route} P={P} {case}", nchw(from_pt(dx), N, H, W), xd.grad + nchw(prev.double(), N, H, W), TOL[P])
     # weight / bias gradient
     gw = torch.empty(cout, cin, k, k, device=DEV)
     db = torch.empty(cout, device=DEV)
@@ -170,6 +176,9 @@ FOLDED_BN_CASES = [
     (256, 512, 1, 2, 0, 1, 16, 24, False, False),    # downsample.0 + downsample.1 (no relu)
     (3, 64, 7, 2, 3, 2, 32, 40, True, False),        # stem conv1 + bn1 + relu -> conv_small
     (40, 24, 3, 1, 1, 1, 12, 12, True, True),        # odd channel counts -> the generic conv_igemm tiles
+    (256, 256, 3, 1, 1, 1, 32, 32, True, False),     # layer3 conv2 of one 512 x 512 image -> conv_tiny
+    (1024, 256, 1, 1, 0, 1, 32, 32, True, False),    # layer3 conv1 -> conv_tiny
+    (256, 1024, 1, 1, 0, 1, 32, 32, True, True),     # layer3 conv3 + identity -> conv_tiny
 ]
 
 
@@ -204,9 +213,11 @@ def test_conv_with_folded_inference_batchnorm(case, P, dt):
     y = alloc_pt(N * OH * OW, cout, P, DEV)
     rp = to_pt(rows_f32(res).to(DEV), P) if use_res else None
     geom = (N * OH * OW, H, W, OH, OW, k, k, stride, pad)
-    route = ops.conv_auto(xp, pw, cout, geom, N, y=y, bias=shift, oscale=scale, res=rp, relu=relu)
-    torch.cuda.synchronize()
-    check(f"conv+bn {route} P={P} {case}", nchw(from_pt(y), N, OH, OW), ref, TOL[P])
+    for tiny in (False, True):
+        y.t.zero_()
+        route = ops.conv_auto(xp, pw, cout, geom, N, y=y, bias=shift, oscale=scale, res=rp, relu=relu, tiny=tiny)
+        torch.cuda.synchronize()
+        check(f"conv+bn {route} P={P} {case}", nchw(from_pt(y), N, OH, OW), ref, TOL[P])
 
 
 @pytest.mark.parametrize("P", [2, 3])
