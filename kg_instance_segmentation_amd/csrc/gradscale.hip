@@ -17,7 +17,7 @@ struct GradScaleArgs {
 };
 
 // scratch: 2 unsigned, zero on entry (allocated zeroed once; the last workgroup leaves them zero again).  out[0] = S, out[1] = 1 / S.
-__global__ __launch_bounds__(256) void grad_scale_kernel(GradScaleArgs a, unsigned* scratch, float* out) {
+__global__ __launch_bounds__(1024) void grad_scale_kernel(GradScaleArgs a, unsigned* scratch, float* out) {
     unsigned best = 0;
     for (int t = 0; t < a.count; ++t) {
         const float* p = a.p[t];
@@ -30,30 +30,32 @@ __global__ __launch_bounds__(256) void grad_scale_kernel(GradScaleArgs a, unsign
         };
         const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(q)) & 15) == 0;
         const long n4 = vec ? n >> 2 : 0;
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {   // 16-byte loads: the pass is HBM-bound
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {   // 16-byte loads: the pass is HBM-bound
             const f32x4 v = reinterpret_cast<const f32x4*>(p)[i];
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
             if (q) s = reinterpret_cast<const f32x4*>(q)[i];
             take(v[0], s[0], q != nullptr); take(v[1], s[1], q != nullptr); take(v[2], s[2], q != nullptr); take(v[3], s[3], q != nullptr);
         }
-        for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) take(p[i], q ? q[i] : 0.f, q != nullptr);
+        for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) take(p[i], q ? q[i] : 0.f, q != nullptr);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned q = __shfl_xor(best, o, 64); best = q > best ? q : best; }
-    __shared__ unsigned wmax[4];
+    __shared__ unsigned wmax[16];
     __shared__ bool last;
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned m = wmax[0];
-        for (int w = 1; w < 4; ++w) m = wmax[w] > m ? wmax[w] : m;
-        atomicMax(&scratch[0], m);                                         // (max of bit patterns: order-independent, reproducible)
-        __threadfence();
-        last = atomicAdd(&scratch[1], 1u) == gridDim.x - 1;
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = wmax[w] > m ? wmax[w] : m;
+        // (max of bit patterns: order-independent, reproducible.)  Device-scope atomics only, so no fence (a release fence writes the XCD's
+        // L2 back: norm_pool.hip rows_absmax_kernel); the ticket is taken after the max has returned (data dependence through `one`)
+        unsigned one = 1u;
+        const unsigned old = atomicMax(&scratch[0], m);
+        asm volatile("" : "+v"(one) : "v"(old));
+        last = atomicAdd(&scratch[1], one) == gridDim.x - 1;
     }
     __syncthreads();
     if (last && threadIdx.x == 0) {
-        __threadfence();
         const unsigned m = atomicMax(&scratch[0], 0u);
         float S = 1.f;
         if (m != 0 && m < 0x7f800000u) {
@@ -64,8 +66,7 @@ __global__ __launch_bounds__(256) void grad_scale_kernel(GradScaleArgs a, unsign
             S = ldexpf(1.f, k);
         }
         out[0] = S; out[1] = 1.f / S;
-        scratch[0] = 0; scratch[1] = 0;
-        __threadfence();
+        atomicExch(&scratch[0], 0u); atomicExch(&scratch[1], 0u);
     }
 }
 
@@ -84,9 +85,9 @@ extern "C" int kg_grad_scale(const void* const* ptrs, const void* const* probs, 
         a.n[i] = i < n ? counts[i] : 0; total += a.n[i];
     }
     for (int i = 0; i < n; ++i) KG_CHECK_ARG(a.p[i] && a.n[i] >= 0, "kg_grad_scale: null tensor");
-    int blocks = (int)((total + 256 * 16 - 1) / (256 * 16));
-    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-    hipLaunchKernelGGL(grad_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, (unsigned*)scratch, out);
+    int blocks = (int)((total + 1024 * 16 - 1) / (1024 * 16));
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);      // (few, fat workgroups: same-address atomics serialise, rows_absmax_kernel)
+    hipLaunchKernelGGL(grad_scale_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, a, (unsigned*)scratch, out);
     KG_CHECK_LAUNCH("grad_scale");
     return KG_OK;
 }

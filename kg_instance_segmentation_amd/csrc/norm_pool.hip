@@ -560,33 +560,58 @@ extern "C" int kg_add_rows(const void* a, int lda, const void* b, int ldb, const
 // one device scalar per tensor).  A gradient tensor that was written under an earlier (larger) scale -- contributions waiting on
 // tensors further upstream -- is converted when it is next combined or consumed: *= scale_now * (1 / scale_then) <= 1
 // (kg_rows_scale with two device scalars).  All factors are powers of two: exact.  No host round trip.
-__global__ __launch_bounds__(256) void rows_absmax_kernel(const RowsR g, long M, int C8, int target_log2, const float* __restrict__ cum_in,
+__global__ __launch_bounds__(1024) void rows_absmax_kernel(const RowsR g, long M, int C8, int target_log2, const float* __restrict__ cum_in,
                                                           float* __restrict__ cum_out, float* __restrict__ r_out, unsigned* scratch) {
     const long total = M * C8;
     unsigned best = 0;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / C8; const int c = (int)(i - r * C8) * 8;
-        float v[8];
-        rd8(g, r, c, v);
+    // (row, chunk) advance by a constant stride: no division inside the loop; 4 independent 16-byte loads per plane in flight per thread
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long dr = stride / C8; const int dc = (int)(stride - dr * C8);
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    long r = i / C8; int c = (int)(i - r * C8);
+    while (i < total) {
+        float v[4][8];
+        long rr[4]; int cc[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const unsigned b = __float_as_uint(v[e]) & 0x7fffffffu; best = b > best ? b : best; }
+        for (int u = 0; u < 4; ++u) {
+            rr[u] = r; cc[u] = c;
+            r += dr; c += dc;
+            if (c >= C8) { c -= C8; ++r; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + u * stride < total) rd8(g, rr[u], cc[u] * 8, v[u]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const unsigned b = __float_as_uint(v[u][e]) & 0x7fffffffu; best = b > best ? b : best; }
+        i += 4 * stride;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned q = __shfl_xor(best, o, 64); best = q > best ? q : best; }
-    __shared__ unsigned wmax[4];
+    __shared__ unsigned wmax[16];
     __shared__ bool last;
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned m = wmax[0];
-        for (int w = 1; w < 4; ++w) m = wmax[w] > m ? wmax[w] : m;
-        atomicMax(&scratch[0], m);
-        __threadfence();
-        last = atomicAdd(&scratch[1], 1u) == gridDim.x - 1;
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = wmax[w] > m ? wmax[w] : m;
+        // (few, fat workgroups: the two same-address device-scope atomics per workgroup serialise at the memory side, ~13 ns each -- 2048
+        // workgroups spent 54 us there for 8 us of reading.)  The two values travel through device-scope atomics only, so no fence: a device-scope release fence writes this XCD's whole L2 back
+        // (measured in conv_tiny.hip: tens of microseconds per workgroup behind a kernel that left its output dirty in L2).  The ticket
+        // is taken only after the max has RETURNED (data dependence through `one`): the last ticket holder sees every workgroup's max.
+        unsigned one = 1u;
+        const unsigned old = atomicMax(&scratch[0], m);
+        asm volatile("" : "+v"(one) : "v"(old));
+        last = atomicAdd(&scratch[1], one) == gridDim.x - 1;
     }
     __syncthreads();
     if (last && threadIdx.x == 0) {
-        __threadfence();
         const unsigned m = atomicMax(&scratch[0], 0u);
         float r = 1.f;
         if (m != 0 && m < 0x7f800000u) {      // (an all-zero or already overflowed tensor is left as it is)
@@ -598,8 +623,7 @@ __global__ __launch_bounds__(256) void rows_absmax_kernel(const RowsR g, long M,
         }
         const float c = cum_in[0] * r;
         r_out[0] = r; cum_out[0] = c; cum_out[1] = 1.f / c;
-        scratch[0] = 0; scratch[1] = 0;
-        __threadfence();
+        atomicExch(&scratch[0], 0u); atomicExch(&scratch[1], 0u);      // (the next launch's atomics meet zeros)
     }
 }
 __global__ void rows_scale_kernel(bf16_t* __restrict__ p, int ld, int P, int ps, long M, int C8, const float* __restrict__ r,
@@ -626,11 +650,11 @@ extern "C" int kg_rows_rescale(void* g, int ld, long M, int C, int target_log2, 
     KG_CHECK_ARG(g && cum_in && cum_out && r_out && scratch && C % 8 == 0 && ld % 8 == 0, "kg_rows_rescale: bad args");
     if (M == 0) return KG_OK;
     const long total = M * (C / 8);
-    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(rows_absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, RowsR{(const bf16_t*)g, ld, pp.a_planes, pp.a_pstride}, M, C / 8,
+    int blocks = (int)((total + 4095) / 4096); if (blocks > 256) blocks = 256;     // 1024 threads x 4 chunks in flight each; one workgroup per CU
+    hipLaunchKernelGGL(rows_absmax_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, RowsR{(const bf16_t*)g, ld, pp.a_planes, pp.a_pstride}, M, C / 8,
                        target_log2, cum_in, cum_out, r_out, (unsigned*)scratch);
     KG_CHECK_LAUNCH("rows_absmax");
-    int b2 = (int)((total * pp.a_planes + 255) / 256); if (b2 > 16384) b2 = 16384;
+    int b2 = (int)((total * pp.a_planes + 255) / 256); if (b2 > 2048) b2 = 2048;      // (grid-stride; the usual factor is 1 and the kernel returns at once: dispatching 16 384 empty workgroups cost 11 us)
     hipLaunchKernelGGL(rows_scale_kernel, dim3(b2), dim3(256), 0, (hipStream_t)stream, (bf16_t*)g, ld, pp.a_planes, pp.a_pstride, M, C / 8, (const float*)r_out,
                        (const float*)nullptr);
     KG_CHECK_LAUNCH("rows_scale");
@@ -642,7 +666,7 @@ extern "C" int kg_rows_scale(void* g, int ld, long M, int C, const float* r, con
     KG_CHECK_ARG(g && r && C % 8 == 0 && ld % 8 == 0, "kg_rows_scale: bad args");
     if (M == 0) return KG_OK;
     const long total = M * (C / 8) * pp.a_planes;
-    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(rows_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)g, ld, pp.a_planes, pp.a_pstride, M, C / 8, r, r2);
     KG_CHECK_LAUNCH("rows_scale");
     return KG_OK;
@@ -680,7 +704,7 @@ extern "C" int kg_rows_scale_multi(const long* desc, int n, const float* r, cons
     }
     a.n = n;
     if (most == 0) return KG_OK;
-    int blocks = (int)((most + 255) / 256); if (blocks > 4096) blocks = 4096;
+    int blocks = (int)((most + 255) / 256); if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(rows_scale_multi_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, a, r, r2);
     KG_CHECK_LAUNCH("rows_scale_multi");
     return KG_OK;
