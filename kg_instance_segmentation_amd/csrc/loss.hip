@@ -236,6 +236,58 @@ __global__ void grad_pack_kernel(const float* __restrict__ g, const float* __res
         }
     }
 }
+// The same through an LDS transpose (cpad <= 64): a workgroup takes 256 consecutive pixels, reads every channel plane coalesced
+// (one float per thread), and writes the rows as consecutive 16-byte chunks -- the per-pixel version above stores 16 bytes per 128-byte
+// row and thread (2.4 TB/s measured; this one is bound by the reads).
+__global__ __launch_bounds__(256) void grad_pack_tr_kernel(const float* __restrict__ g, const float* __restrict__ prob, bf16_t* __restrict__ out,
+                                                           long total, int C, long HW, int ld, int cpad, int P, int ps, const float* __restrict__ scale) {
+    extern __shared__ float gp_tile[];                       // [cpad][257]
+    const float S = scale ? *scale : 1.f;
+    const int t = threadIdx.x, K = cpad >> 3;
+    for (long i0 = (long)blockIdx.x * 256; i0 < total; i0 += (long)gridDim.x * 256) {
+        if ((HW & 3) == 0) {      // 16-byte reads: thread = (channel t / 64 + 4 k, pixels 4 (t % 64) .. + 3); a quad never straddles two images
+            const int cs = t >> 6, pq = (t & 63) * 4;
+            const long i = i0 + pq;
+            if (i < total) {
+                const long n = i / HW, p = i - n * HW;
+#pragma unroll 2
+                for (int c = cs; c < C; c += 4) {
+                    const long o = (n * C + c) * HW + p;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(g + o);
+                    if (prob) {
+                        const f32x4 q = *reinterpret_cast<const f32x4*>(prob + o);
+                        v[0] *= q[0] * (1.f - q[0]); v[1] *= q[1] * (1.f - q[1]); v[2] *= q[2] * (1.f - q[2]); v[3] *= q[3] * (1.f - q[3]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gp_tile[c * 257 + pq + e] = v[e] * S;
+                }
+            }
+        } else {
+            const long i = i0 + t;
+            if (i < total) {
+                const long n = i / HW, p = i - n * HW;
+                for (int c = 0; c < C; ++c) {
+                    const long o = (n * C + c) * HW + p;
+                    float v = g[o];
+                    if (prob) { const float q = prob[o]; v *= q * (1.f - q); }
+                    gp_tile[c * 257 + t] = v * S;
+                }
+            }
+        }
+        for (int c = C; c < cpad; ++c) gp_tile[c * 257 + t] = 0.f;
+        __syncthreads();
+        for (int q = t; q < 256 * K; q += 256) {
+            const int px = q / K, k8 = q - px * K;
+            if (i0 + px < total) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gp_tile[(k8 * 8 + e) * 257 + px];
+                kg_store_planes<8>(out + (i0 + px) * ld + k8 * 8, P, ps, v, true);
+            }
+        }
+        __syncthreads();
+    }
+}
 // planes: y = out (split-bf16 planes of the packed gradient rows)
 extern "C" int kg_grad_pack(const float* g, const float* prob, void* out, int N, int C, int H, int W, int ld, int cpad,
                             const kg_planes_t* planes, void* stream) {
@@ -244,6 +296,19 @@ extern "C" int kg_grad_pack(const float* g, const float* prob, void* out, int N,
     KG_CHECK_ARG(kg_planes_ok(pp), "kg_grad_pack: bad kg_planes_t");
     long total = (long)N * H * W;
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+    if (cpad <= 64) {
+        const int smem = cpad * 257 * 4;
+        static bool attr_done = false;
+        if (!attr_done) {
+            KG_HIP(hipFuncSetAttribute((const void*)grad_pack_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 257 * 4));
+            attr_done = true;
+        }
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(grad_pack_tr_kernel, dim3(blocks), dim3(256), smem, (hipStream_t)stream, g, prob, (bf16_t*)out, total, C, (long)H * W, ld, cpad,
+                           pp.y_planes, pp.y_pstride, pp.scale);
+        KG_CHECK_LAUNCH("grad_pack_tr");
+        return KG_OK;
+    }
     hipLaunchKernelGGL(grad_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, prob, (bf16_t*)out, N, C,
                        (long)H * W, ld, cpad, pp.y_planes, pp.y_pstride, pp.scale);
     KG_CHECK_LAUNCH("grad_pack");

@@ -603,3 +603,28 @@ def test_rows_rescale_stage_boundary(dt):
     zero = ops.alloc_pt(8, 64, 1, DEV, zero=True, dtype=dt)
     r0, c0 = ops.rows_rescale(zero, 64, torch.tensor([2.0, 0.5], device=DEV))
     assert float(r0) == 1.0 and float(c0[0]) == 2.0
+
+
+@pytest.mark.parametrize("dt", [BF16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", [(2, 5, 16, 33, 37, True), (1, 10, 16, 40, 40, False), (3, 40, 48, 17, 19, False), (1, 64, 64, 16, 16, False), (1, 70, 72, 8, 8, False)])
+def test_grad_pack_matches_torch(case, dt):
+    """kg_grad_pack (fp32 NCHW loss gradient -> rows planes, times p (1 - p) for sigmoid outputs, times the step's gradient scale): the LDS-transpose
+    kernel (cpad <= 64) and the per-pixel one (cpad > 64), pixel counts that are no multiple of the workgroup's 256."""
+    N, C, cpad, H, W, with_prob = case
+    g = torch.Generator().manual_seed(C + H)
+    grad = torch.randn(N, C, H, W, generator=g).to(DEV)
+    prob = torch.rand(N, C, H, W, generator=g).to(DEV) if with_prob else None
+    scale = torch.tensor([4.0], device=DEV)
+    for P in (1, 2):
+        out = ops.alloc_pt(N * H * W, 80, P, DEV, dtype=dt)          # ld = 80 * P > cpad: a column slice
+        out.t.fill_(7.0)
+        view = ops.PT(out.t[:, :cpad], P, out.ps)
+        ops.grad_pack(grad, prob, view, N, C, H, W, cpad, scale=scale)
+        torch.cuda.synchronize()
+        ref = grad * (prob * (1 - prob) if with_prob else 1.0) * 4.0
+        ref = ref.permute(0, 2, 3, 1).reshape(N * H * W, C)
+        got = sum(view.plane(p).float() for p in range(P))
+        tol = {1: 2.0 ** -8 if dt == BF16 else 2.0 ** -11, 2: 2.0 ** -16 if dt == BF16 else 2.0 ** -21}[P]
+        assert float((got[:, :C] - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-7
+        assert float(got[:, C:cpad].abs().max()) == 0.0 if cpad > C else True
+        assert float((out.t[:, cpad:80].float() - 7.0).abs().max()) == 0.0           # columns past cpad untouched
