@@ -75,6 +75,8 @@ int kg_conv2d_halo(const void* x, const void* w, const float* bias, void* y, flo
 /* the three second-layer 7x7 head convolutions of one scale (KGnet.py:161-209 `.2` layers, sigmoid on kp :300) in one launch
  * over the fused hidden rows [N*H*W][>=3C]: w = packed [64 virtual couts][49][3C] (kg_pack_weight_rows), bias64 / vmap[64]
  * indexed by virtual cout (vmap: channel of kp 0-4 | short 5-14 | mid 15-54, or -1); fp32 NCHW outputs */
+/* (maps with < 128 (tile, head) workgroups and 3-product inputs: one workgroup per plane product as well, fp32 partial maps in a library
+ *  scratch, summed in a fixed order by a second launch -- single-image inference) */
 int kg_conv2d_halo_heads2(const void* x, const void* w, const float* bias64, const int* vmap, float* kp, float* sh, float* md,
                           int N, int H, int W, int C, int ldx, int K, int kp_sigmoid, const kg_planes_t* planes, void* stream);   /* kp_sigmoid: 1 = torch.sigmoid on kp as KGnet.py:300, 0 = raw logits.  planes: a = x;
                           w holds [head][virtual planes][C] channels per tap (kg_pack_weight_rows with tap_stride) */

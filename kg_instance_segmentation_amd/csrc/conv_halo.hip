@@ -43,6 +43,9 @@ struct HaloArgs {
     // 3-product input (x_hi * w_lo | x_lo * w_hi | x_hi * w_hi, kg_plane_pairs): walk order of the virtual chunks, see halo_set_walk
     int walk3;
     const float* oscale;   // != null (GM = 0): per-cout factor of the accumulator (kg_planes_t.oscale: folded inference BatchNorm)
+    // GM = 1, small maps: blockIdx.z = plane product (x_hi w_lo | x_lo w_hi | x_hi w_hi) -- a workgroup walks the chunks of ONE product of its
+    // head and stores raw fp32 partial maps part[z][N][55][H*W] (the bias rides on the last product); heads2_finish_kernel adds the three
+    int prod_split; float* part;
 };
 
 // Planed input with the three products of the half-plane policies.  The packed weights keep the plane-major virtual-channel layout of
@@ -166,12 +169,15 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
         if (KG_HALO_SETPRIO) __builtin_amdgcn_s_setprio(0);
     };
 
-    const int nchunks = (GM == 1 && a.head_split) ? (biy + 1) * a.grp_chunks : a.cin_pad / 64;
-    for (int ci = (GM == 1 && a.head_split) ? biy * a.grp_chunks : 0; ci < nchunks; ++ci) {
+    int ci_first = (GM == 1 && a.head_split) ? biy * a.grp_chunks : 0;
+    int nchunks = (GM == 1 && a.head_split) ? (biy + 1) * a.grp_chunks : a.cin_pad / 64;
+    const bool psplit = GM == 1 && a.prod_split;                 // (uniform)
+    if (psplit) { ci_first += blockIdx.z * a.km.n; nchunks = ci_first + a.km.n; }
+    for (int ci = ci_first; ci < nchunks; ++ci) {
         __syncthreads();
         int cc = ci;                               // virtual chunk of this step (weights: channel offset cc * 64 of a tap)
         bool stage = true;                         // (uniform) false: the halo of the previous step is the one this product multiplies
-        if (a.walk3) {
+        if (a.walk3 && !psplit) {
             const int n = a.km.n, grp = 3 * n;     // virtual chunks of one group (GM == 1: one head, else the whole tap): [x_hi w_lo | x_lo w_hi | x_hi w_hi]
             const int base = ci / grp * grp, q = ci - base;
             if (q < 2 * n) cc = base + ((q & 1) ? (q >> 1) : n + (q >> 1));
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     for (int e = 0; e < 16; ++e) ss[e] = sq[e] = 0.f;
     float bv[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+    for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout && !(psplit && blockIdx.z != 2)) ? a.bias[cb + e] : 0.f;
     if (GM == 0 && a.oscale) {           // (uniform; the accumulators are scaled in place: no second 16-register table next to acc)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -517,6 +523,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
             for (int e = 0; e < 16; ++e) {
                 const int ch = vm[e];
                 if (ch < 0 || (a.head_split && (ch < 5 ? 0 : ch < 15 ? 1 : 2) != biy)) continue;
+                if (psplit) { a.part[(((long)blockIdx.z * a.N + nimg) * 55 + ch) * hw + pix] = v[e]; continue; }
                 if (ch < 5) a.y_f32[(nimg * 5 + ch) * hw + pix] = a.kp_raw ? v[e] : 1.f / (1.f + expf(-v[e]));
                 else if (ch < 15) a.f32_b[(nimg * 10 + ch - 5) * hw + pix] = v[e];
                 else a.f32_c[(nimg * 40 + ch - 15) * hw + pix] = v[e];
@@ -553,7 +560,7 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
         KG_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<KS, WC, WPX, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
-    dim3 grid(a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y, GM == 1 ? (a.head_split ? 3 : 1) : kg_cdiv(a.Cout, TC));
+    dim3 grid(a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y, GM == 1 ? (a.head_split ? 3 : 1) : kg_cdiv(a.Cout, TC), (GM == 1 && a.prod_split) ? 3 : 1);
     if (a.stat_part) a.stat_part = (GM == 0 && !a.tiletab) ? kg_conv_stats_claim(grid.x, a.Cout) : nullptr;   // (armed by the caller: BatchNorm statistics)
     static const int use_xcd = getenv("KG_HALO_XCD") ? atoi(getenv("KG_HALO_XCD")) : 1;
     // (not for the widest heads: 24 cout blocks of one tile stream 24 different 3 MB weight slices through the XCD's 4 MB L2: -2 %)
@@ -614,6 +621,20 @@ extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, v
     return KG_ERR_ARG;
 }
 
+// second half of a product-split heads2 launch: out = part[0] + part[1] + part[2] (fixed order: the two low-order products, then hi * hi
+// with the bias), sigmoid on the kp maps (KGnet.py:300) unless raw logits are asked for
+__global__ __launch_bounds__(256) void heads2_finish_kernel(const float* __restrict__ part, long per_z, int N, long hw, float* __restrict__ kp,
+                                                            float* __restrict__ sh, float* __restrict__ md, int kp_raw) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_z; i += (long)gridDim.x * 256) {
+        const float v = part[i] + part[per_z + i] + part[2 * per_z + i];
+        const long pix = i % hw, q = i / hw;
+        const int ch = (int)(q % 55); const long n = q / 55;
+        if (ch < 5) kp[(n * 5 + ch) * hw + pix] = kp_raw ? v : 1.f / (1.f + expf(-v));
+        else if (ch < 15) sh[(n * 10 + ch - 5) * hw + pix] = v;
+        else md[(n * 40 + ch - 15) * hw + pix] = v;
+    }
+}
+
 // The three second-layer 7x7 head convolutions of one scale (KGnet.py:161-209 `.2` layers + torch.sigmoid on kp :300) in
 // one launch.  x: fused hidden rows [N*H*W][ldx] = kp | short | mid hidden, C channels each (C % 64 == 0);
 // w: packed [64 virtual couts][49][3C] (kg_pack_weight_rows with the virtual row of every map channel; blocks of other
@@ -637,6 +658,27 @@ extern "C" int kg_conv2d_halo_heads2(const void* x, const void* w, const float* 
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias64; a.y_f32 = kp; a.f32_b = sh; a.f32_c = md; a.vmap = vmap;
     a.N = N; a.H = H; a.W = W; a.tiles_y = kg_cdiv(H, 16); a.cin_pad = 3 * C * vplanes; a.ldx = ldx; a.Cout = 64; a.K = K;
     a.grp_chunks = vplanes * C / 64;
-    a.head_split = (long)N * kg_cdiv(H, 16) * kg_cdiv(W, 32) < 256;   // too few pixel tiles to fill 256 CUs
+    const long tiles = (long)N * kg_cdiv(H, 16) * kg_cdiv(W, 32);
+    a.head_split = tiles < 256;   // too few pixel tiles to fill 256 CUs
+    // Single-image inference (a 64 x 64 map is 8 tiles x 3 heads = 24 workgroups walking 24 chunks each): one workgroup per plane product
+    // as well, fp32 partial maps in a library scratch (one 32 MB buffer per device, allocated on first use), summed by a second launch.
+    static const int split_mode = getenv("KG_HEADS2_SPLIT") ? atoi(getenv("KG_HEADS2_SPLIT")) : 1;   // 0 never, 1 when < 128 workgroups, 2 whenever it fits
+    const long per_z = (long)N * 55 * H * W;
+    constexpr long PART_FLOATS = 8L << 20;
+    if (split_mode && vplanes == 3 && a.head_split && 3 * per_z <= PART_FLOATS && (split_mode == 2 || tiles * 3 < 128)) {
+        static float* part[16] = {nullptr};
+        int dev = 0;
+        KG_HIP(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 16) {
+            if (!part[dev]) KG_HIP(hipMalloc((void**)&part[dev], PART_FLOATS * sizeof(float)));
+            a.prod_split = 1; a.part = part[dev];
+            const int rc = launch_halo<7, 1, 8, 1>(a, (hipStream_t)stream);
+            if (rc != KG_OK) return rc;
+            int blocks = (int)((per_z + 255) / 256); if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(heads2_finish_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)part[dev], per_z, N, (long)H * W, kp, sh, md, a.kp_raw);
+            KG_CHECK_LAUNCH("heads2_finish");
+            return KG_OK;
+        }
+    }
     return launch_halo<7, 1, 8, 1>(a, (hipStream_t)stream);
 }

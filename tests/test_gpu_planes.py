@@ -220,6 +220,37 @@ def test_conv_with_folded_inference_batchnorm(case, P, dt):
         check(f"conv+bn {route} P={P} {case}", nchw(from_pt(y), N, OH, OW), ref, TOL[P])
 
 
+@pytest.mark.parametrize("dt", [BF16, F16], ids=["bf16x2", "f16x2"])
+@pytest.mark.parametrize("case", [(64, 1, 32, 32), (128, 1, 64, 64), (64, 2, 96, 160), (64, 1, 272, 500)])
+def test_heads2_on_two_plane_inputs(case, dt):
+    """kg_conv2d_halo_heads2 over hi + lo planes (3 products): small maps (< 128 workgroups) run ONE workgroup per (tile, head, plane product)
+    and a finishing launch adds the three fp32 partial maps; larger ones walk the products inside a workgroup (head split / no split).
+    Against three float64 conv2d on the fp32 inputs."""
+    DT[0] = dt
+    C, N, H, W = case
+    g = torch.Generator().manual_seed(C + H)
+    hid = torch.randn(N, 3 * C, H, W, generator=g).clamp_min(0)
+    rows, vmap = ops.heads2_layout()
+    pw = PackedWeight(64, 49, C, DEV, groups=3, xP=2, wP=2)
+    vm = torch.tensor(vmap, dtype=torch.int32, device=DEV)
+    bias64 = torch.zeros(64, device=DEV)
+    refs, outs = [], []
+    for k, co in enumerate((5, 10, 40)):
+        w = torch.randn(co, C, 7, 7, generator=g) / math.sqrt(49 * C)
+        b = torch.randn(co, generator=g)
+        r = F.conv2d(hid[:, k * C:(k + 1) * C].double(), w.double(), b.double(), 1, 3)
+        refs.append(torch.sigmoid(r) if k == 0 else r)
+        rm = torch.tensor(rows[k], dtype=torch.int32, device=DEV)
+        pw.pack_rows(w.to(DEV), rm, group=k)
+        bias64[rm.long()] = b.to(DEV)
+        outs.append(torch.full((N, co, H, W), float("nan"), dtype=torch.float32, device=DEV))
+    xp = to_pt(rows_f32(hid).to(DEV), 2)
+    ops.conv_halo_heads2(xp, pw, bias64, vm, outs[0], outs[1], outs[2], N, H, W, C)
+    torch.cuda.synchronize()
+    for name, o, r in zip(("kp", "short", "mid"), outs, refs):
+        check(f"heads2 {case} {name}", o, r, TOL[2])
+
+
 @pytest.mark.parametrize("P", [2, 3])
 def test_mixed_plane_counts(P):
     DT[0] = BF16
