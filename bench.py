@@ -397,6 +397,31 @@ def grouping_match_rate(S):
     return {"grouping_match_rate": same / max(nref, 1), "grouping_ref_boxes": nref, "postproc_oracle_ms": 1e3 * dtc}
 
 
+def dtype_label(precision):
+    """`dtype` of the bench line = the arithmetic of the WHOLE step, derived from every plane entry of the policy (engine.PRECISIONS):
+    forward planes (backbone, decoder, heads, seg) and the operand planes of the backward pass (dY, x / dY of the weight gradients, W of the
+    input gradients).  A policy whose backward multiplies fewer planes than its forward says so."""
+    from kg_instance_segmentation_amd import engine as kengine
+    pol = kengine.PRECISIONS[precision]
+    half = precision in kengine.HALF_POLICIES
+    fmt, full = ("f16", 2) if half else ("bf16", 3)
+    fwd, bwd = min(pol[:4]), min(pol[4:])
+    name = {1: f"{fmt} single planes", 2: f"hi + lo {fmt} planes" + (" (22 significant bits)" if half else " (16 bits)"), 3: "hi + mid + lo bf16 planes (24 bits)"}
+
+    def side(p):
+        return ("f32-tolerance, " if p >= full else "") + name[min(p, 3)] + f", {kengine_products(p)} MFMA product{'s' if kengine_products(p) > 1 else ''}"
+    if max(pol[:4]) != fwd:
+        f = f"forward: backbone {name[pol[0]]}, rest {name[min(pol[1:4])]}"
+    else:
+        f = "forward: " + side(fwd)
+    return f"{f} / backward: {side(bwd)}; {fmt} MFMA, fp32 accumulate"
+
+
+def kengine_products(P):
+    from kg_instance_segmentation_amd import ops
+    return ops.vplanes(P, P)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -408,9 +433,10 @@ def main():
     ap.add_argument("--mode", choices=["train", "eval", "gt"], default="train",
                     help="eval: inference path (BASELINE configs[4]); gt: ground-truth map generation (SURVEY 8f N1); 1 GPU")
     ap.add_argument("--precision", default=os.environ.get("KG_PRECISION", "fp32"),
-                    help="precision policy of the network (engine.PRECISIONS); the headline is the fp32-faithful default, a bf16 "
-                         "mixed-precision companion line (`mixed`) is measured beside it at 1 GPU")
-    ap.add_argument("--no-companion", action="store_true", help="skip the bf16 mixed-precision companion measurement")
+                    help="precision policy of the network (engine.PRECISIONS); the headline is the default policy (fp32-tolerance forward on hi + lo "
+                         "half planes, single-plane half backward); at 1 GPU two companions are timed beside it: `half` (half mixed precision) and "
+                         "`fp32b2` (hi + lo half planes in the backward pass as well)")
+    ap.add_argument("--no-companion", action="store_true", help="skip the `half` and `fp32b2` companion measurements")
     ap.add_argument("--profile-run", action="store_true", help="warmup + timed steps only (no companion, no second read-back policy, "
                     "no per-kernel pass, no CPU baseline): the command rocprofv3 wraps, so that steps + warmup launches are traced")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -539,17 +565,23 @@ def main():
         torch.cuda.synchronize()
         timer.on = False
     prof_rec, timer.rec = timer.rec, []
-    companion = None
-    if world == 1 and not args.no_companion and args.precision != "half":
+    companions = {}
+    if world == 1 and not args.no_companion:
         main_run = None
         torch.cuda.empty_cache()
         ksteps = max(2, min(args.steps, 10))
-        comp = run_train("half", ksteps, 3, STEP_SYNC, False)
-        companion = {"precision": "half", "dtype": "f16 (single IEEE-half planes: half mixed precision)",
-                     "value": args.batch * ksteps / comp["dt"], "unit": "imgs/s", "ms_per_step": 1e3 * comp["dt"] / ksteps, "steps": ksteps, "warmup": 3,
-                     "last_loss": comp["losses"][-1],
-                     "parity": "NOT the reference's arithmetic: half mixed precision, tests/test_gpu_parity.py holds it to rtol 2e-2 + atol 2e-2 rms"}
-        comp = None
+        notes = {"half": "NOT the reference's arithmetic: half mixed precision, tests/test_gpu_parity.py holds it to rtol 2e-2 + atol 2e-2 rms",
+                 "fp32b2": "hi + lo half planes (3 MFMA products per multiply) in the forward AND the backward pass: the policy whose parameter gradients sit on the "
+                           "fp32 reference's own noise floor against a float64 evaluation (profiles/r04_grad_table.json, tests/test_gpu_gradprec.py)"}
+        for cp in ("half", "fp32b2"):
+            if cp == args.precision:
+                continue
+            comp = run_train(cp, ksteps, 3, STEP_SYNC, False)
+            companions[cp] = {"precision": cp, "dtype": dtype_label(cp), "value": args.batch * ksteps / comp["dt"], "unit": "imgs/s",
+                              "ms_per_step": 1e3 * comp["dt"] / ksteps, "steps": ksteps, "warmup": 3, "last_loss": comp["losses"][-1],
+                              "grad_overflow": bool(comp["overflow"]()), "parity": notes[cp]}
+            comp = None
+            torch.cuda.empty_cache()
     if rank != 0:
         return
     if os.environ.get("KG_BENCH_VERBOSE"):
@@ -571,13 +603,11 @@ def main():
                       "(3 products), c0_conv / decoder / 7x7 heads / seg branch single-plane bf16",
              "trunk2": "as mixed, with c0_conv and the decoder in hi + lo planes as well",
              "bf16": "bf16 MFMA, fp32 accumulation, single-plane bf16 storage everywhere"}
-    half = args.precision in kengine.HALF_POLICIES
-    faithful = (pol[0] >= 2 and pol[2] >= 2) if half else (pol[0] >= 3 and pol[2] >= 3)
+    out_dtype = dtype_label(args.precision)
     out = {"metric": "imgs/s (train fwd+bwd) at 512x512", "value": imgs / dt, "unit": "imgs/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
-           "dtype": (("f32 (as hi + lo IEEE-half planes on f16 MFMA, fp32 accumulate)" if half else "f32 (as hi + mid + lo bf16 planes on bf16 MFMA, fp32 accumulate)")
-                     if faithful else ("f16" if half else "bf16")), "data": "synthetic",
+           "dtype": out_dtype, "data": "synthetic",
            "config": {"workload": f"KGnet train step (forward_dec+forward_seg, 4x DetectionLossAll + SEG_loss, backward, Adam), "
                                   f"batch {args.batch}/GPU, 3x{args.size}x{args.size}, {args.boxes} GT boxes/img, full HIP path",
                       "precision_policy": args.precision, "planes": list(pol), "precision": PDESC.get(args.precision, args.precision),
@@ -587,8 +617,10 @@ def main():
                       "gc_enabled_imgs_per_s": (imgs / gc_on_dt) if gc_on_dt else None,
                       "grad_overflow": overflowed,      # sticky device flag of the half-precision backward (KGnet.grad_overflowed): must be false
                       "step_ms": [round(1e3 * (b - a), 2) for a, b in zip([t0] + marks[:-1], marks)]}}
-    if companion is not None:
-        out["half_companion"] = companion
+    if "half" in companions:
+        out["half_companion"] = companions["half"]
+    if "fp32b2" in companions:
+        out["fp32b2_companion"] = companions["fp32b2"]       # the all-22-bit policy (forward and backward), timed the same way
     if not args.no_kernel_timer:
         if os.environ.get("KG_BENCH_DUMP"):
             timer.rec = prof_rec

@@ -8,10 +8,18 @@ Same surface as the reference: `resnet50(pretrained)` returns an `nn
 with autograd (`loss.backward()` fills `.grad` of all parameters).  There is no PyTorch/CPU fallback
 for the arithmetic: a missing libkgnet_hip.so or a non-GPU tensor raises.
 
-Numerics: the reference computes in fp32.  Here convolutions run on bf16 MFMA with fp32 accumulation over split-bf16
-storage (engine.py, PRECISIONS): `precision="fp32"` (default; env KG_PRECISION) stores every forward tensor as hi + mid + lo
-bf16 planes == the fp32 value exactly (6 MFMA products per multiply; results within rtol 1e-4 / atol 1e-5 of the reference) and
-runs the backward pass on hi + lo planes; "mixed" / "trunk2" / "bf16" are bf16 mixed-precision policies (opt-in).
+Numerics: the reference computes in fp32.  Here convolutions run on 16-bit MFMA with fp32 accumulation over split 16-bit storage
+("planes": engine.py PRECISIONS, csrc/kg_common.h).  `precision=` / env KG_PRECISION / model.set_precision:
+  "fp32" (default): every forward tensor = hi + lo IEEE-half planes (22 significant bits), 3 f16 MFMA products per multiply: forward
+        results within rtol 1e-4 / atol 1e-5 of the reference; the BACKWARD pass multiplies single half planes (11 bits) under a
+        device-side power-of-two gradient scale -- mixed-precision-grade gradients (per-tensor relative L2 error against a float64
+        evaluation: see tests/test_gpu_gradprec.py and profiles/r04_grad_table.json);
+  "fp32b2": hi + lo half planes in the backward pass as well (gradients on the fp32 reference's own noise floor, ~1.7x the step time);
+  "half" / "halfmix": half mixed precision;  "fp32bf" / "fp32bf_full": the same tolerances on bf16 planes (hi + mid + lo, 6 products);
+  "mixed" / "trunk2" / "bf16": bf16 mixed-precision policies (opt-in).
+RANGE of the half policies (nothing is clamped; a violation surfaces as inf / NaN, never silently): packed weights carry a constant
+2^12 scale, so |w| must stay below 16 (load_state_dict / check_half_range() raise on a violation); activations are stored as they are,
+|x| <= 65504; a non-finite parameter gradient raises the sticky flag grad_overflowed().  Use "fp32bf" for weights outside that range.
 Head maps and the feature maps c0..c4 are returned as fp32 tensors like the reference's (KGnet.py:318;
 the feature maps are NCHW-shaped with channels-last memory).
 """
@@ -43,8 +51,7 @@ def _begin_scaled_backward(eng, top_grads, probs=None):
     from . import ops
     gs = ops.grad_scale(top_grads, probs)
     eng.gscale, eng.param_gsc = gs, {}
-    if eng.overflow_flag is None or eng.overflow_flag.device != gs.device:
-        eng.overflow_flag = torch.zeros(1, dtype=torch.int32, device=gs.device)
+    eng.flag_on(gs.device)
     if eng.grad_store is not None:
         eng.grad_store.unscale_of = eng.param_gsc      # data parallel: a bucket's gradients are divided by their scales right before its all-reduce
     return gs
@@ -63,7 +70,7 @@ def _end_scaled_backward(eng, gs, pgrads):
     from . import ops
     store = eng.grad_store
     items = [(k, g) for k, g in pgrads.items() if g is not None and not (store is not None and store.owns(k, g))]
-    ops.scale_tensors([g for _, g in items], [eng.param_gsc[k][1:2] for k, _ in items], flag=eng.overflow_flag)
+    ops.scale_tensors([g for _, g in items], [eng.param_gsc[k][1:2] for k, _ in items], flag=eng.flag_on(gs.device))
     if store is not None:
         store.unscale_pending()
         store.unscale_of = None
@@ -231,6 +238,29 @@ class ResNet(nn.Module):
         if reset and v:
             f.zero_()
         return v
+
+    HALF_WEIGHT_LIMIT = 16.0       # csrc/kg_common.h KG_WSCALE = 2^12: 16 * 4096 = 65536 > IEEE half's 65504
+
+    def check_half_range(self):
+        """Half policies: raises ValueError if a conv weight cannot be packed (|w| * 2^12 beyond IEEE half: |w| >= 16).  One
+        max-reduction per conv weight; called by load_state_dict, callable by hand after writing parameters."""
+        if not self._engine.fmt:
+            return
+        bad = []
+        for k in self._param_keys:
+            w = self.get_tensor(k)
+            if w.dim() == 4 and w.numel():
+                m = float(w.detach().abs().max())
+                if not m < self.HALF_WEIGHT_LIMIT:
+                    bad.append((k, m))
+        if bad:
+            raise ValueError(f"precision={self.precision!r} stores packed weights x 2^12 in IEEE half: |w| must be < {self.HALF_WEIGHT_LIMIT:g}, but "
+                             f"{bad[0][0]} has max |w| = {bad[0][1]:g} ({len(bad)} tensor(s)); use precision='fp32bf' (bf16 planes) for such weights")
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.check_half_range()
+        return r
 
     def invalidate_caches(self):
         """Drop the packed bf16 weight copies and folded BatchNorm constants: call after writing parameters or running

@@ -187,9 +187,18 @@ class Engine:
         self.fmt = 1 if self.dt == ops.F16 else 0
         self.gscale = None         # half build: device {scale, 1 / scale} ALL live gradients of the running backward pass are expressed in
         self.param_gsc = {}        # ... and the scale each parameter gradient was produced in (divided out where it leaves)
-        self.overflow_flag = getattr(self, "overflow_flag", None)     # device int32[1]: a backward pass produced a non-finite gradient (KGnet.grad_overflowed)
+        self.overflow_flag = getattr(self, "overflow_flag", None)     # device int32[1]: a backward pass produced a non-finite gradient (KGnet.grad_overflowed; flag_on)
         self.bpt = self.pt         # backbone planes of the CURRENT forward (see forward_dec)
         self.invalidate_caches()
+
+    def flag_on(self, dev):
+        """The sticky non-finite flag of the half-precision backward (device int32[1]), allocated on first use on `dev`: every
+        ops.scale_tensors call of a backward pass -- dense, seg branch as its own autograd node, data-parallel unscale -- raises it."""
+        if not self.fmt:
+            return None
+        if self.overflow_flag is None or self.overflow_flag.device != dev:
+            self.overflow_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        return self.overflow_flag
 
     def invalidate_caches(self):
         """Forget every packed-weight / folded-BatchNorm copy (call after writing parameters behind PyTorch's back)."""
@@ -711,16 +720,25 @@ class Engine:
             fv.add_grad(gp, masked=False)
         hook = self.grad_hook
         tape, self.tape = self.tape, None
-        while tape:                              # (popped as they run: a closure and the activations only it still holds die right away)
-            fn = tape.pop()
-            n0 = len(self.param_grads)
-            fn()
-            del fn
-            if hook is not None and len(self.param_grads) > n0:      # data-parallel: parameter gradients whose kernels are
-                hook(list(self.param_grads.items())[n0:], False)    # enqueued go to the bucketed all-reduce right away
-        if hook is not None:
-            hook([], True)
-        Var.ENG = None
+        try:
+            while tape:                              # (popped as they run: a closure and the activations only it still holds die right away)
+                fn = tape.pop()
+                n0 = len(self.param_grads)
+                fn()
+                del fn
+                if hook is not None and len(self.param_grads) > n0:      # data-parallel: parameter gradients whose kernels are
+                    hook(list(self.param_grads.items())[n0:], False)    # enqueued go to the bucketed all-reduce right away
+            if hook is not None:
+                hook([], True)
+        except BaseException:
+            # a failing launch must not leave this pass's scale state behind: later add_grad / to_current_scale calls of ANY model in
+            # the process consult Var.ENG, and the next backward of this engine would start from a stale running scale
+            self.gscale, self.param_gsc = None, {}
+            if self.grad_store is not None:
+                self.grad_store.unscale_of = None
+            raise
+        finally:
+            Var.ENG = None
         grads = self.param_grads
         self.param_grads = {}
         return grads

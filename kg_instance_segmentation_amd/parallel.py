@@ -73,9 +73,11 @@ class FlatGradReducer:
     Contract (asserted): ONE backward pass per forward and `optimizer.zero_grad(set_to_none=True)` (PyTorch's default) before every
     forward -- the slot IS `param.grad` and the gradient kernels overwrite it, so gradient accumulation over several backward passes
     cannot be expressed (begin_step raises if a parameter still carries a gradient; deliver raises on a foreign `.grad` tensor).
-    Known divergence from the single-device step: a parameter NO rank produced a gradient for (a skip_combine level no box of the
-    global batch reaches) gets its zero slot as `.grad` here -- Adam then applies a momentum-only update -- where one process
-    leaves `.grad` None and skips it; telling the two apart would need one more collective per step."""
+    finish() also exchanges ONE small MAX all-reduce (len(keys) + 1 int32): the bitmap of the parameters this rank's backward pass
+    produced a gradient for, and the sticky non-finite flag of the half-precision backward (KGnet.grad_overflowed).  A parameter NO
+    rank produced a gradient for (a skip_combine level no box of the global batch reaches) keeps `.grad` None on every rank -- the
+    optimizer skips it exactly as the single-device step does -- and the overflow flag is the same on every rank after finish(), so
+    `if model.grad_overflowed(): skip the step` cannot make replicas diverge (the SUM all-reduce spreads one rank's inf / NaN to all)."""
 
     def __init__(self, bucket_mb=64):
         self.cap = bucket_mb << 20
@@ -113,6 +115,8 @@ class FlatGradReducer:
         self.bucket_of = {k: i for i, (_, _, ks) in enumerate(self.buckets) for k in ks}
         self.missing = [set(ks) for _, _, ks in self.buckets]
         self.inflight, self.seg_launched = [], False
+        self.key_index = {k: i for i, k in enumerate(self.keys)}
+        self.produced = set()                 # keys whose gradient this rank's running step produced (deliver)
         self.unscale_of, self.seg_unscaled = None, False   # half-precision backward: key -> device {scale, 1 / scale} of the gradients the running backward pass produced (engine.param_gsc)
         eng.grad_store = self
         eng.grad_hook = self._on_grads
@@ -148,6 +152,7 @@ class FlatGradReducer:
             raise RuntimeError(f"FlatGradReducer: {key}.grad is a tensor this reducer does not own (zero_grad(set_to_none=False) or a gradient "
                                "accumulated before attach()): call optimizer.zero_grad(set_to_none=True) before every forward")
         param.grad = v
+        self.produced.add(key)
         return None
 
     def begin_step(self):
@@ -160,6 +165,7 @@ class FlatGradReducer:
         self.missing = [set(ks) for _, _, ks in self.buckets]
         self.seg_launched, self.seg_unscaled = False, False
         self._pend_done = set()
+        self.produced = set()
         a, b, _ = self.seg_bucket
         if b > a:
             self.flat[a:b].zero_()
@@ -202,7 +208,7 @@ class FlatGradReducer:
         from . import ops
         ks = [k for k in keys if k in self.unscale_of and k not in self._pend_done]
         if ks:
-            ops.scale_tensors([self.slot[k] for k in ks], [self.unscale_of[k][1:2] for k in ks], flag=self.model._engine.overflow_flag)
+            ops.scale_tensors([self.slot[k] for k in ks], [self.unscale_of[k][1:2] for k in ks], flag=self.model._engine.flag_on(self.flat.device))
             self._pend_done.update(ks)
 
     def unscale_pending(self):
@@ -222,9 +228,15 @@ class FlatGradReducer:
             self.inflight.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
-        """After loss.backward(): reduces whatever was not produced on this rank this step (as zeros / stale-free: a bucket whose
-        gradients were not all produced is reduced as it stands after zero-filling the missing slots) and waits for all reductions."""
-        if world_size() > 1:
+        """After loss.backward(): reduces whatever was not produced on this rank this step (a bucket whose gradients were not all
+        produced is reduced as it stands after zero-filling the missing slots), exchanges the produced-bitmap + non-finite flag (one
+        MAX all-reduce of len(keys) + 1 int32) and waits for all reductions.  Afterwards `.grad` of every parameter SOME rank
+        produced a gradient for is its reduced flat slot, `.grad` of the others stays None, and KGnet.grad_overflowed() answers
+        the same on every rank.  (Reads the bitmap back: one host synchronisation at the end of the backward pass.)"""
+        params = self._params
+        eng = self.model._engine
+        multi = world_size() > 1
+        if multi:
             if not self.seg_launched:
                 self.dense_backward_started()
             for i, (a, b, ks) in enumerate(self.buckets):
@@ -233,14 +245,29 @@ class FlatGradReducer:
                         self.slot[k].zero_()
                     self._launch(a, b, ks, unscale=False)      # (no backward pass is running: whatever this bucket holds is unscaled or zero)
                     self.missing[i] = {None}
+            import numpy as np
+            from . import ops
+            host = np.zeros(len(self.keys) + 1, np.int32)
+            host[[self.key_index[k] for k in self.produced]] = 1
+            vec = ops.h2d(host, self.flat.device) if self.flat.is_cuda else torch.from_numpy(host)
+            flag = getattr(eng, "overflow_flag", None)
+            if flag is not None:
+                vec[-1:].copy_(flag)
+            self.inflight.append(dist.all_reduce(vec, op=dist.ReduceOp.MAX, async_op=True))
             for w in self.inflight:
                 w.wait()
+            if flag is not None:
+                flag.copy_(vec[-1:])                         # every rank holds the global flag
+            got = vec[:-1].cpu().numpy()
+            anyrank = {k for k, i in self.key_index.items() if got[i]}
+        else:
+            anyrank = set(self.produced)
         self.inflight = []
-        # parameters whose gradient never reached autograd (zero contribution on this rank) still need .grad for the optimizer
-        params = dict(self.model.named_parameters())
-        for k, v in self.slot.items():
+        # a parameter another rank produced a gradient for (zero contribution here) still needs .grad for the optimizer; one NO
+        # rank produced a gradient for keeps .grad None, as in the single-device step
+        for k in anyrank:
             if params[k].grad is None:
-                params[k].grad = v
+                params[k].grad = self.slot[k]
 
     reduce = finish
 

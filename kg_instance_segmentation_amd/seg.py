@@ -107,7 +107,7 @@ class _SegFunction(torch.autograd.Function):
         store = eng.grad_store
         if gs is not None:
             items = [(k, g) for k, g in pgrads.items() if g is not None and not (store is not None and store.owns(k, g))]
-            ops.scale_tensors([g for _, g in items], [eng.param_gsc[k][1:2] for k, _ in items], flag=eng.overflow_flag)
+            ops.scale_tensors([g for _, g in items], [eng.param_gsc[k][1:2] for k, _ in items], flag=eng.flag_on(gflat.device))
         for k in ctx.branch.param_keys:
             g = pgrads.get(k)
             if store is not None and g is not None and store.owns(k, g):
@@ -510,7 +510,7 @@ class SegBranch:
             if sc is not eng.gscale:
                 ops.rows_scale(t, c, eng.gscale[0:1], sc[1:2])
         if f32_outs:                                    # fp32 outputs leave unscaled: each divided by the scale it was written in
-            ops.scale_tensors([t for t, _, _ in f32_outs], [sc[1:2] for _, _, sc in f32_outs])
+            ops.scale_tensors([t for t, _, _ in f32_outs], [sc[1:2] for _, _, sc in f32_outs], flag=eng.flag_on(f32_outs[0][0].device))
         # parameters of levels that no box reached get zero gradients (autograd accumulates nothing for None)
         return gfeats, pgrads
 

@@ -1,0 +1,45 @@
+"""Parameter gradients of one KGnet train step from the CPU oracle (TEST INFRASTRUCTURE, not product), in float32 or FLOAT64.
+
+The reference's `loss.backward()` (train.py:148-154) is fp32 autograd.  To tell how far a GPU precision policy's gradients are from the
+reference's, the yardstick has to be finer than fp32: oracle/net.py (pinned against the reference's own outputs, tests/golden/net_*.npz)
+evaluated in float64 is the "true" gradient of the same step, and the same oracle in float32 -- the reference's own arithmetic -- gives the
+noise floor an fp32 implementation cannot get under.  Used by tests/test_gpu_gradprec.py and tools/grad_table.py.
+"""
+import numpy as np
+import torch
+
+from . import net as onet
+
+
+def oracle_grads(sd, x, gt_boxes, gt_masks, gt_lv, H, W, dtype=torch.float64):
+    """One train step (forward incl. seg branch, 4 detection losses + seg loss, backward: train.py:148-153) of the oracle in `dtype`.
+    Returns (loss, {parameter name: gradient tensor (dtype) or None})."""
+    sd = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    names = [k for k, v in sd.items() if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))]
+    for n in names:
+        sd[n].requires_grad_(True)
+    net = onet.Net(sd, training=True)
+    o0, o1, o2, o3, opred = net.forward(x.to(dtype), gt_boxes)
+    loss = sum(onet.detection_loss(p, t.to(dtype)) for p, t in zip((o0, o1, o2, o3), gt_lv))
+    l2 = onet.seg_loss(opred, gt_masks, gt_boxes, H, W)
+    if l2 is not None:
+        loss = loss + l2
+    loss.backward()
+    return float(loss), {n: sd[n].grad for n in names}
+
+
+def rel_l2(got, ref64):
+    """per-tensor relative L2 error ||got - ref|| / ||ref|| in float64 (inf for a zero reference with a non-zero result)"""
+    a = got.detach().double().cpu().flatten()
+    b = ref64.detach().double().cpu().flatten()
+    nb = float(b.norm())
+    d = float((a - b).norm())
+    return d / nb if nb > 0 else (0.0 if d == 0 else float("inf"))
+
+
+def summarize(errs):
+    """errs: {name: relative L2 error}.  median / p90 / max over the tensors + the three worst names"""
+    v = np.array(sorted(errs.values()))
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    return {"n": int(v.size), "median": float(np.median(v)), "p90": float(np.quantile(v, 0.9)), "max": float(v.max()),
+            "worst": [(n, float(e)) for n, e in worst]}

@@ -183,7 +183,7 @@ def seg_loss(predictions, gt_masks, gt_boxes, height, width):
                     y1 = max(0, int(np.int32(np.round(y1)))); x1 = max(0, int(np.int32(np.round(x1))))
                     y2 = min(int(np.int32(np.round(y2))), height - 1); x2 = min(int(np.int32(np.round(x2))), width - 1)
                     gm = nearest_resize(gt_masks[i][g][y1:y2, x1:x2], pr.shape[0], pr.shape[1])
-                    lb = lb + F.binary_cross_entropy(pr, torch.from_numpy(np.ascontiguousarray(gm, np.float32)))
+                    lb = lb + F.binary_cross_entropy(pr, torch.from_numpy(np.ascontiguousarray(gm, np.float32)).to(pr.dtype))      # (.to: the float64 evaluation of oracle/gradref.py)
                     n += 1
                     ran = True
         if n:

@@ -480,6 +480,11 @@ def test_half_range_violation_is_loud(state_dict0):
     bad = step()
     assert not np.isfinite(bad)
     assert m.grad_overflowed() and not m.grad_overflowed()                   # sticky until read, then reset
+    with pytest.raises(ValueError, match="c3_cat_refine.0.weight"):          # the explicit range check names the tensor ...
+        m.check_half_range()
+    with pytest.raises(ValueError, match="fp32bf"):                          # ... and load_state_dict runs it
+        KGnet.resnet50(pretrained=False).load_state_dict(m.state_dict())
+    KGnet.resnet50(pretrained=False, precision="fp32bf").load_state_dict(m.state_dict())       # bf16 planes carry such a weight
 
 
 def test_resnet101_random_init_gradients_stay_in_half_range():

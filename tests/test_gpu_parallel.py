@@ -71,11 +71,11 @@ def test_flat_reducer_and_fused_adam_on_one_rank_rccl_communicator(monkeypatch, 
         g_red, l_red, p_red = run(True)
         assert l_ref == l_red and all(np.isfinite(l_ref))
         for step in range(2):
-            # (a parameter no box reaches has no gradient without the reducer and the zero slot with it: documented divergence)
+            # (a parameter no box of the global batch reaches has no gradient without the reducer and none with it: the produced-bitmap
+            # exchange of finish() leaves its .grad None on every rank)
             bad = [n for n, g in g_ref[step].items() if not torch.equal(g, g_red[step][n])]
             assert not bad, (step, bad[:5])
-            extra = [n for n in g_red[step] if n not in g_ref[step]]
-            assert all(float(g_red[step][n].abs().max()) == 0.0 for n in extra), extra[:5]
+            assert sorted(g_red[step]) == sorted(g_ref[step])
         bad = [n for n in p_ref if not torch.equal(p_ref[n], p_red[n]) and n in g_ref[1]]
         assert not bad, bad[:5]
         dist.barrier()

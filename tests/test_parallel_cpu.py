@@ -85,7 +85,7 @@ def _flat_worker(rank, world, port, out):
         grad_store = None
 
     class Seg:
-        param_keys = ["seg_head.0.weight", "seg_head.0.bias"]
+        param_keys = ["seg_head.0.weight", "seg_head.0.bias", "skip_combine.3.up.0.weight"]
 
     class Node(torch.nn.Module):
         pass
@@ -96,7 +96,8 @@ def _flat_worker(rank, world, port, out):
             super().__init__()
             shapes = {"conv1.weight": (8, 3, 7, 7), "layer1.0.conv1.weight": (300000,), "c0_conv.0.weight": (64, 3, 3, 3), "c4_up_conv.0.weight": (200000,),
                       "c0_cat_refine.0.weight": (64, 128), "kp_head_c0.0.weight": (50000,), "mid_offset_head_c3.2.weight": (400000,),
-                      "seg_head.0.weight": (64, 64, 3, 3), "seg_head.0.bias": (64,)}
+                      "seg_head.0.weight": (64, 64, 3, 3), "seg_head.0.bias": (64,),
+                      "skip_combine.3.up.0.weight": (512, 16, 3, 3)}       # (a pyramid level no box of the global batch reaches: produced by NO rank)
             self._param_keys = list(shapes)
             for k, shp in shapes.items():
                 node = self
@@ -114,16 +115,20 @@ def _flat_worker(rank, world, port, out):
     m = Model()
     red = parallel.FlatGradReducer(bucket_mb=1).attach(m)
     names = dict(m.named_parameters())
-    assert red.keys[:2] == Seg.param_keys and red.keys[2] == "mid_offset_head_c3.2.weight" and red.keys[-1] == "c0_conv.0.weight"
+    assert red.keys[:3] == Seg.param_keys and red.keys[3] == "mid_offset_head_c3.2.weight" and red.keys[-1] == "c0_conv.0.weight"
     assert red.flat.numel() == sum(p.numel() for p in m.parameters()) and len(red.buckets) >= 2
     eng = m._engine
+    eng.overflow_flag = torch.zeros(1, dtype=torch.int32)      # sticky non-finite flag of the half-precision backward (KGnet.grad_overflowed)
+    produced_seg = Seg.param_keys[:2]
     ok = True
     for step in range(2):
         red.begin_step()
+        if step == 1 and rank == 1:
+            eng.overflow_flag.fill_(1)                       # one rank's backward produced a non-finite gradient
         base = red.flat.data_ptr()
         # seg backward runs on rank 0 only (rank 1 has no valid box): its slots must count as zeros there
         if rank == 0:
-            for k in Seg.param_keys:
+            for k in produced_seg:
                 g = eng.grad_store.get(k); g.fill_(7.0 * (step + 1))
                 assert red.owns(k, g) and red.deliver(k, names[k]) is None
             red.seg_done()
@@ -140,8 +145,10 @@ def _flat_worker(rank, world, port, out):
         for i, k in enumerate(order):
             ok = ok and names[k].grad.data_ptr() == red.get(k).data_ptr()            # .grad is the slot: nothing was copied
             ok = ok and float((names[k].grad - 3.0 * (i + 1) * (step + 1)).abs().max()) == 0.0
-        for k in Seg.param_keys:
+        for k in produced_seg:      # produced on rank 0 only: every rank holds the sum
             ok = ok and names[k].grad is not None and float((names[k].grad - 7.0 * (step + 1)).abs().max()) == 0.0
+        ok = ok and names["skip_combine.3.up.0.weight"].grad is None       # produced by no rank: stays None everywhere (as in one process)
+        ok = ok and int(eng.overflow_flag) == (1 if step == 1 else 0)      # the flag of rank 1 is every rank's after finish()
         for p in m.parameters():
             p.grad = None                                  # optimizer.zero_grad(set_to_none=True)
     # the contract is asserted: a forward that starts while a parameter still carries a gradient (no zero_grad: accumulation over
