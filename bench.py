@@ -64,7 +64,7 @@ def make_batch(N, S, nboxes, seed, dev):
 class KernelTimer:
     """HIP-event brackets around every kg_conv2d_igemm / kg_conv2d_wgrad launch on the launch stream."""
 
-    DOMINANT = "conv_halo<7,1>"    # conv_halo_kernel<7,1,8,0>: the 7x7 LDS-halo kernel (forward + input gradient of the head convs)
+    DOMINANT = "conv_halo_kernel<7, 1, 8, 0>"    # the 7x7 LDS-halo kernel (forward + input gradient of the head convs), rocprofv3's name
 
     def __init__(self):
         self.rec = []
@@ -76,6 +76,10 @@ class KernelTimer:
         from kg_instance_segmentation_amd import ops
         timer = self
         orig_conv, orig_wgrad = ops.conv_igemm, ops.conv_wgrad
+        from kg_instance_segmentation_amd import _lib as klib
+
+        def kname(t):      # rocprofv3's name of the kernel the call just launched (kg_last_kernel): the table uses the profiler's names
+            return klib.last_kernel(ops.fmt_of(t))
 
         def flushq():      # the batched weight (re)pack rides in front of a step's first conv launch: keep it out of that launch's bracket
             ops.flush_packs()
@@ -87,7 +91,7 @@ class KernelTimer:
             tile = k.get("tile", 0) or (1 if cout <= 16 else 2 if cout <= 32 else 3 if cout <= 64 else 4)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             flushq(); s.record(); r = orig_conv(x, pw, cout, geom, *a, **k); e.record()
-            timer.rec.append((f"conv_igemm_tile{tile}", 2.0 * M * cout * KH * KW * getattr(pw, "cin_real", pw.cin_pad), s, e, f"M={M} cout={cout} k={KH} cinp={pw.cin_pad} mode={k.get('mode', 0)}"))
+            timer.rec.append((kname(x), 2.0 * M * cout * KH * KW * getattr(pw, "cin_real", pw.cin_pad), s, e, f"M={M} cout={cout} k={KH} cinp={pw.cin_pad} mode={k.get('mode', 0)} tile={tile}"))
             return r
 
         def wgrad(x, dy, cin, cout, geom, grads, *a, **k):
@@ -96,7 +100,7 @@ class KernelTimer:
             M, _, _, _, _, KH, KW, _, _ = geom
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             flushq(); s.record(); r = orig_wgrad(x, dy, cin, cout, geom, grads, *a, **k); e.record()
-            timer.rec.append((f"conv_wgrad_{r}{KH}x{KW}", 2.0 * M * cout * KH * KW * cin, s, e, f"M={M} cout={cout} cin={cin} mode={k.get('mode', 0)}"))
+            timer.rec.append((kname(x) + " (+ split reduction)", 2.0 * M * cout * KH * KW * cin, s, e, f"M={M} cout={cout} cin={cin} k={KH} mode={k.get('mode', 0)} route={r}"))
             return r
         orig_halo = ops.conv_halo
 
@@ -108,7 +112,7 @@ class KernelTimer:
             flushq(); s.record(); r = orig_halo(x, pw, cout, N, H, W, KS, *a, **k); e.record()
             cin = k.get("algo_cin") or getattr(pw, "cin_real", pw.cin_pad)     # real channels (not the 8 / 64 padding, not the plane copies); fused second-layer head dgrad: 5 / 10 / 40 real dY channels per head
             fl = 2.0 * N * H * W * cout * KS * KS * cin
-            timer.rec.append((f"conv_halo<{KS},{wc}>" + ("k1skip" if k.get("k1skip") else ""), fl, s, e, f"N={N} H={H} cout={cout} cinp={pw.cin_pad} products={pw.vp}" + (f" algo_cin={cin}" if "algo_cin" in k else ""), fl * pw.vp))
+            timer.rec.append((kname(x), fl, s, e, f"N={N} H={H} cout={cout} cinp={pw.cin_pad} products={pw.vp}" + (f" algo_cin={cin}" if "algo_cin" in k else ""), fl * pw.vp))
             return r
         orig_1x1 = ops.conv1x1
 
@@ -117,7 +121,7 @@ class KernelTimer:
                 return orig_1x1(x, pw, cout, y, *a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             flushq(); s.record(); r = orig_1x1(x, pw, cout, y, *a, **k); e.record()
-            timer.rec.append(("conv1x1", 2.0 * x.shape[0] * cout * getattr(pw, "cin_real", pw.cin_pad), s, e, f"M={x.shape[0]} cout={cout} K={pw.cin_pad}"))
+            timer.rec.append((kname(x), 2.0 * x.shape[0] * cout * getattr(pw, "cin_real", pw.cin_pad), s, e, f"M={x.shape[0]} cout={cout} K={pw.cin_pad}"))
             return r
         orig_h2 = ops.conv_halo_heads2
 
@@ -126,7 +130,7 @@ class KernelTimer:
                 return orig_h2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             flushq(); s.record(); r = orig_h2(x, pw, bias64, vmap, kp, sh, md, N, H, W, C, **k); e.record()
-            timer.rec.append(("conv_halo_heads2<7>", 2.0 * N * H * W * 55 * 49 * C, s, e, f"N={N} H={H} cout=5+10+40 C={C}"))
+            timer.rec.append((kname(x), 2.0 * N * H * W * 55 * 49 * C, s, e, f"N={N} H={H} cout=5+10+40 C={C}"))
             return r
         # engine/seg call through `ops.<fn>` (and conv_auto resolves these names at call time)
         ops.conv_igemm, ops.conv_wgrad, ops.conv_halo, ops.conv1x1, ops.conv_halo_heads2 = conv, wgrad, halo, c1x1, heads2
@@ -150,35 +154,50 @@ class KernelTimer:
         return {k: {"seconds": v[0], "flops": v[1], "launches": v[2], "mfma_flops": v[3]} for k, v in agg.items()}
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (tools/profile_round.sh ->
-    profiles/*_pmc_hbm.json: 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, gfx950 correction of MI355X_MICROARCH.md), or None."""
+def _build_id():
+    import hashlib
+    from kg_instance_segmentation_amd import _lib as klib
+    h = hashlib.sha256()
+    for path in (klib.LIB_PATH, klib.LIB_F16_PATH):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_file(suffix):
+    """The newest committed rocprofv3 PMC summary (tools/profile_round.sh -> profiles/*_<suffix>.json) that was collected ON THIS BUILD: the file
+    records the sha256 of the two libraries (tools/pmc_summary.py) and is refused when it differs from the libraries this process loads."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), reverse=True):
+    bid = _build_id()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{suffix}.json")), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
-        for k, v in d.items():
-            if k.replace(" ", "") in ("conv_halo_kernel<7,1,8>", "conv_halo_kernel<7,1,8,0>") and "hbm_bytes" in v:
-                return v["hbm_bytes"]
+        if d.get("_build", {}).get("libs_sha256_16") == bid:
+            return d, os.path.basename(path)
+    return None, None
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC pass of THIS build (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, gfx950
+    correction of MI355X_MICROARCH.md), or None when no committed pass matches the loaded libraries."""
+    d, _ = _pmc_file("pmc_hbm")
+    for k, v in (d or {}).items():
+        if k.replace(" ", "") in ("conv_halo_kernel<7,1,8>", "conv_halo_kernel<7,1,8,0>") and "hbm_bytes" in v:
+            return v["hbm_bytes"]
     return None
 
 
 def pmc_mfma():
-    """MFMA-pipe utilisation and effective shader clock of the dominant kernel from the committed PMC pass
-    (profiles/*_pmc_mfma_lds.json: SQ_VALU_MFMA_BUSY_CYCLES summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs), or None."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_mfma_lds.json")), reverse=True):
-        try:
-            d = json.load(open(path))
-        except Exception:
-            continue
-        for k, v in d.items():
-            if k.replace(" ", "") == "conv_halo_kernel<7,1,8,0>" and v.get("GRBM_GUI_ACTIVE"):
-                return {"mfma_busy_frac": (v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (v["GRBM_GUI_ACTIVE"] / 8.0),
-                        "active_cycles_per_launch": v["GRBM_GUI_ACTIVE"] / 8.0,
-                        "lds_bank_conflict_cycles": v.get("SQ_LDS_BANK_CONFLICT")}
+    """MFMA-pipe utilisation of the dominant kernel from the PMC pass of THIS build (SQ_VALU_MFMA_BUSY_CYCLES summed over the 1024 SIMDs,
+    GRBM_GUI_ACTIVE over the 8 XCDs), or None when no committed pass matches the loaded libraries."""
+    d, name = _pmc_file("pmc_mfma_lds")
+    for k, v in (d or {}).items():
+        if k.replace(" ", "") == "conv_halo_kernel<7,1,8,0>" and v.get("GRBM_GUI_ACTIVE"):
+            return {"mfma_busy_frac": (v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (v["GRBM_GUI_ACTIVE"] / 8.0),
+                    "active_cycles_per_launch": v["GRBM_GUI_ACTIVE"] / 8.0,
+                    "lds_bank_conflict_cycles": v.get("SQ_LDS_BANK_CONFLICT"), "file": name}
     return None
 
 
@@ -631,19 +650,21 @@ def main():
             issued = dom["mfma_flops"] / dom["seconds"] / 1e12
             prod = dom["mfma_flops"] / dom["flops"]
             pm = pmc_mfma()
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel<7,1,8,0> (7x7 head convs, forward + input gradient)",
-                               "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS / prod, "unit": "TFLOP/s", "frac": issued / MFMA_BF16_PEAK_TFLOPS,
-                               "products_per_multiply": prod, "mfma_issued_tflops": issued,
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel<7, 1, 8, 0> (7x7 head convs, forward + input gradient)",
+                               "achieved": issued, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / MFMA_BF16_PEAK_TFLOPS,
+                               "achieved_algorithmic": ach, "frac_algorithmic": ach / MFMA_BF16_PEAK_TFLOPS,
+                               "products_per_multiply": prod,
                                "traffic": pmc_traffic(), "avg_launch_ms": 1e3 * dom["seconds"] / dom["launches"],
                                "launches": dom["launches"], "share_of_step": dom["seconds"] / dt,
-                               "pmc": pm and dict(pm, effective_clock_ghz=pm["active_cycles_per_launch"] / (1e9 * dom["seconds"] / dom["launches"]),
-                                                  note="committed rocprofv3 PMC pass: MFMA-pipe busy / active cycles of this kernel; clock = profiled "
-                                                       "active cycles per launch / this run's launch time (DVFS: below 2.4 GHz under MFMA load)") if args.batch == 8 else pm,
-                               "note": "achieved = algorithmic fp32 conv FLOPs (2*N*H*W*Cout*49*Cin) of the launches / their HIP-event time, measured inside "
-                                       "the timed region; every multiply of the policy is evaluated as `products_per_multiply` 16-bit MFMA products (launch-weighted over "
-                                       "the forward and input-gradient launches of this kernel; `fp32`: 3 in the forward, 1 in the input gradients), so "
-                                       "peak = 2500 TFLOP/s dense f16 / bf16 MFMA / products and frac = MFMA-issued FLOP/s / 2500; traffic = HBM bytes per launch "
-                                       "from the committed PMC pass"}
+                               "build": _build_id(),
+                               "pmc": pm and dict(pm, note="rocprofv3 PMC pass of this build (profiles/, build hash checked): MFMA-pipe busy cycles / active "
+                                                          "cycles of this kernel, collected by tools/profile_round.sh on another box run"),
+                               "note": "achieved = 16-bit MFMA FLOPs ISSUED by the launches of this kernel / their HIP-event time, measured inside the timed "
+                                       "region: algorithmic fp32 conv FLOPs (2*N*H*W*Cout*49*Cin, real channel counts) x the plane products each multiply is "
+                                       "evaluated as (`products_per_multiply`, launch-weighted: 3 in the forward launches, 1 in the input-gradient launches of the "
+                                       "default policy); peak = 2500 TFLOP/s dense f16 / bf16 MFMA; frac = achieved / peak.  achieved_algorithmic / "
+                                       "frac_algorithmic = the same launches in fp32-equivalent conv FLOPs (no plane products).  traffic = HBM bytes per launch "
+                                       "from the committed PMC pass of this build, null when the loaded libraries differ from the profiled ones"}
         summ = timer.summary(prof_rec)
         if summ:
             out["kernels"] = {k: {"ms_per_step": 1e3 * v["seconds"] / prof_steps, "tflops": v["flops"] / max(v["seconds"], 1e-12) / 1e12,

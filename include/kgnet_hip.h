@@ -48,6 +48,10 @@ typedef struct kg_planes {
 int kg_rows_format(void);
 
 const char* kg_last_error(void);
+/* Measurement aid: the name rocprofv3 prints (without the argument list) for the conv-family kernel that the calling thread's most recent
+ * kg_conv2d_* / kg_conv1x1 / kg_conv3x3_c64 / kg_conv2d_wgrad* call launched, e.g. "conv_halo_kernel<7, 1, 8, 0>" ("" before the first).
+ * bench.py keys its per-kernel table with it, so that table and the rocprofv3 summaries under profiles/ use the same names. */
+const char* kg_last_kernel(void);
 int kg_version(void);
 int kg_device_arch(char* out, int cap);   /* host buffer */
 int kg_tr_probe(void* out_u16x256, void* stream);                       /* test probe: ds_read_b64_tr_b16 lane map */

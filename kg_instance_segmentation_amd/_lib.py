@@ -87,7 +87,7 @@ _SIGS = {
     "kg_crop_grad_reduce": [P, c_int, P, c_int, c_long, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P],
 }
 _RESTYPE = {"kg_postproc_workspace_bytes": c_long}
-SYMBOLS = tuple(_SIGS) + ("kg_last_error",)
+SYMBOLS = tuple(_SIGS) + ("kg_last_error", "kg_last_kernel")
 
 _lib = None
 _lib_f16 = None
@@ -105,6 +105,8 @@ def _open(path, must_have_all):
     lib = ctypes.CDLL(path)
     lib.kg_last_error.restype = ctypes.c_char_p
     lib.kg_last_error.argtypes = []
+    lib.kg_last_kernel.restype = ctypes.c_char_p
+    lib.kg_last_kernel.argtypes = []
     for name, args in _SIGS.items():
         if must_have_all:
             fn = getattr(lib, name)  # AttributeError => ABI drift, surface it
@@ -138,6 +140,11 @@ def call(name, *args, fmt=0):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise KGLibraryError(f"{name} failed ({rc}): {lib.kg_last_error().decode()}")
+
+
+def last_kernel(fmt=0):
+    """rocprofv3's name of the conv-family kernel this thread's most recent conv call launched (measurement aid, kg_last_kernel)"""
+    return load(fmt).kg_last_kernel().decode()
 
 
 _RAW_STREAM = None

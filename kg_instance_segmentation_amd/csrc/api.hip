@@ -12,6 +12,12 @@ void kg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* kg_last_error(void) { return g_err; }
+
+static thread_local const char* g_kernel = "";
+void kg_note_kernel(const char* name) { g_kernel = name; }
+// Name (as rocprofv3 prints it, without the argument list) of the conv-family kernel the calling thread's most recent kg_conv* / kg_conv2d_wgrad*
+// call launched ("" before the first); helper launches (split reductions, finishing passes) do not change it.
+extern "C" const char* kg_last_kernel(void) { return g_kernel; }
 extern "C" int kg_version(void) { return 101; }
 extern "C" int kg_rows_format(void) { return KG_ROWS_FORMAT; }    // 0: bfloat16 rows (libkgnet_hip.so), 1: IEEE half rows (libkgnet_hip_f16.so)
 

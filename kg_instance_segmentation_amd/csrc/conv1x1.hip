@@ -355,6 +355,7 @@ extern "C" int kg_conv1x1(const void* x, const void* w, const float* bias, void*
         else if (kc == 1) hipLaunchKernelGGL(conv1x1_stream_kernel<1>, dim3((unsigned)gxs, nyb), dim3(256), smem_s, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(conv1x1_stream_kernel<2>, dim3((unsigned)gxs, nyb), dim3(256), smem_s, (hipStream_t)stream, a);
         KG_CHECK_LAUNCH("conv1x1_stream");
+        kg_note_kernel(nb == 4 ? "conv1x1_stream_kernel<1, 4>" : nb == 2 ? "conv1x1_stream_kernel<1, 2>" : kc == 1 ? "conv1x1_stream_kernel<1, 1>" : "conv1x1_stream_kernel<2, 1>");
         return KG_OK;
     }
     const int smem = (K / 64) * 8192;
@@ -373,5 +374,6 @@ extern "C" int kg_conv1x1(const void* x, const void* w, const float* bias, void*
     if (K % 128 == 0) hipLaunchKernelGGL(conv1x1_kernel<4>, dim3((unsigned)gx, ny), dim3(256), smem, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(conv1x1_kernel<2>, dim3((unsigned)gx, ny), dim3(256), smem, (hipStream_t)stream, a);
     KG_CHECK_LAUNCH("conv1x1");
+    kg_note_kernel(K % 128 == 0 ? "conv1x1_kernel<4>" : "conv1x1_kernel<2>");
     return KG_OK;
 }

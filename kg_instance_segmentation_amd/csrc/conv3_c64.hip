@@ -223,5 +223,6 @@ extern "C" int kg_conv3x3_c64(const void* x, const void* w, const float* bias, v
     if (grid > total) grid = total;
     hipLaunchKernelGGL(conv3_c64_kernel, dim3(grid, ny), dim3(512), smem, (hipStream_t)stream, a);
     KG_CHECK_LAUNCH("conv3x3_c64");
+    kg_note_kernel("conv3_c64_kernel");
     return KG_OK;
 }

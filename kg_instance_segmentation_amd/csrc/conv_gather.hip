@@ -205,5 +205,6 @@ int kg_launch_conv_gather(const ConvArgs& a, int cin_pad, hipStream_t st) {
     dim3 grid(kg_cdiv(a.M, 256), kg_cdiv(a.Cout, 128));
     hipLaunchKernelGGL(conv_gather_kernel, grid, dim3(512), smem, st, a, cin_pad / 64);
     KG_CHECK_LAUNCH("conv_gather");
+    kg_note_kernel("conv_gather_kernel");
     return KG_OK;
 }

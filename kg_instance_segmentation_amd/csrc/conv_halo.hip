@@ -567,6 +567,8 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
     a.xcd_map = use_xcd && !a.tiletab && grid.x % 8 == 0 && (grid.y > 1 || use_xcd > 1) && (long)a.Cout * a.K * 2 <= (24L << 20);
     hipLaunchKernelGGL((conv_halo_kernel<KS, WC, WPX, GM>), grid, dim3(WC * WPX * 64), smem, st, a);
     KG_CHECK_LAUNCH("conv_halo");
+    KG_KNAME(kname, "conv_halo_kernel<%d, %d, %d, %d>", KS, WC, WPX, GM);
+    kg_note_kernel(kname);
     return KG_OK;
 }
 

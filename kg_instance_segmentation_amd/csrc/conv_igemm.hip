@@ -219,6 +219,8 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     dim3 grid(kg_cdiv(a.M, TP), kg_cdiv(a.Cout, TC));
     hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, CF, KS>), grid, dim3(NT), smem, st, a);
     KG_CHECK_LAUNCH("conv_igemm");
+    KG_KNAME(kname, "conv_igemm_kernel<%d, %d, %d, %d>", WC, WP, CF, KS);
+    kg_note_kernel(kname);
     return KG_OK;
 }
 

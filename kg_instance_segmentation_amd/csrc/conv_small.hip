@@ -243,6 +243,7 @@ int kg_launch_conv_small(const ConvArgs& a, hipStream_t st) {
     if ((use_mfma || planed || a.oscale) && a.K >= 32 * a.km.total * ((a.ntaps + 3) / 4)) {
         hipLaunchKernelGGL(conv_small_mfma_kernel, dim3((unsigned)((a.M + 255) / 256), kg_cdiv(a.Cout, 64)), dim3(256), 0, st, a);
         KG_CHECK_LAUNCH("conv_small_mfma");
+        kg_note_kernel("conv_small_mfma_kernel");
         return KG_OK;
     }
     const int smem = a.ntaps * 8 * 64 * 4;
@@ -257,6 +258,7 @@ int kg_launch_conv_small(const ConvArgs& a, hipStream_t st) {
     if (gx > groups) gx = groups;
     hipLaunchKernelGGL(conv_small_kernel, dim3((unsigned)gx, kg_cdiv(a.Cout, 64)), dim3(256), smem, st, a);
     KG_CHECK_LAUNCH("conv_small");
+    kg_note_kernel("conv_small_kernel");
     return KG_OK;
 }
 

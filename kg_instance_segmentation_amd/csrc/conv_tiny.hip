@@ -206,6 +206,7 @@ int kg_launch_conv_tiny(const ConvArgs& a, int cin_virt, hipStream_t st) {
     dim3 grid(kg_cdiv(a.M, 64), kg_cdiv(a.Cout, 64), Z);
     hipLaunchKernelGGL(conv_tiny_kernel, grid, dim3(256), smem, st, a, cin_virt / 64, part[dev]);
     KG_CHECK_LAUNCH("conv_tiny");
+    kg_note_kernel("conv_tiny_kernel");
     if (Z > 1) {
         hipLaunchKernelGGL(conv_tiny_finish_kernel, dim3(grid.x, grid.y), dim3(256), 0, st, a, Z, (const float*)part[dev]);
         KG_CHECK_LAUNCH("conv_tiny_finish");

@@ -323,6 +323,7 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
         dim3 grid128(((cin_lim + 127) / 128) * ((cout_lim + 127) / 128), KH * KW, nsplit);
         hipLaunchKernelGGL(conv_wgrad128_kernel, grid128, dim3(256), 0, (hipStream_t)stream, a);
         KG_CHECK_LAUNCH("conv_wgrad128");
+        kg_note_kernel("conv_wgrad128_kernel");
         return KG_OK;
     }
     dim3 grid(((cin_lim + 63) / 64) * ((cout_lim + 63) / 64), KH * KW, nsplit);
@@ -331,6 +332,7 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
     else
         hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     KG_CHECK_LAUNCH("conv_wgrad");
+    kg_note_kernel("conv_wgrad_kernel");
     return KG_OK;
 }
 

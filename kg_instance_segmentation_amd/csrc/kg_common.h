@@ -47,6 +47,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define KG_ERR_HIP 2
 
 void kg_set_error(const char* fmt, ...);
+// Measurement aid (kg_last_kernel, api.hip): every conv-family launcher notes the name of the kernel it launched -- the name rocprofv3
+// prints for it -- so that bench.py's per-kernel table carries the profiler's own kernel names.  Thread-local, a pointer store per launch.
+void kg_note_kernel(const char* name);
+#define KG_KNAME(buf, fmt, ...) static char buf[96] = ""; if (!buf[0]) snprintf(buf, sizeof(buf), fmt, __VA_ARGS__)
 
 #define KG_CHECK_ARG(cond, ...)                 \
     do {                                        \

@@ -309,6 +309,8 @@ static int launch_wg(const WgHaloArgs& a, hipStream_t st) {
     const int n_ci = (a.cin_lim + 16 * CIF - 1) / (16 * CIF), n_co = (a.cout_lim + 63) / 64;
     hipLaunchKernelGGL((wgrad_halo_kernel<KS, CIF, NCF, BIAS>), dim3(n_ci * n_co, a.nsplit), dim3(512), smem, st, a);
     KG_CHECK_LAUNCH("wgrad_halo");
+    KG_KNAME(kname, "wgrad_halo_kernel<%d, %d, %d, %s>", KS, CIF, NCF, BIAS ? "true" : "false");
+    kg_note_kernel(kname);
     return KG_OK;
 }
 

@@ -174,6 +174,8 @@ class Engine:
         self.raw_kp_logits = False   # test hook: inference-only export of the kp LOGITS instead of sigmoid(logits) (KGnet.py:300)
         self.grad_store = None     # parallel.FlatGradReducer: key -> persistent fp32 view the gradient kernels write into directly
         self.grad_hook = None      # parallel.FlatGradReducer.attach: called with [(key, grad)] as backward produces them
+        self.phase_hook = None     # profiling (tools/phase_probe.py): called with ("fwd" | "bwd", label) where forward_dec / backward_dec enter a part of the network
+        self.phase_marks = []
 
     def set_precision(self, precision):
         if precision not in PRECISIONS:
@@ -506,6 +508,11 @@ class Engine:
         y, _, _ = self.conv_bn(b, self.spec(p + ".conv3", planes, planes * 4, 1, bias=False), p + ".bn3", N, OH, OW, True, res=idt, out=out)
         return y, OH, OW
 
+    def _phase(self, label):
+        if self.phase_hook is not None:
+            self.phase_marks.append((label, len(self.tape) if self.tape is not None else 0))
+            self.phase_hook("fwd", label)
+
     def forward_dec(self, img, record):
         """img fp32 [N,3,H,W].  Returns (maps: 12 fp32 NCHW tensors, feats: 5 Vars, dims)."""
         N, _, H, W = img.shape
@@ -528,6 +535,8 @@ class Engine:
         # BatchNorm amplifier of storage errors is gone, and "mixed" batch-1 inference is 25 % faster in plain bf16.)
         self.bpt = self.pt if (self.m.training or not self.eval_downgrade) else min(self.pt, max(self.pd, 1))
         pt, pd = self.bpt, self.pd
+        self.phase_marks = []
+        self._phase("c0_conv")
         x8 = Var(ops.img_pack(img, max(pt, pd), dtype=self.dt), 8, relu=False, req=False)
         dims = [(H, W)]
         # c0 branch (KGnet.py:276): both convs at full resolution; c0 lands in cat0[:, 64:128]
@@ -535,6 +544,7 @@ class Engine:
         c0a, _, _ = self.conv(x8, self.spec("c0_conv.0", 3, 64, 3, 1, 1, P=pd), N, H, W, True)
         c0, _, _ = self.conv(c0a, self.spec("c0_conv.2", 64, 64, 3, 1, 1, P=pd), N, H, W, True, out=cat0.cols(64, 128))
         # stem (KGnet.py:278-282)
+        self._phase("stem")
         H1, W1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         cat1 = ops.alloc_pt(N * H1 * W1, 128, pt, dev, dtype=self.dt)
         c1, _, _ = self.conv_bn(x8, self.spec("conv1", 3, 64, 7, 2, 3, bias=False), "bn1", N, H, W, True, out=cat1.cols(64, 128), bn_stats=False)
@@ -543,6 +553,7 @@ class Engine:
         feats = [c0, c1]
         cats = [cat0, cat1]
         for li, (name, inplanes, planes, blocks, stride) in enumerate(self.m.layers_tab):
+            self._phase(name)
             for b in range(blocks):
                 st = stride if b == 0 else 1
                 Ho, Wo = (Hc - 1) // st + 1, (Wc - 1) // st + 1
@@ -556,6 +567,7 @@ class Engine:
             feats.append(f)
             dims.append((Hc, Wc))
         # top-down decoder (KGnet.py:288-298)
+        self._phase("decoder")
         cur = feats[4]
         catv = {}
         up_ch = {3: (1024, 512), 2: (512, 256), 1: (256, 64), 0: (64, 64)}
@@ -573,12 +585,14 @@ class Engine:
         maps = []
         self.head_slots = []
         for lvl in range(4):
+            self._phase(f"heads_c{lvl}")
             C = arch.HEAD_CH[lvl]
             Hh, Wh = dims[lvl]
             fused = [f"{h}_head_c{lvl}.0" for h, _ in arch.HEADS]
             hid, _, _ = self.conv(catv[lvl], self.spec(f"heads_c{lvl}.0", C, C, 7, 1, 3, fused=fused, P=self.ph), N, Hh, Wh, True)
             outs = self.heads_second(hid, lvl, C, N, Hh, Wh)
             maps.extend(outs)
+        self._phase("end")
         if self.nbt:
             torch._foreach_add_(self.nbt, 1)
             self.nbt = []
@@ -721,7 +735,14 @@ class Engine:
         hook = self.grad_hook
         tape, self.tape = self.tape, None
         try:
+            marks = list(self.phase_marks) if self.phase_hook is not None else None
             while tape:                              # (popped as they run: a closure and the activations only it still holds die right away)
+                if marks is not None:
+                    while marks and marks[-1][1] >= len(tape):
+                        marks.pop()
+                    if marks and marks[-1][0] != getattr(self, "_bwd_phase", None):
+                        self._bwd_phase = marks[-1][0]
+                        self.phase_hook("bwd", self._bwd_phase)
                 fn = tape.pop()
                 n0 = len(self.param_grads)
                 fn()
@@ -730,6 +751,9 @@ class Engine:
                     hook(list(self.param_grads.items())[n0:], False)    # enqueued go to the bucketed all-reduce right away
             if hook is not None:
                 hook([], True)
+            if marks is not None:
+                self._bwd_phase = None
+                self.phase_hook("bwd", "end")
         except BaseException:
             # a failing launch must not leave this pass's scale state behind: later add_grad / to_current_scale calls of ANY model in
             # the process consult Var.ENG, and the next backward of this engine would start from a stale running scale

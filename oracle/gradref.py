@@ -43,3 +43,32 @@ def summarize(errs):
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
     return {"n": int(v.size), "median": float(np.median(v)), "p90": float(np.quantile(v, 0.9)), "max": float(v.max()),
             "worst": [(n, float(e)) for n, e in worst]}
+
+
+def column(g, ref, floor):
+    errs, degenerate = {}, []
+    for n, r in ref.items():
+        if r is None or g.get(n) is None:
+            continue
+        if float(r.double().norm()) / max(r.numel(), 1) ** 0.5 < floor:
+            degenerate.append(n)
+            continue
+        errs[n] = rel_l2(g[n], r)
+    s = summarize(errs)
+    s["degenerate"] = degenerate
+    s["per_tensor"] = errs
+    return s
+
+
+def by_group(errs):
+    """median error per group of parameters (where in the network the error lives)"""
+    groups = {"heads .2 (7x7 second layers)": lambda n: "_head_c" in n and ".2." in n, "heads .0 (7x7 first layers)": lambda n: "_head_c" in n and ".0." in n,
+              "decoder + c0_conv": lambda n: n.startswith(("c0_conv", "c1_up", "c2_up", "c3_up", "c4_up", "c0_cat", "c1_cat", "c2_cat", "c3_cat")),
+              "seg branch": lambda n: n.startswith(("skip_combine", "seg_head")), "layer3": lambda n: n.startswith("layer3"),
+              "layer2": lambda n: n.startswith("layer2"), "layer1": lambda n: n.startswith("layer1"), "stem": lambda n: n.startswith(("conv1", "bn1"))}
+    out = {}
+    for gname, f in groups.items():
+        v = [e for n, e in errs.items() if f(n)]
+        if v:
+            out[gname] = {"median": float(np.median(v)), "max": float(np.max(v)), "n": len(v)}
+    return out

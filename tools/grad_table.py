@@ -52,35 +52,6 @@ def gpu_grads(sd, policy, batch, H, W):
     return float(loss), {n: (p.grad.detach().double().cpu() if p.grad is not None else None) for n, p in m.named_parameters()}
 
 
-def column(g, ref, floor):
-    errs, degenerate = {}, []
-    for n, r in ref.items():
-        if r is None or g.get(n) is None:
-            continue
-        if float(r.double().norm()) / max(r.numel(), 1) ** 0.5 < floor:
-            degenerate.append(n)
-            continue
-        errs[n] = gradref.rel_l2(g[n], r)
-    s = gradref.summarize(errs)
-    s["degenerate"] = degenerate
-    s["per_tensor"] = errs
-    return s
-
-
-def by_group(errs):
-    """median error per group of parameters (where in the network the error lives)"""
-    groups = {"heads .2 (7x7 second layers)": lambda n: "_head_c" in n and ".2." in n, "heads .0 (7x7 first layers)": lambda n: "_head_c" in n and ".0." in n,
-              "decoder + c0_conv": lambda n: n.startswith(("c0_conv", "c1_up", "c2_up", "c3_up", "c4_up", "c0_cat", "c1_cat", "c2_cat", "c3_cat")),
-              "seg branch": lambda n: n.startswith(("skip_combine", "seg_head")), "layer3": lambda n: n.startswith("layer3"),
-              "layer2": lambda n: n.startswith("layer2"), "layer1": lambda n: n.startswith("layer1"), "stem": lambda n: n.startswith(("conv1", "bn1"))}
-    out = {}
-    for gname, f in groups.items():
-        v = [e for n, e in errs.items() if f(n)]
-        if v:
-            out[gname] = {"median": float(np.median(v)), "max": float(np.max(v)), "n": len(v)}
-    return out
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("policies", nargs="*")
@@ -102,20 +73,20 @@ def main():
         sd = weightgen.gen_state_dict(0, variant=fx)
         t0 = time.time(); l64, g64 = gradref.oracle_grads(sd, *batch, S, S, torch.float64); t64 = time.time() - t0
         t0 = time.time(); l32, g32 = gradref.oracle_grads(sd, *batch, S, S, torch.float32); t32 = time.time() - t0
-        res = {"loss_f64": l64, "oracle_seconds": {"f64": t64, "f32": t32}, "oracle_fp32": column(g32, g64, args.floor)}
+        res = {"loss_f64": l64, "oracle_seconds": {"f64": t64, "f32": t32}, "oracle_fp32": gradref.column(g32, g64, args.floor)}
         res["oracle_fp32"]["loss_rel_err"] = abs(l32 - l64) / abs(l64)
         grads = {}
         for p in pols:
             lp, gp = gpu_grads(sd, p, batch, S, S)
             grads[p] = gp
-            res[p] = column(gp, g64, args.floor)
+            res[p] = gradref.column(gp, g64, args.floor)
             res[p]["loss_rel_err"] = abs(lp - l64) / abs(l64)
             res[p]["ratio_to_oracle_fp32"] = {k: res[p][k] / max(res["oracle_fp32"][k], 1e-300) for k in ("median", "p90", "max")}
-            res[p]["groups"] = by_group(res[p]["per_tensor"])
-        res["oracle_fp32"]["groups"] = by_group(res["oracle_fp32"]["per_tensor"])
+            res[p]["groups"] = gradref.by_group(res[p]["per_tensor"])
+        res["oracle_fp32"]["groups"] = gradref.by_group(res["oracle_fp32"]["per_tensor"])
         if "fp32" in grads and "fp32b2" in grads:      # identical forward: the pure effect of single-plane backward operands
-            res["fp32_vs_fp32b2"] = column(grads["fp32"], grads["fp32b2"], args.floor)
-            res["fp32_vs_fp32b2"]["groups"] = by_group(res["fp32_vs_fp32b2"]["per_tensor"])
+            res["fp32_vs_fp32b2"] = gradref.column(grads["fp32"], grads["fp32b2"], args.floor)
+            res["fp32_vs_fp32b2"]["groups"] = gradref.by_group(res["fp32_vs_fp32b2"]["per_tensor"])
         table[fx] = res
         print(f"== fixture {fx}: loss {l64:.6f}; float64 oracle {t64:.0f} s, float32 oracle {t32:.1f} s", flush=True)
         print("| column | median | p90 | max | worst tensor | x oracle_fp32 (median / p90 / max) |")
