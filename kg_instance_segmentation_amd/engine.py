@@ -51,6 +51,7 @@ PRECISIONS = {
 }
 HALF_POLICIES = ("fp32", "fp32b2", "half", "halfmix")
 DEFAULT_PRECISION = "fp32"
+PRE = [0]        # prepack generation counter (Engine.prepack)
 
 
 def default_precision():
@@ -174,6 +175,7 @@ class Engine:
         self.raw_kp_logits = False   # test hook: inference-only export of the kp LOGITS instead of sigmoid(logits) (KGnet.py:300)
         self.grad_store = None     # parallel.FlatGradReducer: key -> persistent fp32 view the gradient kernels write into directly
         self.grad_hook = None      # parallel.FlatGradReducer.attach: called with [(key, grad)] as backward produces them
+        self.prepack_state = None  # prepack(): {"epoch", "stamp", "seg_stamp"} of weights packed ahead of the next training forward
         self.phase_hook = None     # profiling (tools/phase_probe.py): called with ("fwd" | "bwd", label) where forward_dec / backward_dec enter a part of the network
         self.phase_marks = []
 
@@ -206,6 +208,7 @@ class Engine:
         """Forget every packed-weight / folded-BatchNorm copy (call after writing parameters behind PyTorch's back)."""
         self.specs, self.bn_eval, self.fusedT, self.heads2_seen = {}, {}, {}, {}
         self._heads2 = None
+        self.prepack_state = None
 
     # ---- parameters ---------------------------------------------------------------------------
     def P(self, key):
@@ -272,6 +275,29 @@ class Engine:
                 self.prepare_heads2(lvl, C, dev, train)
         finally:
             ops.PACKQ.defer = False
+
+    def prepack(self):
+        """Pack the weights of the NEXT training forward now (optim.Adam(..., prepack=model) calls this right after its update kernel is
+        enqueued): the host builds the pack table and the GPU runs the batched pack while the host would otherwise sit in the step's
+        loss read-back (train.py:156), instead of between that read-back and the first kernel of the next step (the GPU idles there).
+        The next recorded forward reuses these copies iff nothing has written parameters since (ops.PARAM_EPOCH unchanged, tensor
+        versions / pointers unchanged); anything else -- another optimizer, an in-place edit, an eval forward in between -- repacks as
+        before.  Writes through `.data` after the optimizer step and before the forward are invisible to both checks: do not combine
+        them with prepack."""
+        if not self.m.training or not self.specs:
+            return
+        PRE[0] += 1
+        stamp = ("p", PRE[0], 0)
+        saved, self.stamp = self.stamp, stamp
+        seg = self.m._seg
+        seg_saved, seg.stamp = seg.stamp, stamp
+        try:
+            self.prepare_all(True)
+            seg.prepare_all(True)
+            ops.flush_packs()
+        finally:
+            self.stamp, seg.stamp = saved, seg_saved
+        self.prepack_state = {"epoch": ops.PARAM_EPOCH[0], "stamp": stamp}
 
     def prepare(self, s, need_T):
         """(Re)pack weights: every recorded (training) forward repacks -- optimizers that write through `.data` or fused
@@ -529,6 +555,11 @@ class Engine:
             if self.grad_store is not None:
                 self.grad_store.begin_step()
         self.stamp = ("t" if record else "e", self.train_steps, ops.PARAM_EPOCH[0])
+        pre, self.prepack_state = self.prepack_state, None
+        self.m._seg.prepack_stamp = None
+        if record and pre is not None and pre["epoch"] == ops.PARAM_EPOCH[0]:      # weights packed ahead by prepack(): same stamp -> nothing to repack
+            self.stamp = pre["stamp"]
+            self.m._seg.prepack_stamp = pre["stamp"]
         self.prepare_all(record)
         # Backbone planes: the policy's, in train AND eval mode.  (`eval_downgrade` -- opt-in, KG_EVAL_DOWNGRADE=1 or
         # engine.eval_downgrade = True -- runs an eval-mode backbone on the decoder's planes instead: with running statistics the

@@ -128,6 +128,7 @@ class SegBranch:
         self.param_keys += ["seg_head.0.weight", "seg_head.0.bias", "seg_head.2.weight", "seg_head.2.bias"]
         self.packed = {}
         self.train_steps, self.stamp = 0, ("e", 0, 0)     # see Engine.prepare: training forwards always repack
+        self.prepack_stamp = None                         # Engine.prepack / forward_dec: the stamp the weights of this step were packed ahead under
 
     @property
     def P_(self):
@@ -377,6 +378,9 @@ class SegBranch:
         if record:
             self.train_steps += 1
         self.stamp = ("t" if record else "e", self.train_steps, ops.PARAM_EPOCH[0])
+        if record and self.prepack_stamp is not None:
+            self.stamp = self.prepack_stamp
+        self.prepack_stamp = None
         self.prepare_all(record)
         fr = [f if isinstance(f, PT) else self.feat_rows(f) for f in feats]
         CH = arch.FEAT_CH
