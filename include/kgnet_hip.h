@@ -235,6 +235,11 @@ int kg_mask_inter_pairs(const void* a, const void* b, const int* pairs, int npai
 /* ---- per-box segmentation branch (KGnet.py:246-267, 321-350): ragged row bookkeeping ---- */
 int kg_seg_build_rows(const int* boxtab8, int nb, int* rowdesc, int* row2box, int* srcrow, void* stream);
 int kg_rows_gather(const void* src, int ldsrc, const int* srcrow, void* dst, int lddst, long nrows, int C, void* stream);
+/* seg_head.2 (KGnet.py:145-147: Conv2d(64, 1, 3, padding=1), used at KGnet.py:266): the one-output-channel 3x3 conv over the ragged pixel
+ * list as a per-pixel dot product (zero padding at the box border, as each crop is convolved on its own).  x: rows [M][ldx], C = 64 channels
+ * (planes: a); w: fp32 OIHW [1][64][3][3], the master parameter itself; bias: fp32 [1] or NULL; rowdesc: kg_seg_build_rows; y: fp32 [M] logits. */
+int kg_seg_conv3_c1(const void* x, int ldx, int C, const float* w, const float* bias, const int* rowdesc, long M, float* y,
+                    const kg_planes_t* planes, void* stream);
 int kg_f32_to_bf16_rows(const float* acc, void* out, int C, long rows, int ldout, const void* addto, int ldadd,
                         void* stream);
 /* crops of the fp32 feature maps forward_dec returns (KGnet.py:318 -> get_patches :246-256): dst (planes y) = src_f32[srcrow[r]] */

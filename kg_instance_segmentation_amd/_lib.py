@@ -79,6 +79,7 @@ _SIGS = {
     "kg_f64_probe": [P, P, P, c_int, P],
     "kg_seg_build_rows": [P, c_int, P, P, P, P],
     "kg_rows_gather": [P, c_int, P, P, c_int, c_long, c_int, P],
+    "kg_seg_conv3_c1": [P, c_int, c_int, P, P, P, c_long, P, P, P],
     "kg_f32_to_bf16_rows": [P, P, c_int, c_long, c_int, P, c_int, P],
     "kg_rows_gather_f32": [P, c_int, P, P, c_int, c_long, c_int, P, P],
     "kg_planes_to_f32": [P, c_int, P, c_int, c_long, c_int, P, P],

@@ -219,3 +219,62 @@ extern "C" int kg_crop_grad_reduce(const void* ga, int lda, const void* gb, int 
     KG_CHECK_LAUNCH("crop_grad_reduce");
     return KG_OK;
 }
+
+// ---- seg_head.2: the 3x3 conv with ONE output channel (KGnet.py:145-147, Conv2d(64, 1, 3, padding=1)) over the ragged pixel list ----------
+// On the MFMA kernels its single cout is padded to a 64-row tile (98 % of the multiplies are zeros: 0.64 ms per train step at 2 400
+// boxes).  It is a dot product per pixel: 9 taps x C channels.  Here 8 lanes share a pixel (lane = 8-channel chunk, one 16-byte load per
+// tap and plane: the 8 lanes of a pixel read one whole 128-byte row), a lane keeps its 9 x 8 fp32 weights in registers for all the pixels
+// it walks, the taps are neighbour rows of the box-major raster list (row +- w +- 1: zero outside the box, the zero padding of the
+// reference's per-crop conv), and the 8 partial sums meet through three wave shuffles in a fixed order.  Arithmetic: the plane sum of x
+// (the exact stored value) times the fp32 master weight, fp32 FMA chain in (tap, channel) order -- not the 3-product MFMA evaluation,
+// but the same values to fp32 rounding.
+template <int C>
+__global__ __launch_bounds__(256) void seg_conv3_c1_kernel(const bf16_t* __restrict__ x, int ldx, int P, int ps, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, const int2* __restrict__ rowdesc, long M,
+                                                           float* __restrict__ y) {
+    static_assert(C == 64, "one 128-byte row per pixel");
+    const int chunk = threadIdx.x & 7;
+    float wr[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wr[t][e] = w[(chunk * 8 + e) * 9 + t];          // OIHW [1][C][3][3]
+    const float b0 = bias ? bias[0] : 0.f;
+    const long stride = (long)gridDim.x * 32;
+    for (long m = (long)blockIdx.x * 32 + (threadIdx.x >> 3); m < M + 31; m += stride) {     // (all lanes stay in the loop for the shuffles)
+        const bool live = m < M;
+        float acc = 0.f;
+        if (live) {
+            const int2 d = rowdesc[m];
+            const int py = d.x >> 16, px = d.x & 0xffff, h = d.y >> 16, wd = d.y & 0xffff;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                if ((unsigned)(py + dy) >= (unsigned)h || (unsigned)(px + dx) >= (unsigned)wd) continue;
+                const bf16_t* xp = x + (m + (long)dy * wd + dx) * ldx + chunk * 8;
+                float v[8];
+                kg_load_planes8(xp, P, ps, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf(v[e], wr[t][e], acc);
+            }
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (live && chunk == 0) y[m] = acc + b0;
+    }
+}
+// x: rows [M][ldx] (planes a of `planes`), C = 64 channels; w: fp32 OIHW [1][64][3][3] (the master parameter); y: fp32 [M].
+extern "C" int kg_seg_conv3_c1(const void* x, int ldx, int C, const float* w, const float* bias, const int* rowdesc, long M, float* y,
+                               const kg_planes_t* planes, void* stream) {
+    const kg_planes_t pp = kg_planes_or_default(planes);
+    KG_CHECK_ARG(kg_planes_ok(pp), "kg_seg_conv3_c1: bad kg_planes_t");
+    KG_CHECK_ARG(x && w && rowdesc && y && C == 64 && ldx % 8 == 0, "kg_seg_conv3_c1: needs 64 input channels (got %d)", C);
+    if (M == 0) return KG_OK;
+    long blocks = (M + 31) / 32;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(seg_conv3_c1_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, pp.a_planes,
+                       pp.a_pstride, w, bias, (const int2*)rowdesc, M, y);
+    KG_CHECK_LAUNCH("seg_conv3_c1");
+    return KG_OK;
+}

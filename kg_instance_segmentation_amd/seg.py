@@ -7,6 +7,7 @@ Host glue (this file) only computes the integer crop rectangles with the referen
 rounding rules and uploads the box tables.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -75,6 +76,9 @@ class LazyList(list):
 
     def append(self, v):
         self._fill(); super().append(v); self._n = super().__len__()
+
+
+SEG_C1 = os.environ.get("KG_SEG_C1", "1") == "1"       # A/B switch: seg_head.2 on the dot-product kernel (kg_seg_conv3_c1)
 
 
 class SegPredictions(list):
@@ -413,8 +417,15 @@ class SegBranch:
         self.rconv(pre[0], pw, 64, plan.rowdesc[0], rows0, 3, y=hid, bias=b, relu=True, tiles=self.T32(plan, 0, plan.nb[0]),
                    tiles16=self.T16(plan, 0, plan.nb[0]))
         flat = torch.empty(rows0, dtype=torch.float32, device=dev)
-        pw, _, b = self.packw("seg_head.2", record)
-        self.rconv(hid, pw, 1, plan.rowdesc[0], rows0, 3, y_f32=flat, bias=b, tiles=self.T32(plan, 0, plan.nb[0]))
+        if SEG_C1:      # one output channel: a per-pixel dot product kernel (csrc/seg.hip), not a 64-row MFMA tile with 63 zero rows
+            _lib.call("kg_seg_conv3_c1", ptr(ops.base(hid)), ops.ld(hid), 64, ptr(self.P("seg_head.2.weight").detach()),
+                      ptr(self.P("seg_head.2.bias").detach()), ptr(plan.rowdesc[0]), c_long(rows0), ptr(flat), ops.pl(a=hid), stream_ptr(),
+                      fmt=ops.fmt_of(hid))
+            if record:
+                self.packw("seg_head.2", True)          # (the input gradient still multiplies the packed transposed weights)
+        else:
+            pw, _, b = self.packw("seg_head.2", record)
+            self.rconv(hid, pw, 1, plan.rowdesc[0], rows0, 3, y_f32=flat, bias=b, tiles=self.T32(plan, 0, plan.nb[0]))
         self.last_logits = flat.clone() if getattr(self, "keep_logits", False) else None     # test hook: pre-sigmoid values
         ops.sigmoid_(flat)
         # (flat.detach(): `flat` itself becomes an OUTPUT of the autograd node that keeps `saved`; holding the output object there is a

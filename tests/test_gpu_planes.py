@@ -394,3 +394,36 @@ def test_crop_grad_reduce_matches_index_add_and_is_deterministic():
                        __import__("kg_instance_segmentation_amd.seg", fromlist=["BIN_SIZE"]).BIN_SIZE[l], N, h, w, C, None, L.ptr(outp.t), ops.ld(outp),
                        ops.pl(a=ga if ga is not None else gb, b=gb, y=outp), L.stream_ptr())
                 assert torch.equal(from_pt(outp), outs[0])
+
+
+@pytest.mark.parametrize("P,dt", VARIANTS, ids=VIDS)
+def test_seg_head_single_cout_conv_on_ragged_rows(P, dt):
+    """kg_seg_conv3_c1 (seg_head.2, KGnet.py:145-147: Conv2d(64, 1, 3, padding=1) on every crop separately): the per-pixel dot-product
+    kernel over a ragged list of boxes against torch's float64 conv2d of each box with zero padding at the box border."""
+    DT[0] = dt
+    from kg_instance_segmentation_amd._lib import c_long, ptr, stream_ptr
+    g = torch.Generator().manual_seed(5)
+    boxes = [(3, 3), (7, 5), (1, 9), (16, 33), (27, 27), (40, 14), (2, 2)]
+    w = (torch.randn(1, 64, 3, 3, generator=g) * 0.1).to(DEV)
+    b = torch.tensor([0.3], device=DEV)
+    tab, xs, row0 = [], [], 0
+    for i, (h, wd) in enumerate(boxes):
+        tab.append([0, 0, 0, h, wd, row0, 512, 512])
+        xs.append(torch.randn(h * wd, 64, generator=g))
+        row0 += h * wd
+    M = row0
+    x32 = torch.cat(xs).to(DEV)
+    xp = to_pt(x32, P)
+    tabd = torch.tensor(tab, dtype=torch.int32, device=DEV)
+    rd = torch.empty(M, 2, dtype=torch.int32, device=DEV); r2b = torch.empty(M, dtype=torch.int32, device=DEV); sr = torch.empty(M, dtype=torch.int32, device=DEV)
+    _lib.call("kg_seg_build_rows", ptr(tabd), len(boxes), ptr(rd), ptr(r2b), ptr(sr), stream_ptr())
+    y = torch.full((M,), float("nan"), device=DEV)
+    _lib.call("kg_seg_conv3_c1", ptr(ops.base(xp)), ops.ld(xp), 64, ptr(w), ptr(b), ptr(rd), c_long(M), ptr(y), ops.pl(a=xp), stream_ptr(), fmt=ops.fmt_of(xp))
+    xv = from_pt(xp).double().cpu()         # the stored values (the rounding of the planes is the storage's, not the kernel's)
+    ref, off = [], 0
+    for h, wd in boxes:
+        img = xv[off:off + h * wd].view(1, h, wd, 64).permute(0, 3, 1, 2)
+        ref.append(F.conv2d(img, w.double().cpu(), b.double().cpu(), padding=1).reshape(-1))
+        off += h * wd
+    check(f"seg_conv3_c1 P={P}", y, torch.cat(ref), 2e-6)
+    DT[0] = BF16

@@ -44,7 +44,7 @@ def worker(rank, world, port, steps, out):
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        t0 = time.perf_counter()
+        t0 = time.perf_counter(); c0 = time.thread_time()
         opt.zero_grad()
         p0, p1, p2, p3, pred = model(x, gt_boxes)
         if den is None:
@@ -53,14 +53,14 @@ def worker(rank, world, port, steps, out):
             l1 = sum(ldec(p, g, denominators=den[i]) for i, (p, g) in enumerate(zip((p0, p1, p2, p3), gt)))
         loss = l1 + lseg(pred, gt_masks, gt_boxes) / world
         loss.backward()
-        t1 = time.perf_counter()                      # everything up to here is enqueue only
+        t1 = time.perf_counter(); c1 = time.thread_time()      # everything up to here is enqueue only
         if red is not None:
             red.finish()                              # (waits for the collectives: device time, not counted as enqueue)
         opt.step()
         t2 = time.perf_counter()
         float(loss)
         if it >= 2:
-            host.append((1e3 * (t1 - t0), 1e3 * (t2 - t0)))
+            host.append((1e3 * (t1 - t0), 1e3 * (t2 - t0), 1e3 * (c1 - c0)))
     out[rank] = host
     if world > 1:
         dist.destroy_process_group()
@@ -81,10 +81,11 @@ def main():
         mp.spawn(worker, args=(world, port, args.steps, out), nprocs=world, join=True)
         a = [v[0] for r in range(world) for v in out[r]]
         b = [v[1] for r in range(world) for v in out[r]]
-        lines.append(f"   {world} rank(s) on {os.cpu_count()} host cores: enqueue mean {sum(a) / len(a):6.2f} ms, max {max(a):6.2f} ms | "
-                     f"incl. finish + optimizer mean {sum(b) / len(b):6.2f} ms, max {max(b):6.2f} ms")
-    lines.append("(the ranks share ONE GPU here, so the device drains R steps one after the other and finish() waits for it: only the enqueue column "
-                 "is a host measurement)")
+        c = [v[2] for r in range(world) for v in out[r]]
+        lines.append(f"   {world} rank(s) on {os.cpu_count()} host cores: enqueue wall mean {sum(a) / len(a):6.2f} ms, max {max(a):6.2f} ms; CPU time of the enqueueing "
+                     f"thread mean {sum(c) / len(c):6.2f} ms, max {max(c):6.2f} ms | incl. finish + optimizer wall mean {sum(b) / len(b):6.2f} ms, max {max(b):6.2f} ms")
+    lines.append("(the ranks share ONE GPU here: the device drains R steps one after the other, finish() waits for it, and once a rank's hardware queue is "
+                 "full its launches block -- WALL enqueue time with R > 1 therefore contains queue back-pressure; the CPU-time column is the host work itself)")
     txt = "\n".join(lines)
     print(txt)
     if args.out:
