@@ -197,6 +197,172 @@ __global__ __launch_bounds__(64) void hough_sum_heavy_kernel(int HW, const int* 
     }
 }
 
+
+// ---- P1, second formulation (the default): one scatter pass with inline slots ------------------------------------------------------
+// The count -> scan -> fill -> sum pipeline above touches every vote with TWO atomic passes (count, cursor), computes every contribution
+// twice and sorts every cell's votes by selection from global memory (hough_sum_light: 138 us of the c0 map of a 512 x 512 image, the
+// waves wait for their heaviest cell).  Here:
+//   scatter : every vote e takes slot s = atomicAdd(cnt[cell]) (ONE returning atomic); the first HOUGH_K votes of a cell land in its
+//             inline slots [cell][HOUGH_K] (key, value); a later one is parked at ITS OWN index of a source-ordered array
+//             (ovcell[e] = cell, ovval[e] = value; ovcell[e] = -1 for every other vote: no counter, no list);
+//   classify: one thread per cell.  n <= HOUGH_K: the votes are sorted by key in registers (odd-even merge network) and summed in
+//             that order -- the reference's sequential COO order (postprocessing.py:36) -- and the cell is done.  Heavier cells get
+//             a slab of n entries in the compact arrays (one 64-bit atomic per 1024-thread workgroup allocates for all its heavy
+//             cells), copy their inline votes to its head and join the heavy list;
+//   ovfill  : the parked votes move behind the inline ones of their cell's slab (atomic cursor per heavy cell);
+//   heavy   : one wave per heavy cell: rank sort by key in LDS (n <= HOUGH_LCAP; through global scratch beyond), lane 0 adds in order.
+// Every sum is still formed in increasing key order from +0.0 with separate fp64 adds (-ffp-contract=off): bit-identical heat maps.
+#define HOUGH_K 8
+#define HOUGH_LCAP 512
+__global__ void hough_scatter_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W, int* __restrict__ cnt,
+                                     unsigned* __restrict__ ink, double* __restrict__ inv, int* __restrict__ ovcell,
+                                     double* __restrict__ ovval) {
+    const int c = blockIdx.y, HW = H * W;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 4 * HW; e += gridDim.x * blockDim.x) {
+        const int b = e / HW, i = e - b * HW;
+        int cell; double v;
+        int park = -1;
+        if (hough_contrib(kp, soff, H, W, c, b, i, &cell, &v)) {
+            const int cc = c * HW + cell;
+            const int slot = atomicAdd(&cnt[cc], 1);
+            if (slot < HOUGH_K) {
+                ink[(long)cc * HOUGH_K + slot] = (unsigned)e;
+                inv[(long)cc * HOUGH_K + slot] = v;
+            } else {
+                park = cc;
+                ovval[(long)c * 4 * HW + e] = v;
+            }
+        }
+        ovcell[(long)c * 4 * HW + e] = park;
+    }
+}
+__device__ __forceinline__ void hough_cswap(unsigned& ka, double& va, unsigned& kb, double& vb) {
+    const bool sw = kb < ka;
+    const unsigned k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const double v0 = sw ? vb : va, v1 = sw ? va : vb;
+    ka = k0; kb = k1; va = v0; vb = v1;
+}
+// ctr64: low 32 bits = entries allocated in the compact arrays, high 32 bits = heavy cells
+__global__ __launch_bounds__(1024) void hough_classify_kernel(int ncells, const int* __restrict__ cnt, const unsigned* __restrict__ ink,
+                                                              const double* __restrict__ inv, double norm, double* __restrict__ heat,
+                                                              unsigned long long* __restrict__ ctr64, int* __restrict__ ovoff,
+                                                              int* __restrict__ heavy_list, unsigned* __restrict__ skey,
+                                                              double* __restrict__ sval) {
+    __shared__ int s_need[1024], s_hv[1024];
+    __shared__ unsigned long long s_base;
+    const int cc = blockIdx.x * 1024 + threadIdx.x;
+    const int n = cc < ncells ? cnt[cc] : 0;
+    unsigned k[HOUGH_K]; double v[HOUGH_K];
+    if (n > 0) {
+        const uint4 k0 = *reinterpret_cast<const uint4*>(ink + (long)cc * HOUGH_K);
+        const uint4 k1 = n > 4 ? *reinterpret_cast<const uint4*>(ink + (long)cc * HOUGH_K + 4) : make_uint4(0, 0, 0, 0);
+        k[0] = k0.x; k[1] = k0.y; k[2] = k0.z; k[3] = k0.w; k[4] = k1.x; k[5] = k1.y; k[6] = k1.z; k[7] = k1.w;
+#pragma unroll
+        for (int q = 0; q < HOUGH_K / 2; ++q) {
+            if (2 * q < n) { const double2 t = *reinterpret_cast<const double2*>(inv + (long)cc * HOUGH_K + 2 * q); v[2 * q] = t.x; v[2 * q + 1] = t.y; }
+            else { v[2 * q] = 0.; v[2 * q + 1] = 0.; }
+        }
+    }
+    const bool heavy = n > HOUGH_K;
+    if (n > 0 && !heavy) {
+#pragma unroll
+        for (int e = 0; e < HOUGH_K; ++e)
+            if (e >= n) k[e] = 0xffffffffu;                      // (keys are < 4 H W <= 2^28: padding sorts to the end and is never added)
+        // odd-even merge sort network for 8 keys (19 comparators)
+        hough_cswap(k[0], v[0], k[1], v[1]); hough_cswap(k[2], v[2], k[3], v[3]); hough_cswap(k[4], v[4], k[5], v[5]); hough_cswap(k[6], v[6], k[7], v[7]);
+        hough_cswap(k[0], v[0], k[2], v[2]); hough_cswap(k[1], v[1], k[3], v[3]); hough_cswap(k[4], v[4], k[6], v[6]); hough_cswap(k[5], v[5], k[7], v[7]);
+        hough_cswap(k[1], v[1], k[2], v[2]); hough_cswap(k[5], v[5], k[6], v[6]);
+        hough_cswap(k[0], v[0], k[4], v[4]); hough_cswap(k[1], v[1], k[5], v[5]); hough_cswap(k[2], v[2], k[6], v[6]); hough_cswap(k[3], v[3], k[7], v[7]);
+        hough_cswap(k[2], v[2], k[4], v[4]); hough_cswap(k[3], v[3], k[5], v[5]);
+        hough_cswap(k[1], v[1], k[2], v[2]); hough_cswap(k[3], v[3], k[4], v[4]); hough_cswap(k[5], v[5], k[6], v[6]);
+        double s = 0.;
+#pragma unroll
+        for (int e = 0; e < HOUGH_K; ++e)
+            if (e < n) s += v[e];
+        heat[cc] = s / norm;
+    } else if (cc < ncells && n == 0) {
+        heat[cc] = 0. / norm;
+    }
+    // slabs of the heavy cells of this workgroup: exclusive scans over (entries needed, heavy flag), one 64-bit atomic
+    s_need[threadIdx.x] = heavy ? n : 0;
+    s_hv[threadIdx.x] = heavy ? 1 : 0;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int a = threadIdx.x >= d ? s_need[threadIdx.x - d] : 0, b = threadIdx.x >= d ? s_hv[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_need[threadIdx.x] += a; s_hv[threadIdx.x] += b;
+        __syncthreads();
+    }
+    if (threadIdx.x == 1023) {
+        const unsigned long long add = ((unsigned long long)(unsigned)s_hv[1023] << 32) | (unsigned)s_need[1023];
+        s_base = add ? atomicAdd(ctr64, add) : 0ull;
+    }
+    __syncthreads();
+    if (heavy) {
+        const int off = (int)(unsigned)(s_base & 0xffffffffull) + s_need[threadIdx.x] - n;
+        const int hi = (int)(unsigned)(s_base >> 32) + s_hv[threadIdx.x] - 1;
+        ovoff[cc] = off;
+        heavy_list[hi] = cc;
+#pragma unroll
+        for (int e = 0; e < HOUGH_K; ++e) { skey[off + e] = k[e]; sval[off + e] = v[e]; }
+    }
+}
+__global__ void hough_ovfill_kernel(long nvotes, int HW4, const int* __restrict__ ovcell, const double* __restrict__ ovval,
+                                    const int* __restrict__ ovoff, int* __restrict__ ovcur, unsigned* __restrict__ skey,
+                                    double* __restrict__ sval) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvotes; i += (long)gridDim.x * blockDim.x) {
+        const int cc = ovcell[i];
+        if (cc < 0) continue;
+        const int pos = ovoff[cc] + HOUGH_K + atomicAdd(&ovcur[cc], 1);
+        skey[pos] = (unsigned)(i % HW4);
+        sval[pos] = ovval[i];
+    }
+}
+__global__ __launch_bounds__(64) void hough_heavy2_kernel(const int* __restrict__ cnt, const int* __restrict__ ovoff,
+                                                          const unsigned* __restrict__ skey, const double* __restrict__ sval,
+                                                          double* __restrict__ srt, double norm, double* __restrict__ heat,
+                                                          const unsigned long long* __restrict__ ctr64, const int* __restrict__ heavy_list) {
+    __shared__ unsigned lk[HOUGH_LCAP];
+    __shared__ double lv[HOUGH_LCAP];
+    const int nh = (int)(unsigned)(*ctr64 >> 32);
+    for (int h = blockIdx.x; h < nh; h += gridDim.x) {
+        const int cc = heavy_list[h];
+        const int n = cnt[cc], base = ovoff[cc];
+        if (n <= HOUGH_LCAP) {
+            for (int e = threadIdx.x; e < n; e += 64) lk[e] = skey[base + e];
+            __syncthreads();
+            for (int e = threadIdx.x; e < n; e += 64) {
+                const unsigned ke = lk[e];
+                int rank = 0;
+                for (int j = 0; j < n; ++j) rank += lk[j] < ke;
+                lv[rank] = sval[base + e];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double s = 0.;
+                for (int t = 0; t < n; ++t) s += lv[t];
+                heat[cc] = s / norm;
+            }
+            __syncthreads();
+        } else {
+            for (int e = threadIdx.x; e < n; e += 64) {
+                const unsigned ke = skey[base + e];
+                int rank = 0;
+                for (int j = 0; j < n; ++j) rank += skey[base + j] < ke;
+                srt[base + rank] = sval[base + e];
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double s = 0.;
+                for (int t = 0; t < n; ++t) s += srt[base + t];
+                heat[cc] = s / norm;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ---- P2 ---------------------------------------------------------------------------------------
 __constant__ double KG_GW[17] = {
     0x1.18aad19e4159bp-14, 0x1.c98b8c5d0dda5p-12, 0x1.227362b5fc92dp-9, 0x1.1f30504e20207p-7, 0x1.ba4d4125ffd2ap-6,
@@ -294,12 +460,28 @@ __global__ void kp_rank_kernel(const int* __restrict__ npk, int cap, const int* 
                                const int* __restrict__ xs, const int* __restrict__ ys, const double* __restrict__ conf,
                                int* __restrict__ sid, int* __restrict__ sx, int* __restrict__ sy,
                                double* __restrict__ sconf) {
+    // (every thread compares its confidence with all n: the others stream through LDS 256 at a time -- as a loop over global memory the
+    // c0 map of a 512 x 512 image, ~5000 peaks, took 104 us)
+    __shared__ double tile[256];
     int n = *npk; if (n > cap) n = cap;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const double ci = conf[i];
+    const int rounds = (n + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+    for (int r = 0; r < rounds; ++r) {
+        if ((r * gridDim.x + blockIdx.x) * blockDim.x >= n) break;       // (uniform) nothing left for this workgroup
+        const int i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        const bool live = i < n;
+        const double ci = live ? conf[i] : 0.;
         int rank = 0;
-        for (int j = 0; j < n; ++j) { double cj = conf[j]; rank += (cj > ci) || (cj == ci && j < i); }
-        sid[rank] = ids[i]; sx[rank] = xs[i]; sy[rank] = ys[i]; sconf[rank] = ci;
+        for (int j0 = 0; j0 < n; j0 += 256) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < 256; t += blockDim.x)
+                if (j0 + t < n) tile[t] = conf[j0 + t];
+            __syncthreads();
+            const int m = n - j0 < 256 ? n - j0 : 256;
+            if (live) {
+                for (int j = 0; j < m; ++j) { const double cj = tile[j]; rank += (cj > ci) || (cj == ci && j0 + j < i); }
+            }
+        }
+        if (live) { sid[rank] = ids[i]; sx[rank] = xs[i]; sy[rank] = ys[i]; sconf[rank] = ci; }
     }
 }
 // Fast path of the greedy grouping (n <= GK_NL keypoints, image <= 1024 x 1024).  The sequential dependence over the seeds stays, but
@@ -686,6 +868,8 @@ extern "C" long kg_postproc_workspace_bytes(int H, int W, int peak_cap, int skel
     b += al256(peak_cap);                  // alive
     b += al256((size_t)skel_cap * 10 * 4);  // skxy
     b += al256(5 * SCAN_NB * 4);           // chunk sums of the multi-block scan
+    b += al256(5 * HW * HOUGH_K * 4) + al256(5 * HW * HOUGH_K * 8);   // inline vote slots (keys, values) of the scatter formulation
+    b += al256(5 * 4 * HW * 4) + al256(5 * 4 * HW * 8);                // compact keys of the heavy cells' slabs, rank-sort scratch
     return (long)b + 4096;
 }
 
@@ -694,6 +878,7 @@ struct PPWs {
     int *heavy_list, *heavy_n, *blkcount, *blkbase, *npk;
     int *ids, *xs, *ys; double* conf; int *sid, *sx, *sy; double* sconf;
     unsigned char* alive; int* skxy; int nblk; int* scanpart;
+    unsigned* ink; double* inv; unsigned* skey; double* srt;
 };
 static void carve(void* ws, int H, int W, int peak_cap, int skel_cap, PPWs* p) {
     size_t HW = (size_t)H * W;
@@ -712,6 +897,8 @@ static void carve(void* ws, int H, int W, int peak_cap, int skel_cap, PPWs* p) {
     p->sconf = (double*)take((size_t)peak_cap * 8);
     p->alive = (unsigned char*)take(peak_cap); p->skxy = (int*)take((size_t)skel_cap * 10 * 4);
     p->scanpart = (int*)take(5 * SCAN_NB * 4);
+    p->ink = (unsigned*)take(5 * HW * HOUGH_K * 4); p->inv = (double*)take(5 * HW * HOUGH_K * 8);
+    p->skey = (unsigned*)take(5 * 4 * HW * 4); p->srt = (double*)take(5 * 4 * HW * 8);
 }
 
 // ---- phase timing (measurement hook of bench.py --mode eval: the roofline of the HBM-bound phases) ------------------------------------
@@ -770,10 +957,25 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
     const int HW = H * W;
     const double norm = 3.141592653589793 * 25.0;  // np.pi * KP_RADIUS**2 (postprocessing.py:51)
     pp_mark(st);
+    static const int hough_v1 = getenv("KG_HOUGH_V1") ? atoi(getenv("KG_HOUGH_V1")) : 0;      // 1: the count -> scan -> fill -> sum formulation (A/B, bisecting)
+    int gx = (4 * HW + 255) / 256; if (gx > 4096) gx = 4096;
+    if (!hough_v1) {
+        // count | offs | cursor are consecutive in the workspace: ONE memset clears the vote counters (count), the slab cursors (cursor) and,
+        // in the first 8 bytes of `offs`' neighbour heavy_n, nothing -- the 64-bit allocator lives in heavy_n (cleared separately: 8 bytes)
+        KG_HIP(hipMemsetAsync(p.count, 0, (size_t)((unsigned char*)p.cursor - (unsigned char*)p.count) + (size_t)5 * HW * 4, st));
+        KG_HIP(hipMemsetAsync(p.heavy_n, 0, 8, st));
+        unsigned long long* ctr64 = reinterpret_cast<unsigned long long*>(p.heavy_n);
+        hipLaunchKernelGGL(hough_scatter_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.count, p.ink, p.inv, (int*)p.keys, p.vals);
+        hipLaunchKernelGGL(hough_classify_kernel, dim3((5 * HW + 1023) / 1024), dim3(1024), 0, st, 5 * HW, p.count, p.ink, p.inv, norm, p.heat, ctr64,
+                           p.offs, p.heavy_list, p.skey, p.sorted);
+        int go = (int)(((long)20 * HW + 255) / 256); if (go > 8192) go = 8192;
+        hipLaunchKernelGGL(hough_ovfill_kernel, dim3(go), dim3(256), 0, st, (long)20 * HW, 4 * HW, (const int*)p.keys, p.vals, p.offs, p.cursor, p.skey,
+                           p.sorted);
+        hipLaunchKernelGGL(hough_heavy2_kernel, dim3(4096), dim3(64), 0, st, p.count, p.offs, p.skey, p.sorted, p.srt, norm, p.heat, ctr64, p.heavy_list);
+    } else {
     KG_HIP(hipMemsetAsync(p.count, 0, (size_t)5 * HW * 4, st));
     KG_HIP(hipMemsetAsync(p.cursor, 0, (size_t)5 * HW * 4, st));
     KG_HIP(hipMemsetAsync(p.heavy_n, 0, 4, st));
-    int gx = (4 * HW + 255) / 256; if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(hough_count_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.count);
     if (HW >= 65536 && HW % 4 == 0) {
         const int chunk = (int)(((HW + SCAN_NB - 1) / SCAN_NB + 3) / 4 * 4);
@@ -788,6 +990,7 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
                        p.heavy_n, p.heavy_list);
     hipLaunchKernelGGL(hough_sum_heavy_kernel, dim3(2048), dim3(64), 0, st, HW, p.count, p.offs, p.keys, p.vals, p.sorted, norm,
                        p.heat, p.heavy_n, p.heavy_list);
+    }
     int gg = (5 * HW + 255) / 256; if (gg > 8192) gg = 8192;
     pp_mark(st);
     hipLaunchKernelGGL(gauss_kernel<0>, dim3(gg), dim3(256), 0, st, p.heat, p.tmp, 5, H, W);
@@ -799,7 +1002,7 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
     hipLaunchKernelGGL(peaks_total_kernel, dim3(1), dim3(64), 0, st, p.blkcount, p.blkbase, p.nblk, p.npk);
     hipLaunchKernelGGL(peaks_kernel<1>, dim3(p.nblk), dim3(256), 0, st, p.blur, H, W, thresh, (int*)nullptr, p.blkbase, peak_cap,
                        p.ids, p.xs, p.ys, p.conf);
-    hipLaunchKernelGGL(kp_rank_kernel, dim3(256), dim3(256), 0, st, p.npk, peak_cap, p.ids, p.xs, p.ys, p.conf, p.sid, p.sx, p.sy,
+    hipLaunchKernelGGL(kp_rank_kernel, dim3(1024), dim3(64), 0, st, p.npk, peak_cap, p.ids, p.xs, p.ys, p.conf, p.sid, p.sx, p.sy,
                        p.sconf);
     pp_mark(st);
     static bool group_attr = false;
