@@ -52,7 +52,7 @@ __global__ void hough_count_kernel(const float* __restrict__ kp, const float* __
     }
 }
 // exclusive scan of count[c][0..HW) -> offs; one block (1024 threads) per channel.
-__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ count, int* __restrict__ offs, int n) {
+__global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ count, int* __restrict__ offs, int n, int* __restrict__ total = nullptr) {
     __shared__ int tot[1024];
     const int* in = count + (long)blockIdx.x * n;
     int* out = offs + (long)blockIdx.x * n;
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ coun
     }
     int run = threadIdx.x ? tot[threadIdx.x - 1] : 0;
     for (int i = b0; i < b0 + per && i < n; ++i) { int v = in[i]; out[i] = run; run += v; }
+    if (total && threadIdx.x == 1023) total[blockIdx.x] = tot[1023];      // sum of the whole row (the peak count: no separate launch)
 }
 // Multi-block exclusive scan of `rows` independent arrays of n ints (the single-workgroup kernel above reads 4 KB-strided runs:
 // 1.8 ms for the 5 x 1024^2 Hough cell counts).  SCAN_NB chunks per row: chunk sums, then every chunk scans itself behind the
@@ -460,28 +461,26 @@ __global__ void kp_rank_kernel(const int* __restrict__ npk, int cap, const int* 
                                const int* __restrict__ xs, const int* __restrict__ ys, const double* __restrict__ conf,
                                int* __restrict__ sid, int* __restrict__ sx, int* __restrict__ sy,
                                double* __restrict__ sconf) {
-    // (every thread compares its confidence with all n: the others stream through LDS 256 at a time -- as a loop over global memory the
-    // c0 map of a 512 x 512 image, ~5000 peaks, took 104 us)
+    // Rank of peak i = number of peaks that precede it in the stable descending order.  16 lanes share a peak (lane = every 16th
+    // candidate of a 256-entry LDS tile), their partial counts meet through four shuffles: the fp64 compares are the cost of this
+    // kernel (as one thread per peak over global memory the c0 map of a 512 x 512 image -- ~8000 peaks -- took 105-120 us).
     __shared__ double tile[256];
     int n = *npk; if (n > cap) n = cap;
-    const int rounds = (n + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
-    for (int r = 0; r < rounds; ++r) {
-        if ((r * gridDim.x + blockIdx.x) * blockDim.x >= n) break;       // (uniform) nothing left for this workgroup
-        const int i = (r * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    const int sub = threadIdx.x & 15, loc = threadIdx.x >> 4;            // blockDim.x == 256: 16 peaks per workgroup and round
+    for (int i0 = blockIdx.x * 16; i0 < n; i0 += gridDim.x * 16) {
+        const int i = i0 + loc;
         const bool live = i < n;
         const double ci = live ? conf[i] : 0.;
         int rank = 0;
         for (int j0 = 0; j0 < n; j0 += 256) {
             __syncthreads();
-            for (int t = threadIdx.x; t < 256; t += blockDim.x)
-                if (j0 + t < n) tile[t] = conf[j0 + t];
+            if (j0 + (int)threadIdx.x < n) tile[threadIdx.x] = conf[j0 + threadIdx.x];
             __syncthreads();
             const int m = n - j0 < 256 ? n - j0 : 256;
-            if (live) {
-                for (int j = 0; j < m; ++j) { const double cj = tile[j]; rank += (cj > ci) || (cj == ci && j0 + j < i); }
-            }
+            for (int j = sub; j < m; j += 16) { const double cj = tile[j]; rank += (cj > ci) || (cj == ci && j0 + j < i); }
         }
-        if (live) { sid[rank] = ids[i]; sx[rank] = xs[i]; sy[rank] = ys[i]; sconf[rank] = ci; }
+        rank += __shfl_xor(rank, 1, 64); rank += __shfl_xor(rank, 2, 64); rank += __shfl_xor(rank, 4, 64); rank += __shfl_xor(rank, 8, 64);
+        if (live && sub == 0) { sid[rank] = ids[i]; sx[rank] = xs[i]; sy[rank] = ys[i]; sconf[rank] = ci; }
     }
 }
 // Fast path of the greedy grouping (n <= GK_NL keypoints, image <= 1024 x 1024).  The sequential dependence over the seeds stays, but
@@ -884,11 +883,12 @@ static void carve(void* ws, int H, int W, int peak_cap, int skel_cap, PPWs* p) {
     size_t HW = (size_t)H * W;
     unsigned char* q = (unsigned char*)ws;
     auto take = [&](size_t bytes) { void* r = q; q += al256(bytes); return r; };
+    p->heavy_n = (int*)take(256);      // (counters first: ONE memset clears them together with count .. cursor)
     p->count = (int*)take(5 * HW * 4); p->offs = (int*)take(5 * HW * 4); p->cursor = (int*)take(5 * HW * 4);
     p->keys = (unsigned*)take(5 * 4 * HW * 4);
     p->vals = (double*)take(5 * 4 * HW * 8); p->sorted = (double*)take(5 * 4 * HW * 8);
     p->heat = (double*)take(5 * HW * 8); p->tmp = (double*)take(5 * HW * 8); p->blur = (double*)take(5 * HW * 8);
-    p->heavy_list = (int*)take(5 * HW * 4); p->heavy_n = (int*)take(256);
+    p->heavy_list = (int*)take(5 * HW * 4); (void)take(256);
     p->nblk = (int)((5 * HW + 1023) / 1024);
     p->blkcount = (int*)take((size_t)p->nblk * 4); p->blkbase = (int*)take((size_t)p->nblk * 4); p->npk = (int*)take(256);
     p->ids = (int*)take((size_t)peak_cap * 4); p->xs = (int*)take((size_t)peak_cap * 4); p->ys = (int*)take((size_t)peak_cap * 4);
@@ -960,10 +960,9 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
     static const int hough_v1 = getenv("KG_HOUGH_V1") ? atoi(getenv("KG_HOUGH_V1")) : 0;      // 1: the count -> scan -> fill -> sum formulation (A/B, bisecting)
     int gx = (4 * HW + 255) / 256; if (gx > 4096) gx = 4096;
     if (!hough_v1) {
-        // count | offs | cursor are consecutive in the workspace: ONE memset clears the vote counters (count), the slab cursors (cursor) and,
-        // in the first 8 bytes of `offs`' neighbour heavy_n, nothing -- the 64-bit allocator lives in heavy_n (cleared separately: 8 bytes)
-        KG_HIP(hipMemsetAsync(p.count, 0, (size_t)((unsigned char*)p.cursor - (unsigned char*)p.count) + (size_t)5 * HW * 4, st));
-        KG_HIP(hipMemsetAsync(p.heavy_n, 0, 8, st));
+        // heavy_n (the 64-bit slab allocator) | count | offs | cursor are consecutive in the workspace: ONE memset clears the allocator, the
+        // vote counters (count) and the slab cursors (cursor)
+        KG_HIP(hipMemsetAsync(p.heavy_n, 0, (size_t)((unsigned char*)p.cursor - (unsigned char*)p.heavy_n) + (size_t)5 * HW * 4, st));
         unsigned long long* ctr64 = reinterpret_cast<unsigned long long*>(p.heavy_n);
         hipLaunchKernelGGL(hough_scatter_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.count, p.ink, p.inv, (int*)p.keys, p.vals);
         hipLaunchKernelGGL(hough_classify_kernel, dim3((5 * HW + 1023) / 1024), dim3(1024), 0, st, 5 * HW, p.count, p.ink, p.inv, norm, p.heat, ctr64,
@@ -982,7 +981,7 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
         hipLaunchKernelGGL(scan_sums_kernel, dim3(SCAN_NB, 5), dim3(256), 0, st, p.count, p.scanpart, HW, chunk);
         hipLaunchKernelGGL(scan_chunks_kernel, dim3(SCAN_NB, 5), dim3(256), 0, st, p.count, p.scanpart, p.offs, HW, chunk);
     } else {
-        hipLaunchKernelGGL(scan_kernel, dim3(5), dim3(1024), 0, st, p.count, p.offs, HW);
+        hipLaunchKernelGGL(scan_kernel, dim3(5), dim3(1024), 0, st, p.count, p.offs, HW, (int*)nullptr);
     }
     hipLaunchKernelGGL(hough_fill_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.offs, p.cursor, p.keys, p.vals);
     int gc = (HW + 255) / 256; if (gc > 4096) gc = 4096;
@@ -998,11 +997,10 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
     pp_mark(st);
     hipLaunchKernelGGL(peaks_kernel<0>, dim3(p.nblk), dim3(256), 0, st, p.blur, H, W, thresh, p.blkcount, (const int*)nullptr, 0,
                        (int*)nullptr, (int*)nullptr, (int*)nullptr, (double*)nullptr);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, p.blkcount, p.blkbase, p.nblk);
-    hipLaunchKernelGGL(peaks_total_kernel, dim3(1), dim3(64), 0, st, p.blkcount, p.blkbase, p.nblk, p.npk);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, p.blkcount, p.blkbase, p.nblk, p.npk);
     hipLaunchKernelGGL(peaks_kernel<1>, dim3(p.nblk), dim3(256), 0, st, p.blur, H, W, thresh, (int*)nullptr, p.blkbase, peak_cap,
                        p.ids, p.xs, p.ys, p.conf);
-    hipLaunchKernelGGL(kp_rank_kernel, dim3(1024), dim3(64), 0, st, p.npk, peak_cap, p.ids, p.xs, p.ys, p.conf, p.sid, p.sx, p.sy,
+    hipLaunchKernelGGL(kp_rank_kernel, dim3(512), dim3(256), 0, st, p.npk, peak_cap, p.ids, p.xs, p.ys, p.conf, p.sid, p.sx, p.sy,
                        p.sconf);
     pp_mark(st);
     static bool group_attr = false;
