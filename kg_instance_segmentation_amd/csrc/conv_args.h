@@ -115,8 +115,14 @@ __device__ __forceinline__ EpiArgs kg_epi(const ConvArgs& a) {
     return EpiArgs{a.y, a.res, a.mask, a.ldy, a.ldres, a.ldmask, a.Cout, a.relu, a.yP, a.yps, a.rP, a.rps};
 }
 
-// conv_gather.hip: the deep-prefetch variant for cin_pad % 64 == 0 and bf16 row outputs
-int kg_launch_conv_gather(const ConvArgs& a, int cin_pad, hipStream_t st);
+// conv_gather.hip: the deep-prefetch variant for cin_pad % 64 == 0 and bf16 row outputs.  stats_ok: the caller's launch may carry the
+// BatchNorm statistics epilogue (the launcher claims the armed side channel with the tile count of the variant it picks).
+int kg_launch_conv_gather(ConvArgs a, int cin_pad, hipStream_t st, bool stats_ok);
+// conv_tiny.hip: K-split finishing pass shared by conv_tiny and conv_gather -- partials [tile64][Z][4 pixel groups][16 values][64 lanes] of
+// 64-pixel x 64-cout tiles (tile64 = cout tile * npt64 + pixel tile) are added in slot order and run through the shared epilogue
+// (+ BatchNorm statistics per 64-pixel tile when a.stat_part is set).  kg_splitk_scratch: the per-device scratch (slots of 4096 floats).
+int kg_launch_splitk_finish(const ConvArgs& a, int Z, const float* part, int npt64, int nct64, hipStream_t st);
+float* kg_splitk_scratch(long slots);
 // conv_tiny.hip: split-K variant for launches with too few output tiles (tile = 6: cin_pad % 64 == 0, dense modes, rows output)
 int kg_launch_conv_tiny(const ConvArgs& a, int cin_virt, hipStream_t st);
 // conv_small.hip: direct VALU kernel for cin_pad == 8 (image / single-channel inputs)

@@ -14,13 +14,18 @@
 //   * workgroup = 8 waves = 256 pixels x 128 couts, wave tile 64 x 64 (16 MFMA per k-step), same fragment layouts and
 //     epilogue as the other conv kernels (weights = MFMA A, each lane ends with 16 consecutive couts of one pixel).
 #include "conv_args.h"
+#include <stdlib.h>
 
 __device__ uint4 kg_gather_zero_line[8];
 
 #define KG_GLDS(src, dst) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-__global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, const int ncc) {
+// K split (gridDim.z > 1, sk_part != null): workgroup z multiplies the stages [z * per, (z + 1) * per) of the (tap, virtual chunk) sequence and
+// stores its raw fp32 accumulators as four 64 x 64 partial tiles in conv_tiny's slot layout; kg_launch_splitk_finish adds the slots in z order
+// and runs the epilogue (+ statistics).  For launches whose output gives < 128 workgroups: the layer-2 / layer-3 convs of a batch-8 step
+// (M = 8192 pixels x 256 couts = 64 workgroups, each walking up to 48 stages alone on a quarter of the chip).
+__global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, const int ncc, float* __restrict__ sk_part) {
     constexpr int TP = 256, TC = 128, NS = 3, XB = TP * 128, WB = TC * 128, STAGE = XB + WB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -57,10 +62,16 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
     const bf16_t* zline = reinterpret_cast<const bf16_t*>(kg_gather_zero_line) + cs * 8;
     const int smask = (1 << a.stride_log2) - 1;
 
+    const int nstage_all = a.ntaps * ncc;
+    const int per = (nstage_all + gridDim.z - 1) / gridDim.z;
+    const int s_begin = blockIdx.z * per;
+    const int nstage = (s_begin + per < nstage_all ? s_begin + per : nstage_all) - s_begin;     // (the launcher keeps every split non-empty)
     const bf16_t* xsrc[4];
-    int i_tap = 0, i_cc = 0, i_slot = 0;
+    int i_tap = s_begin / ncc, i_cc = s_begin - i_tap * ncc, i_slot = 0;
+    bool first = true;
     auto issue = [&]() {   // global -> LDS loads of the next (tap, 64-channel chunk) stage into ring slot i_slot
-        if (i_cc == 0) {   // new tap: resolve the source row of the thread's 4 pixels
+        if (i_cc == 0 || first) {   // new tap: resolve the source row of the thread's 4 pixels
+            first = false;
             const int dy = i_tap / a.KW, dx = i_tap - dy * a.KW;
             const int dyo = dy - a.pad, dxo = dx - a.pad;
 #pragma unroll
@@ -121,7 +132,6 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nstage = a.ntaps * ncc;
     const unsigned lds0 = lds_addr(smem);
     issue();
     if (nstage > 1) issue();
@@ -163,6 +173,18 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
         c_slot = c_slot == NS - 1 ? 0 : c_slot + 1;
     }
 
+    if (sk_part) {   // (uniform) K split: raw partial tiles, slot = ((tile64 * Z + z) * 4 + pixel group) * 1024 + value * 64 + lane
+        const long npt64 = (long)gridDim.x * 4;
+        const long tile64 = (long)(blockIdx.y * 2 + wcw) * npt64 + blockIdx.x * 4 + wp;
+        float* slot = sk_part + (tile64 * gridDim.z + blockIdx.z) * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slot[j * 1024 + (i * 4 + r) * 64 + lane] = acc[i][j][r];
+        return;
+    }
     // ---- epilogue: lane owns pixel row m and couts cb .. cb+15 --------------------------------------------------------------
     const int cb = c0 + wcw * 64 + g * 16;
     const bool stats = a.stat_part != nullptr;                 // (uniform)
@@ -195,7 +217,7 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
     }
 }
 
-int kg_launch_conv_gather(const ConvArgs& a, int cin_pad, hipStream_t st) {
+int kg_launch_conv_gather(ConvArgs a, int cin_pad, hipStream_t st, bool stats_ok) {
     constexpr int smem = 3 * (256 * 128 + 128 * 128);
     static bool attr_done = false;
     if (!attr_done) {
@@ -203,8 +225,27 @@ int kg_launch_conv_gather(const ConvArgs& a, int cin_pad, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(kg_cdiv(a.M, 256), kg_cdiv(a.Cout, 128));
-    hipLaunchKernelGGL(conv_gather_kernel, grid, dim3(512), smem, st, a, cin_pad / 64);
+    // K split for under-filled launches (KG_GATHER_SPLIT: 0 = never; default: below 128 workgroups, >= 4 stages per split, <= 8 splits)
+    static const int split_wgs = getenv("KG_GATHER_SPLIT") ? atoi(getenv("KG_GATHER_SPLIT")) : 128;
+    const int wgs = (int)(grid.x * grid.y), nstage = a.ntaps * (cin_pad / 64);
+    int Z = 1;
+    if (split_wgs > 0 && wgs <= split_wgs && nstage >= 8) {
+        Z = kg_cdiv(256, wgs);
+        if (Z > nstage / 4) Z = nstage / 4;
+        if (Z > 8) Z = 8;
+        while (Z > 1 && (Z - 1) * kg_cdiv(nstage, Z) >= nstage) --Z;      // every split owns at least one stage
+    }
+    float* part = nullptr;
+    const int npt64 = (int)grid.x * 4, nct64 = (int)grid.y * 2;
+    if (Z > 1) {
+        part = kg_splitk_scratch((long)npt64 * nct64 * Z);
+        if (!part) Z = 1;
+    }
+    if (stats_ok) a.stat_part = kg_conv_stats_claim(Z > 1 ? npt64 : (int)grid.x, a.Cout);   // (BatchNorm statistics, when armed: per 64- or 256-pixel tile)
+    grid.z = Z;
+    hipLaunchKernelGGL(conv_gather_kernel, grid, dim3(512), smem, st, a, cin_pad / 64, Z > 1 ? part : (float*)nullptr);
     KG_CHECK_LAUNCH("conv_gather");
     kg_note_kernel("conv_gather_kernel");
+    if (Z > 1) return kg_launch_splitk_finish(a, Z, part, npt64, nct64, st);
     return KG_OK;
 }

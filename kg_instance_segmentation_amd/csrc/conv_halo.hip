@@ -46,6 +46,10 @@ struct HaloArgs {
     // GM = 1, small maps: blockIdx.z = plane product (x_hi w_lo | x_lo w_hi | x_hi w_hi) -- a workgroup walks the chunks of ONE product of its
     // head and stores raw fp32 partial maps part[z][N][55][H*W] (the bias rides on the last product); heads2_finish_kernel adds the three
     int prod_split; float* part;
+    // GM = 0, under-filled launches (the layer-2 / layer-3 3x3 convs of a batch-8 step: 64 .. 128 workgroups): blockIdx.z walks the z-th part of
+    // the chunk sequence and stores its raw fp32 accumulators (kpart: [cout block][tile][z][wave][16 values][64 lanes]); conv_halo_finish_kernel
+    // adds the parts in z order -- the order of the unsplit walk -- and runs the epilogue (+ statistics)
+    int ksplit; float* kpart;
 };
 
 // Planed input with the three products of the half-plane policies.  The packed weights keep the plane-major virtual-channel layout of
@@ -173,6 +177,13 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     int nchunks = (GM == 1 && a.head_split) ? (biy + 1) * a.grp_chunks : a.cin_pad / 64;
     const bool psplit = GM == 1 && a.prod_split;                 // (uniform)
     if (psplit) { ci_first += blockIdx.z * a.km.n; nchunks = ci_first + a.km.n; }
+    const bool ksplit = GM == 0 && a.ksplit > 1;                 // (uniform)
+    if (ksplit) {
+        const int per = (nchunks + a.ksplit - 1) / a.ksplit;
+        ci_first = blockIdx.z * per;
+        if (ci_first + per < nchunks) nchunks = ci_first + per;
+    }
+    const int ci_begin = ci_first;
     for (int ci = ci_first; ci < nchunks; ++ci) {
         __syncthreads();
         int cc = ci;                               // virtual chunk of this step (weights: channel offset cc * 64 of a tap)
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
             const int n = a.km.n, grp = 3 * n;     // virtual chunks of one group (GM == 1: one head, else the whole tap): [x_hi w_lo | x_lo w_hi | x_hi w_hi]
             const int base = ci / grp * grp, q = ci - base;
             if (q < 2 * n) cc = base + ((q & 1) ? (q >> 1) : n + (q >> 1));
-            else { cc = base + 2 * n + (grp - 1 - q); stage = q > 2 * n; }
+            else { cc = base + 2 * n + (grp - 1 - q); stage = q > 2 * n || ci == ci_begin; }
         }
         int xo;                                    // X-side element offset of this (virtual) chunk
         if constexpr (GM == 1) { const int hd = cc / a.grp_chunks; xo = hd * a.grp_C + a.km.xoff(cc - hd * a.grp_chunks); }
@@ -480,6 +491,16 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
         }
     }
 
+    if (ksplit) {   // raw partial accumulators of this part of the chunk walk; conv_halo_finish_kernel completes the tile
+        float* slot = a.kpart + ((((long)biy * gridDim.x + bix) * a.ksplit + blockIdx.z) * (WC * WPX) + wave) * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slot[((i * 4 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+        return;
+    }
     // ---- epilogue: lane owns pixel (oy0 + wp*4 + j, ox0 + lm) and couts cb .. cb+15 ----------------------
     const int cb = c0 + wc * 64 + g * 16;
     const bool stats = GM == 0 && a.stat_part != nullptr;      // (uniform)
@@ -550,6 +571,63 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     }
 }
 
+// second half of a chunk-split launch (HaloArgs.ksplit): same grid (pixel tiles, cout blocks) and thread decomposition as the main kernel;
+// the parts are added in z order, then bias / folded BatchNorm / residual / ReLU / mask / statistics / plane store exactly as in its epilogue
+template <int WC, int WPX>
+__global__ __launch_bounds__(WC * WPX * 64) void conv_halo_finish_kernel(const HaloArgs a) {
+    constexpr int TW = 4 * WPX, TC = WC * 64;
+    __shared__ float red[WPX * TC * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave / WPX, wp = wave % WPX;
+    const int lm = lane & 15, g = lane >> 4;
+    const int bix = blockIdx.x, biy = blockIdx.y;
+    int oy0, ox0, Hd, Wd;
+    long rowbase;
+    if (a.tiletab) {
+        const int4 tt = a.tiletab[bix];
+        rowbase = tt.x; Hd = tt.y >> 16; Wd = tt.y & 0xffff; oy0 = tt.z >> 16; ox0 = tt.z & 0xffff;
+    } else {
+        int bt = bix;
+        const int tx = bt % a.tiles_x; bt /= a.tiles_x;
+        const int ty = bt % a.tiles_y; const int n = bt / a.tiles_y;
+        oy0 = ty * 16; ox0 = tx * TW; Hd = a.H; Wd = a.W; rowbase = (long)n * a.H * a.W;
+    }
+    const int c0 = biy * TC;
+    const float* slot = a.kpart + ((((long)biy * gridDim.x + bix) * a.ksplit) * (WC * WPX) + wave) * 4096;
+    float accv[64];
+#pragma unroll
+    for (int e = 0; e < 64; ++e) accv[e] = slot[e * 64 + lane];
+    for (int z = 1; z < a.ksplit; ++z)
+#pragma unroll
+        for (int e = 0; e < 64; ++e) accv[e] += slot[(long)z * (WC * WPX) * 4096 + e * 64 + lane];
+    const int cb = c0 + wc * 64 + g * 16;
+    const bool stats = a.stat_part != nullptr;                 // (uniform)
+    if (cb >= a.Cout && !stats) return;
+    float ss[16], sq[16], bv[16], sv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        ss[e] = sq[e] = 0.f;
+        bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+        sv[e] = (a.oscale && cb + e < a.Cout) ? a.oscale[cb + e] : 1.f;
+    }
+    const EpiArgs ep{a.y, a.res, a.mask, a.ldy, a.ldres, a.ldmask, a.Cout, a.relu, a.yP, a.yps, a.rP, a.rps};
+    const int ox = ox0 + (wp >> 2) * 16 + lm;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int oy = oy0 + (wp & 3) * 4 + j;
+        if (oy >= Hd || ox >= Wd || cb >= a.Cout) continue;
+        const long m = rowbase + (long)oy * Wd + ox;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(accv[(i * 4 + j) * 4 + r] * sv[i * 4 + r]) + bv[i * 4 + r];
+        if (stats) kg_stat_add(ss, sq, v);
+        kg_conv_epilogue<16>(ep, m, cb, v);
+    }
+    if (stats) kg_stat_commit<WPX, TC>(ss, sq, red, wp, wc * 64 + g * 16, lm, a.stat_part + (long)bix * a.Cout * 2, c0, a.Cout);
+}
+
 template <int KS, int WC, int WPX, int GM = 0>
 static int launch_halo(HaloArgs a, hipStream_t st) {
     constexpr int TW = 4 * WPX, HWD = TW + KS - 1, TC = WC * 64;
@@ -562,6 +640,19 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
     }
     dim3 grid(a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y, GM == 1 ? (a.head_split ? 3 : 1) : kg_cdiv(a.Cout, TC), (GM == 1 && a.prod_split) ? 3 : 1);
     if (a.stat_part) a.stat_part = (GM == 0 && !a.tiletab) ? kg_conv_stats_claim(grid.x, a.Cout) : nullptr;   // (armed by the caller: BatchNorm statistics)
+    // chunk split of under-filled 3x3 launches (KG_HALO_SPLIT: 0 = never; default: at most 128 workgroups, >= 2 chunks per part, <= 8 parts)
+    static const int split_wgs = getenv("KG_HALO_SPLIT") ? atoi(getenv("KG_HALO_SPLIT")) : 128;
+    if (GM == 0 && KS == 3 && split_wgs > 0 && a.y && !a.y_f32 && (int)(grid.x * grid.y) <= split_wgs) {
+        const int nch = a.cin_pad / 64, wgs = (int)(grid.x * grid.y);
+        int Z = kg_cdiv(256, wgs);
+        if (Z > nch / 2) Z = nch / 2;
+        if (Z > 8) Z = 8;
+        while (Z > 1 && (Z - 1) * kg_cdiv(nch, Z) >= nch) --Z;
+        if (Z > 1) {
+            float* part = kg_splitk_scratch((long)wgs * Z * (WC * WPX));
+            if (part) { a.ksplit = Z; a.kpart = part; grid.z = Z; }
+        }
+    }
     static const int use_xcd = getenv("KG_HALO_XCD") ? atoi(getenv("KG_HALO_XCD")) : 1;
     // (not for the widest heads: 24 cout blocks of one tile stream 24 different 3 MB weight slices through the XCD's 4 MB L2: -2 %)
     a.xcd_map = use_xcd && !a.tiletab && grid.x % 8 == 0 && (grid.y > 1 || use_xcd > 1) && (long)a.Cout * a.K * 2 <= (24L << 20);
@@ -569,6 +660,10 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
     KG_CHECK_LAUNCH("conv_halo");
     KG_KNAME(kname, "conv_halo_kernel<%d, %d, %d, %d>", KS, WC, WPX, GM);
     kg_note_kernel(kname);
+    if (a.ksplit > 1) {
+        hipLaunchKernelGGL((conv_halo_finish_kernel<WC, WPX>), dim3(grid.x, grid.y), dim3(WC * WPX * 64), 0, st, a);
+        KG_CHECK_LAUNCH("conv_halo_finish");
+    }
     return KG_OK;
 }
 

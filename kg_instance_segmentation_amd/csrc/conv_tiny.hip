@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256) void conv_tiny_kernel(const ConvArgs a, const 
 }
 
 // second half of a K-split launch: grid = (pixel tiles, cout tiles), wave w = pixel group w; partials added in slot order z = 0, 1, ...
+// (also the finishing pass of conv_gather's K split; a.stat_part: BatchNorm statistics of the output, one partial per 64-pixel tile)
 __global__ __launch_bounds__(256) void conv_tiny_finish_kernel(const ConvArgs a, const int Z, const float* __restrict__ sk_part) {
+    __shared__ float red[4 * 64 * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lm = lane & 15, g = lane >> 4;
     const int cb = blockIdx.y * 64 + g * 16;
@@ -167,7 +169,9 @@ __global__ __launch_bounds__(256) void conv_tiny_finish_kernel(const ConvArgs a,
     for (int z = 1; z < Z; ++z)
 #pragma unroll
         for (int e = 0; e < 16; ++e) sum[e] += base[(long)z * 4096 + e * 64 + lane];
-    if (cb >= a.Cout || m >= a.M) return;
+    const bool stats = a.stat_part != nullptr;                 // (uniform)
+    const bool live = cb < a.Cout && m < a.M;
+    if (!live && !stats) return;
     float v[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -175,8 +179,29 @@ __global__ __launch_bounds__(256) void conv_tiny_finish_kernel(const ConvArgs a,
         const float bv = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
         v[e] = KG_ACC(sum[e]) * sc + bv;
     }
+    float ss[16], sq[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ss[e] = sq[e] = 0.f;
+    if (stats && live) kg_stat_add(ss, sq, v);
     const EpiArgs ep = kg_epi(a);
-    kg_conv_epilogue<16>(ep, m, cb, v);
+    if (live) kg_conv_epilogue<16>(ep, m, cb, v);
+    if (stats) kg_stat_commit<4, 64>(ss, sq, red, wave, g * 16, lm, a.stat_part + (long)blockIdx.x * a.Cout * 2, blockIdx.y * 64, a.Cout);
+}
+
+static constexpr int KG_SPLITK_MAX_SLOTS = 8192;               // 16 KB each
+float* kg_splitk_scratch(long slots) {
+    // one grow-never buffer per device, allocated on first use (launches on ONE stream at a time per device, like every scratch of this
+    // library: the slots are free again when the finishing launch has run)
+    static float* part[16] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || slots > KG_SPLITK_MAX_SLOTS) return nullptr;
+    if (!part[dev] && hipMalloc((void**)&part[dev], (size_t)KG_SPLITK_MAX_SLOTS * 4096 * sizeof(float)) != hipSuccess) return nullptr;
+    return part[dev];
+}
+int kg_launch_splitk_finish(const ConvArgs& a, int Z, const float* part, int npt64, int nct64, hipStream_t st) {
+    hipLaunchKernelGGL(conv_tiny_finish_kernel, dim3(npt64, nct64), dim3(256), 0, st, a, Z, part);
+    KG_CHECK_LAUNCH("conv_splitk_finish");
+    return KG_OK;
 }
 
 // a.km must map 64-channel units (kg_make_kmap(cin_pad, 64, ...)); cin_virt = virtual channels per tap.
@@ -184,16 +209,12 @@ __global__ __launch_bounds__(256) void conv_tiny_finish_kernel(const ConvArgs a,
 // time per device, like every scratch of this library: the slots are free again when the finishing launch has run).
 int kg_launch_conv_tiny(const ConvArgs& a, int cin_virt, hipStream_t st) {
     constexpr int smem = 4 * 4 * 16 * 64 * 4;
-    constexpr int MAX_SLOTS = 4096;                              // 16 KB each
+    constexpr int MAX_SLOTS = KG_SPLITK_MAX_SLOTS;
     static bool attr_done = false;
     if (!attr_done) {
         KG_HIP(hipFuncSetAttribute((const void*)conv_tiny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
-    static float* part[16] = {nullptr};
-    int dev = 0;
-    KG_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) { kg_set_error("conv_tiny: device index %d out of range", dev); return KG_ERR_ARG; }
     const int tiles = kg_cdiv(a.M, 64) * kg_cdiv(a.Cout, 64);
     const int nunits = a.ntaps * (cin_virt / 64);
     static const int target = getenv("KG_CONV_TINY_TARGET") ? atoi(getenv("KG_CONV_TINY_TARGET")) : 256;   // workgroups a launch should reach
@@ -202,14 +223,15 @@ int kg_launch_conv_tiny(const ConvArgs& a, int cin_virt, hipStream_t st) {
     if (Z > nunits / (4 * min_units)) Z = nunits / (4 * min_units);
     if (Z > 16) Z = 16;
     if (Z < 1 || (long)tiles * Z > MAX_SLOTS) Z = 1;
-    if (Z > 1 && !part[dev]) KG_HIP(hipMalloc((void**)&part[dev], (size_t)MAX_SLOTS * 4096 * sizeof(float)));
+    float* part = nullptr;
+    if (Z > 1) {
+        part = kg_splitk_scratch((long)tiles * Z);
+        if (!part) { kg_set_error("conv_tiny: no split-K scratch"); return KG_ERR_HIP; }
+    }
     dim3 grid(kg_cdiv(a.M, 64), kg_cdiv(a.Cout, 64), Z);
-    hipLaunchKernelGGL(conv_tiny_kernel, grid, dim3(256), smem, st, a, cin_virt / 64, part[dev]);
+    hipLaunchKernelGGL(conv_tiny_kernel, grid, dim3(256), smem, st, a, cin_virt / 64, part);
     KG_CHECK_LAUNCH("conv_tiny");
     kg_note_kernel("conv_tiny_kernel");
-    if (Z > 1) {
-        hipLaunchKernelGGL(conv_tiny_finish_kernel, dim3(grid.x, grid.y), dim3(256), 0, st, a, Z, (const float*)part[dev]);
-        KG_CHECK_LAUNCH("conv_tiny_finish");
-    }
+    if (Z > 1) return kg_launch_splitk_finish(a, Z, part, grid.x, grid.y, st);
     return KG_OK;
 }

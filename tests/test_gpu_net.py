@@ -87,14 +87,18 @@ def test_forward_dec_eval(golden, model, state_dict0, name):
                 worst_kp_logit = max(worst_kp_logit, e)
             else:
                 e = rel_l2(got, ref)
-                print(f"[{name} c{l}.{nm}] rel_l2={e:.4f} max_abs={float(np.abs(got - ref).max()):.4f} ref_absmax={float(np.abs(ref).max()):.3f}")
+                print(f"[{name} c{l}.{nm}] rel_l2={e:.2e} max_abs={float(np.abs(got - ref).max()):.4f} ref_absmax={float(np.abs(ref).max()):.3f}")
                 worst = max(worst, e)
     for l, f in enumerate(feats):
         ref = g[f"{name}.eval.feat{l}"]
         got = sub(f, 5)[:, ::7]
-        print(f"[{name} feat{l}] rel_l2={rel_l2(got, ref):.4f}")
-        assert rel_l2(got, ref) <= 3e-2
-    assert worst <= 3e-2 and worst_kp <= 0.03 and worst_kp_logit <= 3e-2
+        print(f"[{name} feat{l}] rel_l2={rel_l2(got, ref):.2e}")
+        assert rel_l2(got, ref) <= 2e-5
+    # default policy (fp32-tolerance forward on hi + lo half planes) on the reference's random init, logits +-500: measured offset maps
+    # <= 5e-6 relative L2, unsaturated kp logits <= 3e-4 (a few dozen pixels), no pixel with |dp| > 0.05; the bounds are 2x that
+    # (round 2's `mixed` policy needed 3e-2 / 3 % here)
+    print(f"worst: offsets {worst:.2e}, kp logits {worst_kp_logit:.2e}, flipped pixels {worst_kp:.4f}")
+    assert worst <= 1e-5 and worst_kp == 0.0 and worst_kp_logit <= 6e-4
     if name == "b":
         boxes = [g["b.boxes0"], g["b.boxes1"]]
         with torch.no_grad():
@@ -124,8 +128,8 @@ def test_train_step_matches_golden(golden, model, state_dict0):
     l2 = lseg(pred, gt_masks, gt_boxes)
     print("loss_dec", [float(v) for v in l1], "ref", g["train.loss_dec"], "loss_seg", float(l2), float(g["train.loss_seg"]))
     assert [len(p) for p in pred[0]] == list(g["train.npatch"])
-    np.testing.assert_allclose([float(v) for v in l1], g["train.loss_dec"], rtol=1e-2)
-    assert abs(float(l2) - float(g["train.loss_seg"])) <= 1e-2 * abs(float(g["train.loss_seg"]))
+    np.testing.assert_allclose([float(v) for v in l1], g["train.loss_dec"], rtol=2e-5)
+    assert abs(float(l2) - float(g["train.loss_seg"])) <= 2e-5 * abs(float(g["train.loss_seg"]))
     (sum(l1) + l2).backward()
     torch.cuda.synchronize()
     names = [str(n) for n in g["train.grad_names"]]
@@ -162,9 +166,14 @@ def test_train_step_matches_golden(golden, model, state_dict0):
         ref = g[f"train.grad.{k}"].ravel().astype(np.float64); got = params[k].grad.cpu().numpy().ravel().astype(np.float64)
         cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
         print(f"[grad {k} vs the reference's] cos={cos:.5f} rel_l2={rel_l2(got, ref):.4f}")
-        assert cos >= 0.98, k
-    assert rows[0][0] >= 0.98, rows[:5]
-    assert np.all(np.abs(ratio - 1) <= 0.1), ("gradient norms off vs the fp32 reference", float(ratio.min()), float(ratio.max()))
+        assert cos >= 0.9992, k
+    # Raw random init in train mode is chaotic (the fp32 reference itself is 26 % from a float64 evaluation of the same step on this
+    # fixture: profiles/r04_grad_table.json), so these bounds measure agreement of two fp32-grade forward passes, not backward precision
+    # (tests/test_gpu_gradprec.py does that on the calibrated fixture).  Measured with the default policy: min cosine 0.99964 (relative L2
+    # 2.7e-2 on bn1.bias), norms within 0.43 %; asserted at 2x (round 2's `mixed` bounds here were 0.98 / 10 %).
+    assert rows[0][0] >= 0.9992, rows[:5]
+    assert max(r[2] for r in rows) <= 5.5e-2, max(rows, key=lambda r: r[2])
+    assert np.all(np.abs(ratio - 1) <= 1e-2), ("gradient norms off vs the fp32 reference", float(ratio.min()), float(ratio.max()))
     sd = model.state_dict()
     for k in ("bn1.running_mean", "bn1.running_var", "layer3.5.bn3.running_mean", "layer3.5.bn3.running_var", "layer2.0.downsample.1.running_var"):
         np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"train.stat.{k}"], rtol=5e-3, atol=5e-4)
