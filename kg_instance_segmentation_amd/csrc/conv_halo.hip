@@ -20,6 +20,9 @@
 #ifndef KG_HALO_SETPRIO
 #define KG_HALO_SETPRIO 0
 #endif
+#ifndef KG_NARROW_V2
+#define KG_NARROW_V2 1      // narrow (kp / short) chunks of the grouped second-layer heads: kernel-column stages + sliding halo-row window
+#endif
 
 __device__ uint4 kg_halo_zero_line[8];   // 128 zero bytes: source of the padding pixels of a halo
 
@@ -253,6 +256,84 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
             if (head_n < 2) {
                 constexpr int ROWB = 7 * 2048;
                 const int wave_n = __builtin_amdgcn_readfirstlane(wave);
+#if KG_NARROW_V2
+                // Round 4: the stage of the narrow ring is a kernel COLUMN (the 7 taps (ky, kx) of one kx), not a kernel row, and the B side is
+                // walked as a sliding window over halo ROWS: for a fixed (kx, k-step) the four output rows of a wave and the seven ky taps touch
+                // only 10 distinct halo-row fragments -- row R serves every (output row j, tap ky) with j + ky = R.  A step (kx, k-step, ky)
+                // needs one new weight fragment and one new halo row (four at ky = 0): 17 LDS reads per 28 MFMAs instead of 35 -- the kp /
+                // short chunks were LDS-read bound (5 x ds_read_b128 per 4 MFMAs saturate the LDS pipe of a CU at the MFMA rate).
+                const bf16_t* nsrc[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {                     // piece e of a column stage: tap ky = e >> 7, row rho = (e >> 3) & 15, 16-byte slot e & 7
+                    const int e = tid + k * 512, kyl = e >> 7, rho = (e >> 3) & 15, sl = e & 7;
+                    const int r = 16 * (rho >> 2) + 4 * head_n + (rho & 3);
+                    const int key = 2 * (rho >> 2) + ((rho >> 1) & 1);
+                    nsrc[k] = a.w + (long)r * a.K + (long)(kyl * KS) * a.cin_pad + cc * 64 + ((sl ^ key) * 8);
+                }
+                auto nload = [&](int kx) {                        // kernel column kx -> stage kx % 3 (896 pieces: waves 0..5 issue two loads, 6..7 one)
+                    unsigned char* dst = wbuf + (kx % 3) * ROWB + wave_n * 1024;
+                    const long ro = (long)kx * a.cin_pad;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nsrc[0] + ro),
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                    if (wave_n < 6)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nsrc[1] + ro),
+                                                         (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
+                };
+                nload(0); nload(1);
+                int a_n[2];
+                {
+                    const int keyl = 2 * (lm >> 2) + ((lm >> 1) & 1);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) a_n[s2] = lm * 128 + (((4 * s2 + g) ^ keyl) * 16);
+                }
+                const unsigned ldsn = lds_addr(smem);
+                const unsigned pbase = ldsn + (((wp & 3) * 4) * HWD + xb) * 128;       // the lane's pixel of halo row 0 of its wave (tap kx = 0)
+                auto narrow = [&](auto hc) {
+                    constexpr int HD = decltype(hc)::value;
+#pragma unroll 1
+                    for (int kx = 0; kx < KS; ++kx) {
+                        if (kx + 1 < KS) {                        // column kx has landed; the loads of column kx+1 may stay in flight
+                            if (wave_n < 6) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        if (kx + 2 < KS) nload(kx + 2);           // into the stage of column kx-1, which every wave has left
+                        const unsigned wa = ldsn + HALO_BYTES + (kx % 3) * ROWB;
+                        const int key = (xb + kx) & 6;            // (forward only: flip == 0)
+                        unsigned hb[2];
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) hb[s2] = pbase + kx * 128 + (((4 * s2 + g) ^ key) << 4);
+                        bf16x8 fa[3], fb[2][6];
+                        // step T = (k-step T / 7, tap row ky = T % 7): its reads = the weight fragment + the halo rows it is the first to touch
+                        auto issue = [&](auto tc) {
+                            constexpr int T = decltype(tc)::value, S2 = T / KS, KY = T % KS;
+                            lds_rd128<KY * 2048>(fa[T % 3], wa + a_n[S2]);
+                            if constexpr (KY == 0) {
+                                lds_rd128<0>(fb[S2][0], hb[S2]); lds_rd128<HWD * 128>(fb[S2][1], hb[S2]);
+                                lds_rd128<2 * HWD * 128>(fb[S2][2], hb[S2]); lds_rd128<3 * HWD * 128>(fb[S2][3], hb[S2]);
+                            } else {
+                                lds_rd128<(KY + 3) * HWD * 128>(fb[S2][(KY + 3) % 6], hb[S2]);
+                            }
+                        };
+                        auto nreads = [](int T) constexpr { return T >= 2 * KS ? 0 : (T % KS == 0 ? 5 : 2); };
+                        auto stepn = [&](auto tc) {
+                            constexpr int T = decltype(tc)::value, S2 = T / KS, KY = T % KS;
+                            if constexpr (T + 2 < 2 * KS) issue(std::integral_constant<int, T + 2>{});
+                            constexpr int PEND = nreads(T + 1) + nreads(T + 2);        // reads issued after this step's: they may stay in flight
+                            asm volatile("s_waitcnt lgkmcnt(%5)"
+                                         : "+v"(fa[T % 3]), "+v"(fb[S2][KY % 6]), "+v"(fb[S2][(KY + 1) % 6]), "+v"(fb[S2][(KY + 2) % 6]), "+v"(fb[S2][(KY + 3) % 6])
+                                         : "n"(PEND));
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[HD][j] = KG_MFMA16(fa[T % 3], fb[S2][(KY + j) % 6], acc[HD][j]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        };
+                        issue(std::integral_constant<int, 0>{});
+                        issue(std::integral_constant<int, 1>{});
+                        [&]<int... Ns>(std::integer_sequence<int, Ns...>) { (stepn(std::integral_constant<int, Ns>{}), ...); }(std::make_integer_sequence<int, 2 * KS>{});
+                    }
+                };
+#else
                 const bf16_t* nsrc[2];
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {                     // piece e of a row: tap kx = e >> 7, row rho = (e >> 3) & 15, 16-byte slot e & 7
@@ -312,6 +393,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                         [&]<int... Ns>(std::integer_sequence<int, Ns...>) { (stepn(std::integral_constant<int, Ns>{}), ...); }(std::make_integer_sequence<int, 2 * KS>{});
                     }
                 };
+#endif
                 if (head_n == 0) narrow(std::integral_constant<int, 0>{});
                 else narrow(std::integral_constant<int, 1>{});
                 continue;
