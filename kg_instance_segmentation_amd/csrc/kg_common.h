@@ -117,6 +117,22 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {   // LDS byte addr
 
 static inline int kg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// i = q * d + r for a flat element index i >= 0 and a (wave-uniform) divisor d > 0.  The elementwise kernels decompose a 64-bit flat
+// index per 16-byte chunk; a 64-bit integer division is ~100 VALU instructions on gfx950 -- as much as the rest of such a thread -- so:
+// a shift when d is a power of two (scalar test, d is a kernel argument), a 32-bit division when i fits, the 64-bit one otherwise.
+__device__ __forceinline__ void kg_divmod(long i, int d, long* q, int* r) {
+    if ((d & (d - 1)) == 0) {
+        const int sh = __builtin_ctz((unsigned)d);
+        *q = i >> sh; *r = (int)(i & (long)(d - 1));
+    } else if ((unsigned long)i <= 0xffffffffUL) {
+        const unsigned qi = (unsigned)i / (unsigned)d;
+        *q = (long)qi; *r = (int)((unsigned)i - qi * (unsigned)d);
+    } else {
+        const long qq = i / d;
+        *q = qq; *r = (int)(i - qq * d);
+    }
+}
+
 // Side channel of kg_conv_stats_begin / kg_conv_stats_end (api.hip): the NEXT conv launch of this host thread that supports it
 // writes the BatchNorm statistics partials of its output (conv_args.h) into `part` and records its pixel-tile count.
 struct KgConvStats { float* part; long cap_floats; int nb; };

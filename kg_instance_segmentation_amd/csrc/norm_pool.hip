@@ -206,7 +206,7 @@ __global__ void bn_apply_kernel(const RowsR x, const float* __restrict__ scale,
                                 const RowsW y, long M, int C8, int relu) {
     long total = M * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / C8; int c = (int)(i - r * C8) * 8;
+        long r; int c; kg_divmod(i, C8, &r, &c); c *= 8;
         float v[8];
         rd8(x, r, c, v);
 #pragma unroll
@@ -245,7 +245,7 @@ __global__ void bn_bwd_apply_kernel(const RowsR x, const RowsR dy,
     const int C8 = C / 8;
     long total = M * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / C8; int c = (int)(i - r * C8) * 8;
+        long r; int c; kg_divmod(i, C8, &r, &c); c *= 8;
         float xs[8], ds[8], v[8];
         rd8(x, r, c, xs); rd8(dy, r, c, ds);
 #pragma unroll
@@ -306,8 +306,8 @@ __global__ void maxpool_fwd_kernel(const RowsR x, const RowsW y, unsigned char* 
                                    int W, int OH, int OW, int C8) {
     long total = (long)N * OH * OW * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C8) * 8; long p = i / C8;
-        int ox = (int)(p % OW); long q = p / OW; int oy = (int)(q % OH); long n = q / OH;
+        long p; int c; kg_divmod(i, C8, &p, &c); c *= 8;
+        int ox, oy; long q, n; kg_divmod(p, OW, &q, &ox); kg_divmod(q, OH, &n, &oy);
         float best[8]; int arg[8];
         pool_window_max(x, n * H * W, H, W, oy, ox, c, best, arg);
         wr8(y, p, c, best);
@@ -324,8 +324,8 @@ __global__ void maxpool_bwd_kernel(const RowsR x, const RowsR dy, const unsigned
                                    const RowsW dx, int N, int H, int W, int OH, int OW, int C8) {
     long total = (long)N * H * W * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C8) * 8; long p = i / C8;
-        int ix = (int)(p % W); long q = p / W; int iy = (int)(q % H); long n = q / H;
+        long p; int c; kg_divmod(i, C8, &p, &c); c *= 8;
+        int ix, iy; long q, n; kg_divmod(p, W, &q, &ix); kg_divmod(q, H, &n, &iy);
         float g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] = 0.f;
@@ -401,7 +401,7 @@ __global__ void bilinear_fwd_kernel(const RowsR x, const RowsW y, int IH,
                                     const int* __restrict__ row2box) {
     long total = total_rows * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C8) * 8; long p = i / C8;
+        long p; int c; kg_divmod(i, C8, &p, &c); c *= 8;
         long in0; int ih, iw, oh, ow, oy, ox;
         if (desc) {
             BilBox b = desc[row2box[p]];
@@ -409,7 +409,7 @@ __global__ void bilinear_fwd_kernel(const RowsR x, const RowsW y, int IH,
             ih = b.ih; iw = b.iw; oh = b.oh; ow = b.ow; oy = loc / ow; ox = loc - oy * ow; in0 = b.in_row0;
         } else {
             ih = IH; iw = IW; oh = OH; ow = OW;
-            ox = (int)(p % OW); long q = p / OW; oy = (int)(q % OH); in0 = (q / OH) * IH * IW;
+            long q, nimg; kg_divmod(p, OW, &q, &ox); kg_divmod(q, OH, &nimg, &oy); in0 = nimg * IH * IW;
         }
         int y0, y1, x0, x1; float ly, lx;
         bil_src(oy, (float)ih / (float)oh, ih, &y0, &y1, &ly);
@@ -436,7 +436,7 @@ __global__ void bilinear_bwd_kernel(const RowsR dy, const RowsW dx, int IH,
                                     const int* __restrict__ row2box, const bf16_t* __restrict__ mask, int ldmask) {
     long total = total_rows * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C8) * 8; long p = i / C8;
+        long p; int c; kg_divmod(i, C8, &p, &c); c *= 8;
         long out0; int ih, iw, oh, ow, iy, ix;
         if (desc) {
             BilBox b = desc[row2box[p]];
@@ -444,7 +444,7 @@ __global__ void bilinear_bwd_kernel(const RowsR dy, const RowsW dx, int IH,
             ih = b.ih; iw = b.iw; oh = b.oh; ow = b.ow; iy = loc / iw; ix = loc - iy * iw; out0 = b.out_row0;
         } else {
             ih = IH; iw = IW; oh = OH; ow = OW;
-            ix = (int)(p % IW); long q = p / IW; iy = (int)(q % IH); out0 = (q / IH) * OH * OW;
+            long q, nimg; kg_divmod(p, IW, &q, &ix); kg_divmod(q, IH, &nimg, &iy); out0 = nimg * OH * OW;
         }
         const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
         int ylo, yhi, xlo, xhi;
@@ -514,7 +514,7 @@ __global__ void add_rows_kernel(const RowsR a, const RowsR b,
                                 const bf16_t* __restrict__ m, int ldm, const RowsW y, long M, int C8) {
     long total = M * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / C8; int c = (int)(i - r * C8) * 8;
+        long r; int c; kg_divmod(i, C8, &r, &c); c *= 8;
         float v[8];
         rd8(a, r, c, v);
         if (b.p) {

@@ -30,7 +30,7 @@ __global__ void rows_gather_kernel(const bf16_t* __restrict__ src, int ldsrc, co
                                    bf16_t* __restrict__ dst, int lddst, long nrows, int C8) {
     long total = nrows * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / C8; int c = (int)(i - r * C8) * 8;
+        long r; int c; kg_divmod(i, C8, &r, &c); c *= 8;
         *reinterpret_cast<uint4*>(dst + r * lddst + c) = *reinterpret_cast<const uint4*>(src + (long)srcrow[r] * ldsrc + c);
     }
 }
@@ -51,7 +51,7 @@ __global__ void f32_to_bf16_rows_kernel(const float* __restrict__ acc, bf16_t* _
                                         int ldout, const bf16_t* __restrict__ addto, int ldadd) {
     long total = rows * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / C8; int c = (int)(i - r * C8) * 8;
+        long r; int c; kg_divmod(i, C8, &r, &c); c *= 8;
         const float* a = acc + (r * C8) * 8 + c;
         float v[8];
 #pragma unroll
@@ -84,7 +84,7 @@ __global__ void rows_gather_f32_kernel(const float* __restrict__ src, int ldsrc,
                                        bf16_t* __restrict__ dst, int lddst, int P, int ps, long nrows, int C8) {
     long total = nrows * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / C8; int c = (int)(i - r * C8) * 8;
+        long r; int c; kg_divmod(i, C8, &r, &c); c *= 8;
         const float4* sp = reinterpret_cast<const float4*>(src + (long)srcrow[r] * ldsrc + c);
         const float4 a = sp[0], b = sp[1];
         float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -111,7 +111,7 @@ __global__ void planes_to_f32_kernel(const bf16_t* __restrict__ x, int ldx, int 
                                      long rows, int C8) {
     long total = rows * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / C8; int c = (int)(i - r * C8) * 8;
+        long r; int c; kg_divmod(i, C8, &r, &c); c *= 8;
         float v[8];
         kg_load_planes8(x + r * ldx + c, P, ps, v);
         float4* op = reinterpret_cast<float4*>(out + r * ldout + c);
@@ -139,7 +139,7 @@ __global__ void f32_to_planes_kernel(const float* __restrict__ acc, int ldacc, b
     long total = rows * C8;
     const float S = scale ? *scale : 1.f;       // (gradients entering the half build's backward pass: gradscale.hip; addto is already scaled)
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / C8; int c = (int)(i - r * C8) * 8;
+        long r; int c; kg_divmod(i, C8, &r, &c); c *= 8;
         const float4* sp = reinterpret_cast<const float4*>(acc + r * ldacc + c);
         const float4 a = sp[0], b = sp[1];
         float v[8] = {a.x * S, a.y * S, a.z * S, a.w * S, b.x * S, b.y * S, b.z * S, b.w * S};
@@ -180,8 +180,8 @@ __global__ void crop_grad_reduce_kernel(const bf16_t* __restrict__ ga, int lda, 
                                         float* __restrict__ out, bf16_t* __restrict__ outp, int ldo, int oP, int ops_, long npix, int C8) {
     long total = npix * C8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long p = i / C8; int c = (int)(i - p * C8) * 8;
-        const int x = (int)(p % W); long q = p / W; const int y = (int)(q % H); const int n = (int)(q / H);
+        long p; int c; kg_divmod(i, C8, &p, &c); c *= 8;
+        int x, y; long q, nl; kg_divmod(p, W, &q, &x); kg_divmod(q, H, &nl, &y); const int n = (int)nl;
         const int bin = (n * BY + y / BS) * BX + x / BS;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int k = bin_start[bin]; k < bin_start[bin + 1]; ++k) {
