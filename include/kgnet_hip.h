@@ -89,6 +89,12 @@ int kg_conv2d_halo_heads2(const void* x, const void* w, const float* bias64, con
 int kg_conv3x3_c64(const void* x, const void* w, const float* bias, void* y, const void* res, const void* mask, int N, int H, int W,
                    int ldx, int Cout, int ldy, int ldres, int ldmask, int K, int flip, int relu, const int* tiletab16, int ntiles,
                    void* stream);
+/* Weight-stationary variant for the full-resolution 64 -> 64 channel 3x3 convs of the fp32-tolerance forward pass (c0_conv.2 KGnet.py:139-142,
+ * c1_up_conv :153, seg_head.0 :145-147, skip_combine.0.up :116-119): x in hi + lo planes (planes->a_planes == 2), w packed by kg_pack_weight
+ * with x_planes = w_planes = 2 (K >= 9 * 192), y = ReLU?(conv + bias) in 1 or 2 planes.  Dense (N images of H x W) or ragged
+ * (tiletab8: one {row0, (h << 16) | w, (oy0 << 16) | ox0, 0} entry per 8 x 16 tile of a box). */
+int kg_conv3x3_ws(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int ldx, int ldy, int K, int relu,
+                  const int* tiletab8, int ntiles, const kg_planes_t* planes, void* stream);
 /* 1x1 stride-1 convolution / its input gradient as a streaming GEMM over rows (dense or ragged): weight slab resident in
  * LDS, pixel fragments straight from global memory, persistent workgroups (KGnet.py:64-99,101-111,155-158) */
 int kg_conv1x1(const void* x, const void* w, const float* bias, void* y, const void* res, const void* mask, long M, int K,

@@ -30,6 +30,7 @@ _SIGS = {
     "kg_conv2d_halo": [P, P, P, P, P, P, P] + [c_int] * 15 + [P, c_int, c_int, P, P],
     "kg_conv1x1": [P, P, P, P, P, P, c_long] + [c_int] * 8 + [P],
     "kg_conv3x3_c64": [P, P, P, P, P, P] + [c_int] * 11 + [P, c_int, P],
+    "kg_conv3x3_ws": [P, P, P, P] + [c_int] * 7 + [P, c_int, P, P],
     "kg_pack_weight": [P, P] + [c_int] * 11 + [P],
     "kg_pack_weight_rows": [P, P] + [c_int] * 6 + [P, c_int, c_int, c_int, c_int, P],
     "kg_pack_weight_batch": [P, c_int, c_int, P],

@@ -297,14 +297,24 @@ IM2COL_WGRAD = __import__("os").environ.get("KG_IM2COL_WGRAD", "1") == "1"
 HALO_WC = int(__import__("os").environ.get("KG_HALO_WC", "0"))   # tuning override (0 = library default)
 
 
+USE_WS = __import__("os").environ.get("KG_CONV3_WS", "1") == "1"     # A/B switch of the weight-stationary 64 -> 64 kernel (conv3_ws.hip)
+
+
 def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, flip=False, wc=0,
-              tiletab=None, total_rows=0, k1skip=False, algo_cin=None, tiletab16=None, oscale=None):
+              tiletab=None, total_rows=0, k1skip=False, algo_cin=None, tiletab16=None, oscale=None, tiletab8=None):
     """Stride-1 "same" KSxKS conv (or its input gradient when flip) with the input halo resident in LDS.
     tiletab (int32 [ntiles,4] device tensor): ragged boxes instead of N images of HxW.
     k1skip (7x7 only): the packed weights are zero for channels 32..63 of every 64-channel chunk.
     algo_cin: number of input channels that carry data (FLOP accounting of bench.py's timer; unused here)."""
     flush_packs()
     assert nplanes(x)[0] == pw.xP, (nplanes(x), pw.xP)
+    if (USE_WS and KS == 3 and pw.cin_pad == 64 and cout == 64 and pw.xP == 2 and pw.wP == 2 and y is not None and y_f32 is None and res is None
+            and mask is None and not flip and oscale is None and wc == 0 and HALO_WC == 0 and (tiletab is None or tiletab8 is not None)
+            and nplanes(y)[0] <= 2 and not conv_stats_armed()):
+        # full-resolution 64 -> 64 convs on hi + lo planes: weights in registers, two workgroups per CU (conv3_ws.hip)
+        _lib.call("kg_conv3x3_ws", ptr(_rows(x)), ptr(pw.buf), ptr(bias), ptr(base(y)), N, H, W, ld(x), ld(y), pw.K, 1 if relu else 0,
+                  ptr(tiletab8), tiletab8.shape[0] if tiletab8 is not None else 0, pl(a=x, y=y, w=pw.wP), stream_ptr(), fmt=fmt_of(x))
+        return
     planes = pl(a=x, b=res, y=y, w=pw.wP, oscale=oscale)      # (oscale: folded inference BatchNorm, y = act(acc * oscale + bias + res))
     x, y, res, mask = base(x), base(y), base(res), base(mask)
     if (USE_C3 and planes is None and KS == 3 and pw.cin_pad == 64 and y is not None and y_f32 is None and wc == 0 and HALO_WC == 0
@@ -532,11 +542,20 @@ def bn_stats_train(x, C, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5):
 CONV_BN_STATS = __import__("os").environ.get("KG_CONV_BN_STATS", "1") == "1"   # BatchNorm statistics in the producing conv's epilogue
 
 
+_STATS_ARMED = [False]
+
+
+def conv_stats_armed():
+    """True between conv_stats_begin and conv_stats_end: the next conv launch must be one that carries the statistics epilogue"""
+    return _STATS_ARMED[0]
+
+
 def conv_stats_begin(dev, fmt=0):
     """Arms the next conv launch of this thread (in the library of rows format `fmt`) to also write the BatchNorm statistics
     partials of its output (kg_conv_stats_begin)."""
     part = scratch_f32(1 << 21, dev, "bnpart")
     _lib.call("kg_conv_stats_begin", ptr(part), c_long(part.numel()), fmt=fmt)
+    _STATS_ARMED[0] = True
     return part
 
 
@@ -544,6 +563,7 @@ def conv_stats_end(fmt=0):
     """Pixel tiles the armed conv wrote partials for (0: its kernel has no statistics epilogue); disarms."""
     import ctypes
     nb = ctypes.c_int(0)
+    _STATS_ARMED[0] = False
     _lib.call("kg_conv_stats_end", ctypes.byref(nb), fmt=fmt)
     return nb.value
 

@@ -252,6 +252,7 @@ class SegBranch:
             return out
         t32 = [tile_table(l, 16, 32) for l in range(5)]
         t16 = [tile_table(l, 16, 16) for l in range(5)]
+        t8 = [tile_table(0, 8, 16)]              # c0 crops: 8 x 16 tiles of the weight-stationary 64 -> 64 kernel (conv3_ws.hip)
 
         def cum(l, th, tw):
             h, w = p.hw[l]
@@ -259,6 +260,7 @@ class SegBranch:
             np.cumsum(((h + th - 1) // th) * ((w + tw - 1) // tw), out=c[1:])
             return c
         p.t32_cum = [cum(l, 16, 32) for l in range(5)]; p.t16_cum = [cum(l, 16, 16) for l in range(5)]
+        p.t8_cum = [cum(0, 8, 16)]
         # bin grid of the deterministic crop-gradient reduction (kg_crop_grad_reduce): per level, CSR lists of the boxes that
         # touch each BIN x BIN bin of each image, in ascending box order
         bin_start, bin_boxes = [], []
@@ -280,7 +282,7 @@ class SegBranch:
                 raise _lib.KGLibraryError(f"kg_host_bin_csr: {got} incidences, expected {cap}")
             bin_start.append(st); bin_boxes.append(bb)
         blob = np.concatenate([t.ravel() for t in tabs] + [b.ravel() for b in bil] + [t.ravel() for t in t32] + [t.ravel() for t in t16]
-                              + bin_start + bin_boxes).astype(np.int32)
+                              + [t.ravel() for t in t8] + bin_start + bin_boxes).astype(np.int32)
         dblob = ops.h2d(blob, dev)
         off = 0
         p.tab_d, p.bil_d = [], []
@@ -293,6 +295,9 @@ class SegBranch:
             p.t32_d.append(dblob[off:off + t.size].view(-1, 4)); off += t.size
         for t in t16:
             p.t16_d.append(dblob[off:off + t.size].view(-1, 4)); off += t.size
+        p.t8_d = []
+        for t in t8:
+            p.t8_d.append(dblob[off:off + t.size].view(-1, 4)); off += t.size
         p.bin_start_d, p.bin_boxes_d = [], []
         for t in bin_start:
             p.bin_start_d.append(dblob[off:off + t.size]); off += t.size
@@ -352,20 +357,24 @@ class SegBranch:
     def galloc(self, rows, C, dev):
         return ops.alloc_pt(rows, C, self.Pg, dev, dtype=self.dt)
 
-    def rconv(self, x, pw, cout, rowdesc, M, k, y=None, y_f32=None, bias=None, relu=False, mask=None, mode=2, tiles=None, tiles16=None):
+    def rconv(self, x, pw, cout, rowdesc, M, k, y=None, y_f32=None, bias=None, relu=False, mask=None, mode=2, tiles=None, tiles16=None, tiles8=None):
         """Ragged conv (mode 2) or its input gradient (mode 3).  3x3 convs over 64-channel-aligned inputs run on the
         LDS-halo kernel with one (box, 16x32 tile) entry per workgroup; the rest on the gather implicit GEMM.
         `tiles` = (tile table of the first `M` rows' boxes); boxes are a prefix, so a prefix of the table is used."""
         if (ops.USE_HALO and k == 3 and tiles is not None and tiles.shape[0] > 0 and pw.cin_pad % 64 == 0 and x.shape[1] >= pw.cin_pad
                 and M >= 0.35 * tiles.shape[0] * 512):     # tiles mostly full: tiny deep-level crops stay on the gather kernel
             ops.conv_halo(x, pw, cout, 0, 0, 0, 3, y=y, y_f32=y_f32, bias=bias, relu=relu, mask=mask, flip=(mode == 3),
-                          tiletab=tiles, total_rows=M, tiletab16=tiles16)
+                          tiletab=tiles, total_rows=M, tiletab16=tiles16, tiletab8=tiles8)
             return
         if k == 1 and y is not None and ops.can_1x1(self._head(x, M), pw, 1, 1, 0, self._head(y, M), y_f32):
             ops.conv1x1(ops.base(x)[:M], pw, cout, ops.base(y)[:M], bias=bias, mask=mask[:M] if mask is not None else None, relu=relu)
             return
         geom = (M, 0, 0, M, 1, k, k, 1, (k - 1) // 2)
         ops.conv_igemm(x, pw, cout, geom, y=y, y_f32=y_f32, bias=bias, relu=relu, mask=mask, mode=mode, rowdesc=rowdesc)
+
+    @staticmethod
+    def T8(plan, l, nboxes):
+        return plan.t8_d[l][:int(plan.t8_cum[l][nboxes])] if l < len(plan.t8_d) else None
 
     @staticmethod
     def T32(plan, l, nboxes):
@@ -405,7 +414,7 @@ class SegBranch:
                 cat = self.alloc(rowsC, ccat, dev)
                 pw, _, b = self.packw(f"skip_combine.{l}.up.0", record)
                 self.rconv(uin, pw, cout, plan.rowdesc[l], rowsC, 3, y=cat.cols(CH[l], CH[l] + cout), bias=b, relu=True,
-                           tiles=self.T32(plan, l, nc), tiles16=self.T16(plan, l, nc))
+                           tiles=self.T32(plan, l, nc), tiles16=self.T16(plan, l, nc), tiles8=self.T8(plan, l, nc))
                 self.gather(fr[l], plan.srcrow[l], cat.cols(0, CH[l]), rowsC, CH[l])
                 pw, _, b = self.packw(f"skip_combine.{l}.cat_conv.0", record)
                 self.rconv(cat, pw, cout, plan.rowdesc[l], rowsC, 1, y=pre[l].rows(0, rowsC), bias=b, relu=True)
@@ -415,7 +424,7 @@ class SegBranch:
         hid = self.alloc(rows0, 64, dev)
         pw, _, b = self.packw("seg_head.0", record)
         self.rconv(pre[0], pw, 64, plan.rowdesc[0], rows0, 3, y=hid, bias=b, relu=True, tiles=self.T32(plan, 0, plan.nb[0]),
-                   tiles16=self.T16(plan, 0, plan.nb[0]))
+                   tiles16=self.T16(plan, 0, plan.nb[0]), tiles8=self.T8(plan, 0, plan.nb[0]))
         flat = torch.empty(rows0, dtype=torch.float32, device=dev)
         if SEG_C1:      # one output channel: a per-pixel dot product kernel (csrc/seg.hip), not a 64-row MFMA tile with 63 zero rows
             _lib.call("kg_seg_conv3_c1", ptr(ops.base(hid)), ops.ld(hid), 64, ptr(self.P("seg_head.2.weight").detach()),

@@ -427,3 +427,65 @@ def test_seg_head_single_cout_conv_on_ragged_rows(P, dt):
         off += h * wd
     check(f"seg_conv3_c1 P={P}", y, torch.cat(ref), 2e-6)
     DT[0] = BF16
+
+
+@pytest.mark.parametrize("dt", [BF16, F16], ids=["bf16x2", "f16x2"])
+@pytest.mark.parametrize("case", [(1, 8, 16), (2, 37, 53), (1, 64, 64)])
+def test_weight_stationary_3x3_c64_dense(case, dt):
+    """kg_conv3x3_ws (conv3_ws.hip): 64 -> 64 channels, hi + lo planes of x and w (3 products), bias + ReLU, two output planes, against
+    torch's float64 conv2d on the stored values; also into a column slice of a wider two-plane buffer (the decoder writes its concat buffer)."""
+    DT[0] = dt
+    N, H, W = case
+    g = torch.Generator().manual_seed(N * 1000 + H)
+    x32 = torch.randn(N, 64, H, W, generator=g).to(DEV)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(DEV)
+    b = (torch.randn(64, generator=g) * 0.1).to(DEV)
+    xp = to_pt(rows_f32(x32), 2)
+    pw = PackedWeight(64, 9, 64, DEV, xP=2, wP=2)
+    pw.pack(w)
+    for ctot, c0 in ((64, 0), (128, 64)):
+        ybuf = alloc_pt(N * H * W, ctot, 2, DEV)
+        y = ybuf.cols(c0, c0 + 64)
+        ops.conv_halo(xp, pw, 64, N, H, W, 3, y=y, bias=b, relu=True)
+        assert _lib.last_kernel(ops.fmt_of(xp)) == "conv3_ws_kernel"
+        ref = F.relu(F.conv2d(nchw(from_pt(xp), N, H, W).double().cpu(), w.double().cpu(), b.double().cpu(), padding=1))
+        check(f"conv3_ws dense {case} ctot={ctot}", nchw(from_pt(y), N, H, W), ref, TOL[2])
+    DT[0] = BF16
+
+
+@pytest.mark.parametrize("dt", [BF16, F16], ids=["bf16x2", "f16x2"])
+def test_weight_stationary_3x3_c64_ragged(dt):
+    """the same kernel over a ragged list of boxes (8 x 16 tile table of kg_host_tile_table): every box is convolved on its own (zero padding
+    at the box border), one output plane (what the half-precision policies' single-plane consumers read) and two"""
+    import ctypes
+    DT[0] = dt
+    g = torch.Generator().manual_seed(9)
+    boxes = [(3, 3), (8, 16), (9, 17), (27, 27), (40, 14), (2, 33), (16, 5)]
+    hs = np.array([b[0] for b in boxes], np.int32); ws_ = np.array([b[1] for b in boxes], np.int32)
+    row0 = np.zeros(len(boxes) + 1, np.int64); np.cumsum(hs.astype(np.int64) * ws_, out=row0[1:])
+    M = int(row0[-1])
+    cnt = int((((hs + 7) // 8) * ((ws_ + 15) // 16)).sum())
+    tab = np.empty((cnt, 4), np.int32)
+    r0 = np.ascontiguousarray(row0[:-1])
+    got = _lib.load().kg_host_tile_table(ctypes.c_void_p(hs.ctypes.data), ctypes.c_void_p(ws_.ctypes.data), ctypes.c_void_p(r0.ctypes.data), len(boxes), 8, 16,
+                                         ctypes.c_void_p(tab.ctypes.data), cnt)
+    assert got == cnt
+    t8 = torch.from_numpy(tab).to(DEV)
+    x32 = torch.randn(M, 64, generator=g).to(DEV)
+    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(DEV)
+    b = (torch.randn(64, generator=g) * 0.1).to(DEV)
+    xp = to_pt(x32, 2)
+    pw = PackedWeight(64, 9, 64, DEV, xP=2, wP=2)
+    pw.pack(w)
+    xv = from_pt(xp).double().cpu()
+    ref = []
+    for (h, wd), off in zip(boxes, row0[:-1]):
+        img = xv[off:off + h * wd].view(1, h, wd, 64).permute(0, 3, 1, 2)
+        ref.append(F.conv2d(img, w.double().cpu(), b.double().cpu(), padding=1)[0].permute(1, 2, 0).reshape(h * wd, 64))
+    ref = torch.cat(ref)
+    for yP in (2, 1):
+        y = alloc_pt(M, 64, yP, DEV)
+        ops.conv_halo(xp, pw, 64, 0, 0, 0, 3, y=y, bias=b, relu=False, tiletab=t8, total_rows=M, tiletab8=t8)
+        assert _lib.last_kernel(ops.fmt_of(xp)) == "conv3_ws_kernel"
+        check(f"conv3_ws ragged yP={yP}", from_pt(y), ref, TOL[2] if yP == 2 else TOL[1])
+    DT[0] = BF16
