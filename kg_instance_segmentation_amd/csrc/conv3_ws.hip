@@ -15,7 +15,15 @@
 //     their own accumulator (added to acc_hi once, in the epilogue): no ordering constraint between the products, nothing staged twice;
 //   * 8 x 16 tiles also fit the ragged boxes of the seg branch better than 16 x 32 ones (fill 67 % against 50 % for sides in [14, 40)).
 // Epilogue: bias, ReLU, hi + lo plane store (a lane holds 4 consecutive couts of one pixel: 8-byte stores).
+// Measured (tools/ws_probe.py, dense 8 x 512 x 512, random data): 0.52 ms against 0.55 ms for conv_halo<3>; inside the train step (ReLU-sparse
+// data) 0.42 ms per launch against 0.57 (dense) / 0.73 (ragged).  Switching parts off: the memory phases alone run at the HBM rate (0.27 ms),
+// the MFMA phase alone at the MFMA rate (0.25 ms) -- and they ADD UP: the two workgroups of a CU stay in phase (a start-up delay of the odd
+// workgroups does not persist), so what is left is a halo prefetch inside the workgroup (double-buffered halo, fragment reads from inline asm:
+// the compiler orders every LDS read behind a pending LDS-DMA).  Tried and dropped: the output through an LDS tile as whole 128-byte lines
+// (+7 % in the step), four tile rows per pass (spills at 256 registers).
 #include "kg_common.h"
+
+__device__ uint4 kg_ws_zero_line[8];   // 128 zero bytes: source of the padding pixels of a halo
 
 struct WsArgs {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y;
@@ -68,34 +76,28 @@ __global__ __launch_bounds__(256, 2) void conv3_ws_kernel(const WsArgs a) {
             oy0 = ty * TH; ox0 = tx * TW; Hd = a.H; Wd = a.W; rowbase = (long)n * a.H * a.W;
         }
         __syncthreads();                                   // every wave has left the previous tile's halo
-        // ---- stage the (10 x 18)-pixel halo of both planes: 2 880 pieces of 16 bytes, in three batches of four loads per thread (a batch's
-        // loads are all issued before its LDS stores; 16 staging registers next to the 144 weight registers -- one batch of 12 spilled)
-        constexpr int NP = 2 * HH * HW_ * 8, RND = (NP + 255) / 256, BATCH = 4;
-        static_assert(RND % BATCH == 0, "staging batches");
+        // ---- stage the (10 x 18)-pixel halo of both planes: 2 880 pieces of 16 bytes by LDS-direct loads (global_load_lds_dwordx4: no staging
+        // registers next to the 144 weight registers, all 12 rounds in flight at once -- as three register batches of four loads the kernel
+        // took 0.49 instead of 0.43 ms per launch).  The destination of a wave's load is lane-linear, so the XOR swizzle of the 16-byte channel
+        // slots is applied to the SOURCE chunk (an involution inside the pixel's 128-byte line); pixels outside the image / box read a zero line.
+        constexpr int NP = 2 * HH * HW_ * 8, RND = (NP + 255) / 256;
 #pragma unroll 1
-        for (int q0 = 0; q0 < RND; q0 += BATCH) {
-            uint4 hreg[BATCH];
-#pragma unroll
-            for (int q = 0; q < BATCH; ++q) {
-                const int e = tid + (q0 + q) * 256;
+        for (int q = 0; q < RND; ++q) {
+            const int e = tid + q * 256;
+            if (e < NP) {
                 const int p = e / (HH * HW_ * 8), rem = e - p * (HH * HW_ * 8);
-                const int hp = rem >> 3, c = rem & 7;
+                const int hp = rem >> 3, cs = rem & 7;
                 const int hy = hp / HW_, hx = hp - hy * HW_;
+                const int c = cs ^ (hx & 6);
                 const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (e < NP && (unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd)
-                    v = *reinterpret_cast<const uint4*>(a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + (long)p * a.xps + c * 8);
-                hreg[q] = v;
-            }
-#pragma unroll
-            for (int q = 0; q < BATCH; ++q) {
-                const int e = tid + (q0 + q) * 256;
-                const int p = e / (HH * HW_ * 8), rem = e - p * (HH * HW_ * 8);
-                const int hp = rem >> 3, c = rem & 7;
-                const int hx = hp % HW_;
-                if (e < NP) *reinterpret_cast<uint4*>(halo + p * PLANE + hp * 128 + ((c ^ (hx & 6)) * 16)) = hreg[q];
+                const bf16_t* src = reinterpret_cast<const bf16_t*>(kg_ws_zero_line) + c * 8;
+                if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd)
+                    src = a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + (long)p * a.xps + c * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(halo + (q * 256 + wave * 64) * 16), 16, 0, 0);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
         // ---- two tile rows (16-pixel fragments) at a time: 4 independent accumulators
