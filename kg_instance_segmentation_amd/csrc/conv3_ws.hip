@@ -18,8 +18,11 @@
 // Measured (tools/ws_probe.py, dense 8 x 512 x 512, random data): 0.52 ms against 0.55 ms for conv_halo<3>; inside the train step (ReLU-sparse
 // data) 0.42 ms per launch against 0.57 (dense) / 0.73 (ragged).  Switching parts off: the memory phases alone run at the HBM rate (0.27 ms),
 // the MFMA phase alone at the MFMA rate (0.25 ms) -- and they ADD UP: the two workgroups of a CU stay in phase (a start-up delay of the odd
-// workgroups does not persist), so what is left is a halo prefetch inside the workgroup (double-buffered halo, fragment reads from inline asm:
-// the compiler orders every LDS read behind a pending LDS-DMA).  Tried and dropped: the output through an LDS tile as whole 128-byte lines
+// workgroups does not persist), or so it seemed: the obvious remedy -- ONE 8-wave workgroup per CU, double-buffered halo, the LDS-direct loads of tile
+// k + 1 issued before the MFMA phase of tile k, fragment reads from inline asm behind counted lgkmcnt (the compiler orders every LDS read it sees
+// behind a pending LDS-DMA) -- was written, is bit-correct, and runs at the SAME speed (0.528 against 0.512 ms here, +-0 in the step): the
+// phases are not what adds up.  The 8-byte stores (32 bytes per pixel and wave, four waves per 128-byte line at four different times) are the
+// remaining suspect: without them the register-staged first version ran in 0.14 ms.  Tried and dropped: the output through an LDS tile as whole 128-byte lines
 // (+7 % in the step), four tile rows per pass (spills at 256 registers).
 #include "kg_common.h"
 
