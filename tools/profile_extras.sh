@@ -3,7 +3,7 @@
 tag=${1:-r03}
 O=$PWD/gpurun_out
 mkdir -p $O
-python tools/pareto.py --out $O/${tag}_pareto.json --steps 8 fp32 fp32b2 halfmix half fp32bf fp32bf_full fp32bf_w1d1 trunk2 mixed bf16 > $O/${tag}_pareto.log 2>&1
+python tools/pareto.py --out $O/${tag}_pareto.json --steps 8 ${PARETO_POLICIES:-fp32 fp32b2 halfmix half fp32bf fp32bf_full fp32bf_w1d1 trunk2 mixed bf16} > $O/${tag}_pareto.log 2>&1
 python bench.py --steps 6 --warmup 2 --batch 16 --no-companion --no-cpu-baseline > $O/${tag}_bench_bs16.json 2>/dev/null
 KG_BENCH_SYNC=0 python bench.py --steps 10 --warmup 3 --no-companion --no-cpu-baseline > $O/${tag}_bench_nosync.json 2>/dev/null
 python bench.py --mode eval --steps 10 > $O/${tag}_eval.json 2>/dev/null
