@@ -7,7 +7,7 @@ GROUPS = [
     ("7x7 heads: conv_halo<7,1,8,0> forward + input gradient (the dominant kernel)", lambda n: "conv_halo_kernel<7, 1, 8, 0>" in n),
     ("7x7 heads: grouped second layers <7,1,8,1> + their fused input gradient <7,1,8,2>", lambda n: "conv_halo_kernel<7, 1, 8, 1>" in n or "conv_halo_kernel<7, 1, 8, 2>" in n),
     ("7x7 heads: weight gradients wgrad_halo<7,...>", lambda n: "wgrad_halo_kernel<7" in n),
-    ("3x3: conv_halo<3> + conv3_c64 + wgrad_halo<3>", lambda n: "conv_halo_kernel<3" in n or "conv3_c64" in n or "wgrad_halo_kernel<3" in n),
+    ("3x3: conv_halo<3> + conv3_ws + conv3_c64 + wgrad_halo<3>", lambda n: "conv_halo_kernel<3" in n or "conv3_c64" in n or "conv3_ws" in n or "wgrad_halo_kernel<3" in n),
     ("conv_gather", lambda n: "conv_gather" in n),
     ("gather weight gradients conv_wgrad128 / conv_wgrad", lambda n: "conv_wgrad" in n),
     ("conv1x1_*, conv_small, im2col, conv_igemm", lambda n: "conv1x1" in n or "conv_small" in n or "im2col" in n or "conv_igemm" in n),
@@ -16,6 +16,8 @@ GROUPS = [
     ("bilinear, max-pool, gradient joins, packing of the map gradients", lambda n: "bilinear" in n or "maxpool" in n or "add_rows" in n or "grad_pack" in n or "img_pack" in n),
     ("seg plumbing, losses", lambda n: any(k in n for k in ("crop_grad", "rows_gather", "seg_", "det_loss", "gt_maps", "sum_final", "sigmoid_inplace", "planes_to", "f32_to"))),
     ("weight packing + Adam", lambda n: "pack_weight" in n or "adam" in n),
+    ("finishing passes of the K splits", lambda n: "conv_tiny_finish" in n or "conv_halo_finish" in n),
+    ("gradient-scale bookkeeping (grad_scale, rows_absmax / rows_scale*, scale_tensors)", lambda n: any(k in n for k in ("grad_scale", "rows_absmax", "rows_scale", "scale_tensors"))),
 ]
 
 
