@@ -111,7 +111,12 @@ class KernelTimer:
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             flushq(); s.record(); r = orig_halo(x, pw, cout, N, H, W, KS, *a, **k); e.record()
             cin = k.get("algo_cin") or getattr(pw, "cin_real", pw.cin_pad)     # real channels (not the 8 / 64 padding, not the plane copies); fused second-layer head dgrad: 5 / 10 / 40 real dY channels per head
-            fl = 2.0 * N * H * W * cout * KS * KS * cin
+            px = N * H * W
+            if px == 0:      # ragged per-box crops (seg branch): the pixels of the tiles the launch walks (8 x 16 on conv3_ws, else 16 x 32)
+                t8, t16 = k.get("tiletab8"), k.get("tiletab")
+                ws = kname(x).startswith("conv3_ws")
+                px = t8.shape[0] * 128 if (ws and t8 is not None) else (t16.shape[0] * 512 if t16 is not None else 0)
+            fl = 2.0 * px * cout * KS * KS * cin
             timer.rec.append((kname(x), fl, s, e, f"N={N} H={H} cout={cout} cinp={pw.cin_pad} products={pw.vp}" + (f" algo_cin={cin}" if "algo_cin" in k else ""), fl * pw.vp))
             return r
         orig_1x1 = ops.conv1x1

@@ -5,13 +5,13 @@
 usage: python tools/roofline_check.py [tag]   ->  algorithmic FLOPs per step of conv_halo<7,1> (k1skip excluded: another instantiation),
 MFMA-issued FLOPs (x products), and both divided by the profiler's duration of conv_halo_kernel<7, 1, 8, 0> and by 2.5 PFLOP/s."""
 import csv, re, sys, os
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 alg = issued = ms_ev = 0.0
 n = 0
 for line in open(os.path.join(root, f"{tag}_bench_launches.txt")):
-    m = re.match(r"\s*([\d.]+) ms/step\s+([\d.]+) TF\s+x\s*([\d.]+)\s+(\S+)\s+(.*)", line)
-    if not m or m.group(4) != "conv_halo<7,1>":
+    m = re.match(r"\s*([\d.]+) ms/step\s+([\d.]+) TF\s+x\s*([\d.]+)\s+(\S.*?)\s{2,}(.*)", line)
+    if not m or m.group(4).replace(" ", "") not in ("conv_halo<7,1>", "conv_halo_kernel<7,1,8,0>"):
         continue
     ms, tf, cnt, desc = float(m.group(1)), float(m.group(2)), float(m.group(3)), m.group(5)
     prod = int(re.search(r"products=(\d+)", desc).group(1)) if "products=" in desc else 1
