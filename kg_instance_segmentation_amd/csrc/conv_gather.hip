@@ -25,6 +25,13 @@ __device__ uint4 kg_gather_zero_line[8];
 // stores its raw fp32 accumulators as four 64 x 64 partial tiles in conv_tiny's slot layout; kg_launch_splitk_finish adds the slots in z order
 // and runs the epilogue (+ statistics).  For launches whose output gives < 128 workgroups: the layer-2 / layer-3 convs of a batch-8 step
 // (M = 8192 pixels x 256 couts = 64 workgroups, each walking up to 48 stages alone on a quarter of the chip).
+//
+// P2 (hi + lo planes on BOTH operands, the fp32-tolerance forward pass): the three products x_hi w_lo, x_lo w_hi, x_hi w_hi of a channel range
+// share their operands, so a stage holds 32 channels of BOTH planes instead of 64 channels of one -- 128-byte rows [x_hi | x_lo] and
+// [w_lo | w_hi] (the w_lo / w_hi copies of virtual planes 0 / 1 of the packed row), same ring, same swizzle, same fragment addresses -- and
+// feeds 48 MFMAs instead of 32: 2/3 of the global -> LDS traffic and of the fragment reads per product (the virtual-plane walk stages every
+// x plane and w_hi twice).  The low-order products have their own accumulator, added once before the epilogue.
+template <bool P2>
 __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, const int ncc, float* __restrict__ sk_part) {
     constexpr int TP = 256, TC = 128, NS = 3, XB = TP * 128, WB = TC * 128, STAGE = XB + WB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -33,7 +40,7 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
     const int wp = wave & 3, wcw = wave >> 2;
     const int lm = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * TP, c0 = blockIdx.y * TC;
-    const int cin_pad = ncc * 64;
+    const int tapK = P2 ? ncc * 96 : ncc * 64;                              // packed weight elements per tap (P2: ncc 32-channel chunks, 3 virtual planes)
 
     // ---- staging assignment: thread -> 16-byte slot cs of rows rr + 64 q ------------------------------------------------
     const int cs = tid & 7, rr = tid >> 3;
@@ -58,7 +65,9 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
     }
     const bf16_t* wrow[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) wrow[q] = a.w + (long)(c0 + q * 64 + rr) * a.K + wchunk * 8;   // packed rows are padded past Cout
+    for (int q = 0; q < 2; ++q)   // packed rows are padded past Cout.  P2: slots 0-3 = w_lo (virtual plane 0), 4-7 = w_hi (virtual plane 1)
+        wrow[q] = a.w + (long)(c0 + q * 64 + rr) * a.K + (P2 ? (wchunk >> 2) * (ncc * 32) + (wchunk & 3) * 8 : wchunk * 8);
+    const int xfix = P2 ? (xchunk >> 2) * a.km.xps + (xchunk & 3) * 8 : xchunk * 8;               // P2: slots 0-3 = x plane 0 (hi), 4-7 = plane 1 (lo)
     const bf16_t* zline = reinterpret_cast<const bf16_t*>(kg_gather_zero_line) + cs * 8;
     const int smask = (1 << a.stride_log2) - 1;
 
@@ -94,17 +103,17 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
                     ok = ok && (unsigned)iy < (unsigned)ph[q] && (unsigned)ix < (unsigned)pw[q];
                     row = pbase[q] + (long)sy * pw[q] + sx;
                 }
-                xsrc[q] = ok ? a.x + row * a.ldx + xchunk * 8 : nullptr;
+                xsrc[q] = ok ? a.x + row * a.ldx + xfix : nullptr;
             }
         }
         unsigned char* st = smem + i_slot * STAGE + wave * 1024;
-        const int xo = a.km.xoff(i_cc);      // planes: virtual chunk -> (x plane, channel chunk)
+        const int xo = P2 ? i_cc * 32 : a.km.xoff(i_cc);      // planes: virtual chunk -> (x plane, channel chunk)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bf16_t* src = xsrc[q] ? xsrc[q] + xo : zline;
             KG_GLDS(src, st + q * 8192);
         }
-        const long woff = (long)i_tap * cin_pad + i_cc * 64;
+        const long woff = (long)i_tap * tapK + i_cc * (P2 ? 32 : 64);
 #pragma unroll
         for (int q = 0; q < 2; ++q) KG_GLDS(wrow[q] + woff, st + XB + q * 8192);
         if (++i_cc == ncc) { i_cc = 0; ++i_tap; }
@@ -126,11 +135,14 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
 #pragma unroll
         for (int s = 0; s < 2; ++s) b_off[j][s] = r * 128 + (((4 * s + g) ^ ((r >> 1) & 7)) * 16);
     }
-    f32x4 acc[4][4];
+    f32x4 acc[4][4], acl[P2 ? 4 : 1][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) {
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (P2) acl[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 
     const unsigned lds0 = lds_addr(smem);
     issue();
@@ -157,6 +169,28 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
             lds_rd128<0>(bfr[k][0], ba); lds_rd128<2048>(bfr[k][1], ba); lds_rd128<4096>(bfr[k][2], ba); lds_rd128<6144>(bfr[k][3], ba);
         }
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (P2) {
+            // af[0] = w_lo, bfr[0] = x_hi, af[1] = w_hi, bfr[1] = x_lo (32 channels each): low-order products into acl
+            lgkm_wait<8>(af[0], bfr[0]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acl[i][j] = KG_MFMA16(af[0][i], bfr[0][j], acl[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < nstage && wave >= 4) { issue(); __builtin_amdgcn_sched_barrier(0); }
+            lgkm_wait<4>(af[1], bfr[0]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = KG_MFMA16(af[1][i], bfr[0][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            lgkm_wait<0>(af[1], bfr[1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acl[i][j] = KG_MFMA16(af[1][i], bfr[1][j], acl[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (k == 0) lgkm_wait<8>(af[0], bfr[0]);
@@ -169,10 +203,17 @@ __global__ __launch_bounds__(512) void conv_gather_kernel(const ConvArgs a, cons
             __builtin_amdgcn_sched_barrier(0);   // the MFMAs of k-step 0 stay in front of the wait for k-step 1
             if (k == 0 && s + 2 < nstage && wave >= 4) { issue(); __builtin_amdgcn_sched_barrier(0); }
         }
+        }
         __builtin_amdgcn_s_setprio(0);
         c_slot = c_slot == NS - 1 ? 0 : c_slot + 1;
     }
 
+    if constexpr (P2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] += acl[i][j];
+    }
     if (sk_part) {   // (uniform) K split: raw partial tiles, slot = ((tile64 * Z + z) * 4 + pixel group) * 1024 + value * 64 + lane
         const long npt64 = (long)gridDim.x * 4;
         const long tile64 = (long)(blockIdx.y * 2 + wcw) * npt64 + blockIdx.x * 4 + wp;
@@ -221,13 +262,19 @@ int kg_launch_conv_gather(ConvArgs a, int cin_pad, hipStream_t st, bool stats_ok
     constexpr int smem = 3 * (256 * 128 + 128 * 128);
     static bool attr_done = false;
     if (!attr_done) {
-        KG_HIP(hipFuncSetAttribute((const void*)conv_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        KG_HIP(hipFuncSetAttribute((const void*)conv_gather_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        KG_HIP(hipFuncSetAttribute((const void*)conv_gather_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
     dim3 grid(kg_cdiv(a.M, 256), kg_cdiv(a.Cout, 128));
+    // hi + lo planes on both operands (3 virtual planes: x_hi w_lo, x_lo w_hi, x_hi w_hi): paired stages of 32 channels (KG_GATHER_P2=0: the
+    // virtual-plane walk)
+    static const int use_p2 = getenv("KG_GATHER_P2") ? atoi(getenv("KG_GATHER_P2")) : 1;
+    const bool p2 = use_p2 && a.km.total == 3 * a.km.n && a.km.xtab == (0u | (1u << 2) | (0u << 4));
+    const int cin_real = p2 ? cin_pad / 3 : cin_pad;
     // K split for under-filled launches (KG_GATHER_SPLIT: 0 = never; default: below 128 workgroups, >= 4 stages per split, <= 8 splits)
     static const int split_wgs = getenv("KG_GATHER_SPLIT") ? atoi(getenv("KG_GATHER_SPLIT")) : 128;
-    const int wgs = (int)(grid.x * grid.y), nstage = a.ntaps * (cin_pad / 64);
+    const int wgs = (int)(grid.x * grid.y), nstage = p2 ? a.ntaps * (cin_real / 32) : a.ntaps * (cin_pad / 64);
     int Z = 1;
     if (split_wgs > 0 && wgs <= split_wgs && nstage >= 8) {
         Z = kg_cdiv(256, wgs);
@@ -243,9 +290,10 @@ int kg_launch_conv_gather(ConvArgs a, int cin_pad, hipStream_t st, bool stats_ok
     }
     if (stats_ok) a.stat_part = kg_conv_stats_claim(Z > 1 ? npt64 : (int)grid.x, a.Cout);   // (BatchNorm statistics, when armed: per 64- or 256-pixel tile)
     grid.z = Z;
-    hipLaunchKernelGGL(conv_gather_kernel, grid, dim3(512), smem, st, a, cin_pad / 64, Z > 1 ? part : (float*)nullptr);
+    if (p2) hipLaunchKernelGGL(conv_gather_kernel<true>, grid, dim3(512), smem, st, a, cin_real / 32, Z > 1 ? part : (float*)nullptr);
+    else hipLaunchKernelGGL(conv_gather_kernel<false>, grid, dim3(512), smem, st, a, cin_pad / 64, Z > 1 ? part : (float*)nullptr);
     KG_CHECK_LAUNCH("conv_gather");
-    kg_note_kernel("conv_gather_kernel");
+    kg_note_kernel(p2 ? "conv_gather_kernel<true>" : "conv_gather_kernel<false>");
     if (Z > 1) return kg_launch_splitk_finish(a, Z, part, npt64, nct64, st);
     return KG_OK;
 }
