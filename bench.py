@@ -64,7 +64,9 @@ def make_batch(N, S, nboxes, seed, dev):
 class KernelTimer:
     """HIP-event brackets around every kg_conv2d_igemm / kg_conv2d_wgrad launch on the launch stream."""
 
-    DOMINANT = "conv_halo_kernel<7, 1, 8, 0>"    # the 7x7 LDS-halo kernel (forward + input gradient of the head convs), rocprofv3's name
+    # the 7x7 LDS-halo kernel (forward + input gradient of the first-layer head convs), rocprofv3's names: the double-buffered kernel, or
+    # (KG_HALO7_DB=0) the single-buffered one it replaced in round 4
+    DOMINANT = ("conv_halo7_db_kernel", "conv_halo_kernel<7, 1, 8, 0>")
 
     def __init__(self):
         self.rec = []
@@ -189,7 +191,7 @@ def pmc_traffic():
     correction of MI355X_MICROARCH.md), or None when no committed pass matches the loaded libraries."""
     d, _ = _pmc_file("pmc_hbm")
     for k, v in (d or {}).items():
-        if k.replace(" ", "") in ("conv_halo_kernel<7,1,8>", "conv_halo_kernel<7,1,8,0>") and "hbm_bytes" in v:
+        if k.replace(" ", "") in ("conv_halo_kernel<7,1,8>", "conv_halo_kernel<7,1,8,0>", "conv_halo7_db_kernel") and "hbm_bytes" in v:
             return v["hbm_bytes"]
     return None
 
@@ -199,7 +201,7 @@ def pmc_mfma():
     GRBM_GUI_ACTIVE over the 8 XCDs), or None when no committed pass matches the loaded libraries."""
     d, name = _pmc_file("pmc_mfma_lds")
     for k, v in (d or {}).items():
-        if k.replace(" ", "") == "conv_halo_kernel<7,1,8,0>" and v.get("GRBM_GUI_ACTIVE"):
+        if k.replace(" ", "") in ("conv_halo_kernel<7,1,8,0>", "conv_halo7_db_kernel") and v.get("GRBM_GUI_ACTIVE"):
             return {"mfma_busy_frac": (v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (v["GRBM_GUI_ACTIVE"] / 8.0),
                     "active_cycles_per_launch": v["GRBM_GUI_ACTIVE"] / 8.0,
                     "lds_bank_conflict_cycles": v.get("SQ_LDS_BANK_CONFLICT"), "file": name}
@@ -650,13 +652,15 @@ def main():
         if os.environ.get("KG_BENCH_DUMP"):
             timer.rec = prof_rec
             timer.dump(os.environ["KG_BENCH_DUMP"], prof_steps)
-        dom = timer.summary(dom_rec).get(KernelTimer.DOMINANT)
+        dsum = timer.summary(dom_rec)
+        dom_name = next((n for n in KernelTimer.DOMINANT if n in dsum), None)
+        dom = dsum.get(dom_name)
         if dom:
             ach = dom["flops"] / dom["seconds"] / 1e12
             issued = dom["mfma_flops"] / dom["seconds"] / 1e12
             prod = dom["mfma_flops"] / dom["flops"]
             pm = pmc_mfma()
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel<7, 1, 8, 0> (7x7 head convs, forward + input gradient)",
+            out["roofline"] = {"bound": "mfma", "kernel": dom_name + " (7x7 first-layer head convs, forward + input gradient)",
                                "achieved": issued, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / MFMA_BF16_PEAK_TFLOPS,
                                "achieved_algorithmic": ach, "frac_algorithmic": ach / MFMA_BF16_PEAK_TFLOPS,
                                "products_per_multiply": prod,

@@ -380,6 +380,20 @@ def test_conv_halo_forward_and_dgrad(case):
         report(f"halo_dgrad{case}", nchw_of(dx.cpu(), N, H, W), x.grad * (msk > 0), atol=2e-2, rtol=1e-2)
 
 
+def test_double_buffered_7x7_halo_kernel_matches():
+    """conv_halo7_db_kernel (KG_HALO7_DB=1: 32-channel halves, double-buffered halo, ring running across chunks; csrc/conv_halo.hip) stays in the
+    library as the measured alternative to the single-buffered 7x7 kernel: the halo and plane conv tests in a process that selects it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KG_HALO7_DB="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), os.path.join(root, "tests", "test_gpu_planes.py"),
+                        "-q", "-x", "-k", "test_conv_halo_forward_and_dgrad or test_conv_forward_dgrad_wgrad_planes"],
+                       capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 WGRAD_HALO_CASES = [(64, 64, 3, 2, 20, 28), (64, 192, 7, 1, 32, 32), (64, 5, 7, 1, 16, 24), (3, 64, 3, 1, 24, 24),
                     (256, 128, 3, 1, 16, 16), (128, 64, 7, 2, 18, 21), (1024, 512, 3, 1, 8, 8),
                     (64, 10, 7, 1, 20, 20), (128, 40, 7, 1, 17, 33), (64, 1, 3, 2, 19, 23)]

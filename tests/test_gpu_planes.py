@@ -103,6 +103,7 @@ PLANE_CONV_CASES = [
     (64, 64, 3, 1, 1, 2, 20, 28, True, True),        # conv_halo<3>, 64 channels (conv3_c64 is bf16-only)
     (256, 128, 3, 1, 1, 1, 12, 20, True, True),      # conv_halo<3>
     (64, 192, 7, 1, 3, 1, 16, 24, True, True),       # conv_halo<7>
+    (128, 64, 7, 1, 3, 2, 20, 36, True, True),       # conv_halo<7>, two channel chunks per plane (the shared-halo walk over several chunks)
     (128, 64, 1, 1, 0, 2, 16, 16, True, True),       # 1x1 -> conv_gather (64 couts)
     (64, 256, 1, 1, 0, 2, 16, 16, False, False),     # 1x1 -> conv_gather
     (128, 128, 3, 2, 1, 2, 18, 22, False, False),    # strided 3x3 -> conv_gather

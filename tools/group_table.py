@@ -4,7 +4,7 @@ import csv
 import sys
 
 GROUPS = [
-    ("7x7 heads: conv_halo<7,1,8,0> forward + input gradient (the dominant kernel)", lambda n: "conv_halo_kernel<7, 1, 8, 0>" in n),
+    ("7x7 heads: conv_halo<7,1,8,0> forward + input gradient (the dominant kernel)", lambda n: "conv_halo_kernel<7, 1, 8, 0>" in n or "conv_halo7_db_kernel" in n),
     ("7x7 heads: grouped second layers <7,1,8,1> + their fused input gradient <7,1,8,2>", lambda n: "conv_halo_kernel<7, 1, 8, 1>" in n or "conv_halo_kernel<7, 1, 8, 2>" in n),
     ("7x7 heads: weight gradients wgrad_halo<7,...>", lambda n: "wgrad_halo_kernel<7" in n),
     ("3x3: conv_halo<3> + conv3_ws + conv3_c64 + wgrad_halo<3>", lambda n: "conv_halo_kernel<3" in n or "conv3_c64" in n or "conv3_ws" in n or "wgrad_halo_kernel<3" in n),
