@@ -139,6 +139,14 @@ int kg_wgrad_reduce_multi(const float* part, float* const* grads_oihw, const int
    kg_conv2d_wgrad_halo (dbp), db [bias_C]; bias_part == NULL: weights only */
 int kg_wgrad_reduce_bias(const float* part, float* const* grads_oihw, const int* counts, int ngrads, int Cin, int KH, int KW,
                          int nsplit, long split_stride, int accumulate, const float* bias_part, float* db, int bias_C, void* stream);
+/* Deferred reductions: between kg_wgrad_reduce_defer(1) and kg_wgrad_reduce_defer(0) the three reduce entry points above only record their
+   job (per calling thread; the caller keeps every partial buffer alive and unmodified), kg_wgrad_reduce_flush launches the recorded jobs
+   twelve per launch -- each with the block decomposition of its own single launch, so the sums are the same bits.  The reference has no
+   counterpart (autograd's conv backward returns finished gradients, train.py:148-154); this only cuts ~70 launches of a few microseconds
+   out of a backward pass. */
+int kg_wgrad_reduce_defer(int on);
+int kg_wgrad_reduce_pending(void);
+int kg_wgrad_reduce_flush(void* stream);
 int kg_bias_grad(const void* dy, float* db, float* scratch, int scratch_floats, int M, int C, int ld, int accumulate,
                  void* stream);
 int kg_set_wgrad_tr(int use_transpose_read);   /* test switch: LDS transpose-read vs scalar fragment loads */

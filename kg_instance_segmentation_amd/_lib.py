@@ -43,6 +43,9 @@ _SIGS = {
     "kg_wgrad_reduce": [P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, P],
     "kg_wgrad_reduce_multi": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, P],
     "kg_wgrad_reduce_bias": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_long, c_int, P, P, c_int, P],
+    "kg_wgrad_reduce_defer": [c_int],
+    "kg_wgrad_reduce_pending": [],
+    "kg_wgrad_reduce_flush": [P],
     "kg_bias_grad": [P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "kg_img_pack": [P, P, c_int, c_int, c_int, c_int, c_int, P, P],
     "kg_bn_stats_train": [P, c_int, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P, c_int, P, P],

@@ -10,6 +10,8 @@
 // [split][co][tap][ci] fp32 buffer reduced (deterministically) by kg_wgrad_reduce.
 #include "kg_common.h"
 #include <stdlib.h>
+#include <vector>
+#include <string.h>
 
 struct WgradArgs {
     const bf16_t* x; const bf16_t* dy; float* dwp; const int2* rowdesc;
@@ -342,16 +344,15 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
 struct ReduceDst { float* g[4]; int end[4]; const float* bias_part; float* db; int bias_C; };   // bias_part != null: one more block row sums the bias partials [S][bias_C]   // output tensor k holds the rows [end[k-1], end[k]) of the fused conv (heads sharing an input)
 // G = blockDim.x / (taps * CH) >= 2 (small layers with many splits, e.g. 3x3 64 -> 64 with 256 splits): G thread groups each sum a
 // contiguous range of the splits in order, then group 0 adds the G partial sums in group order -- still one fixed summation order.
+// (bx, by, NT: the block coordinates and thread count of the job this block works on -- the launch's own for the single-job kernel, the
+// job's for the batched one, whose blocks may be larger: threads >= NT only take part in the barriers)
 template <int CH>   // ci chunk per block: 64 for big layers, 16 to get enough blocks on small ones
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, const ReduceDst dst4,
-                                                            int Cout, int Cin, int taps, int S, long split_stride,
-                                                            int accumulate) {
-    __shared__ float tile[49 * (CH + 1)];
-    __shared__ float red[1024];
-    if ((int)blockIdx.x >= Cout) {   // the bias-gradient partials of the same conv (kg_conv2d_wgrad_halo's all-ones unit): one wave per channel,
-        if (blockIdx.y != 0) return; // lanes stride over the splits, as bias_grad_final_kernel sums them (same order, same bits)
-        const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;     // (whole waves only: blockDim.x need not be a multiple of 64)
-        const int c = ((int)blockIdx.x - Cout) * nw + (int)(threadIdx.x >> 6);
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, const ReduceDst& dst4, int Cout, int Cin, int taps, int S,
+                                                  long split_stride, int accumulate, int bx, int by, int NT, float* tile, float* red) {
+    if (bx >= Cout) {   // the bias-gradient partials of the same conv (kg_conv2d_wgrad_halo's all-ones unit): one wave per channel,
+        if (by != 0) return; // lanes stride over the splits, as bias_grad_final_kernel sums them (same order, same bits)
+        const int lane = threadIdx.x & 63, nw = NT >> 6;     // (whole waves only: NT need not be a multiple of 64)
+        const int c = (bx - Cout) * nw + (int)(threadIdx.x >> 6);
         if ((int)(threadIdx.x >> 6) >= nw || c >= dst4.bias_C) return;
         float sb = 0.f;
         for (int b = lane; b < S; b += 64) sb += dst4.bias_part[(long)b * dst4.bias_C + c];
@@ -360,12 +361,12 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
         if (lane == 0) dst4.db[c] = accumulate ? dst4.db[c] + sb : sb;
         return;
     }
-    const int co = blockIdx.x, ci0 = blockIdx.y * CH;
+    const int co = bx, ci0 = by * CH;
     int k = 0, row0 = 0;
     while (k < 3 && co >= dst4.end[k]) { row0 = dst4.end[k]; ++k; }
     float* __restrict__ grad = dst4.g[k] - (long)row0 * Cin * taps;   // so that row `co` of the fused conv lands in row co - row0
     const int nci = Cin - ci0 < CH ? Cin - ci0 : CH;
-    const int E = taps * CH, NT = blockDim.x;
+    const int E = taps * CH;
     const int G = NT >= 2 * E ? NT / E : 1;
     auto sum_range = [&](const float* src, int k0, int k1) {
         float s = 0.f;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
             tile[tap * (CH + 1) + ci] = s;
         }
     } else {
-        for (int e = threadIdx.x; e < E; e += NT) {
+        for (int e = threadIdx.x; e < E && (int)threadIdx.x < NT; e += NT) {
             const int tap = e / CH, ci = e - tap * CH;
             float s = 0.f;
             if (ci < nci) s = sum_range(part + ((long)co * taps + tap) * Cin + ci0 + ci, 0, S);
@@ -406,22 +407,46 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     }
     __syncthreads();
     float* dst = grad + ((long)co * Cin + ci0) * taps;
-    for (int j = threadIdx.x; j < nci * taps; j += NT) {
+    for (int j = threadIdx.x; j < nci * taps && (int)threadIdx.x < NT; j += NT) {
         const int ci = j / taps, tap = j - ci * taps;
         const float v = tile[tap * (CH + 1) + ci];
         dst[j] = accumulate ? dst[j] + v : v;
     }
 }
+template <int CH>
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, const ReduceDst dst4,
+                                                            int Cout, int Cin, int taps, int S, long split_stride,
+                                                            int accumulate) {
+    __shared__ float tile[49 * (CH + 1)];
+    __shared__ float red[1024];
+    wgrad_reduce_body<CH>(part, dst4, Cout, Cin, taps, S, split_stride, accumulate, (int)blockIdx.x, (int)blockIdx.y, (int)blockDim.x, tile, red);
+}
+// Batched form: the reductions of up to REDUCE_BATCH convs in one launch (a backward pass of the bench step issues ~80 of them, most a few
+// microseconds long).  A block belongs to the job whose block range holds blockIdx.x and runs that job's single-launch decomposition --
+// same thread count, same groups, same order: the same bits.
+constexpr int REDUCE_BATCH = 12;
+struct ReduceJob { const float* part; ReduceDst d; long split_stride; int Cout, Cin, taps, S, accumulate, nt, gx, blk0; };
+struct ReduceBatch { ReduceJob j[REDUCE_BATCH]; int n; };
+template <int CH>
+__global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const ReduceBatch b) {
+    __shared__ float tile[49 * (CH + 1)];
+    __shared__ float red[1024];
+    int k = 0;
+    while (k + 1 < b.n && (int)blockIdx.x >= b.j[k + 1].blk0) ++k;
+    const ReduceJob& q = b.j[k];
+    const int local = (int)blockIdx.x - q.blk0;
+    wgrad_reduce_body<CH>(q.part, q.d, q.Cout, q.Cin, q.taps, q.S, q.split_stride, q.accumulate, local % q.gx, local / q.gx, q.nt, tile, red);
+}
 
-static int launch_reduce(const float* part, const ReduceDst& d, int Cout, int Cin, int taps, int nsplit, long split_stride, int accumulate,
-                         hipStream_t st) {
+// the single-launch decomposition of one reduction: CH, threads per block, grid
+struct ReduceShape { int ch, nt, gx, gy; };
+static ReduceShape reduce_shape(const ReduceDst& d, int Cout, int Cin, int taps, int nsplit) {
+    ReduceShape r;
     // (bias partials: extra block columns after the Cout weight rows, one wave per channel)
     if ((long)Cout * ((Cin + 63) / 64) >= 2048) {
-        const int xb = Cout + (d.bias_part ? (d.bias_C + 3) / 4 : 0);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(xb, (Cin + 63) / 64), dim3(256), 0, st, part, d, Cout, Cin, taps, nsplit,
-                           split_stride, accumulate);
-    }
-    else {
+        r.ch = 64; r.nt = 256;
+        r.gx = Cout + (d.bias_part ? (d.bias_C + 3) / 4 : 0); r.gy = (Cin + 63) / 64;
+    } else {
         int nt = 256;
         const int E = taps * 16;
         if (2 * E <= 1024 && nsplit >= 16) {       // few elements, many splits: several thread groups share the splits
@@ -429,11 +454,55 @@ static int launch_reduce(const float* part, const ReduceDst& d, int Cout, int Ci
             if (G > nsplit / 8) G = nsplit / 8;
             if (G >= 2) nt = E * G;
         }
-        const int xb = Cout + (d.bias_part ? (d.bias_C + nt / 64 - 1) / (nt / 64) : 0);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(xb, (Cin + 15) / 16), dim3(nt), 0, st, part, d, Cout, Cin, taps, nsplit,
-                           split_stride, accumulate);
+        r.ch = 16; r.nt = nt;
+        r.gx = Cout + (d.bias_part ? (d.bias_C + nt / 64 - 1) / (nt / 64) : 0); r.gy = (Cin + 15) / 16;
     }
+    return r;
+}
+// Deferred reductions (kg_wgrad_reduce_defer(1) ... kg_wgrad_reduce_flush): while deferral is on, the reduce entry points only record
+// their job (the caller keeps the partial buffers alive and untouched until the flush); the flush launches them REDUCE_BATCH at a time.
+static thread_local int g_reduce_defer = 0;
+static thread_local std::vector<ReduceJob> g_reduce_q[2];     // [0]: CH = 16 jobs, [1]: CH = 64 jobs
+static int launch_reduce(const float* part, const ReduceDst& d, int Cout, int Cin, int taps, int nsplit, long split_stride, int accumulate,
+                         hipStream_t st) {
+    const ReduceShape r = reduce_shape(d, Cout, Cin, taps, nsplit);
+    if (g_reduce_defer) {
+        ReduceJob q;
+        q.part = part; q.d = d; q.split_stride = split_stride; q.Cout = Cout; q.Cin = Cin; q.taps = taps; q.S = nsplit; q.accumulate = accumulate;
+        q.nt = r.nt; q.gx = r.gx; q.blk0 = r.gx * r.gy;     // (blk0 holds the job's block count until the flush lays the jobs out)
+        g_reduce_q[r.ch == 64].push_back(q);
+        return KG_OK;
+    }
+    if (r.ch == 64)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(r.gx, r.gy), dim3(r.nt), 0, st, part, d, Cout, Cin, taps, nsplit, split_stride, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(r.gx, r.gy), dim3(r.nt), 0, st, part, d, Cout, Cin, taps, nsplit, split_stride, accumulate);
     KG_CHECK_LAUNCH("wgrad_reduce");
+    return KG_OK;
+}
+extern "C" int kg_wgrad_reduce_defer(int on) { g_reduce_defer = on; return KG_OK; }
+extern "C" int kg_wgrad_reduce_pending(void) { return (int)(g_reduce_q[0].size() + g_reduce_q[1].size()); }
+extern "C" int kg_wgrad_reduce_flush(void* stream) {
+    for (int c = 0; c < 2; ++c) {
+        std::vector<ReduceJob>& q = g_reduce_q[c];
+        for (size_t i0 = 0; i0 < q.size(); i0 += REDUCE_BATCH) {
+            ReduceBatch b;
+            memset(&b, 0, sizeof(b));
+            int blocks = 0, nt = 64;
+            b.n = (int)(q.size() - i0 < (size_t)REDUCE_BATCH ? q.size() - i0 : REDUCE_BATCH);
+            for (int k = 0; k < b.n; ++k) {
+                b.j[k] = q[i0 + k];
+                const int nb = b.j[k].blk0;
+                b.j[k].blk0 = blocks; blocks += nb;
+                if (b.j[k].nt > nt) nt = b.j[k].nt;
+            }
+            nt = (nt + 63) / 64 * 64;
+            if (c) hipLaunchKernelGGL(wgrad_reduce_batch_kernel<64>, dim3(blocks), dim3(nt), 0, (hipStream_t)stream, b);
+            else hipLaunchKernelGGL(wgrad_reduce_batch_kernel<16>, dim3(blocks), dim3(nt), 0, (hipStream_t)stream, b);
+            if (hipGetLastError() != hipSuccess) { q.clear(); kg_set_error("kg_wgrad_reduce_flush: launch failed"); return KG_ERR_HIP; }
+        }
+        q.clear();
+    }
     return KG_OK;
 }
 

@@ -248,6 +248,7 @@ class Engine:
         if self.grad_store is not None:
             v = self.grad_store.get(key)
             if v is not None:
+                ops.flush_wgrad()        # (g may come out of a split reduction that is only recorded so far)
                 v.copy_(g)
                 return v
         return g
@@ -765,6 +766,7 @@ class Engine:
             fv.add_grad(gp, masked=False)
         hook = self.grad_hook
         tape, self.tape = self.tape, None
+        ops.WGQ.begin()                  # the split reductions of the weight gradients are recorded and run a dozen per launch
         try:
             marks = list(self.phase_marks) if self.phase_hook is not None else None
             while tape:                              # (popped as they run: a closure and the activations only it still holds die right away)
@@ -794,6 +796,7 @@ class Engine:
             raise
         finally:
             Var.ENG = None
+            ops.WGQ.end()
         grads = self.param_grads
         self.param_grads = {}
         return grads

@@ -6,6 +6,7 @@ and streams here; every arithmetic kernel is hand-written HIP behind the C ABI.
 """
 import functools
 import math
+import os
 
 import torch
 
@@ -26,6 +27,67 @@ def scratch_f32(nfloats, dev, tag="default"):
         t = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=dev)
         _scratch[key] = t
     return t
+
+
+class WgradReduceQueue:
+    """Deferred split reductions of the weight gradients (kg_wgrad_reduce_defer / _flush): while `on`, conv_wgrad bump-allocates its fp32
+    partials from one arena and only records the reduction; flush() runs the recorded reductions twelve per launch.  Flush points: the arena
+    is full, a gradient is about to be read (scale_tensors, a data-parallel bucket's all-reduce), the end of a backward pass."""
+
+    ARENA = int(os.environ.get("KG_WGRAD_ARENA_MB", "256")) << 18       # floats
+    SMALL = 4 << 20                                                    # partial sets above 16 MB are reduced at once (nothing to gain)
+
+    def __init__(self):
+        self.enabled = os.environ.get("KG_WGRAD_BATCH", "1") != "0"
+        self.on, self.depth = False, 0
+        self.arena, self.off = None, 0
+
+    def begin(self):
+        self.depth += 1
+        if self.enabled and not self.on:
+            self.on = True
+            for fmt in (0, 1):
+                _lib.call("kg_wgrad_reduce_defer", 1, fmt=fmt)
+
+    def end(self):
+        self.depth -= 1
+        if self.depth <= 0 and self.on:
+            self.depth = 0
+            self.flush()
+            self.on = False
+            for fmt in (0, 1):
+                _lib.call("kg_wgrad_reduce_defer", 0, fmt=fmt)
+
+    def flush(self):
+        if self.on:
+            for fmt in (0, 1):
+                _lib.call("kg_wgrad_reduce_flush", stream_ptr(), fmt=fmt)
+            self.off = 0
+
+    def alloc(self, nfloats, dev, tag):
+        """partials buffer of a conv_wgrad call: the shared per-tag scratch (reduced right away) or, while deferring, a slice of the arena"""
+        if not self.on:
+            return scratch_f32(nfloats, dev, tag), False
+        n = (int(nfloats) + 63) // 64 * 64
+        if n > self.SMALL:
+            return scratch_f32(nfloats, dev, tag), True        # (True: the caller flushes right after recording -- the scratch is shared)
+        if self.arena is None or self.arena.device != torch.device(dev):
+            self.flush()
+            self.arena = torch.empty(self.ARENA, dtype=torch.float32, device=dev)
+        if self.off + n > self.ARENA:
+            self.flush()
+        t = self.arena[self.off:self.off + n]
+        self.off += n
+        return t, False
+
+
+WGQ = WgradReduceQueue()
+
+
+def flush_wgrad():
+    """launches the weight-gradient reductions recorded so far (no-op outside a deferring backward pass)"""
+    if WGQ.on:
+        WGQ.flush()
 
 
 def h2d(arr, dev):
@@ -453,6 +515,7 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
         g, off, cnt = grads[0]
         tmp = torch.empty(cout, Kc, 1, 1, dtype=torch.float32, device=xb.device)
         conv_wgrad(col if xP > 1 else col.t, dy, Kc, cout, (M, OH, OW, OH, OW, 1, 1, 1, 0), [(tmp, off, cnt)])
+        flush_wgrad()       # (tmp is read right away)
         g.copy_(tmp.view(cnt, KH * KW, cin).permute(0, 2, 1).reshape(g.shape))     # [co][tap][ci] -> OIHW
         if bias_out is not None:
             bias_grad(dy, cout, bias_out)
@@ -469,9 +532,12 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
         nblk = math.ceil(cin_lim / cit) * math.ceil(cout_lim / 64)
         tiles = tiletab16.shape[0] if tiletab16 is not None else N * math.ceil(H / 16) * math.ceil(W / 16)
         S = halo_wgrad_splits(nblk, tiles * np_, cit, KH * KW, nelem)      # (plane products = more tiles to walk)
-        part = scratch_f32(S * nelem, xb.device, "wgrad")
+        part, big = WGQ.alloc(S * nelem, xb.device, "wgrad")
         fused_bias = bias_out is not None and not planed
-        dbp = scratch_f32(S * cout, xb.device, "wgrad_bias") if fused_bias else None
+        dbp = None
+        if fused_bias:
+            dbp, big2 = WGQ.alloc(S * cout, xb.device, "wgrad_bias")
+            big = big or big2
         _lib.call("kg_conv2d_wgrad_halo", ptr(xb), ptr(dyb), ptr(part), N or 0, H, W, ld(xb), ld(dyb), cin, cout, cin_lim, cout_lim, KH, S,
                   c_long(nelem), ptr(tiletab16), tiletab16.shape[0] if tiletab16 is not None else 0, ptr(dbp), planes, stream_ptr(), fmt=fmt_of(x))
         if dbp is None and bias_out is not None:       # planed operands: the all-ones unit would count every plane product
@@ -479,7 +545,7 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
     else:
         dbp = None
         S = wgrad_splits(M * np_, cin_lim, cout_lim, KH * KW, nelem)
-        part = scratch_f32(S * nelem, xb.device, "wgrad")
+        part, big = WGQ.alloc(S * nelem, xb.device, "wgrad")
         _lib.call("kg_conv2d_wgrad", ptr(xb), ptr(dyb), ptr(part), ptr(rowdesc), M, H, W, OH, OW, ld(xb), ld(dyb), cin, cout, cin_lim, cout_lim,
                   KH, KW, stride, pad, 1, mode, S, c_long(nelem), planes, stream_ptr(), fmt=fmt_of(xb))
         if bias_out is not None:
@@ -497,6 +563,8 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
             _lib.call("kg_bias_grad_final", ptr(dbp), ptr(bias_out), S, cout, acc, stream_ptr())
         for g, off, cnt in grads:
             _lib.call("kg_wgrad_reduce", ctypes_offset(part, off * KH * KW * cin), ptr(g), cnt, cin, KH, KW, S, c_long(nelem), acc, stream_ptr())
+    if big:
+        WGQ.flush()
     return "halo" if halo else "gather"
 
 
@@ -682,6 +750,7 @@ def scale_tensors(tensors, scale, flag=None):
     one per tensor (parameters of different backbone stages carry different cumulative scales, rows_rescale).  flag (optional device
     int32[1]): set to 1 when a result is inf / NaN."""
     import numpy as np
+    flush_wgrad()       # (the tensors may be weight gradients whose split reductions are still recorded only)
     scales = scale if isinstance(scale, (list, tuple)) else [scale] * len(tensors)
     pairs = [(t, sc) for t, sc in zip(tensors, scales) if t is not None and t.numel() > 0]
     if not pairs:

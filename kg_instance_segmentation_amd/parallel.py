@@ -222,6 +222,8 @@ class FlatGradReducer:
     def _launch(self, a, b, keys, unscale=True):
         """a bucket is complete on this rank: divide out the backward pass's power-of-two scales (half-precision build), then
         SUM-all-reduce it in place"""
+        from . import ops
+        ops.flush_wgrad()                 # the bucket's gradients may still be recorded split reductions (ops.WgradReduceQueue)
         if unscale:
             self._unscale(keys)
         if world_size() > 1:

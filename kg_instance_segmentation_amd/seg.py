@@ -464,6 +464,13 @@ class SegBranch:
             self.rconv(g, pwT, cin, rowdesc, M, k, y=dx, mask=mask, mode=3, tiles=t32, tiles16=t16)
 
     def run_backward(self, plan, saved, gflat, feat_shapes, gscale=None):
+        ops.WGQ.begin()                  # (split reductions of the weight gradients: recorded, run a dozen per launch; ops.WgradReduceQueue)
+        try:
+            return self._run_backward(plan, saved, gflat, feat_shapes, gscale)
+        finally:
+            ops.WGQ.end()
+
+    def _run_backward(self, plan, saved, gflat, feat_shapes, gscale=None):
         """gscale (half build): truthy when the engine carries a running gradient scale (engine.gscale, set by the caller from
         ops.grad_scale): gflat enters times that scale; after every level the gradient that moves on to the next coarser level is
         re-normalised on the device together with the feature gradients already produced (the adjoint of the 2x bilinear upsampling
