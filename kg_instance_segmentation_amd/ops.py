@@ -34,8 +34,8 @@ class WgradReduceQueue:
     partials from one arena and only records the reduction; flush() runs the recorded reductions twelve per launch.  Flush points: the arena
     is full, a gradient is about to be read (scale_tensors, a data-parallel bucket's all-reduce), the end of a backward pass."""
 
-    ARENA = int(os.environ.get("KG_WGRAD_ARENA_MB", "256")) << 18       # floats
-    SMALL = 4 << 20                                                    # partial sets above 16 MB are reduced at once (nothing to gain)
+    ARENA = int(os.environ.get("KG_WGRAD_ARENA_MB", "3072")) << 18      # floats (the partial sets of a bench step's backward: ~2 GB)
+    SMALL = ARENA // 8                                                 # larger partial sets are reduced at once from the shared scratch
 
     def __init__(self):
         self.enabled = os.environ.get("KG_WGRAD_BATCH", "1") != "0"
