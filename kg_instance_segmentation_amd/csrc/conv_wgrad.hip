@@ -293,6 +293,192 @@ __global__ __launch_bounds__(256) void conv_wgrad128_kernel(const WgradArgs a) {
         }
 }
 
+// ---- 256 x 128 output tile, LDS-direct ring (cout >= 256, cin >= 128) ------------------------------------------------------------------
+// conv_wgrad128_kernel keeps ONE 64-pixel chunk of global loads in flight (registers, one __syncthreads per chunk): a chunk is 32 MFMAs
+// per wave = 0.25 us against a load latency of 1-2 us, so the ragged 3x3 levels of the seg branch ran at 0.30 PFLOP/s (MFMA pipes 10 % busy).
+// Here, as in conv_gather.hip: 8 waves, three 48 KB stages ([2][64 px][128 couts] of dY + [64 px][128 cins] of X), two of them in flight by
+// LDS-direct loads behind a counted s_waitcnt vmcnt(6); the 32-byte-unit swizzle of the transpose reads is applied to the source chunk;
+// transpose reads from inline asm, k-step 1's behind the MFMAs of k-step 0.  Ragged rows (mode 2) need rowdesc[m] to place the tap's input
+// row: it is fetched ONE stage ahead of the loads that use it and issued BEFORE the stage in between, so the counted wait covers it.
+__device__ uint4 kg_wgr_zero_line[16];
+template <int OFF>
+__device__ __forceinline__ void wgr_rd_tr64(bf16x4& d, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int MODE>   // 0: 1x1 stride-1 dense (input row = output row), 1: dense with taps / stride, 2: ragged rows (rowdesc)
+__global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(const WgradArgs a) {
+    constexpr int NS = 3, HB = 64 * 256, STAGE = 3 * HB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave >> 1, wci = wave & 1;
+    const int n_ci_tiles = (a.cin_lim + 127) / 128;
+    const int ci0 = (blockIdx.x % n_ci_tiles) * 128, co0 = (blockIdx.x / n_ci_tiles) * 256;
+    const int tap = blockIdx.y, split = blockIdx.z;
+    const int tdy = tap / a.KW, tdx = tap - tdy * a.KW;
+    const int d_y = tdy * a.dil - a.pad, d_x = tdx * a.dil - a.pad;
+    const int ohw = a.OH * a.OW;
+
+    // staging: thread -> rows r0, r0 + 32 of each of the three 64-row tiles, LDS slot s16 = source chunk c16 under the unit swizzle
+    const int r0 = tid >> 4, s16 = tid & 15;
+    const int c16 = (((s16 >> 1) ^ tr_f8(r0)) << 1) | (s16 & 1);          // (tr_f8(r0 + 32) == tr_f8(r0))
+    const bool y_ok0 = co0 + c16 * 8 < a.cout_lim, y_ok1 = co0 + 128 + c16 * 8 < a.cout_lim, x_ok = ci0 + c16 * 8 < a.cin_lim;
+    const bf16_t* zline = reinterpret_cast<const bf16_t*>(kg_wgr_zero_line);
+    const int total_chunks = a.wp.n * a.chunks_per_plane;
+    const int cbeg = split * a.chunks_per_split;
+    int cend = cbeg + a.chunks_per_split;
+    if (cend > total_chunks) cend = total_chunks;
+    const int nst = cend - cbeg;
+    // input row of output pixel m for this tap (-1: padding / outside); mode 2 reads rowdesc (fetched a stage ahead, see below)
+    auto row_of = [&](int m, int2 d) -> long {
+        if (m >= a.M) return -1;
+        if (MODE == 0) return m;
+        if (MODE == 2) {
+            const int y = (d.x >> 16) + d_y, x = (d.x & 0xffff) + d_x, h = d.y >> 16, w = d.y & 0xffff;
+            return ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) ? (long)m + (long)d_y * w + d_x : -1;
+        }
+        const int n = m / ohw, rem = m - n * ohw;
+        const int oy = rem / a.OW, ox = rem - oy * a.OW;
+        const int iy = (oy << a.stride_log2) + d_y, ix = (ox << a.stride_log2) + d_x;
+        return ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? ((long)n * a.H + iy) * a.W + ix : -1;
+    };
+    // Ragged rows: the rowdesc entries of a stage's 64 pixels ride into LDS with the loads of the stage TWO before it (wave 0, two more
+    // LDS-direct loads of 256 bytes), so the thread that places stage s + 2 reads them from LDS when stage s has landed -- a register load
+    // of rowdesc inside the loop makes hipcc wait vmcnt(0) before its first use, i.e. for every stage in flight.
+    constexpr bool ragged = MODE == 2;
+    unsigned char* rdl = smem + NS * STAGE;                       // [NS][64] int2
+    auto rd_global = [&](int vchunk, int2 (&rd)[2]) {             // prologue only: nothing is in flight yet
+        const int pr = vchunk / a.chunks_per_plane, chunk = vchunk - pr * a.chunks_per_plane;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int m = chunk * 64 + r0 + 32 * k;
+            rd[k] = (ragged && vchunk < cend && m < a.M) ? a.rowdesc[m] : make_int2(0, 0);
+        }
+    };
+    auto rd_lds = [&](int slot, int2 (&rd)[2]) {
+        if (!ragged) { rd[0] = rd[1] = make_int2(0, 0); return; }
+        const unsigned ad = lds_addr(rdl) + slot * 512 + r0 * 8;
+        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)" : "=&v"(rd[0]), "=&v"(rd[1]) : "v"(ad) : "memory");
+    };
+    int i_slot = 0;
+    auto issue = [&](int vchunk, const int2 (&rd)[2]) {        // the six LDS-direct loads of a stage (+ wave 0, ragged: the rowdesc of stage vchunk + 2)
+        const int pr = vchunk / a.chunks_per_plane, chunk = vchunk - pr * a.chunks_per_plane;   // (product, chunk): uniform
+        const bf16_t* xpl = a.x + a.wp.xoff[pr] + ci0 + c16 * 8;
+        const bf16_t* dpl = a.dy + a.wp.doff[pr] + co0 + c16 * 8;
+        unsigned char* st = smem + i_slot * STAGE + wave * 1024;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int m = chunk * 64 + r0 + 32 * k;
+            const bool in = m < a.M;
+            const bf16_t* s0 = (in && y_ok0) ? dpl + (long)m * a.lddy : zline;
+            const bf16_t* s1 = (in && y_ok1) ? dpl + (long)m * a.lddy + 128 : zline;
+            const long row = row_of(m, rd[k]);
+            const bf16_t* s2 = (row >= 0 && x_ok) ? xpl + row * a.ldx : zline;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s0, (__attribute__((address_space(3))) void*)(st + k * 8192), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s1, (__attribute__((address_space(3))) void*)(st + HB + k * 8192), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s2, (__attribute__((address_space(3))) void*)(st + 2 * HB + k * 8192), 16, 0, 0);
+        }
+        if (ragged && wave == 0) {
+            const int v2 = vchunk + 2;
+            const int pr2 = v2 / a.chunks_per_plane, chunk2 = v2 - pr2 * a.chunks_per_plane;
+            const int* rdw = reinterpret_cast<const int*>(a.rowdesc);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {                         // 128 dwords = two 4-byte loads per lane (exact bounds: no read past entry M - 1)
+                const long w = (long)chunk2 * 128 + k * 64 + lane;
+                const void* src = (v2 < cend && w < 2L * a.M) ? (const void*)(rdw + w) : (const void*)zline;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(rdl + i_slot * 512 + k * 256), 4, 0, 0);
+            }
+        }
+        i_slot = i_slot == NS - 1 ? 0 : i_slot + 1;
+    };
+
+    // transpose-read addresses: fragment f of a 128-channel tile = 16 channels cf = base + f; lane (i, G): row p0 + 8 G + 4 h + (i >> 2)
+    const unsigned lds0 = lds_addr(smem);
+    unsigned fa[4], fb[4];
+    {
+        const int i = lane & 15, G = lane >> 4;
+        const int r = G * 8 + (i >> 2);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            fa[f] = lds0 + (wco >> 1) * HB + r * 256 + ((((wco & 1) * 4 + f) ^ tr_f8(r)) * 32) + (i & 3) * 8;
+            fb[f] = lds0 + 2 * HB + r * 256 + (((wci * 4 + f) ^ tr_f8(r)) * 32) + (i & 3) * 8;
+        }
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool w8 = ragged && wave == 0;                          // (uniform) this wave issues 8 loads per stage
+    if (nst > 0) {
+        int2 rd0[2], rd1[2];
+        rd_global(cbeg, rd0); rd_global(cbeg + 1, rd1);
+        issue(cbeg, rd0);
+        if (nst > 1) issue(cbeg + 1, rd1);
+    }
+    int c_slot = 0;
+    for (int s = 0; s < nst; ++s) {
+        if (s + 1 < nst) {          // stage s (and the rowdesc of stage s + 2 that rode with it) has landed; stage s + 1 may stay in flight
+            if (w8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 2 < nst) {
+            int2 rd[2];
+            rd_lds(c_slot, rd);
+            issue(cbeg + s + 2, rd);
+        }
+        const unsigned sb = c_slot * STAGE;
+        bf16x4 av[2][4][2], bv[2][4][2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                if (k == 0) { wgr_rd_tr64<0>(av[0][f][0], fa[f] + sb); wgr_rd_tr64<1024>(av[0][f][1], fa[f] + sb); }
+                else { wgr_rd_tr64<8192>(av[1][f][0], fa[f] + sb); wgr_rd_tr64<8192 + 1024>(av[1][f][1], fa[f] + sb); }
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                if (k == 0) { wgr_rd_tr64<0>(bv[0][f][0], fb[f] + sb); wgr_rd_tr64<1024>(bv[0][f][1], fb[f] + sb); }
+                else { wgr_rd_tr64<8192>(bv[1][f][0], fb[f] + sb); wgr_rd_tr64<8192 + 1024>(bv[1][f][1], fb[f] + sb); }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k == 0) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");       // (16 reads of k-step 1 may stay in flight; the counter saturates at 15)
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                asm volatile("" : "+v"(av[k][f][0]), "+v"(av[k][f][1]), "+v"(bv[k][f][0]), "+v"(bv[k][f][1]));
+                af[f] = __builtin_shufflevector(av[k][f][0], av[k][f][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                bf[f] = __builtin_shufflevector(bv[k][f][0], bv[k][f][1], 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = KG_MFMA16(af[i], bf[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        c_slot = c_slot == NS - 1 ? 0 : c_slot + 1;
+    }
+    float* out = a.dwp + (long)split * a.split_stride;
+    const int lm = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ci = ci0 + (wci * 4 + j) * 16 + lm;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + (wco * 4 + i) * 16 + g * 4 + r;
+                if (co < a.Cout && ci < a.Cin) out[((long)co * a.ntaps + tap) * a.Cin + ci] = acc[i][j][r];
+            }
+        }
+}
+
 static int g_wgrad_use_tr = 1;
 extern "C" int kg_set_wgrad_tr(int use_tr) { g_wgrad_use_tr = use_tr; return KG_OK; }
 
@@ -321,6 +507,24 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
     a.chunks_per_split = (total_chunks + nsplit - 1) / nsplit;
     a.split_stride = split_stride;
     static const int use128 = getenv("KG_WGRAD128") ? atoi(getenv("KG_WGRAD128")) : 1;
+    static const int use_ring = getenv("KG_WGRAD_RING") ? atoi(getenv("KG_WGRAD_RING")) : 1;
+    if (use_ring && g_wgrad_use_tr && cin_lim >= 128 && cout_lim >= 256) {      // (ops.wgrad_splits sizes nsplit for this tile under the same condition)
+        constexpr int smem = 3 * 3 * 64 * 256 + 3 * 512;
+        static bool attr_done = false;
+        if (!attr_done) {
+            KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_done = true;
+        }
+        dim3 gridr(((cin_lim + 127) / 128) * ((cout_lim + 255) / 256), KH * KW, nsplit);
+        if (a.mode >= 2) hipLaunchKernelGGL(conv_wgrad_ring_kernel<2>, gridr, dim3(512), smem, (hipStream_t)stream, a);
+        else if (a.direct) hipLaunchKernelGGL(conv_wgrad_ring_kernel<0>, gridr, dim3(512), smem, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(conv_wgrad_ring_kernel<1>, gridr, dim3(512), smem, (hipStream_t)stream, a);
+        KG_CHECK_LAUNCH("conv_wgrad_ring");
+        kg_note_kernel("conv_wgrad_ring_kernel");
+        return KG_OK;
+    }
     if (use128 && g_wgrad_use_tr && cin_lim >= 128 && cout_lim >= 128) {
         dim3 grid128(((cin_lim + 127) / 128) * ((cout_lim + 127) / 128), KH * KW, nsplit);
         hipLaunchKernelGGL(conv_wgrad128_kernel, grid128, dim3(256), 0, (hipStream_t)stream, a);

@@ -455,10 +455,20 @@ def conv_auto(x, pw, cout, geom, N, y=None, y_f32=None, bias=None, res=None, mas
     return "igemm"
 
 
+WGRAD_RING = os.environ.get("KG_WGRAD_RING", "1") != "0"
+
+
 def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):
+    chunks = math.ceil(M / 64)
+    if WGRAD_RING and WGRAD128 and cin_lim >= 128 and cout_lim >= 256:
+        # conv_wgrad_ring_kernel (256 x 128 tiles, 144 KB of LDS: one workgroup per CU): one round of at most 256 workgroups, or two
+        base = math.ceil(cin_lim / 128) * math.ceil(cout_lim / 256) * taps
+        s = max(1, min(256 // base if base <= 256 else 1, max(1, chunks // 3)))
+        while s > 1 and s * nelem * 4 > (768 << 20):
+            s -= 1
+        return s
     t = 128 if (WGRAD128 and cin_lim >= 128 and cout_lim >= 128) else 64      # output tile of kg_conv2d_wgrad
     base = math.ceil(cin_lim / t) * math.ceil(cout_lim / t) * taps
-    chunks = math.ceil(M / 64)
     s = max(1, min(math.ceil(2048 / base), max(1, chunks // 4)))
     while s > 1 and s * nelem * 4 > (768 << 20):
         s -= 1

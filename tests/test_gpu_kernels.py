@@ -192,7 +192,9 @@ def test_conv_dgrad(case):
 
 
 WGRAD_CASES = [(64, 64, 3, 1, 1, 2, 20, 28), (64, 192, 7, 1, 3, 1, 16, 24), (64, 64, 3, 2, 1, 2, 18, 22), (256, 512, 1, 2, 0, 1, 16, 24),
-               (3, 64, 7, 2, 3, 2, 32, 40), (64, 5, 7, 1, 3, 1, 16, 16), (1024, 512, 1, 1, 0, 1, 8, 8)]
+               (3, 64, 7, 2, 3, 2, 32, 40), (64, 5, 7, 1, 3, 1, 16, 16), (1024, 512, 1, 1, 0, 1, 8, 8),
+               # conv_wgrad_ring_kernel (cout >= 256, cin >= 128): 3x3 taps with a partial last chunk; ragged channel tiles; many chunks per split
+               (128, 256, 3, 1, 1, 2, 20, 28), (192, 300, 1, 1, 0, 1, 24, 20), (256, 256, 1, 1, 0, 4, 48, 40)]
 
 
 @pytest.mark.parametrize("use_tr", [1, 0])
