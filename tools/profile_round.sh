@@ -8,7 +8,7 @@ R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
-python bench.py --steps 10 --warmup 3 > $O/${tag}_bench_n1.json 2> $O/${tag}_bench.err
+python bench.py --steps 10 --warmup 3 > $O/${tag}_bench_n1.json 2> $O/${tag}_bench.err      # (re-taken at the end, once the PMC files of this build exist)
 KG_BENCH_DUMP=$O/${tag}_bench_launches.txt python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-companion > /dev/null 2>&1
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/${tag}_prof -o p -- python $R/bench.py --steps 10 --warmup 3 --profile-run > $O/${tag}_prof.log 2>&1
@@ -27,3 +27,9 @@ rm -rf $O/${tag}_pmc_a $O/${tag}_pmc_b
 rocprofv3 --kernel-trace --output-format csv -d $O/${tag}_shp -o p -- python $R/bench.py --steps 4 --warmup 1 --profile-run > $O/${tag}_shp.log 2>&1
 python $R/tools/rocprof_shapes.py $(find $O/${tag}_shp -name "*kernel_trace.csv" | head -1) $O/${tag}_bench_launch_shapes.csv 5 >> $O/${tag}_prof.log 2>&1
 rm -rf $O/${tag}_shp
+# the bench line again, now that the counter files of THIS build exist: bench.py fills roofline.traffic / roofline.pmc from profiles/*_pmc_*.json
+# only when their build hash matches the loaded libraries
+cd $R
+cp $O/${tag}_pmc_hbm.json $O/${tag}_pmc_mfma_lds.json $R/profiles/
+python bench.py --steps 10 --warmup 3 > $O/${tag}_bench_n1.json 2> $O/${tag}_bench.err
+cut -c1-400 $O/${tag}_bench_n1.json
