@@ -24,23 +24,24 @@ struct ConvArgs {
 // per channel: part[(tile * Cout + c) * 2 + {0, 1}] -- the layout bn_finalize_train_kernel combines in double, in tile order.
 // Everything is a fixed order: the statistics are reproducible like the two-pass ones (they are taken from the fp32 accumulators,
 // before the split-bf16 rounding of the store).
-__device__ __forceinline__ void kg_stat_add(float (&s)[16], float (&q)[16], const float (&v)[16]) {
+template <int NV>
+__device__ __forceinline__ void kg_stat_add(float (&s)[NV], float (&q)[NV], const float (&v)[NV]) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+    for (int e = 0; e < NV; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
 }
-// NW pixel waves (index wrow) share a cout tile of NC channels; this lane holds channels cl0 .. cl0+15 of it.  red: LDS, NW * NC * 2
+// NW pixel waves (index wrow) share a cout tile of NC channels; this lane holds channels cl0 .. cl0+NV-1 of it.  red: LDS, NW * NC * 2
 // floats, no longer read by anybody (the caller has passed a barrier since the last tile access).  part_tile = part + tile * Cout * 2.
-template <int NW, int NC>
-__device__ __forceinline__ void kg_stat_commit(float (&s)[16], float (&q)[16], float* red, int wrow, int cl0, int lm, float* part_tile,
+template <int NW, int NC, int NV>
+__device__ __forceinline__ void kg_stat_commit(float (&s)[NV], float (&q)[NV], float* red, int wrow, int cl0, int lm, float* part_tile,
                                                int c0, int Cout) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < NV; ++e) {
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { s[e] += __shfl_xor(s[e], o, 64); q[e] += __shfl_xor(q[e], o, 64); }
     }
     if (lm == 0) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { red[(wrow * NC + cl0 + e) * 2] = s[e]; red[(wrow * NC + cl0 + e) * 2 + 1] = q[e]; }
+        for (int e = 0; e < NV; ++e) { red[(wrow * NC + cl0 + e) * 2] = s[e]; red[(wrow * NC + cl0 + e) * 2 + 1] = q[e]; }
     }
     __syncthreads();
     for (int t = threadIdx.x; t < NC * 2; t += blockDim.x) {

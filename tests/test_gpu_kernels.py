@@ -382,6 +382,19 @@ def test_conv_halo_forward_and_dgrad(case):
         report(f"halo_dgrad{case}", nchw_of(dx.cpu(), N, H, W), x.grad * (msk > 0), atol=2e-2, rtol=1e-2)
 
 
+def test_gather_128x64_variant_on_small_problems():
+    """conv_gather's 4-wave 128-pixel x 64-cout variant serves launches of >= 512 tiles; KG_GATHER_N64=1 sends every 64-cout gather conv
+    of the small test problems through it (plain and paired planes, dense / ragged, with the BatchNorm-statistics epilogue)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KG_GATHER_N64="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_planes.py"), os.path.join(root, "tests", "test_gpu_blocks.py"),
+                        os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x"], capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_double_buffered_7x7_halo_kernel_matches():
     """conv_halo7_db_kernel (KG_HALO7_DB=1: 32-channel halves, double-buffered halo, ring running across chunks; csrc/conv_halo.hip) stays in the
     library as the measured alternative to the single-buffered 7x7 kernel: the halo and plane conv tests in a process that selects it."""

@@ -105,6 +105,7 @@ PLANE_CONV_CASES = [
     (64, 192, 7, 1, 3, 1, 16, 24, True, True),       # conv_halo<7>
     (128, 64, 7, 1, 3, 2, 20, 36, True, True),       # conv_halo<7>, two channel chunks per plane (the shared-halo walk over several chunks)
     (128, 64, 1, 1, 0, 2, 16, 16, True, True),       # 1x1 -> conv_gather (64 couts)
+    (128, 64, 1, 1, 0, 2, 192, 176, True, True),     # 1x1, 64 couts, 528 tiles of 128 pixels -> conv_gather's 128 x 64 variant
     (64, 256, 1, 1, 0, 2, 16, 16, False, False),     # 1x1 -> conv_gather
     (128, 128, 3, 2, 1, 2, 18, 22, False, False),    # strided 3x3 -> conv_gather
     (256, 512, 1, 2, 0, 1, 16, 24, False, False),    # strided 1x1
