@@ -64,8 +64,10 @@ class WgradReduceQueue:
                 _lib.call("kg_wgrad_reduce_flush", stream_ptr(), fmt=fmt)
             self.off = 0
 
-    def alloc(self, nfloats, dev, tag):
-        """partials buffer of a conv_wgrad call: the shared per-tag scratch (reduced right away) or, while deferring, a slice of the arena"""
+    def alloc(self, nfloats, dev, tag, extra=0):
+        """partials buffer of a conv_wgrad call: the shared per-tag scratch (reduced right away) or, while deferring, a slice of the arena.
+        extra: floats the same call will ask for next (its bias partials) -- a flush between the two requests of ONE call would restart the
+        arena underneath the first buffer before its reduction is recorded"""
         if not self.on:
             return scratch_f32(nfloats, dev, tag), False
         n = (int(nfloats) + 63) // 64 * 64
@@ -74,7 +76,7 @@ class WgradReduceQueue:
         if self.arena is None or self.arena.device != torch.device(dev):
             self.flush()
             self.arena = torch.empty(self.ARENA, dtype=torch.float32, device=dev)
-        if self.off + n > self.ARENA:
+        if self.off + n + (int(extra) + 63) // 64 * 64 > self.ARENA:
             self.flush()
         t = self.arena[self.off:self.off + n]
         self.off += n
@@ -542,8 +544,8 @@ def conv_wgrad(x, dy, cin, cout, geom, grads, mode=0, rowdesc=None, accumulate=F
         nblk = math.ceil(cin_lim / cit) * math.ceil(cout_lim / 64)
         tiles = tiletab16.shape[0] if tiletab16 is not None else N * math.ceil(H / 16) * math.ceil(W / 16)
         S = halo_wgrad_splits(nblk, tiles * np_, cit, KH * KW, nelem)      # (plane products = more tiles to walk)
-        part, big = WGQ.alloc(S * nelem, xb.device, "wgrad")
         fused_bias = bias_out is not None and not planed
+        part, big = WGQ.alloc(S * nelem, xb.device, "wgrad", extra=S * cout if fused_bias else 0)
         dbp = None
         if fused_bias:
             dbp, big2 = WGQ.alloc(S * cout, xb.device, "wgrad_bias")
