@@ -305,15 +305,16 @@ template <int OFF>
 __device__ __forceinline__ void wgr_rd_tr64(bf16x4& d, unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
-template <int MODE>   // 0: 1x1 stride-1 dense (input row = output row), 1: dense with taps / stride, 2: ragged rows (rowdesc)
+// NH = 1 (cout < 256): 128 x 128 tile, one dY tile per stage (32 KB stages, four loads per thread), wave tile 32 couts x 64 cins.
+template <int MODE, int NH>   // MODE 0: 1x1 stride-1 dense (input row = output row), 1: dense with taps / stride, 2: ragged rows (rowdesc)
 __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(const WgradArgs a) {
-    constexpr int NS = 3, HB = 64 * 256, STAGE = 3 * HB;
+    constexpr int NS = 3, HB = 64 * 256, STAGE = (NH + 1) * HB, NF = 2 * NH;     // NF: 16-cout fragments of a wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave >> 1, wci = wave & 1;
     const int n_ci_tiles = (a.cin_lim + 127) / 128;
-    const int ci0 = (blockIdx.x % n_ci_tiles) * 128, co0 = (blockIdx.x / n_ci_tiles) * 256;
+    const int ci0 = (blockIdx.x % n_ci_tiles) * 128, co0 = (blockIdx.x / n_ci_tiles) * (128 * NH);
     const int tap = blockIdx.y, split = blockIdx.z;
     const int tdy = tap / a.KW, tdx = tap - tdy * a.KW;
     const int d_y = tdy * a.dil - a.pad, d_x = tdx * a.dil - a.pad;
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(const WgradArgs a)
     // staging: thread -> rows r0, r0 + 32 of each of the three 64-row tiles, LDS slot s16 = source chunk c16 under the unit swizzle
     const int r0 = tid >> 4, s16 = tid & 15;
     const int c16 = (((s16 >> 1) ^ tr_f8(r0)) << 1) | (s16 & 1);          // (tr_f8(r0 + 32) == tr_f8(r0))
-    const bool y_ok0 = co0 + c16 * 8 < a.cout_lim, y_ok1 = co0 + 128 + c16 * 8 < a.cout_lim, x_ok = ci0 + c16 * 8 < a.cin_lim;
+    const bool y_ok0 = co0 + c16 * 8 < a.cout_lim, y_ok1 = NH == 2 && co0 + 128 + c16 * 8 < a.cout_lim, x_ok = ci0 + c16 * 8 < a.cin_lim;
     const bf16_t* zline = reinterpret_cast<const bf16_t*>(kg_wgr_zero_line);
     const int total_chunks = a.wp.n * a.chunks_per_plane;
     const int cbeg = split * a.chunks_per_split;
@@ -372,11 +373,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(const WgradArgs a)
             const bool in = m < a.M;
             const bf16_t* s0 = (in && y_ok0) ? dpl + (long)m * a.lddy : zline;
             const bf16_t* s1 = (in && y_ok1) ? dpl + (long)m * a.lddy + 128 : zline;
+            (void)s1;
             const long row = row_of(m, rd[k]);
             const bf16_t* s2 = (row >= 0 && x_ok) ? xpl + row * a.ldx : zline;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s0, (__attribute__((address_space(3))) void*)(st + k * 8192), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s1, (__attribute__((address_space(3))) void*)(st + HB + k * 8192), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s2, (__attribute__((address_space(3))) void*)(st + 2 * HB + k * 8192), 16, 0, 0);
+            if constexpr (NH == 2)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s1, (__attribute__((address_space(3))) void*)(st + HB + k * 8192), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s2, (__attribute__((address_space(3))) void*)(st + NH * HB + k * 8192), 16, 0, 0);
         }
         if (ragged && wave == 0) {
             const int v2 = vchunk + 2;
@@ -394,19 +397,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(const WgradArgs a)
 
     // transpose-read addresses: fragment f of a 128-channel tile = 16 channels cf = base + f; lane (i, G): row p0 + 8 G + 4 h + (i >> 2)
     const unsigned lds0 = lds_addr(smem);
-    unsigned fa[4], fb[4];
+    unsigned fa[NF], fb[4];
     {
         const int i = lane & 15, G = lane >> 4;
         const int r = G * 8 + (i >> 2);
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            fa[f] = lds0 + (wco >> 1) * HB + r * 256 + ((((wco & 1) * 4 + f) ^ tr_f8(r)) * 32) + (i & 3) * 8;
-            fb[f] = lds0 + 2 * HB + r * 256 + (((wci * 4 + f) ^ tr_f8(r)) * 32) + (i & 3) * 8;
+            if (f < NF) fa[f] = lds0 + (NH == 2 ? (wco >> 1) * HB : 0) + r * 256 + (((NH == 2 ? (wco & 1) * 4 + f : wco * 2 + f) ^ tr_f8(r)) * 32) + (i & 3) * 8;
+            fb[f] = lds0 + NH * HB + r * 256 + (((wci * 4 + f) ^ tr_f8(r)) * 32) + (i & 3) * 8;
         }
     }
-    f32x4 acc[4][4];
+    f32x4 acc[NF][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NF; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -420,8 +423,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(const WgradArgs a)
     int c_slot = 0;
     for (int s = 0; s < nst; ++s) {
         if (s + 1 < nst) {          // stage s (and the rowdesc of stage s + 2 that rode with it) has landed; stage s + 1 may stay in flight
-            if (w8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if (w8) { if constexpr (NH == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+            else { if constexpr (NH == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -431,11 +434,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(const WgradArgs a)
             issue(cbeg + s + 2, rd);
         }
         const unsigned sb = c_slot * STAGE;
-        bf16x4 av[2][4][2], bv[2][4][2];
+        bf16x4 av[2][NF][2], bv[2][4][2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
+            for (int f = 0; f < NF; ++f) {
                 if (k == 0) { wgr_rd_tr64<0>(av[0][f][0], fa[f] + sb); wgr_rd_tr64<1024>(av[0][f][1], fa[f] + sb); }
                 else { wgr_rd_tr64<8192>(av[1][f][0], fa[f] + sb); wgr_rd_tr64<8192 + 1024>(av[1][f][1], fa[f] + sb); }
             }
@@ -447,17 +450,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(const WgradArgs a)
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            if (k == 0) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");       // (16 reads of k-step 1 may stay in flight; the counter saturates at 15)
+            if (k == 0) { if constexpr (NH == 2) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); }   // (the reads of k-step 1 -- 16 / 12 -- may stay in flight; the counter saturates at 15)
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            bf16x8 af[4], bf[4];
+            bf16x8 af[NF], bf[4];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                asm volatile("" : "+v"(av[k][f][0]), "+v"(av[k][f][1]), "+v"(bv[k][f][0]), "+v"(bv[k][f][1]));
-                af[f] = __builtin_shufflevector(av[k][f][0], av[k][f][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                asm volatile("" : "+v"(bv[k][f][0]), "+v"(bv[k][f][1]));
                 bf[f] = __builtin_shufflevector(bv[k][f][0], bv[k][f][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                if (f < NF) {
+                    asm volatile("" : "+v"(av[k][f][0]), "+v"(av[k][f][1]));
+                    af[f] = __builtin_shufflevector(av[k][f][0], av[k][f][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NF; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = KG_MFMA16(af[i], bf[j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
@@ -467,13 +473,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_ring_kernel(const WgradArgs a)
     float* out = a.dwp + (long)split * a.split_stride;
     const int lm = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NF; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ci = ci0 + (wci * 4 + j) * 16 + lm;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + (wco * 4 + i) * 16 + g * 4 + r;
+                const int co = co0 + (wco * NF + i) * 16 + g * 4 + r;
                 if (co < a.Cout && ci < a.Cin) out[((long)co * a.ntaps + tap) * a.Cin + ci] = acc[i][j][r];
             }
         }
@@ -508,21 +514,30 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
     a.split_stride = split_stride;
     static const int use128 = getenv("KG_WGRAD128") ? atoi(getenv("KG_WGRAD128")) : 1;
     static const int use_ring = getenv("KG_WGRAD_RING") ? atoi(getenv("KG_WGRAD_RING")) : 1;
-    if (use_ring && g_wgrad_use_tr && cin_lim >= 128 && cout_lim >= 256) {      // (ops.wgrad_splits sizes nsplit for this tile under the same condition)
-        constexpr int smem = 3 * 3 * 64 * 256 + 3 * 512;
+    if (use_ring && g_wgrad_use_tr && cin_lim >= 128 && cout_lim >= 64) {   // (ops.wgrad_splits sizes nsplit for these tiles under the same condition)
+        const int nh = cout_lim >= 256 ? 2 : 1;
+        const int smem = 3 * (nh + 1) * 64 * 256 + 3 * 512;
         static bool attr_done = false;
         if (!attr_done) {
-            KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            constexpr int smem2 = 3 * 3 * 64 * 256 + 3 * 512, smem1 = 3 * 2 * 64 * 256 + 3 * 512;
+            KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
+            KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
+            KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
+            KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1));
+            KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1));
+            KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1));
             attr_done = true;
         }
-        dim3 gridr(((cin_lim + 127) / 128) * ((cout_lim + 255) / 256), KH * KW, nsplit);
-        if (a.mode >= 2) hipLaunchKernelGGL(conv_wgrad_ring_kernel<2>, gridr, dim3(512), smem, (hipStream_t)stream, a);
-        else if (a.direct) hipLaunchKernelGGL(conv_wgrad_ring_kernel<0>, gridr, dim3(512), smem, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(conv_wgrad_ring_kernel<1>, gridr, dim3(512), smem, (hipStream_t)stream, a);
+        dim3 gridr(((cin_lim + 127) / 128) * ((cout_lim + 128 * nh - 1) / (128 * nh)), KH * KW, nsplit);
+        const int md = a.mode >= 2 ? 2 : (a.direct ? 0 : 1);
+#define KG_RING_LAUNCH(M_, H_) hipLaunchKernelGGL((conv_wgrad_ring_kernel<M_, H_>), gridr, dim3(512), smem, (hipStream_t)stream, a)
+        if (nh == 2) { if (md == 2) KG_RING_LAUNCH(2, 2); else if (md == 0) KG_RING_LAUNCH(0, 2); else KG_RING_LAUNCH(1, 2); }
+        else { if (md == 2) KG_RING_LAUNCH(2, 1); else if (md == 0) KG_RING_LAUNCH(0, 1); else KG_RING_LAUNCH(1, 1); }
+#undef KG_RING_LAUNCH
         KG_CHECK_LAUNCH("conv_wgrad_ring");
-        kg_note_kernel("conv_wgrad_ring_kernel");
+        static const char* const names[2][3] = {{"conv_wgrad_ring_kernel<0, 1>", "conv_wgrad_ring_kernel<1, 1>", "conv_wgrad_ring_kernel<2, 1>"},
+                                                {"conv_wgrad_ring_kernel<0, 2>", "conv_wgrad_ring_kernel<1, 2>", "conv_wgrad_ring_kernel<2, 2>"}};
+        kg_note_kernel(names[nh - 1][md]);
         return KG_OK;
     }
     if (use128 && g_wgrad_use_tr && cin_lim >= 128 && cout_lim >= 128) {

@@ -462,9 +462,10 @@ WGRAD_RING = os.environ.get("KG_WGRAD_RING", "1") != "0"
 
 def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):
     chunks = math.ceil(M / 64)
-    if WGRAD_RING and WGRAD128 and cin_lim >= 128 and cout_lim >= 256:
-        # conv_wgrad_ring_kernel (256 x 128 tiles, 144 KB of LDS: one workgroup per CU): one round of at most 256 workgroups, or two
-        base = math.ceil(cin_lim / 128) * math.ceil(cout_lim / 256) * taps
+    if WGRAD_RING and WGRAD128 and cin_lim >= 128 and cout_lim >= 64:
+        # conv_wgrad_ring_kernel (256 x 128 tiles, or 128 x 128 below 256 couts; 144 / 96 KB of LDS: one workgroup per CU): one round of at
+        # most 256 workgroups
+        base = math.ceil(cin_lim / 128) * math.ceil(cout_lim / (256 if cout_lim >= 256 else 128)) * taps
         s = max(1, min(256 // base if base <= 256 else 1, max(1, chunks // 3)))
         while s > 1 and s * nelem * 4 > (768 << 20):
             s -= 1
