@@ -391,7 +391,7 @@ def test_gather_128x64_variant_on_small_problems():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, KG_GATHER_N64="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_planes.py"), os.path.join(root, "tests", "test_gpu_blocks.py"),
-                        os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x"], capture_output=True, text=True, env=env, cwd=root)
+                        "-q", "-x"], capture_output=True, text=True, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
