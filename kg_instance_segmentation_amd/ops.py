@@ -458,6 +458,7 @@ def conv_auto(x, pw, cout, geom, N, y=None, y_f32=None, bias=None, res=None, mas
 
 
 WGRAD_RING = os.environ.get("KG_WGRAD_RING", "1") != "0"
+WGRAD_RING_WGS = int(os.environ.get("KG_WGRAD_RING_WGS", "256"))      # workgroups of a ring launch (one 96 / 144 KB workgroup per CU)
 
 
 def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):
@@ -466,7 +467,7 @@ def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):
         # conv_wgrad_ring_kernel (256 x 128 tiles, or 128 x 128 below 256 couts; 144 / 96 KB of LDS: one workgroup per CU): one round of at
         # most 256 workgroups
         base = math.ceil(cin_lim / 128) * math.ceil(cout_lim / (256 if cout_lim >= 256 else 128)) * taps
-        s = max(1, min(256 // base if base <= 256 else 1, max(1, chunks // 3)))
+        s = max(1, min(WGRAD_RING_WGS // base if base <= WGRAD_RING_WGS else 1, max(1, chunks // 3)))
         while s > 1 and s * nelem * 4 > (768 << 20):
             s -= 1
         return s
