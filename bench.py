@@ -102,7 +102,7 @@ class KernelTimer:
             M, _, _, _, _, KH, KW, _, _ = geom
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             flushq(); s.record(); r = orig_wgrad(x, dy, cin, cout, geom, grads, *a, **k); e.record()
-            timer.rec.append((kname(x) + " (+ split reduction)", 2.0 * M * cout * KH * KW * cin, s, e, f"M={M} cout={cout} cin={cin} k={KH} mode={k.get('mode', 0)} route={r}"))
+            timer.rec.append((kname(x) + " (weight gradient; its split reduction runs in the batched flush)", 2.0 * M * cout * KH * KW * cin, s, e, f"M={M} cout={cout} cin={cin} k={KH} mode={k.get('mode', 0)} route={r}"))
             return r
         orig_halo = ops.conv_halo
 
@@ -114,10 +114,8 @@ class KernelTimer:
             flushq(); s.record(); r = orig_halo(x, pw, cout, N, H, W, KS, *a, **k); e.record()
             cin = k.get("algo_cin") or getattr(pw, "cin_real", pw.cin_pad)     # real channels (not the 8 / 64 padding, not the plane copies); fused second-layer head dgrad: 5 / 10 / 40 real dY channels per head
             px = N * H * W
-            if px == 0:      # ragged per-box crops (seg branch): the pixels of the tiles the launch walks (8 x 16 on conv3_ws, else 16 x 32)
-                t8, t16 = k.get("tiletab8"), k.get("tiletab")
-                ws = kname(x).startswith("conv3_ws")
-                px = t8.shape[0] * 128 if (ws and t8 is not None) else (t16.shape[0] * 512 if t16 is not None else 0)
+            if px == 0:      # ragged per-box crops (seg branch): the REAL pixels of the boxes (rconv's row count), not the padded tile area
+                px = int(k.get("total_rows") or 0)
             fl = 2.0 * px * cout * KS * KS * cin
             timer.rec.append((kname(x), fl, s, e, f"N={N} H={H} cout={cout} cinp={pw.cin_pad} products={pw.vp}" + (f" algo_cin={cin}" if "algo_cin" in k else ""), fl * pw.vp))
             return r
@@ -448,6 +446,22 @@ def kengine_products(P):
     return ops.vplanes(P, P)
 
 
+def self_launch_cmd(n, argv, port):
+    """The command `python bench.py --gpus N` re-runs itself as: the driver's own launcher line (one rank per GPU over RCCL)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a pre-spawned world (no WORLD_SIZE in the environment): re-run this very command line under
+    torch.distributed.run on 127.0.0.1 with a free port and hand its exit code back.  Rank 0's JSON line goes to our stdout untouched."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    return subprocess.run(self_launch_cmd(n, sys.argv[1:], port), env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -476,6 +490,8 @@ def main():
     from kg_instance_segmentation_amd.seg_loss import SEG_loss
     import torch.distributed as dist
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))       # plain `python bench.py --gpus N`: spawn the N ranks ourselves
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")

@@ -18,7 +18,7 @@ Numerics: the reference computes in fp32.  Here convolutions run on 16-bit MFMA 
   "half" / "halfmix": half mixed precision;  "fp32bf" / "fp32bf_full": the same tolerances on bf16 planes (hi + mid + lo, 6 products);
   "mixed" / "trunk2" / "bf16": bf16 mixed-precision policies (opt-in).
 RANGE of the half policies (nothing is clamped; a violation surfaces as inf / NaN, never silently): packed weights carry a constant
-2^12 scale, so |w| must stay below 16 (load_state_dict / check_half_range() raise on a violation); activations are stored as they are,
+2^12 scale, so |w| must stay below 16 (check_half_range() raises on a violation; load_state_dict switches such a checkpoint to the bf16-plane sibling policy with a warning); activations are stored as they are,
 |x| <= 65504; a non-finite parameter gradient raises the sticky flag grad_overflowed().  Use "fp32bf" for weights outside that range.
 Head maps and the feature maps c0..c4 are returned as fp32 tensors like the reference's (KGnet.py:318;
 the feature maps are NCHW-shaped with channels-last memory).
@@ -241,25 +241,41 @@ class ResNet(nn.Module):
 
     HALF_WEIGHT_LIMIT = 16.0       # csrc/kg_common.h KG_WSCALE = 2^12: 16 * 4096 = 65536 > IEEE half's 65504
 
-    def check_half_range(self):
-        """Half policies: raises ValueError if a conv weight cannot be packed (|w| * 2^12 beyond IEEE half: |w| >= 16).  One
-        max-reduction per conv weight; called by load_state_dict, callable by hand after writing parameters."""
+    BF16_SIBLING = {"fp32": "fp32bf", "fp32b2": "fp32bf_full", "half": "bf16", "halfmix": "mixed"}      # same planes plan on bf16 rows (8-bit exponent)
+
+    def half_range_violations(self):
+        """Half policies: [(key, max |w|)] of the conv weights that cannot be packed (|w| * 2^12 beyond IEEE half: |w| >= 16, or non-finite).
+        ONE multi-tensor max reduction over all conv weights and one read-back."""
         if not self._engine.fmt:
-            return
-        bad = []
-        for k in self._param_keys:
-            w = self.get_tensor(k)
-            if w.dim() == 4 and w.numel():
-                m = float(w.detach().abs().max())
-                if not m < self.HALF_WEIGHT_LIMIT:
-                    bad.append((k, m))
+            return []
+        keys = [k for k in self._param_keys if self.get_tensor(k).dim() == 4 and self.get_tensor(k).numel()]
+        if not keys:
+            return []
+        with torch.no_grad():
+            ms = torch.stack(torch._foreach_norm([self.get_tensor(k).detach() for k in keys], float("inf"))).float().cpu().numpy()
+        return [(k, float(m)) for k, m in zip(keys, ms) if not m < self.HALF_WEIGHT_LIMIT]
+
+    def check_half_range(self):
+        """Half policies: raises ValueError if a conv weight cannot be packed (|w| >= 16); callable by hand after writing parameters."""
+        bad = self.half_range_violations()
         if bad:
             raise ValueError(f"precision={self.precision!r} stores packed weights x 2^12 in IEEE half: |w| must be < {self.HALF_WEIGHT_LIMIT:g}, but "
                              f"{bad[0][0]} has max |w| = {bad[0][1]:g} ({len(bad)} tensor(s)); use precision='fp32bf' (bf16 planes) for such weights")
 
     def load_state_dict(self, state_dict, strict=True, **kw):
+        """As nn.Module.load_state_dict (KGnet.py:384-385, test.py:60-61 load any checkpoint).  A checkpoint whose conv weights leave the
+        half policies' range (|w| >= 16) switches the model to the policy's bf16-plane sibling (same tolerance class, 8-bit exponent; "fp32" ->
+        "fp32bf") with a warning instead of failing; KG_HALF_RANGE=raise restores the hard error."""
         r = super().load_state_dict(state_dict, strict=strict, **kw)
-        self.check_half_range()
+        bad = self.half_range_violations()
+        if bad:
+            if os.environ.get("KG_HALF_RANGE", "fallback") == "raise":
+                self.check_half_range()
+            sib = self.BF16_SIBLING[self.precision]
+            warnings.warn(f"KGnet: {len(bad)} conv weight tensor(s) (e.g. {bad[0][0]}, max |w| = {bad[0][1]:g}) are outside the range of precision="
+                          f"{self.precision!r} (packed weights x 2^12 in IEEE half: |w| < {self.HALF_WEIGHT_LIMIT:g}); switching this model to "
+                          f"precision={sib!r} (bf16 planes)", RuntimeWarning, stacklevel=2)
+            self.set_precision(sib)
         return r
 
     def invalidate_caches(self):

@@ -710,258 +710,6 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_finish_kernel(const H
     if (stats) kg_stat_commit<WPX, TC>(ss, sq, red, wp, wc * 64 + g * 16, lm, a.stat_part + (long)bix * a.Cout * 2, c0, a.Cout);
 }
 
-// ---- 7x7, 64 couts x (16 x 32) pixels, double-buffered halo (the first-layer head convs and their input gradients) ------------------
-// MEASURED ALTERNATIVE, not the default (KG_HALO7_DB=1 selects it; results are bit-identical): 3-8 % slower than conv_halo_kernel<7, 1, 8, 0>.
-// Both run the socket at its 1400 W cap (tools/power_probe.sh: 1330-1380 W, shader clock 1.95-2.08 GHz of 2.4), so filling the staging
-// bubbles buys nothing -- an idle MFMA pipe is returned as clock -- while the extra LDS-direct issue and address arithmetic inside the tap
-// loop cost power: without any prefetch the loop equals the single-buffered kernel (18.9 against 18.7 ms over the six bench launches,
-// tools/halo7_probe.py), with it 20.3 ms.  Kept as the record of that experiment and for re-measurement on other power budgets.
-// conv_halo_kernel<7, 1, 8, 0> stages the 107 KB halo of a 64-channel chunk with every wave waiting for it (nothing else fits in LDS), 49
-// taps x 2 k-steps later the next one: 4 us of an idle MFMA pipe per 29 us chunk walk.  Here the chunk is 32 channels -- ONE k-step per
-// tap -- and the halo has two regions of 64-byte pixel rows: while the 49 taps of one half walk region r, the next half's 52 KB land in
-// region r ^ 1 (LDS-direct loads, one 8 KB piece per thread group issued at the first seven pair starts, counted by the same vmcnt waits
-// as the weight ring).  The same LDS as before (2 x 52 KB + the 48 KB ring).  The weight ring keeps its shape: a slot = 8 KB = the
-// [64 couts][32 ch] slices of TWO taps, one barrier per two slots (64 MFMAs per wave), and it runs on across halves and chunks -- the
-// slots of the next half's first stages are filled behind the last taps of this one, so there is no drain anywhere between the first tap
-// of a workgroup and its epilogue.  64-byte rows need their own swizzles: pixel row hx keeps its four 16-byte slots at s ^ ((hx & 4) >> 1),
-// weight row r at s ^ (-(r >> 4) & 3) -- each conflict-free for every ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...: the 16 lanes of a
-// group cover 16 consecutive pixels once, the middle eight one k-slot over) at every tap shift.
-__global__ __launch_bounds__(512) void conv_halo7_db_kernel(const HaloArgs a) {
-    constexpr int KS = 7, PAD = 3, TW = 32, HWD = TW + KS - 1, HPIX = (16 + KS - 1) * HWD, T = KS * KS, NSTG = (T + 1) / 2, NSL = 6;
-    constexpr int NPIECE = (HPIX * 4 + 255) / 256, RBYTES = HPIX * 64, SLOT = 8192, RING = 2 * RBYTES;
-    static_assert(NPIECE <= NSTG, "one halo piece per stage");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lm = lane & 15, g = lane >> 4;
-    int oy0, ox0, Hd, Wd;
-    long rowbase;
-    int bix = blockIdx.x, biy = blockIdx.y;
-    if (a.xcd_map) {
-        const int L = blockIdx.y * gridDim.x + blockIdx.x;
-        const int xcd = L & 7, slot = L >> 3;
-        biy = slot % gridDim.y;
-        bix = xcd * (gridDim.x >> 3) + slot / gridDim.y;
-    }
-    if (a.tiletab) {
-        const int4 tt = a.tiletab[bix];
-        rowbase = tt.x; Hd = tt.y >> 16; Wd = tt.y & 0xffff; oy0 = tt.z >> 16; ox0 = tt.z & 0xffff;
-    } else {
-        int bt = bix;
-        const int tx = bt % a.tiles_x; bt /= a.tiles_x;
-        const int ty = bt % a.tiles_y; const int n = bt / a.tiles_y;
-        oy0 = ty * 16; ox0 = tx * TW; Hd = a.H; Wd = a.W; rowbase = (long)n * a.H * a.W;
-    }
-    const int c0 = biy * 64;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // fragment addresses: weights row r = (lm >> 2) * 16 + 4 i + (lm & 3) (fragment i: immediate i * 256), pixels: kb[kx] = the lane's pixel of
-    // output row (wave & 3) * 4 for a tap whose halo-x shift is fx(kx) (fragment j: immediate j * HWD * 64; the tap adds a scalar)
-    const unsigned lds0 = lds_addr(smem);
-    const unsigned a_off = lds0 + RING + ((lm >> 2) * 16 + (lm & 3)) * 64 + ((g ^ ((-(lm >> 2)) & 3)) << 4);
-    const int xb = (wave >> 2) * 16 + lm;
-    unsigned kb[KS];
-#pragma unroll
-    for (int kx = 0; kx < KS; ++kx) {
-        const int fx = a.flip ? KS - 1 - kx : kx;
-        kb[kx] = lds0 + (((wave & 3) * 4) * HWD + xb) * 64 + ((g ^ (((xb + fx) & 4) >> 1)) << 4);
-    }
-    const int tap0 = a.flip ? ((KS - 1) * HWD + (KS - 1)) * 64 : 0;
-    const int sx = a.flip ? -64 : 64, sy = a.flip ? -HWD * 64 : HWD * 64;
-
-    // The loads of a wave complete in order (one vmcnt), so a wave that has a halo piece in flight -- 52 KB of pixel rows, mostly from HBM --
-    // would make its counted waits for the weight ring wait for that piece too (measured: 1.97 ms per launch against 1.53 without the prefetch).
-    // Waves 0..3 (one per SIMD) therefore fill the ring, waves 4..7 (the other wave of every SIMD) the halo: they only wait for their pieces
-    // before the last barrier of a half.
-    const bool ringwave = wave < 4;                            // (uniform)
-    // halo piece q of a region (waves 4..7): thread -> 16-byte slot (t & 3) of halo pixel (t >> 2) + 64 q, t = tid - 256
-    const bf16_t* zline = reinterpret_cast<const bf16_t*>(kg_halo_zero_line);
-    auto hpiece = [&](int q, int region, int xoff) {
-        int tl = tid - 256;
-        asm volatile("" : "+v"(tl));      // (the piece addresses are loop-invariant per thread: hoisted out of the half loop they cost 20 registers)
-        const int e = tl + q * 256;
-        if (e < HPIX * 4) {
-            const int p = e >> 2, cs = e & 3;
-            const int hy = p / HWD, hx = p - hy * HWD;
-            const int c = cs ^ ((hx & 4) >> 1);
-            const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
-            const bf16_t* src = zline + c * 8;
-            if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd) src = a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + xoff + c * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(smem + region * RBYTES + (q * 256 + (wave - 4) * 64) * 16), 16, 0, 0);
-        }
-    };
-    // weight stage L of a half (waves 0..3): the [64 couts][32 ch] slices of taps 2L, 2L + 1 (thread: row (tid >> 2) & 63, slot tid & 3; two loads)
-    const int wrow = (tid >> 2) & 63;
-    const bf16_t* wthr = a.w + (long)(c0 + wrow) * a.K + (((tid & 3) ^ ((-(wrow >> 4)) & 3)) * 8);
-    int sbr[NSL];                      // ring slot (byte offset) of the stage with local index % 6 == q; rotated by 25 % 6 after every half
-#pragma unroll
-    for (int q = 0; q < NSL; ++q) sbr[q] = q * SLOT;
-    auto wstage = [&](int wb, int L, int slot_bytes) {                 // wb: (uniform) channel offset of the half inside a tap
-        if (!ringwave) return;
-        const bf16_t* wt = wthr;
-        asm volatile("" : "+v"(wt));       // (keeps the 25 per-stage pointers from being precomputed -- and spilled -- outside the half loop)
-        const bf16_t* src = wt + ((long)(2 * L) * a.cin_pad + wb);
-        unsigned char* dst = smem + RING + slot_bytes + wave * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        if (L != NSTG - 1) src += a.cin_pad;                           // tap 49 does not exist: the second load fetches tap 48 again (never read)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, 0);
-    };
-
-    // walk of the virtual 64-channel chunks (as in conv_halo_kernel: every low-order product before the first hi * hi product, one x_hi halo
-    // serving two products); a chunk is two halves s = 0, 1 in regions 0, 1
-    const int nwalk = a.cin_pad / 64;
-    auto decode = [&](int ci, int& cc, bool& stage) {
-        cc = ci; stage = true;
-        if (a.walk3) {
-            const int n = a.km.n, grp = 3 * n;
-            const int base = ci / grp * grp, q = ci - base;
-            if (q < 2 * n) cc = base + ((q & 1) ? (q >> 1) : n + (q >> 1));
-            else { cc = base + 2 * n + (grp - 1 - q); stage = q > 2 * n || ci == 0; }
-        }
-    };
-    int cc_cur; bool st_cur;
-    decode(0, cc_cur, st_cur);
-    int xo_cur = a.km.xoff(cc_cur);
-    int w_cur = cc_cur * 64;
-    if (!ringwave) {
-#pragma unroll 1
-        for (int q = 0; q < NPIECE; ++q) hpiece(q, 0, xo_cur);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        wstage(w_cur, 0, sbr[0]); wstage(w_cur, 1, sbr[1]); wstage(w_cur, 2, sbr[2]); wstage(w_cur, 3, sbr[3]);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    bf16x8 a0[4], b0[4], a1[4], b1[4];
-    const int nhalf = 2 * nwalk;
-#pragma unroll 1
-    for (int h = 0; h < nhalf; ++h) {
-        const int s = h & 1;
-        // the half after this one: its weights follow in the ring, its halo goes to region s ^ 1 unless that region already holds it
-        const bool has_next = h + 1 < nhalf;
-        int cc_n = cc_cur; bool st_n = st_cur;
-        if (s == 1 && has_next) decode((h + 1) >> 1, cc_n, st_n);
-        const int xo_n = a.km.xoff(cc_n) + (s ^ 1) * 32;
-        const int w_n = has_next ? cc_n * 64 + (s ^ 1) * 32 : w_cur;                 // (no next half: the tail fetches valid memory that nobody reads)
-        const bool pf = has_next && st_n;
-        const bool pfw = pf && !ringwave;                  // (uniform) this wave prefetches
-        const unsigned rb = s * RBYTES;                    // byte offset of this half's region
-        int tapb = tap0;                                   // halo byte offset of tap (ky, kx = 0)
-
-        auto ldA = [&](bf16x8 (&af)[4], int slot_bytes, int hf) {
-            const unsigned ad = a_off + slot_bytes + hf * 4096;
-            lds_rd128<0>(af[0], ad); lds_rd128<256>(af[1], ad); lds_rd128<512>(af[2], ad); lds_rd128<768>(af[3], ad);
-        };
-        auto ldB = [&](bf16x8 (&bfr)[4], int tb, unsigned kbv) {
-            const unsigned ad = kbv + rb + tb;
-            lds_rd128<0>(bfr[0], ad); lds_rd128<HWD * 64>(bfr[1], ad); lds_rd128<2 * HWD * 64>(bfr[2], ad); lds_rd128<3 * HWD * 64>(bfr[3], ad);
-        };
-        auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[4]) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = KG_MFMA16(af[i], bfr[j], acc[i][j]);
-        };
-        ldA(a0, sbr[0], 0); ldB(b0, tapb, kb[0]);
-        auto stage = [&](auto jc) {
-            constexpr int J = decltype(jc)::value;
-            constexpr int t0 = 2 * J, t1 = 2 * J + 1;
-            constexpr int kx1 = t1 % KS;
-            constexpr bool has1 = t1 < T, last = J == NSTG - 1;
-            {   // stage J + 4 into the slot of stage J - 2, which every wave has left (one stage per stage: the two waves of a SIMD never
-                // sit in LDS-direct issue at the same time -- the ring wave here, the halo wave behind the first tap)
-                constexpr int L4 = J + 4;
-                if constexpr (L4 < NSTG) wstage(w_cur, L4, sbr[L4 % NSL]); else wstage(w_n, L4 - NSTG, sbr[L4 % NSL]);
-            }
-            // tap t0 sits in (a0, b0); t1 goes to (a1, b1), the first tap of the next stage to (a0, b0) behind the MFMAs of t0
-            if constexpr (has1) {
-                constexpr bool wrap1 = kx1 == 0;                    // t1 starts a kernel row
-                const int tb1 = wrap1 ? tapb + sy : tapb + kx1 * sx;
-                ldA(a1, sbr[J % NSL], 1); ldB(b1, tb1, kb[kx1]);
-                lgkm_wait<8>(a0, b0);
-            } else lgkm_wait<0>(a0, b0);
-            mma(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (J < NPIECE) { if (pfw) { hpiece(J, s ^ 1, xo_n); __builtin_amdgcn_sched_barrier(0); } }
-            if constexpr (kx1 == 0 && has1) tapb += sy;             // (t1 is the first tap of its row)
-            if constexpr (!last) {
-                constexpr int t2 = t0 + 2, kx2 = t2 % KS;
-                if constexpr (kx2 == 0) tapb += sy;
-                ldA(a0, sbr[(J + 1) % NSL], 0); ldB(b0, tapb + kx2 * sx, kb[kx2]);
-            }
-            if constexpr (has1) {
-                if constexpr (!last) lgkm_wait<8>(a1, b1); else lgkm_wait<0>(a1, b1);
-                mma(a1, b1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (J % 2 == 1 || last) {    // pair end: the stages up to J + 3 must be visible behind the barrier; the two loads of the newest one may stay in flight
-                if (ringwave) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next half's halo has landed
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-        };
-        [&]<int... Js>(std::integer_sequence<int, Js...>) { (stage(std::integral_constant<int, Js>{}), ...); }(std::make_integer_sequence<int, NSTG>{});
-        {   // 25 stages per half: the slot of the next half's stage q is the one of this half's stage q + 25
-            int sb2[NSL];
-#pragma unroll
-            for (int q = 0; q < NSL; ++q) sb2[q] = sbr[(q + NSTG) % NSL];
-#pragma unroll
-            for (int q = 0; q < NSL; ++q) sbr[q] = sb2[q];
-        }
-        cc_cur = cc_n; st_cur = st_n; xo_cur = xo_n; w_cur = w_n;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail's dummy stages
-
-    // ---- epilogue: lane owns pixel (oy0 + (wave & 3) * 4 + j, ox0 + xb) and couts cb .. cb+15 (as conv_halo_kernel) ----------------------
-    const int cb = c0 + g * 16;
-    if (cb >= a.Cout) return;
-    float bv[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
-    if (a.oscale) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float sc = cb + e < a.Cout ? a.oscale[cb + e] : 1.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[e >> 2][j][e & 3] *= sc;
-        }
-    }
-    const EpiArgs ep{a.y, a.res, a.mask, a.ldy, a.ldres, a.ldmask, a.Cout, a.relu, a.yP, a.yps, a.rP, a.rps};
-    const int ox = ox0 + xb;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int oy = oy0 + (wave & 3) * 4 + j;
-        if (oy >= Hd || ox >= Wd) continue;
-        const long m = rowbase + (long)oy * Wd + ox;
-        float v[16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(acc[i][j][r]) + bv[i * 4 + r];
-        if (a.y_f32) {
-            if (a.relu) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = kg_relu(v[e]);
-            }
-            const long hw = a.tiletab ? (long)a.f32_hw : (long)a.H * a.W;
-            const long nimg = a.tiletab ? 0 : rowbase / hw, pix = a.tiletab ? m : (long)oy * Wd + ox;
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if (cb + e < a.Cout) a.y_f32[(nimg * a.f32_C + cb + e) * hw + pix] = v[e];
-        }
-        if (a.y) kg_conv_epilogue<16>(ep, m, cb, v);
-    }
-}
-
 template <int KS, int WC, int WPX, int GM = 0>
 static int launch_halo(HaloArgs a, hipStream_t st) {
     constexpr int TW = 4 * WPX, HWD = TW + KS - 1, TC = WC * 64;
@@ -990,22 +738,6 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
     static const int use_xcd = getenv("KG_HALO_XCD") ? atoi(getenv("KG_HALO_XCD")) : 1;
     // (not for the widest heads: 24 cout blocks of one tile stream 24 different 3 MB weight slices through the XCD's 4 MB L2: -2 %)
     a.xcd_map = use_xcd && !a.tiletab && grid.x % 8 == 0 && (grid.y > 1 || use_xcd > 1) && (long)a.Cout * a.K * 2 <= (24L << 20);
-    if constexpr (KS == 7 && WC == 1 && WPX == 8 && GM == 0) {
-        // KG_HALO7_DB=1: the double-buffered 32-channel-halves kernel (bit-identical results; measured 3-8 % SLOWER than the single-buffered
-        // kernel: the socket sits at its 1400 W power cap in both, and the extra LDS-direct issue + address arithmetic costs clock)
-        static const int use_db = getenv("KG_HALO7_DB") ? atoi(getenv("KG_HALO7_DB")) : 0;
-        if (use_db && !a.stat_part && a.ksplit <= 1) {
-            static bool db_attr = false;
-            if (!db_attr) {
-                KG_HIP(hipFuncSetAttribute((const void*)conv_halo7_db_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                db_attr = true;
-            }
-            hipLaunchKernelGGL(conv_halo7_db_kernel, grid, dim3(512), smem, st, a);
-            KG_CHECK_LAUNCH("conv_halo7_db");
-            kg_note_kernel("conv_halo7_db_kernel");
-            return KG_OK;
-        }
-    }
     hipLaunchKernelGGL((conv_halo_kernel<KS, WC, WPX, GM>), grid, dim3(WC * WPX * 64), smem, st, a);
     KG_CHECK_LAUNCH("conv_halo");
     KG_KNAME(kname, "conv_halo_kernel<%d, %d, %d, %d>", KS, WC, WPX, GM);

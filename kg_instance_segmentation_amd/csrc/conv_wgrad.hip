@@ -699,7 +699,11 @@ static int launch_reduce(const float* part, const ReduceDst& d, int Cout, int Ci
     KG_CHECK_LAUNCH("wgrad_reduce");
     return KG_OK;
 }
-extern "C" int kg_wgrad_reduce_defer(int on) { g_reduce_defer = on; return KG_OK; }
+extern "C" int kg_wgrad_reduce_defer(int on) {
+    g_reduce_defer = on;
+    if (!on) { g_reduce_q[0].clear(); g_reduce_q[1].clear(); }     // (empty after a successful flush; after a failed one nothing stale may stay)
+    return KG_OK;
+}
 extern "C" int kg_wgrad_reduce_pending(void) { return (int)(g_reduce_q[0].size() + g_reduce_q[1].size()); }
 extern "C" int kg_wgrad_reduce_flush(void* stream) {
     for (int c = 0; c < 2; ++c) {
@@ -718,7 +722,10 @@ extern "C" int kg_wgrad_reduce_flush(void* stream) {
             nt = (nt + 63) / 64 * 64;
             if (c) hipLaunchKernelGGL(wgrad_reduce_batch_kernel<64>, dim3(blocks), dim3(nt), 0, (hipStream_t)stream, b);
             else hipLaunchKernelGGL(wgrad_reduce_batch_kernel<16>, dim3(blocks), dim3(nt), 0, (hipStream_t)stream, b);
-            if (hipGetLastError() != hipSuccess) { q.clear(); kg_set_error("kg_wgrad_reduce_flush: launch failed"); return KG_ERR_HIP; }
+            if (hipGetLastError() != hipSuccess) {      // drop EVERY recorded job: none may outlive the tensors its pointers name
+                g_reduce_q[0].clear(); g_reduce_q[1].clear();
+                kg_set_error("kg_wgrad_reduce_flush: launch failed"); return KG_ERR_HIP;
+            }
         }
         q.clear();
     }

@@ -173,6 +173,8 @@ class Engine:
         self.eval_downgrade = os.environ.get("KG_EVAL_DOWNGRADE", "0") == "1"     # opt-in: eval-mode backbone on the decoder's planes ("mixed": plain bf16 inference)
         self.fuse_eval_bn = os.environ.get("KG_FUSE_EVAL_BN", "1") == "1"       # inference: conv -> bn (-> + res) (-> relu) as ONE launch (conv_bn)
         self.raw_kp_logits = False   # test hook: inference-only export of the kp LOGITS instead of sigmoid(logits) (KGnet.py:300)
+        self.keep_kp_logits = False  # test hook, any mode: a second grouped launch without the sigmoid fills kp_logits[level] (the maps the losses see stay probabilities)
+        self.kp_logits = {}
         self.grad_store = None     # parallel.FlatGradReducer: key -> persistent fp32 view the gradient kernels write into directly
         self.grad_hook = None      # parallel.FlatGradReducer.attach: called with [(key, grad)] as backward produces them
         self.prepack_state = None  # prepack(): {"epoch", "stamp", "seg_stamp"} of weights packed ahead of the next training forward
@@ -695,6 +697,10 @@ class Engine:
         outs = [torch.empty(N, co, H, W, dtype=torch.float32, device=dev) for _, co in arch.HEADS]
         ops.conv_halo_heads2(hid.t, pwF, bias64, self.heads2_tables(dev)["vmap"], outs[0], outs[1], outs[2], N, H, W, C,
                              kp_sigmoid=not self.raw_kp_logits)
+        if self.keep_kp_logits:
+            side = [torch.empty_like(o) for o in outs]
+            ops.conv_halo_heads2(hid.t, pwF, bias64, self.heads2_tables(dev)["vmap"], side[0], side[1], side[2], N, H, W, C, kp_sigmoid=False)
+            self.kp_logits[lvl] = side[0]
         slot = {"grad": None}
         self.head_slots.append((slot, lvl, N, H, W))
         if train:

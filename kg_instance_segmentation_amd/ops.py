@@ -32,20 +32,24 @@ def scratch_f32(nfloats, dev, tag="default"):
 class WgradReduceQueue:
     """Deferred split reductions of the weight gradients (kg_wgrad_reduce_defer / _flush): while `on`, conv_wgrad bump-allocates its fp32
     partials from one arena and only records the reduction; flush() runs the recorded reductions twelve per launch.  Flush points: the arena
-    is full, a gradient is about to be read (scale_tensors, a data-parallel bucket's all-reduce), the end of a backward pass."""
+    is full, a gradient is about to be read (scale_tensors, a data-parallel bucket's all-reduce), the end of a backward pass.
+    The arena starts at ARENA0 and grows to the high-water mark of a backward pass (what the pass asked for in total, capped at
+    KG_WGRAD_ARENA_MB, default 3 GB; a bench step at batch 8 x 512^2 asks for ~2 GB): a small model or batch keeps a small arena, the first
+    step of a large one pays a few extra flushes."""
 
-    ARENA = int(os.environ.get("KG_WGRAD_ARENA_MB", "3072")) << 18      # floats (the partial sets of a bench step's backward: ~2 GB)
+    ARENA = int(os.environ.get("KG_WGRAD_ARENA_MB", "3072")) << 18      # cap, floats
+    ARENA0 = min(ARENA, 64 << 18)                                       # first allocation (64 MB)
     SMALL = ARENA // 8                                                 # larger partial sets are reduced at once from the shared scratch
 
     def __init__(self):
         self.enabled = os.environ.get("KG_WGRAD_BATCH", "1") != "0"
         self.on, self.depth = False, 0
-        self.arena, self.off = None, 0
+        self.arena, self.off, self.need = None, 0, 0
 
     def begin(self):
         self.depth += 1
         if self.enabled and not self.on:
-            self.on = True
+            self.on, self.need = True, 0
             for fmt in (0, 1):
                 _lib.call("kg_wgrad_reduce_defer", 1, fmt=fmt)
 
@@ -53,16 +57,29 @@ class WgradReduceQueue:
         self.depth -= 1
         if self.depth <= 0 and self.on:
             self.depth = 0
-            self.flush()
-            self.on = False
-            for fmt in (0, 1):
-                _lib.call("kg_wgrad_reduce_defer", 0, fmt=fmt)
+            try:
+                self.flush()
+            finally:           # a failed flush must not leave the library recording jobs that point into freed gradient tensors
+                self.on, self.off = False, 0
+                for fmt in (0, 1):
+                    _lib.call("kg_wgrad_reduce_defer", 0, fmt=fmt)
+            if self.arena is not None and self.need > self.arena.numel() and self.arena.numel() < self.ARENA:
+                dev = self.arena.device       # the pass wanted more than the arena holds: the next one gets its high-water mark
+                self.arena = None
+                self.arena = torch.empty(min(self.ARENA, self.need), dtype=torch.float32, device=dev)
 
     def flush(self):
         if self.on:
-            for fmt in (0, 1):
-                _lib.call("kg_wgrad_reduce_flush", stream_ptr(), fmt=fmt)
-            self.off = 0
+            try:
+                for fmt in (0, 1):
+                    _lib.call("kg_wgrad_reduce_flush", stream_ptr(), fmt=fmt)
+            finally:
+                self.off = 0
+
+    def release(self):
+        """drops the arena (it is re-grown by the next backward pass)"""
+        if not self.on:
+            self.arena, self.off = None, 0
 
     def alloc(self, nfloats, dev, tag, extra=0):
         """partials buffer of a conv_wgrad call: the shared per-tag scratch (reduced right away) or, while deferring, a slice of the arena.
@@ -73,10 +90,14 @@ class WgradReduceQueue:
         n = (int(nfloats) + 63) // 64 * 64
         if n > self.SMALL:
             return scratch_f32(nfloats, dev, tag), True        # (True: the caller flushes right after recording -- the scratch is shared)
-        if self.arena is None or self.arena.device != torch.device(dev):
-            self.flush()
-            self.arena = torch.empty(self.ARENA, dtype=torch.float32, device=dev)
-        if self.off + n + (int(extra) + 63) // 64 * 64 > self.ARENA:
+        ne = n + (int(extra) + 63) // 64 * 64
+        self.need += n
+        if self.arena is None or self.arena.device != torch.device(dev) or ne > self.arena.numel():
+            self.flush()          # (the recorded reductions read the old arena on this stream; its memory is recycled in stream order)
+            size = max(self.ARENA0, ne, 0 if self.arena is None else min(self.ARENA, 2 * self.arena.numel()))
+            self.arena = None
+            self.arena = torch.empty(size, dtype=torch.float32, device=dev)
+        if self.off + ne > self.arena.numel():
             self.flush()
         t = self.arena[self.off:self.off + n]
         self.off += n
@@ -461,9 +482,22 @@ WGRAD_RING = os.environ.get("KG_WGRAD_RING", "1") != "0"
 WGRAD_RING_WGS = int(os.environ.get("KG_WGRAD_RING_WGS", "256"))      # workgroups of a ring launch (one 96 / 144 KB workgroup per CU)
 
 
+WGRAD_TR = [True]      # mirror of the library's kg_set_wgrad_tr switch (set_wgrad_tr below keeps the two in step)
+
+
+def set_wgrad_tr(on):
+    """test switch of kg_conv2d_wgrad: LDS transpose reads (default) or scalar fragment loads -- both libraries and the split sizing"""
+    WGRAD_TR[0] = bool(on)
+    for fmt in (0, 1):
+        _lib.call("kg_set_wgrad_tr", 1 if on else 0, fmt=fmt)
+
+
 def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):
+    """pixel splits of kg_conv2d_wgrad, sized for the tile the library will pick: the conditions below are kg_conv2d_wgrad's own
+    (conv_wgrad.hip: ring iff KG_WGRAD_RING && transpose reads && cin >= 128 && cout >= 64; 128 x 128 iff KG_WGRAD128 && transpose reads
+    && cin, cout >= 128)"""
     chunks = math.ceil(M / 64)
-    if WGRAD_RING and WGRAD128 and cin_lim >= 128 and cout_lim >= 64:
+    if WGRAD_RING and WGRAD_TR[0] and cin_lim >= 128 and cout_lim >= 64:
         # conv_wgrad_ring_kernel (256 x 128 tiles, or 128 x 128 below 256 couts; 144 / 96 KB of LDS: one workgroup per CU): one round of at
         # most 256 workgroups
         base = math.ceil(cin_lim / 128) * math.ceil(cout_lim / (256 if cout_lim >= 256 else 128)) * taps
@@ -471,7 +505,7 @@ def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):
         while s > 1 and s * nelem * 4 > (768 << 20):
             s -= 1
         return s
-    t = 128 if (WGRAD128 and cin_lim >= 128 and cout_lim >= 128) else 64      # output tile of kg_conv2d_wgrad
+    t = 128 if (WGRAD128 and WGRAD_TR[0] and cin_lim >= 128 and cout_lim >= 128) else 64      # output tile of kg_conv2d_wgrad
     base = math.ceil(cin_lim / t) * math.ceil(cout_lim / t) * taps
     s = max(1, min(math.ceil(2048 / base), max(1, chunks // 4)))
     while s > 1 and s * nelem * 4 > (768 << 20):

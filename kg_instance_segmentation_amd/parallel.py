@@ -79,8 +79,12 @@ class FlatGradReducer:
     optimizer skips it exactly as the single-device step does -- and the overflow flag is the same on every rank after finish(), so
     `if model.grad_overflowed(): skip the step` cannot make replicas diverge (the SUM all-reduce spreads one rank's inf / NaN to all)."""
 
-    def __init__(self, bucket_mb=64):
+    def __init__(self, bucket_mb=64, tail_mb=8, tail_total_mb=32):
         self.cap = bucket_mb << 20
+        # the LAST bucket's all-reduce starts when the backward pass ends and is exposed in full: the final `tail_total_mb` of the
+        # buffer (the 115 small backbone / c0_conv tensors, ~24 MB) go out in pieces of <= tail_mb, so what is left after the last
+        # gradient kernel is one small piece (round 4's single 24 MB tail bucket was issued 0.04 ms before finish())
+        self.tail_cap, self.tail_total = tail_mb << 20, tail_total_mb << 20
         self.model = None
 
     def attach(self, model):
@@ -108,7 +112,8 @@ class FlatGradReducer:
         start = off
         for k in order:
             cur.append(k); size += params[k].numel() * 4; off += params[k].numel()
-            if size >= self.cap:
+            left = (total - off) * 4                  # bytes of the gradients still to come after this one
+            if size >= (self.cap if left + size > self.tail_total else self.tail_cap):
                 self.buckets.append((start, off, cur)); cur, size, start = [], 0, off
         if cur:
             self.buckets.append((start, off, cur))

@@ -305,3 +305,14 @@ def test_half_build_loads_and_exports_the_rows_entry_points(lib):
     assert ctypes.sizeof(ops._Planes) == 56 and ops._Planes.scale.offset == 40 and ops._Planes.oscale.offset == 48
     hdr = open(os.path.join(ROOT, "include", "kgnet_hip.h")).read()
     assert "int reserved_;" in hdr and "const float* scale;" in hdr
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` without WORLD_SIZE re-runs itself as the driver's launcher line (bench.self_launch_cmd): one rank per GPU
+    under torch.distributed.run on 127.0.0.1, the user's flags passed through."""
+    import bench
+    cmd = bench.self_launch_cmd(8, ["--gpus", "8", "--steps", "3"], 29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "3"]

@@ -150,3 +150,25 @@ def test_multi_rank_step_equals_sequential_shards(world):
     # every rank holds the SAME reduced gradients and parameters, bit for bit (they all read one all-reduce result)
     for r in range(1, world):
         assert all(out[r][1][k] == out[0][1][k] for k in ref_g) and all(out[r][2][k] == out[0][2][k] for k in ref_p)
+
+
+def test_bench_gpus2_launches_itself():
+    """`python bench.py --gpus 2 ...` with NO pre-spawned world (the driver's plain command line): bench.py re-runs itself under
+    torch.distributed.run, both ranks on GPU 0 over gloo (a 1-GPU box; KG_FORCE_DEVICE / KG_DIST_BACKEND are the hooks of
+    parallel.init_from_env), and rank 0 prints ONE JSON line of the data-parallel step: n_gpus 2, global batch = 2 x batch, finite loss."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(KG_FORCE_DEVICE="0", KG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--size", "128",
+                        "--boxes", "8", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2" and out["scaling"] == "weak"
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["value"] > 0
+    assert np.isfinite(out["config"]["last_loss"]) and out["config"]["grad_overflow"] is False
+    assert abs(out["value"] - 4 * 2 / (out["ms_per_step"] * 2e-3)) <= 1e-6 * out["value"]

@@ -212,12 +212,12 @@ def test_conv_wgrad(case, use_tr):
     xr = torch.zeros(N * H * W, cin_pad, dtype=BF16); xr[:, :cin] = rows_of(x)
     dyr = torch.zeros(N * OH * OW, cpad, dtype=BF16); dyr[:, :cout] = rows_of(dy)
     gw = torch.full((cout, cin, k, k), float("nan"), dtype=torch.float32, device=DEV)
-    _lib.call("kg_set_wgrad_tr", use_tr)
+    ops.set_wgrad_tr(use_tr)
     try:
         ops.conv_wgrad(xr.to(DEV), dyr.to(DEV), cin, cout, (N * OH * OW, H, W, OH, OW, k, k, stride, pad), [(gw, 0, cout)])
         torch.cuda.synchronize()
     finally:
-        _lib.call("kg_set_wgrad_tr", 1)
+        ops.set_wgrad_tr(1)
     scale = float(w.grad.abs().max())
     report(f"conv_wgrad{case} tr={use_tr}", gw.cpu(), w.grad, atol=2e-4 * scale, rtol=1e-4)
     db = torch.empty(cout, dtype=torch.float32, device=DEV)
@@ -392,20 +392,6 @@ def test_gather_128x64_variant_on_small_problems():
     env = dict(os.environ, KG_GATHER_N64="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_planes.py"), os.path.join(root, "tests", "test_gpu_blocks.py"),
                         "-q", "-x"], capture_output=True, text=True, env=env, cwd=root)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-def test_double_buffered_7x7_halo_kernel_matches():
-    """conv_halo7_db_kernel (KG_HALO7_DB=1: 32-channel halves, double-buffered halo, ring running across chunks; csrc/conv_halo.hip) stays in the
-    library as the measured alternative to the single-buffered 7x7 kernel: the halo and plane conv tests in a process that selects it."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, KG_HALO7_DB="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), os.path.join(root, "tests", "test_gpu_planes.py"),
-                        "-q", "-x", "-k", "test_conv_halo_forward_and_dgrad or test_conv_forward_dgrad_wgrad_planes"],
-                       capture_output=True, text=True, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 

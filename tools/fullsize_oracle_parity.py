@@ -1,0 +1,122 @@
+#!/usr/bin/env python
+"""GPU box: TRAIN-mode forward of BASELINE's configuration (batch 8 x 512 x 512, 300 boxes per image; calibrated weights) element-wise
+against the reference-pinned CPU oracle (oracle/net.py) evaluated in float32 -- the reference's own arithmetic -- AND in float64:
+kp logits, short / mid offsets, seg logits, the five losses.  Three columns per map, all as worst |d| / bound with
+bound = atol + rtol |ref| (rtol 1e-4; atol 1e-5 literal for logits, 1e-5 * OFFSET_ATOL_SCALE[map] for the offset maps):
+    policy vs oracle32   -- the parity statement of SURVEY 8d at the bench configuration
+    policy vs oracle64   -- distance from the true value
+    oracle32 vs oracle64 -- what the reference's own fp32 arithmetic loses at this size (the floor)
+
+    python tools/fullsize_oracle_parity.py [batch] [size] [boxes] [policy,policy,...] > profiles/r05_fullsize_oracle_parity.txt"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from kg_instance_segmentation_amd import KGnet
+from kg_instance_segmentation_amd.loss import DetectionLossAll
+from kg_instance_segmentation_amd.seg_loss import SEG_loss
+from oracle import net as onet, synth, weightgen
+
+RTOL, ATOL = 1e-4, 1e-5
+# stated per-map constants of the offset maps' atol (pixels; the maps' rms on this fixture is 1-6 px): atol = 1e-5 * scale
+OFFSET_ATOL_SCALE = {"short": 2.0, "mid": 6.0}
+
+
+def bound_of(name, ref):
+    kind = name.split(".")[-1]
+    a = ATOL * OFFSET_ATOL_SCALE.get(kind, 1.0)
+    return a + RTOL * ref.abs()
+
+
+def worst_ratio(name, got, ref):
+    got, ref = got.double(), ref.double()
+    r = (got - ref).abs() / bound_of(name, ref)
+    return float(r.max()), float((r > 1).double().mean()), float(ref.pow(2).mean().sqrt()), float((got - ref).abs().max())
+
+
+def oracle_forward(sd, x, boxes, gt_lv, gt_masks, S, dtype):
+    t0 = time.time()
+    sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    net = onet.Net(sd, training=True)
+    with torch.no_grad():
+        o = net.forward(x.to(dtype), boxes)
+        maps = {}
+        for l in range(4):
+            maps[f"c{l}.kp_logit"] = net.kp_logits[l]
+            maps[f"c{l}.short"] = o[l][1]
+            maps[f"c{l}.mid"] = o[l][2]
+        seg = torch.cat([z.reshape(-1) for per in net.seg_logits for z in per])
+        maps["seg_logit"] = seg
+        losses = [float(onet.detection_loss(o[l], gt_lv[l].to(dtype))) for l in range(4)]
+        losses.append(float(onet.seg_loss(o[4], gt_masks, boxes, S, S)))
+    return maps, losses, time.time() - t0
+
+
+def gpu_forward(sd, x, boxes, gt_lv, gt_masks, S, policy, dev):
+    m = KGnet.resnet50(pretrained=False, precision=policy)
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    m._engine.keep_kp_logits = True
+    m._seg.keep_logits = True
+    ldec, lseg = DetectionLossAll(5), SEG_loss(S, S)
+    with torch.no_grad():
+        d = m(x.to(dev), boxes)
+        maps = {}
+        for l in range(4):
+            maps[f"c{l}.kp_logit"] = m._engine.kp_logits[l].cpu()
+            maps[f"c{l}.short"] = d[l][1].cpu()
+            maps[f"c{l}.mid"] = d[l][2].cpu()
+        # the product's ragged logits are box-major in the order of its own plan; the oracle's are image-major, box order: same order
+        meta, flat = d[4].kg_meta, m._seg.last_logits
+        order = sorted(range(len(meta["off"])), key=lambda j: (int(meta["img"][j]), j))
+        maps["seg_logit"] = torch.cat([flat[int(meta["off"][j]):int(meta["off"][j]) + int(meta["h"][j]) * int(meta["w"][j])] for j in order]).cpu()
+        losses = [float(ldec(d[l], gt_lv[l].to(dev))) for l in range(4)] + [float(lseg(d[4], gt_masks, boxes))]
+    del m
+    torch.cuda.empty_cache()
+    return maps, losses
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+    NB = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+    policies = sys.argv[4].split(",") if len(sys.argv) > 4 else ["fp32"]
+    torch.set_num_threads(min(os.cpu_count() or 8, 64))
+    dev = torch.device("cuda", 0)
+    sd = weightgen.gen_state_dict(0, variant="cal")
+    x, boxes, masks, gt_lv = synth.train_batch(N, S, S, 41, n_boxes=NB, smin=14, smax=40)
+    print(f"train-mode forward, batch {N} x {S} x {S}, {NB} boxes/img, calibrated weights; {torch.get_num_threads()} host threads")
+    o32, l32, t32 = oracle_forward(sd, x, boxes, gt_lv, masks, S, torch.float32)
+    o64, l64, t64 = oracle_forward(sd, x, boxes, gt_lv, masks, S, torch.float64)
+    print(f"oracle float32 {t32:.1f} s, float64 {t64:.1f} s")
+    print("losses oracle64:", ["%.8f" % v for v in l64])
+    print("losses oracle32:", ["%.8f" % v for v in l32], " max rel vs 64: %.2e" % max(abs(a - b) / abs(b) for a, b in zip(l32, l64)))
+    res = {}
+    for pol in policies:
+        g, lg = gpu_forward(sd, x, boxes, gt_lv, masks, S, pol, dev)
+        res[pol] = g
+        print(f"losses {pol:>9}:", ["%.8f" % v for v in lg], " max rel vs 32: %.2e  vs 64: %.2e" %
+              (max(abs(a - b) / abs(b) for a, b in zip(lg, l32)), max(abs(a - b) / abs(b) for a, b in zip(lg, l64))))
+    print()
+    print("%-14s %9s %8s | %-28s" % ("map", "elements", "rms", "oracle32 vs oracle64: worst |d|/bound (frac > 1)  max|d|") + "".join(
+        f" | {p}: vs oracle32, vs oracle64 (frac > 1)" for p in policies))
+    worst = {p: [0.0, 0.0] for p in policies}
+    floor = 0.0
+    for name in o64:
+        assert o32[name].shape == o64[name].shape
+        a = worst_ratio(name, o32[name], o64[name])
+        floor = max(floor, a[0])
+        line = "%-14s %9d %8.3g | %6.3f (%.1e) %.2e" % (name, o64[name].numel(), a[2], a[0], a[1], a[3])
+        for p in policies:
+            assert res[p][name].shape == o64[name].shape, (name, res[p][name].shape, o64[name].shape)
+            b = worst_ratio(name, res[p][name], o32[name])
+            c = worst_ratio(name, res[p][name], o64[name])
+            worst[p][0] = max(worst[p][0], b[0]); worst[p][1] = max(worst[p][1], c[0])
+            line += " | %6.3f (%.1e)  %6.3f (%.1e)" % (b[0], b[1], c[0], c[1])
+        print(line)
+    print()
+    print("worst over all maps: oracle32 vs oracle64 %.3f" % floor + "".join(f"; {p}: vs oracle32 {worst[p][0]:.3f}, vs oracle64 {worst[p][1]:.3f}" for p in policies))
+
+
+if __name__ == "__main__":
+    main()
