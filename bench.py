@@ -64,9 +64,10 @@ def make_batch(N, S, nboxes, seed, dev):
 class KernelTimer:
     """HIP-event brackets around every kg_conv2d_igemm / kg_conv2d_wgrad launch on the launch stream."""
 
-    # the 7x7 LDS-halo kernel (forward + input gradient of the first-layer head convs), rocprofv3's names: the double-buffered kernel, or
-    # (KG_HALO7_DB=0) the single-buffered one it replaced in round 4
-    DOMINANT = ("conv_halo7_db_kernel", "conv_halo_kernel<7, 1, 8, 0>")
+    # the 7x7 LDS-halo kernel family (forward + input gradient of the first-layer head convs), rocprofv3's names: the 8-wave kernel and
+    # (round 5) its 4-wave sibling with the blocked accumulation, which serves the multi-chunk 3-product forward launches -- the same
+    # workgroup tile, LDS image and load protocol; the roofline entry is taken over the launches of both
+    DOMINANT = ("conv_halo_kernel<7, 1, 8, 0>", "conv_halo7_w4_kernel<false>", "conv_halo7_w4_kernel<true>")
 
     def __init__(self):
         self.rec = []
@@ -188,22 +189,26 @@ def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC pass of THIS build (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, gfx950
     correction of MI355X_MICROARCH.md), or None when no committed pass matches the loaded libraries."""
     d, _ = _pmc_file("pmc_hbm")
-    for k, v in (d or {}).items():
-        if k.replace(" ", "") in ("conv_halo_kernel<7,1,8>", "conv_halo_kernel<7,1,8,0>", "conv_halo7_db_kernel") and "hbm_bytes" in v:
-            return v["hbm_bytes"]
-    return None
+    fam = {n.replace(" ", "") for n in KernelTimer.DOMINANT}
+    rows = [v for k, v in (d or {}).items() if k.replace(" ", "") in fam and "hbm_bytes" in v]
+    if not rows:
+        return None
+    return sum(v["hbm_bytes"] * v["launches"] for v in rows) / sum(v["launches"] for v in rows)      # launch-weighted over the family
 
 
 def pmc_mfma():
     """MFMA-pipe utilisation of the dominant kernel from the PMC pass of THIS build (SQ_VALU_MFMA_BUSY_CYCLES summed over the 1024 SIMDs,
     GRBM_GUI_ACTIVE over the 8 XCDs), or None when no committed pass matches the loaded libraries."""
     d, name = _pmc_file("pmc_mfma_lds")
-    for k, v in (d or {}).items():
-        if k.replace(" ", "") in ("conv_halo_kernel<7,1,8,0>", "conv_halo7_db_kernel") and v.get("GRBM_GUI_ACTIVE"):
-            return {"mfma_busy_frac": (v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (v["GRBM_GUI_ACTIVE"] / 8.0),
-                    "active_cycles_per_launch": v["GRBM_GUI_ACTIVE"] / 8.0,
-                    "lds_bank_conflict_cycles": v.get("SQ_LDS_BANK_CONFLICT"), "file": name}
-    return None
+    fam = {n.replace(" ", "") for n in KernelTimer.DOMINANT}
+    rows = [v for k, v in (d or {}).items() if k.replace(" ", "") in fam and v.get("GRBM_GUI_ACTIVE")]
+    if not rows:
+        return None
+    L = sum(v["launches"] for v in rows)
+    busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] * v["launches"] for v in rows) / 1024.0
+    act = sum(v["GRBM_GUI_ACTIVE"] * v["launches"] for v in rows) / 8.0
+    return {"mfma_busy_frac": busy / act, "active_cycles_per_launch": act / L,
+            "lds_bank_conflict_cycles": sum((v.get("SQ_LDS_BANK_CONFLICT") or 0.0) * v["launches"] for v in rows) / L, "file": name}
 
 
 def eval_inputs(S, n, seed):
@@ -669,8 +674,9 @@ def main():
             timer.rec = prof_rec
             timer.dump(os.environ["KG_BENCH_DUMP"], prof_steps)
         dsum = timer.summary(dom_rec)
-        dom_name = next((n for n in KernelTimer.DOMINANT if n in dsum), None)
-        dom = dsum.get(dom_name)
+        fam = [n for n in KernelTimer.DOMINANT if n in dsum]
+        dom = {k: sum(dsum[n][k] for n in fam) for k in ("seconds", "flops", "launches", "mfma_flops")} if fam else None
+        dom_name = " + ".join(fam)
         if dom:
             ach = dom["flops"] / dom["seconds"] / 1e12
             issued = dom["mfma_flops"] / dom["seconds"] / 1e12
@@ -682,6 +688,8 @@ def main():
                                "products_per_multiply": prod,
                                "traffic": pmc_traffic(), "avg_launch_ms": 1e3 * dom["seconds"] / dom["launches"],
                                "launches": dom["launches"], "share_of_step": dom["seconds"] / dt,
+                               "per_kernel": {n: {"launches": dsum[n]["launches"], "avg_launch_ms": 1e3 * dsum[n]["seconds"] / dsum[n]["launches"],
+                                                  "mfma_issued_tflops": dsum[n]["mfma_flops"] / dsum[n]["seconds"] / 1e12} for n in fam},
                                "build": _build_id(),
                                "pmc": pm and dict(pm, note="rocprofv3 PMC pass of this build (profiles/, build hash checked): MFMA-pipe busy cycles / active "
                                                           "cycles of this kernel, collected by tools/profile_round.sh on another box run"),

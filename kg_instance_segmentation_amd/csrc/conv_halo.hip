@@ -46,8 +46,11 @@ struct HaloArgs {
     // 3-product input (x_hi * w_lo | x_lo * w_hi | x_hi * w_hi, kg_plane_pairs): walk order of the virtual chunks, see halo_set_walk
     int walk3;
     const float* oscale;   // != null (GM = 0): per-cout factor of the accumulator (kg_planes_t.oscale: folded inference BatchNorm)
-    // GM = 1, small maps: blockIdx.z = plane product (x_hi w_lo | x_lo w_hi | x_hi w_hi) -- a workgroup walks the chunks of ONE product of its
-    // head and stores raw fp32 partial maps part[z][N][55][H*W] (the bias rides on the last product); heads2_finish_kernel adds the three
+    // GM = 1: blockIdx.z = (plane product: x_hi w_lo | x_lo w_hi | x_hi w_hi) * prod_split + part -- a workgroup walks ONE part (of prod_split) of
+    // the chunks of ONE product of its head and stores raw fp32 partial maps part[z][N][55][H*W] (the bias rides on the last z);
+    // heads2_finish_kernel adds the 3 * prod_split maps in float64.  Small maps: more workgroups; wide heads (C >= 256): a BLOCKED accumulation --
+    // one fp32 MFMA chain per few chunks instead of 49 * C / 32 additions into one accumulator (tools/micro/mfma_accum.hip: the chain's
+    // rounding error grows with sqrt(length); torch-CPU's fp32 convs, the reference's arithmetic, do not show that growth)
     int prod_split; float* part;
     // GM = 0, under-filled launches (the layer-2 / layer-3 3x3 convs of a batch-8 step: 64 .. 128 workgroups): blockIdx.z walks the z-th part of
     // the chunk sequence and stores its raw fp32 accumulators (kpart: [cout block][tile][z][wave][16 values][64 lanes]); conv_halo_finish_kernel
@@ -179,7 +182,12 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     int ci_first = (GM == 1 && a.head_split) ? biy * a.grp_chunks : 0;
     int nchunks = (GM == 1 && a.head_split) ? (biy + 1) * a.grp_chunks : a.cin_pad / 64;
     const bool psplit = GM == 1 && a.prod_split;                 // (uniform)
-    if (psplit) { ci_first += blockIdx.z * a.km.n; nchunks = ci_first + a.km.n; }
+    if (psplit) {
+        const int prod = blockIdx.z / a.prod_split, prt = blockIdx.z - prod * a.prod_split;
+        const int per = (a.km.n + a.prod_split - 1) / a.prod_split, pend = ci_first + (prod + 1) * a.km.n;
+        ci_first += prod * a.km.n + prt * per;
+        nchunks = ci_first + per < pend ? ci_first + per : pend;       // (an empty part stores zeros)
+    }
     const bool ksplit = GM == 0 && a.ksplit > 1;                 // (uniform)
     if (ksplit) {
         const int per = (nchunks + a.ksplit - 1) / a.ksplit;
@@ -592,7 +600,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     for (int e = 0; e < 16; ++e) ss[e] = sq[e] = 0.f;
     float bv[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout && !(psplit && blockIdx.z != 2)) ? a.bias[cb + e] : 0.f;
+    for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout && !(psplit && blockIdx.z != gridDim.z - 1)) ? a.bias[cb + e] : 0.f;
     if (GM == 0 && a.oscale) {           // (uniform; the accumulators are scaled in place: no second 16-register table next to acc)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -710,6 +718,208 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_finish_kernel(const H
     if (stats) kg_stat_commit<WPX, TC>(ss, sq, red, wp, wc * 64 + g * 16, lm, a.stat_part + (long)bix * a.Cout * 2, c0, a.Cout);
 }
 
+// ---- 7x7, 64 couts x (16 x 32) pixels on FOUR waves with a BLOCKED accumulation (round 5) ----------------------------------------------
+// Same workgroup tile, same LDS image (107 KB halo of a 64-channel chunk + the 6-slot weight ring) and the same load protocol as
+// conv_halo_kernel<7, 1, 8, 0> (LDS-direct loads, two taps per raw barrier behind a counted vmcnt, fragment reads from inline asm one k-step
+// ahead), but ONE wave per SIMD: a wave owns 64 couts x 128 pixels (four rows of BOTH 16-pixel halves of the tile: 4 weight + 8 pixel
+// fragments feed 32 MFMAs per k-step -- 12 ds_read_b128 per 32 MFMAs instead of 8 per 16) and may use 512 registers.  What the registers
+// buy is a SECOND accumulator: a 7x7 conv over C channels adds 49 * C / 32 MFMA results into one fp32 register, and the rounding error
+// of such a chain grows with the square root of its length (tools/micro/mfma_accum.hip: 3.6e-7 relative after 98 MFMAs, 1.0e-6 after
+// 784 = C 512; torch-CPU's fp32 convs, the reference's arithmetic, stay at 3.7e-7 for every C: profiles/r05_head_error_probe.txt).  Here
+// the chain is cut at every 64-channel chunk (98 MFMAs): `acc` restarts from zero and the finished block is added to `tot` with VALU adds
+// -- 3.7e-7 for every C.  The adds (128 accumulator reads + adds per wave) sit where the MFMA pipe idles anyway: behind the issue of the
+// NEXT chunk's halo and first weight slices, in front of the wait for them.  (Cutting every 14 taps as well measured 2.2e-7 and 10 % more
+// time: the adds of a block that ends inside the tap loop stall the MFMA pipe of a wave that has the SIMD to itself.)
+// Every tap offset is an instruction immediate (the 49 taps are a compile-time sequence, FLIP is a template parameter): no VALU in the loop
+// besides the pointer bumps of the ring loads.  Dense launches with bf16 / half row outputs only (no fp32 export, no statistics, no chunk
+// split, no ragged tiles): the first-layer head convs (KGnet.py:161-209 `.0`) and their input gradients.
+template <bool FLIP>
+__global__ __launch_bounds__(256) void conv_halo7_w4_kernel(const HaloArgs a) {
+    constexpr int KS = 7, PAD = 3, TW = 32, HWD = TW + KS - 1, HPIX = (16 + KS - 1) * HWD, T = KS * KS, NT = 256, NSL = 6, WPT = 2;
+    constexpr int HALO_BYTES = HPIX * 128, WBUF_BYTES = 64 * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* halo = smem;
+    unsigned char* wbuf = smem + HALO_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // wave = row group of the tile (rows 4 * wave .. + 3)
+    const int lm = lane & 15, g = lane >> 4;
+    int bix = blockIdx.x, biy = blockIdx.y;
+    if (a.xcd_map) {
+        const int L = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = L & 7, slot = L >> 3;
+        biy = slot % gridDim.y;
+        bix = xcd * (gridDim.x >> 3) + slot / gridDim.y;
+    }
+    int bt = bix;
+    const int tx = bt % a.tiles_x; bt /= a.tiles_x;
+    const int ty = bt % a.tiles_y; const int n = bt / a.tiles_y;
+    const int oy0 = ty * 16, ox0 = tx * TW, Hd = a.H, Wd = a.W;
+    const long rowbase = (long)n * a.H * a.W;
+    const int c0 = biy * 64;
+
+    f32x4 acc[4][8], tot[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const unsigned lds0 = lds_addr(smem);
+    // weight fragments: row r = (lm >> 2) * 16 + i * 4 + (lm & 3) of the slot (the lane ends with 16 consecutive couts); the swizzle key of the
+    // row does not depend on i, fragment i adds the immediate i * 512, the ring slot the immediate slot * 8192
+    unsigned aaddr[2];
+    {
+        const int r = (lm >> 2) * 16 + (lm & 3);
+        const int key = 2 * ((r >> 4) & 3) + ((r >> 1) & 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) aaddr[s] = lds0 + HALO_BYTES + r * 128 + (((4 * s + g) ^ key) * 16);
+    }
+    // pixel fragments: the lane's pixel (row 4 * wave, column lm) + swizzled 16-byte chunk of k-step s for a tap whose halo-x shift is fx;
+    // row j adds the immediate j * HWD * 128, the second half of the tile 16 * 128 (same key: 16 & 6 == 0), the tap its compile-time offset
+    unsigned baddr[KS][2];
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+        const int fx = FLIP ? KS - 1 - kx : kx;
+        const int key = (lm + fx) & 6;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) baddr[kx][s] = lds0 + ((wave * 4) * HWD + lm) * 128 + (((4 * s + g) ^ key) * 16);
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int nchunks = a.cin_pad / 64;
+    for (int ci = 0; ci < nchunks; ++ci) {
+        __syncthreads();
+        int cc = ci;
+        bool stage = true;
+        if (a.walk3) {      // low-order products of every chunk first, then hi * hi backwards (halo_set_walk)
+            const int nn = a.km.n, grp = 3 * nn;
+            const int base = ci / grp * grp, q = ci - base;
+            if (q < 2 * nn) cc = base + ((q & 1) ? (q >> 1) : nn + (q >> 1));
+            else { cc = base + 2 * nn + (grp - 1 - q); stage = q > 2 * nn || ci == 0; }
+        }
+        const int xo = a.km.xoff(cc);
+        if (stage) {
+            constexpr int HPT = (HPIX * 8 + NT - 1) / NT;
+#pragma unroll 1
+            for (int q = 0; q < HPT; ++q) {
+                const int e = tid + q * NT;
+                if (e < HPIX * 8) {
+                    const int p = e >> 3, cs = e & 7;
+                    const int hy = p / HWD, hx = p - hy * HWD;
+                    const int c = cs ^ (hx & 6);
+                    const int iy = oy0 + hy - PAD, ix = ox0 + hx - PAD;
+                    const bf16_t* src = reinterpret_cast<const bf16_t*>(kg_halo_zero_line) + c * 8;
+                    if ((unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd)
+                        src = a.x + (rowbase + (long)iy * Wd + ix) * a.ldx + xo + c * 8;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(halo + (q * NT + wave_u * 64) * 16), 16, 0, 0);
+                }
+            }
+        }
+        const bf16_t* wsrc[WPT];
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int e = tid + i * NT, r = e >> 3, cs = e & 7;
+            wsrc[i] = a.w + (long)(c0 + r) * a.K + cc * 64 + (cs ^ (2 * ((r >> 4) & 3) + ((r >> 1) & 1))) * 8;
+        }
+        auto wglds = [&](int slot_bytes) {
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc[i],
+                                                 (__attribute__((address_space(3))) void*)(wbuf + slot_bytes + (i * NT + wave_u * 64) * 16), 16, 0, 0);
+                wsrc[i] += a.cin_pad;
+            }
+        };
+        wglds(0); wglds(WBUF_BYTES); wglds(2 * WBUF_BYTES); wglds(3 * WBUF_BYTES);
+        if (ci > 0) {       // the previous chunk's block joins the total while this chunk's loads are in flight
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { tot[i][j] += acc[i][j]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");            // halo + taps 0..2 have landed; tap 3 may still be in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        bf16x8 a0[4], b0[8], a1[4], b1[8];
+        auto ldA = [&](bf16x8 (&af)[4], auto tc, auto sc) {
+            constexpr int SL = (decltype(tc)::value % NSL) * WBUF_BYTES, S = decltype(sc)::value;
+            lds_rd128<SL>(af[0], aaddr[S]); lds_rd128<SL + 512>(af[1], aaddr[S]); lds_rd128<SL + 1024>(af[2], aaddr[S]); lds_rd128<SL + 1536>(af[3], aaddr[S]);
+        };
+        auto ldB = [&](bf16x8 (&bf)[8], auto tc, auto sc) {
+            constexpr int TT = decltype(tc)::value, S = decltype(sc)::value, KY = TT / KS, KX = TT % KS;
+            constexpr int OFF = FLIP ? ((KS - 1 - KY) * HWD + (KS - 1 - KX)) * 128 : (KY * HWD + KX) * 128;
+            const unsigned ad = baddr[KX][S];
+            lds_rd128<OFF>(bf[0], ad); lds_rd128<OFF + HWD * 128>(bf[1], ad); lds_rd128<OFF + 2 * HWD * 128>(bf[2], ad); lds_rd128<OFF + 3 * HWD * 128>(bf[3], ad);
+            lds_rd128<OFF + 2048>(bf[4], ad); lds_rd128<OFF + 2048 + HWD * 128>(bf[5], ad); lds_rd128<OFF + 2048 + 2 * HWD * 128>(bf[6], ad);
+            lds_rd128<OFF + 2048 + 3 * HWD * 128>(bf[7], ad);
+        };
+        auto lwait = [&](bf16x8 (&af)[4], bf16x8 (&bf)[8], auto nc) {       // at most N later reads outstanding (LDS reads return in order)
+            asm volatile("s_waitcnt lgkmcnt(%12)"
+                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]),
+                           "+v"(bf[6]), "+v"(bf[7])
+                         : "n"(decltype(nc)::value));
+        };
+        auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bf)[8]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = KG_MFMA16(af[i], bf[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        ldA(a0, I0{}, I0{}); ldB(b0, I0{}, I0{});
+        auto tap = [&](auto tc) {
+            constexpr int TT = decltype(tc)::value;
+            if constexpr (!(TT & 1)) {     // pair start: taps t + 4, t + 5 into the slots of taps t - 2, t - 1, which every wave has left
+                if constexpr (TT + 4 < T) wglds(((TT + 4) % NSL) * WBUF_BYTES);
+                if constexpr (TT + 5 < T) wglds(((TT + 5) % NSL) * WBUF_BYTES);
+            }
+            ldA(a1, tc, I1{}); ldB(b1, tc, I1{});
+            lwait(a0, b0, std::integral_constant<int, 12>{});
+            mma(a0, b0);
+            if constexpr (TT + 1 < T) {
+                ldA(a0, std::integral_constant<int, TT + 1>{}, I0{}); ldB(b0, std::integral_constant<int, TT + 1>{}, I0{});
+                lwait(a1, b1, std::integral_constant<int, 12>{});
+            } else lwait(a1, b1, I0{});
+            mma(a1, b1);
+            if constexpr ((TT & 1) && TT + 1 < T) {   // pair end: taps t + 1 .. t + 3 visible after the barrier; tap t + 4 may stay in flight
+                if constexpr (TT + 4 < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        };
+        [&]<int... Ns>(std::integer_sequence<int, Ns...>) { (tap(std::integral_constant<int, Ns>{}), ...); }(std::make_integer_sequence<int, T>{});
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tot[i][j] += acc[i][j];
+    // ---- epilogue: lane owns pixels (oy0 + 4 * wave + j, ox0 + 16 * h + lm) and couts cb .. cb + 15 ----------------------
+    const int cb = c0 + g * 16;
+    if (cb >= a.Cout) return;
+    float bv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+    const EpiArgs ep{a.y, a.res, a.mask, a.ldy, a.ldres, a.ldmask, a.Cout, a.relu, a.yP, a.yps, a.rP, a.rps};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ox = ox0 + h * 16 + lm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int oy = oy0 + wave * 4 + j;
+            if (oy >= Hd || ox >= Wd) continue;
+            const long m = rowbase + (long)oy * Wd + ox;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(tot[i][h * 4 + j][r]) + bv[i * 4 + r];
+            kg_conv_epilogue<16>(ep, m, cb, v);
+        }
+    }
+}
+
 template <int KS, int WC, int WPX, int GM = 0>
 static int launch_halo(HaloArgs a, hipStream_t st) {
     constexpr int TW = 4 * WPX, HWD = TW + KS - 1, TC = WC * 64;
@@ -720,7 +930,7 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
         KG_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<KS, WC, WPX, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
-    dim3 grid(a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y, GM == 1 ? (a.head_split ? 3 : 1) : kg_cdiv(a.Cout, TC), (GM == 1 && a.prod_split) ? 3 : 1);
+    dim3 grid(a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y, GM == 1 ? (a.head_split ? 3 : 1) : kg_cdiv(a.Cout, TC), (GM == 1 && a.prod_split) ? 3 * a.prod_split : 1);
     if (a.stat_part) a.stat_part = (GM == 0 && !a.tiletab) ? kg_conv_stats_claim(grid.x, a.Cout) : nullptr;   // (armed by the caller: BatchNorm statistics)
     // chunk split of under-filled 3x3 launches (KG_HALO_SPLIT: 0 = never; default: at most 128 workgroups, >= 2 chunks per part, <= 8 parts)
     static const int split_wgs = getenv("KG_HALO_SPLIT") ? atoi(getenv("KG_HALO_SPLIT")) : 128;
@@ -738,6 +948,25 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
     static const int use_xcd = getenv("KG_HALO_XCD") ? atoi(getenv("KG_HALO_XCD")) : 1;
     // (not for the widest heads: 24 cout blocks of one tile stream 24 different 3 MB weight slices through the XCD's 4 MB L2: -2 %)
     a.xcd_map = use_xcd && !a.tiletab && grid.x % 8 == 0 && (grid.y > 1 || use_xcd > 1) && (long)a.Cout * a.K * 2 <= (24L << 20);
+    if constexpr (KS == 7 && WC == 1 && WPX == 8 && GM == 0) {
+        // KG_HALO7_W4: 0 = never; 1 (default) = the 3-product forward launches with >= 2 channel chunks (C >= 128: where the blocked
+        // accumulation matters for the fp32 tolerance); 2 = every dense rows-output launch (forward and input gradient)
+        static const int w4 = getenv("KG_HALO7_W4") ? atoi(getenv("KG_HALO7_W4")) : 1;
+        const bool ok = !a.tiletab && a.y && !a.y_f32 && !a.stat_part && !a.oscale && a.ksplit <= 1;
+        if (ok && (w4 >= 2 || (w4 == 1 && a.walk3 && a.km.n >= 2))) {
+            static bool w4_attr = false;
+            if (!w4_attr) {
+                KG_HIP(hipFuncSetAttribute((const void*)conv_halo7_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                KG_HIP(hipFuncSetAttribute((const void*)conv_halo7_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                w4_attr = true;
+            }
+            if (a.flip) hipLaunchKernelGGL(conv_halo7_w4_kernel<true>, grid, dim3(256), smem, st, a);
+            else hipLaunchKernelGGL(conv_halo7_w4_kernel<false>, grid, dim3(256), smem, st, a);
+            KG_CHECK_LAUNCH("conv_halo7_w4");
+            kg_note_kernel(a.flip ? "conv_halo7_w4_kernel<true>" : "conv_halo7_w4_kernel<false>");
+            return KG_OK;
+        }
+    }
     hipLaunchKernelGGL((conv_halo_kernel<KS, WC, WPX, GM>), grid, dim3(WC * WPX * 64), smem, st, a);
     KG_CHECK_LAUNCH("conv_halo");
     KG_KNAME(kname, "conv_halo_kernel<%d, %d, %d, %d>", KS, WC, WPX, GM);
@@ -800,12 +1029,14 @@ extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, v
     return KG_ERR_ARG;
 }
 
-// second half of a product-split heads2 launch: out = part[0] + part[1] + part[2] (fixed order: the two low-order products, then hi * hi
-// with the bias), sigmoid on the kp maps (KGnet.py:300) unless raw logits are asked for
-__global__ __launch_bounds__(256) void heads2_finish_kernel(const float* __restrict__ part, long per_z, int N, long hw, float* __restrict__ kp,
+// second half of a split heads2 launch: out = sum of the Z = 3 * prod_split partial maps in z order (the low-order products first, hi * hi last,
+// the bias inside the last one), added in float64 and rounded once; sigmoid on the kp maps (KGnet.py:300) unless raw logits are asked for
+__global__ __launch_bounds__(256) void heads2_finish_kernel(const float* __restrict__ part, long per_z, int Z, int N, long hw, float* __restrict__ kp,
                                                             float* __restrict__ sh, float* __restrict__ md, int kp_raw) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_z; i += (long)gridDim.x * 256) {
-        const float v = part[i] + part[per_z + i] + part[2 * per_z + i];
+        double acc = 0.;
+        for (int z = 0; z < Z; ++z) acc += (double)part[z * per_z + i];
+        const float v = (float)acc;
         const long pix = i % hw, q = i / hw;
         const int ch = (int)(q % 55); const long n = q / 55;
         if (ch < 5) kp[(n * 5 + ch) * hw + pix] = kp_raw ? v : 1.f / (1.f + expf(-v));
@@ -839,22 +1070,38 @@ extern "C" int kg_conv2d_halo_heads2(const void* x, const void* w, const float* 
     a.grp_chunks = vplanes * C / 64;
     const long tiles = (long)N * kg_cdiv(H, 16) * kg_cdiv(W, 32);
     a.head_split = tiles < 256;   // too few pixel tiles to fill 256 CUs
-    // Single-image inference (a 64 x 64 map is 8 tiles x 3 heads = 24 workgroups walking 24 chunks each): one workgroup per plane product
-    // as well, fp32 partial maps in a library scratch (one 32 MB buffer per device, allocated on first use), summed by a second launch.
-    static const int split_mode = getenv("KG_HEADS2_SPLIT") ? atoi(getenv("KG_HEADS2_SPLIT")) : 1;   // 0 never, 1 when < 128 workgroups, 2 whenever it fits
+    // Split launches: one workgroup per (tile, head, plane product, chunk part) with fp32 partial maps (55 channels: a few MB per part) in a
+    // library scratch (one buffer per device, grown on demand), summed by a second launch in float64.
+    //  * small maps (single-image inference: a 64 x 64 map is 8 tiles x 3 heads = 24 workgroups walking 24 chunks each): one part per product;
+    //  * wide heads (C >= 256: 4 / 8 chunks per product, 392 / 784 MFMA additions into one accumulator in the hi * hi product): parts of
+    //    KG_HEADS2_KPART chunks (default 2) -- blocked accumulation, see HaloArgs.prod_split.
+    static const int split_mode = getenv("KG_HEADS2_SPLIT") ? atoi(getenv("KG_HEADS2_SPLIT")) : 1;   // 0 never, 1 small maps + wide heads, 2 whenever it fits
+    static const int kpart = getenv("KG_HEADS2_KPART") ? atoi(getenv("KG_HEADS2_KPART")) : 2;        // chunks per part of a wide head (0: no blocked accumulation)
     const long per_z = (long)N * 55 * H * W;
-    constexpr long PART_FLOATS = 8L << 20;
-    if (split_mode && vplanes == 3 && a.head_split && 3 * per_z <= PART_FLOATS && (split_mode == 2 || tiles * 3 < 128)) {
+    const int nchunk = C / 64;
+    const int parts = (kpart > 0 && nchunk >= 4) ? kg_cdiv(nchunk, kpart) : 1;
+    const bool want = split_mode && vplanes == 3 && (parts > 1 || (a.head_split && (split_mode == 2 || tiles * 3 < 128)));
+    if (want && 3L * parts * per_z <= (96L << 20)) {
         static float* part[16] = {nullptr};
+        static long part_floats[16] = {0};
         int dev = 0;
         KG_HIP(hipGetDevice(&dev));
         if (dev >= 0 && dev < 16) {
-            if (!part[dev]) KG_HIP(hipMalloc((void**)&part[dev], PART_FLOATS * sizeof(float)));
-            a.prod_split = 1; a.part = part[dev];
+            const long need = 3L * parts * per_z;
+            if (part_floats[dev] < need) {
+                if (part[dev]) KG_HIP(hipFree(part[dev]));
+                part[dev] = nullptr; part_floats[dev] = 0;
+                const long sz = need > (8L << 20) ? need : (8L << 20);
+                KG_HIP(hipMalloc((void**)&part[dev], sz * sizeof(float)));
+                part_floats[dev] = sz;
+            }
+            a.head_split = 1;
+            a.prod_split = parts; a.part = part[dev];
             const int rc = launch_halo<7, 1, 8, 1>(a, (hipStream_t)stream);
             if (rc != KG_OK) return rc;
-            int blocks = (int)((per_z + 255) / 256); if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(heads2_finish_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)part[dev], per_z, N, (long)H * W, kp, sh, md, a.kp_raw);
+            int blocks = (int)((per_z + 255) / 256); if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(heads2_finish_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)part[dev], per_z, 3 * parts, N, (long)H * W, kp, sh, md,
+                               a.kp_raw);
             KG_CHECK_LAUNCH("heads2_finish");
             return KG_OK;
         }

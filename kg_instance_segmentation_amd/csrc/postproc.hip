@@ -4,8 +4,8 @@
 // fused operation of the reference (np.linalg.norm -> ddot) is written as an explicit fma().
 //
 // Stages (all on the caller's stream, no host sync inside):
-//   P1 Hough vote   : count -> scan -> fill -> per-cell ordered sum (reproduces the sequential
-//                     COO scatter order: corner block, then raster index)
+//   P1 Hough vote   : one scatter pass with inline slots per cell -> per-cell ordered sum (reproduces the
+//                     sequential COO scatter order: corner block, then raster index)
 //   P2 Gaussian     : separable 17-tap, scipy's symmetric pairing order, 'reflect' border
 //   P3 peaks        : cross-footprint local max == value, > thresh, ordered compaction
 //   P4 grouping     : greedy confidence-ordered star matching, one workgroup (4 waves = 4 edges)
@@ -20,37 +20,6 @@ __device__ __forceinline__ int f2i_np(double v) {  // numpy f64 -> int32 cast on
     return (int)v;
 }
 
-// One vote contribution of source pixel i (corner b) of channel c.  Returns false when dropped.
-__device__ __forceinline__ bool hough_contrib(const float* __restrict__ kp, const float* __restrict__ soff, int H,
-                                              int W, int c, int b, int i, int* cell, double* val) {
-    const long HW = (long)H * W;
-    const int y = i / W, x = i - y * W;
-    const double xs = (double)x + (double)soff[(long)(2 * c) * HW + i];
-    const double ys = (double)y + (double)soff[(long)(2 * c + 1) * HW + i];
-    const double ps = (double)kp[(long)c * HW + i];
-    const int fx = f2i_np(floor(xs)), fy = f2i_np(floor(ys));
-    const int cx = f2i_np(ceil(xs)), cy = f2i_np(ceil(ys));
-    const double dx = xs - (double)fx, dy = ys - (double)fy;
-    int I, J; double v;
-    switch (b) {
-        case 0: I = fy; J = fx; v = ps * (1. - dx) * (1. - dy); break;
-        case 1: I = fy; J = cx; v = ps * dx * (1. - dy); break;
-        case 2: I = cy; J = fx; v = ps * dy * (1. - dx); break;
-        default: I = cy; J = cx; v = ps * dy * dx; break;
-    }
-    if (I < 0 || I >= H || J < 0 || J >= W) return false;
-    *cell = I * W + J; *val = v;
-    return true;
-}
-
-__global__ void hough_count_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W,
-                                   int* __restrict__ count) {
-    const int c = blockIdx.y, HW = H * W;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 4 * HW; e += gridDim.x * blockDim.x) {
-        int b = e / HW, i = e - b * HW, cell; double v;
-        if (hough_contrib(kp, soff, H, W, c, b, i, &cell, &v)) atomicAdd(&count[c * HW + cell], 1);
-    }
-}
 // exclusive scan of count[c][0..HW) -> offs; one block (1024 threads) per channel.
 __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ count, int* __restrict__ offs, int n, int* __restrict__ total = nullptr) {
     __shared__ int tot[1024];
@@ -71,141 +40,16 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ coun
     for (int i = b0; i < b0 + per && i < n; ++i) { int v = in[i]; out[i] = run; run += v; }
     if (total && threadIdx.x == 1023) total[blockIdx.x] = tot[1023];      // sum of the whole row (the peak count: no separate launch)
 }
-// Multi-block exclusive scan of `rows` independent arrays of n ints (the single-workgroup kernel above reads 4 KB-strided runs:
-// 1.8 ms for the 5 x 1024^2 Hough cell counts).  SCAN_NB chunks per row: chunk sums, then every chunk scans itself behind the
-// prefix of the chunk sums before it (int4 accesses, 1024 elements per round of the workgroup).
-#define SCAN_NB 256
-__global__ __launch_bounds__(256) void scan_sums_kernel(const int* __restrict__ count, int* __restrict__ part, int n, int chunk) {
-    const int* in = count + (long)blockIdx.y * n;
-    const int b0 = blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
-    int s = 0;
-    for (int i = b0 + threadIdx.x * 4; i < b1; i += 1024) {       // chunk % 4 == 0, n % 4 == 0
-        const int4 v = *reinterpret_cast<const int4*>(in + i);
-        s += v.x + v.y + v.z + v.w;
-    }
-    __shared__ int red[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.y * SCAN_NB + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-__global__ __launch_bounds__(256) void scan_chunks_kernel(const int* __restrict__ count, const int* __restrict__ part,
-                                                          int* __restrict__ offs, int n, int chunk) {
-    const int* in = count + (long)blockIdx.y * n;
-    int* out = offs + (long)blockIdx.y * n;
-    __shared__ int wsum[4];
-    __shared__ int s_carry;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {   // prefix of the chunk sums before this chunk
-        int s = 0;
-        for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) s += part[blockIdx.y * SCAN_NB + b];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-        if (lane == 0) wsum[wave] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __syncthreads();
-    }
-    const int b0 = blockIdx.x * chunk, b1 = b0 + chunk < n ? b0 + chunk : n;
-    for (int r0 = b0; r0 < b1; r0 += 1024) {
-        const int i = r0 + threadIdx.x * 4;
-        int4 v = make_int4(0, 0, 0, 0);
-        if (i < b1) v = *reinterpret_cast<const int4*>(in + i);
-        const int tsum = v.x + v.y + v.z + v.w;
-        int inc = tsum;                                          // inclusive scan over the wave
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        int base = s_carry;
-        for (int w = 0; w < wave; ++w) base += wsum[w];
-        const int ex = base + inc - tsum;
-        if (i < b1) *reinterpret_cast<int4*>(out + i) = make_int4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
-        __syncthreads();
-        if (threadIdx.x == 255) s_carry = base + inc;
-        __syncthreads();
-    }
-}
-__global__ void hough_fill_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W,
-                                  const int* __restrict__ offs, int* __restrict__ cursor,
-                                  unsigned* __restrict__ keys, double* __restrict__ vals) {
-    const int c = blockIdx.y, HW = H * W;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 4 * HW; e += gridDim.x * blockDim.x) {
-        int b = e / HW, i = e - b * HW, cell; double v;
-        if (hough_contrib(kp, soff, H, W, c, b, i, &cell, &v)) {
-            int slot = offs[c * HW + cell] + atomicAdd(&cursor[c * HW + cell], 1);
-            keys[(long)c * 4 * HW + slot] = (unsigned)e;
-            vals[(long)c * 4 * HW + slot] = v;
-        }
-    }
-}
-// Ordered per-cell sum.  Cells with <= 24 votes: one thread, selection by increasing key.  Heavier
-// cells are queued and handled by one wave each (rank sort, then lane 0 adds in order).
-#define HOUGH_LIGHT 24
-__global__ void hough_sum_light_kernel(int HW, const int* __restrict__ count, const int* __restrict__ offs,
-                                       const unsigned* __restrict__ keys, const double* __restrict__ vals,
-                                       double norm, double* __restrict__ heat, int* __restrict__ heavy_n,
-                                       int* __restrict__ heavy_list) {
-    const int c = blockIdx.y;
-    for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < HW; cell += gridDim.x * blockDim.x) {
-        const int n = count[c * HW + cell];
-        if (n > HOUGH_LIGHT) { heavy_list[atomicAdd(heavy_n, 1)] = c * HW + cell; continue; }
-        const unsigned* k = keys + (long)c * 4 * HW + offs[c * HW + cell];
-        const double* v = vals + (long)c * 4 * HW + offs[c * HW + cell];
-        double s = 0.;
-        long last = -1;
-        for (int t = 0; t < n; ++t) {
-            unsigned best = 0xffffffffu; int bi = 0;
-            for (int j = 0; j < n; ++j) {
-                unsigned kj = k[j];
-                if ((long)kj > last && kj < best) { best = kj; bi = j; }
-            }
-            s += v[bi];
-            last = best;
-        }
-        heat[(long)c * HW + cell] = s / norm;
-    }
-}
-__global__ __launch_bounds__(64) void hough_sum_heavy_kernel(int HW, const int* __restrict__ count,
-                                                             const int* __restrict__ offs,
-                                                             const unsigned* __restrict__ keys,
-                                                             const double* __restrict__ vals,
-                                                             double* __restrict__ sorted, double norm,
-                                                             double* __restrict__ heat, const int* __restrict__ heavy_n,
-                                                             const int* __restrict__ heavy_list) {
-    const int nh = *heavy_n;
-    for (int h = blockIdx.x; h < nh; h += gridDim.x) {
-        const int cc = heavy_list[h];
-        const int c = cc / HW;
-        const int n = count[cc];
-        const long base = (long)c * 4 * HW + offs[cc];
-        const unsigned* k = keys + base;
-        for (int e = threadIdx.x; e < n; e += 64) {
-            const unsigned ke = k[e];
-            int rank = 0;
-            for (int j = 0; j < n; ++j) rank += k[j] < ke;
-            sorted[base + rank] = vals[base + e];
-        }
-        __threadfence_block();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double s = 0.;
-            for (int t = 0; t < n; ++t) s += sorted[base + t];
-            heat[cc] = s / norm;
-        }
-        __syncthreads();
-    }
-}
-
-
-// ---- P1, second formulation (the default): one scatter pass with inline slots ------------------------------------------------------
-// The count -> scan -> fill -> sum pipeline above touches every vote with TWO atomic passes (count, cursor), computes every contribution
-// twice and sorts every cell's votes by selection from global memory (hough_sum_light: 138 us of the c0 map of a 512 x 512 image, the
-// waves wait for their heaviest cell).  Here:
-//   scatter : every vote e takes slot s = atomicAdd(cnt[cell]) (ONE returning atomic); the first HOUGH_K votes of a cell land in its
-//             inline slots [cell][HOUGH_K] (key, value); a later one is parked at ITS OWN index of a source-ordered array
-//             (ovcell[e] = cell, ovval[e] = value; ovcell[e] = -1 for every other vote: no counter, no list);
+// ---- P1: one scatter pass with inline slots -----------------------------------------------------------------------------------------
+// (Round 1's count -> scan -> fill -> sum pipeline touched every vote with two atomic passes, computed every contribution twice and sorted
+// every cell's votes by selection from global memory; it is gone from the sources since round 5 -- git history, docs/history.md.)
+//   scatter : one thread per (channel, SOURCE pixel): the vote position and the four bilinear weights are computed once
+//             (postprocessing.py:16-37) and the four votes go out back to back -- their cells are neighbours, so the returning atomics and
+//             the inline-slot stores of a wave hit a compact set of L2 lines.  A vote whose value is +-0.0 is dropped: every sum starts
+//             from +0.0, and x + (+-0.0) == x for every x that can stand in such a sum (+0.0 + -0.0 == +0.0 as well), so the heat map keeps
+//             its bits -- and with integer-valued offsets three of the four weights are exactly 0, with kp == 0 all four.  Vote e = corner *
+//             HW + pixel takes slot s = atomicAdd(cnt[cell]) (ONE returning atomic); the first HOUGH_K votes of a cell land in its inline slots
+//             [cell][HOUGH_K] (key, value); a later one is appended to the parked list (cell, key, value; one counter);
 //   classify: one thread per cell.  n <= HOUGH_K: the votes are sorted by key in registers (odd-even merge network) and summed in
 //             that order -- the reference's sequential COO order (postprocessing.py:36) -- and the cell is done.  Heavier cells get
 //             a slab of n entries in the compact arrays (one 64-bit atomic per 1024-thread workgroup allocates for all its heavy
@@ -215,26 +59,39 @@ __global__ __launch_bounds__(64) void hough_sum_heavy_kernel(int HW, const int* 
 // Every sum is still formed in increasing key order from +0.0 with separate fp64 adds (-ffp-contract=off): bit-identical heat maps.
 #define HOUGH_K 8
 #define HOUGH_LCAP 512
-__global__ void hough_scatter_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W, int* __restrict__ cnt,
-                                     unsigned* __restrict__ ink, double* __restrict__ inv, int* __restrict__ ovcell,
-                                     double* __restrict__ ovval) {
+__global__ __launch_bounds__(256) void hough_scatter_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W,
+                                                            int* __restrict__ cnt, unsigned* __restrict__ ink, double* __restrict__ inv,
+                                                            int* __restrict__ ovn, unsigned long long* __restrict__ ovkey, double* __restrict__ ovval) {
     const int c = blockIdx.y, HW = H * W;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 4 * HW; e += gridDim.x * blockDim.x) {
-        const int b = e / HW, i = e - b * HW;
-        int cell; double v;
-        int park = -1;
-        if (hough_contrib(kp, soff, H, W, c, b, i, &cell, &v)) {
-            const int cc = c * HW + cell;
-            const int slot = atomicAdd(&cnt[cc], 1);
-            if (slot < HOUGH_K) {
-                ink[(long)cc * HOUGH_K + slot] = (unsigned)e;
-                inv[(long)cc * HOUGH_K + slot] = v;
-            } else {
-                park = cc;
-                ovval[(long)c * 4 * HW + e] = v;
-            }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    const int y = i / W, x = i - y * W;
+    const double xs = (double)x + (double)soff[(long)(2 * c) * HW + i];
+    const double ys = (double)y + (double)soff[(long)(2 * c + 1) * HW + i];
+    const double ps = (double)kp[(long)c * HW + i];
+    const int fx = f2i_np(floor(xs)), fy = f2i_np(floor(ys));
+    const int cx = f2i_np(ceil(xs)), cy = f2i_np(ceil(ys));
+    const double dx = xs - (double)fx, dy = ys - (double)fy;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int I = b < 2 ? fy : cy, J = (b & 1) ? cx : fx;
+        double v;                                                        // (left-to-right products, as NumPy evaluates postprocessing.py:24-27)
+        if (b == 0) v = ps * (1. - dx) * (1. - dy);
+        else if (b == 1) v = ps * dx * (1. - dy);
+        else if (b == 2) v = ps * dy * (1. - dx);
+        else v = ps * dy * dx;
+        if (I < 0 || I >= H || J < 0 || J >= W || v == 0.) continue;     // out of the map (postprocessing.py:34-35) / a zero addend (NaN is kept)
+        const int cc = c * HW + I * W + J;
+        const unsigned e = (unsigned)(b * HW + i);
+        const int slot = atomicAdd(&cnt[cc], 1);
+        if (slot < HOUGH_K) {
+            ink[(long)cc * HOUGH_K + slot] = e;
+            inv[(long)cc * HOUGH_K + slot] = v;
+        } else {
+            const int pos = atomicAdd(ovn, 1);
+            ovkey[pos] = ((unsigned long long)(unsigned)cc << 32) | e;
+            ovval[pos] = v;
         }
-        ovcell[(long)c * 4 * HW + e] = park;
     }
 }
 __device__ __forceinline__ void hough_cswap(unsigned& ka, double& va, unsigned& kb, double& vb) {
@@ -308,14 +165,15 @@ __global__ __launch_bounds__(1024) void hough_classify_kernel(int ncells, const 
         for (int e = 0; e < HOUGH_K; ++e) { skey[off + e] = k[e]; sval[off + e] = v[e]; }
     }
 }
-__global__ void hough_ovfill_kernel(long nvotes, int HW4, const int* __restrict__ ovcell, const double* __restrict__ ovval,
+__global__ void hough_ovfill_kernel(const int* __restrict__ ovn, const unsigned long long* __restrict__ ovkey, const double* __restrict__ ovval,
                                     const int* __restrict__ ovoff, int* __restrict__ ovcur, unsigned* __restrict__ skey,
                                     double* __restrict__ sval) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvotes; i += (long)gridDim.x * blockDim.x) {
-        const int cc = ovcell[i];
-        if (cc < 0) continue;
+    const int nv = *ovn;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
+        const unsigned long long k = ovkey[i];
+        const int cc = (int)(unsigned)(k >> 32);
         const int pos = ovoff[cc] + HOUGH_K + atomicAdd(&ovcur[cc], 1);
-        skey[pos] = (unsigned)(i % HW4);
+        skey[pos] = (unsigned)(k & 0xffffffffull);
         sval[pos] = ovval[i];
     }
 }
@@ -857,7 +715,7 @@ static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" long kg_postproc_workspace_bytes(int H, int W, int peak_cap, int skel_cap) {
     size_t HW = (size_t)H * W, b = 0;
     b += al256(5 * HW * 4) * 3;            // count, offs, cursor
-    b += al256(5 * 4 * HW * 4);            // keys
+    b += al256(5 * 4 * HW * 8);            // parked votes: (cell, key)
     b += al256(5 * 4 * HW * 8) * 2;        // vals, sorted
     b += al256(5 * HW * 8) * 3;            // heat, tmp, blur
     b += al256(5 * HW * 4) + 256;          // heavy list + counter
@@ -866,17 +724,16 @@ extern "C" long kg_postproc_workspace_bytes(int H, int W, int peak_cap, int skel
     b += (al256((size_t)peak_cap * 4) * 3 + al256((size_t)peak_cap * 8)) * 2;  // peaks + sorted peaks
     b += al256(peak_cap);                  // alive
     b += al256((size_t)skel_cap * 10 * 4);  // skxy
-    b += al256(5 * SCAN_NB * 4);           // chunk sums of the multi-block scan
     b += al256(5 * HW * HOUGH_K * 4) + al256(5 * HW * HOUGH_K * 8);   // inline vote slots (keys, values) of the scatter formulation
     b += al256(5 * 4 * HW * 4) + al256(5 * 4 * HW * 8);                // compact keys of the heavy cells' slabs, rank-sort scratch
     return (long)b + 4096;
 }
 
 struct PPWs {
-    int *count, *offs, *cursor; unsigned* keys; double *vals, *sorted, *heat, *tmp, *blur;
+    int *count, *offs, *cursor; unsigned long long* keys; double *vals, *sorted, *heat, *tmp, *blur;
     int *heavy_list, *heavy_n, *blkcount, *blkbase, *npk;
     int *ids, *xs, *ys; double* conf; int *sid, *sx, *sy; double* sconf;
-    unsigned char* alive; int* skxy; int nblk; int* scanpart;
+    unsigned char* alive; int* skxy; int nblk;
     unsigned* ink; double* inv; unsigned* skey; double* srt;
 };
 static void carve(void* ws, int H, int W, int peak_cap, int skel_cap, PPWs* p) {
@@ -885,7 +742,7 @@ static void carve(void* ws, int H, int W, int peak_cap, int skel_cap, PPWs* p) {
     auto take = [&](size_t bytes) { void* r = q; q += al256(bytes); return r; };
     p->heavy_n = (int*)take(256);      // (counters first: ONE memset clears them together with count .. cursor)
     p->count = (int*)take(5 * HW * 4); p->offs = (int*)take(5 * HW * 4); p->cursor = (int*)take(5 * HW * 4);
-    p->keys = (unsigned*)take(5 * 4 * HW * 4);
+    p->keys = (unsigned long long*)take(5 * 4 * HW * 8);
     p->vals = (double*)take(5 * 4 * HW * 8); p->sorted = (double*)take(5 * 4 * HW * 8);
     p->heat = (double*)take(5 * HW * 8); p->tmp = (double*)take(5 * HW * 8); p->blur = (double*)take(5 * HW * 8);
     p->heavy_list = (int*)take(5 * HW * 4); (void)take(256);
@@ -896,7 +753,6 @@ static void carve(void* ws, int H, int W, int peak_cap, int skel_cap, PPWs* p) {
     p->sid = (int*)take((size_t)peak_cap * 4); p->sx = (int*)take((size_t)peak_cap * 4); p->sy = (int*)take((size_t)peak_cap * 4);
     p->sconf = (double*)take((size_t)peak_cap * 8);
     p->alive = (unsigned char*)take(peak_cap); p->skxy = (int*)take((size_t)skel_cap * 10 * 4);
-    p->scanpart = (int*)take(5 * SCAN_NB * 4);
     p->ink = (unsigned*)take(5 * HW * HOUGH_K * 4); p->inv = (double*)take(5 * HW * HOUGH_K * 8);
     p->skey = (unsigned*)take(5 * 4 * HW * 4); p->srt = (double*)take(5 * 4 * HW * 8);
 }
@@ -957,38 +813,18 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
     const int HW = H * W;
     const double norm = 3.141592653589793 * 25.0;  // np.pi * KP_RADIUS**2 (postprocessing.py:51)
     pp_mark(st);
-    static const int hough_v1 = getenv("KG_HOUGH_V1") ? atoi(getenv("KG_HOUGH_V1")) : 0;      // 1: the count -> scan -> fill -> sum formulation (A/B, bisecting)
-    int gx = (4 * HW + 255) / 256; if (gx > 4096) gx = 4096;
-    if (!hough_v1) {
-        // heavy_n (the 64-bit slab allocator) | count | offs | cursor are consecutive in the workspace: ONE memset clears the allocator, the
-        // vote counters (count) and the slab cursors (cursor)
+    {
+        // heavy_n (the 64-bit slab allocator, + the parked-vote counter 16 bytes further) | count | offs | cursor are consecutive in the
+        // workspace: ONE memset clears the allocators, the vote counters (count) and the slab cursors (cursor)
         KG_HIP(hipMemsetAsync(p.heavy_n, 0, (size_t)((unsigned char*)p.cursor - (unsigned char*)p.heavy_n) + (size_t)5 * HW * 4, st));
         unsigned long long* ctr64 = reinterpret_cast<unsigned long long*>(p.heavy_n);
-        hipLaunchKernelGGL(hough_scatter_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.count, p.ink, p.inv, (int*)p.keys, p.vals);
+        int* ovn = p.heavy_n + 4;
+        hipLaunchKernelGGL(hough_scatter_kernel, dim3((HW + 255) / 256, 5), dim3(256), 0, st, kp, soff, H, W, p.count, p.ink, p.inv, ovn, p.keys, p.vals);
         hipLaunchKernelGGL(hough_classify_kernel, dim3((5 * HW + 1023) / 1024), dim3(1024), 0, st, 5 * HW, p.count, p.ink, p.inv, norm, p.heat, ctr64,
                            p.offs, p.heavy_list, p.skey, p.sorted);
-        int go = (int)(((long)20 * HW + 255) / 256); if (go > 8192) go = 8192;
-        hipLaunchKernelGGL(hough_ovfill_kernel, dim3(go), dim3(256), 0, st, (long)20 * HW, 4 * HW, (const int*)p.keys, p.vals, p.offs, p.cursor, p.skey,
-                           p.sorted);
+        hipLaunchKernelGGL(hough_ovfill_kernel, dim3(1024), dim3(256), 0, st, (const int*)ovn, (const unsigned long long*)p.keys, (const double*)p.vals,
+                           p.offs, p.cursor, p.skey, p.sorted);
         hipLaunchKernelGGL(hough_heavy2_kernel, dim3(4096), dim3(64), 0, st, p.count, p.offs, p.skey, p.sorted, p.srt, norm, p.heat, ctr64, p.heavy_list);
-    } else {
-    KG_HIP(hipMemsetAsync(p.count, 0, (size_t)5 * HW * 4, st));
-    KG_HIP(hipMemsetAsync(p.cursor, 0, (size_t)5 * HW * 4, st));
-    KG_HIP(hipMemsetAsync(p.heavy_n, 0, 4, st));
-    hipLaunchKernelGGL(hough_count_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.count);
-    if (HW >= 65536 && HW % 4 == 0) {
-        const int chunk = (int)(((HW + SCAN_NB - 1) / SCAN_NB + 3) / 4 * 4);
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(SCAN_NB, 5), dim3(256), 0, st, p.count, p.scanpart, HW, chunk);
-        hipLaunchKernelGGL(scan_chunks_kernel, dim3(SCAN_NB, 5), dim3(256), 0, st, p.count, p.scanpart, p.offs, HW, chunk);
-    } else {
-        hipLaunchKernelGGL(scan_kernel, dim3(5), dim3(1024), 0, st, p.count, p.offs, HW, (int*)nullptr);
-    }
-    hipLaunchKernelGGL(hough_fill_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.offs, p.cursor, p.keys, p.vals);
-    int gc = (HW + 255) / 256; if (gc > 4096) gc = 4096;
-    hipLaunchKernelGGL(hough_sum_light_kernel, dim3(gc, 5), dim3(256), 0, st, HW, p.count, p.offs, p.keys, p.vals, norm, p.heat,
-                       p.heavy_n, p.heavy_list);
-    hipLaunchKernelGGL(hough_sum_heavy_kernel, dim3(2048), dim3(64), 0, st, HW, p.count, p.offs, p.keys, p.vals, p.sorted, norm,
-                       p.heat, p.heavy_n, p.heavy_list);
     }
     int gg = (5 * HW + 255) / 256; if (gg > 8192) gg = 8192;
     pp_mark(st);

@@ -1,0 +1,127 @@
+"""GPU parity AT THE BENCH CONFIGURATION (BASELINE configs[1]: batch 8 x 3 x 512 x 512, 300 GT boxes per image, train mode; the reference's
+train.py:148-154): the default policy's train-mode forward element-wise against the reference-pinned CPU oracle (oracle/net.py) evaluated in
+float32 -- the reference's own arithmetic -- AND in float64, every kp logit / short / mid offset / seg logit of the batch, plus the five losses
+and every parameter gradient against the float32 oracle's autograd.
+
+What can and cannot hold at this size (measured, profiles/r05_fullsize_oracle_parity.txt): two float32-grade evaluations of this network are
+each ~1.3-1.4 bounds (rtol 1e-4, atol 1e-5) from the float64 value -- the reference's own fp32 arithmetic included: 12 544 / 25 088-term dot
+products in the c2 / c3 heads on top of 50 layers -- so "<= 1.0 against the float32 oracle" is not a statement any fp32 implementation can
+make here.  What is asserted instead:
+  * the policy is AS CLOSE TO FLOAT64 AS THE REFERENCE'S ARITHMETIC IS: worst |d| / bound of (policy vs oracle64) <= FLOOR_SLACK x the same
+    number of (oracle32 vs oracle64), over all 13 maps;
+  * against the float32 oracle it stays within the sum of the two distances (and an absolute cap), with at most a 1e-3 fraction of any map's
+    elements beyond the bound;
+  * losses within 1e-6 of float64; every parameter gradient: cosine >= 0.9999 and norm within 2e-3 of the float32 oracle's.
+Bounds: |d| <= atol + 1e-4 |ref| with atol 1e-5 for the logits (literally) and the stated per-map constants 2e-5 (short offsets,
+rms 3-4 px) / 6e-5 (mid offsets, rms 5-7 px) -- no rms scaling."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+FLOOR_SLACK = 1.10      # policy-vs-float64 may exceed oracle32-vs-float64 by 10 % (max statistics over 1e8 elements; measured ratio in the docstring of the test)
+ABS_CAP_VS_ORACLE32 = 2.5
+
+
+def test_train_step_at_bench_configuration_vs_oracle_fp32_and_fp64():
+    """measured on MI355X (r05, this build): see the printed table; profiles/r05_fullsize_oracle_parity.txt holds a copy"""
+    import fullsize_oracle_parity as fs
+    from kg_instance_segmentation_amd import KGnet
+    from kg_instance_segmentation_amd.loss import DetectionLossAll
+    from kg_instance_segmentation_amd.seg_loss import SEG_loss
+    from oracle import net as onet, synth, weightgen
+    N, S, NB = 8, 512, 300
+    torch.set_num_threads(min(os.cpu_count() or 8, 64))
+    dev = torch.device("cuda", 0)
+    sd = weightgen.gen_state_dict(0, variant="cal")
+    x, boxes, masks, gt_lv = synth.train_batch(N, S, S, 41, n_boxes=NB, smin=14, smax=40)
+
+    # ---- the product: forward (maps, logits through the test hooks), losses, backward ----------------------------------------
+    m = KGnet.resnet50(pretrained=False, precision="fp32")
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    m._engine.keep_kp_logits = True
+    m._seg.keep_logits = True
+    ldec, lseg = DetectionLossAll(5), SEG_loss(S, S)
+    d = m(x.to(dev), boxes)
+    got = {}
+    for l in range(4):
+        got[f"c{l}.kp_logit"] = m._engine.kp_logits[l].cpu()
+        got[f"c{l}.short"] = d[l][1].detach().cpu()
+        got[f"c{l}.mid"] = d[l][2].detach().cpu()
+    meta, flat = d[4].kg_meta, m._seg.last_logits
+    order = sorted(range(len(meta["off"])), key=lambda j: (int(meta["img"][j]), j))
+    got["seg_logit"] = torch.cat([flat[int(meta["off"][j]):int(meta["off"][j]) + int(meta["h"][j]) * int(meta["w"][j])] for j in order]).cpu()
+    l1 = [ldec(d[l], gt_lv[l].to(dev)) for l in range(4)]
+    l2 = lseg(d[4], masks, boxes)
+    (sum(l1) + l2).backward()
+    torch.cuda.synchronize()
+    assert not m.grad_overflowed()
+    lg = [float(v) for v in l1] + [float(l2)]
+    grads = {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}
+    del m, d, l1, l2
+    torch.cuda.empty_cache()
+
+    # ---- oracle float32 WITH autograd (the reference's train.py:148-153), oracle float64 forward ---------------------------------
+    t0 = time.time()
+    osd = {k: v.clone() for k, v in sd.items()}
+    names = [k for k, v in osd.items() if v.is_floating_point() and "running" not in k]
+    for n in names:
+        osd[n].requires_grad_(True)
+    net = onet.Net(osd, training=True)
+    o = net.forward(x, boxes)
+    o32 = {}
+    for l in range(4):
+        o32[f"c{l}.kp_logit"] = net.kp_logits[l].detach()
+        o32[f"c{l}.short"] = o[l][1].detach()
+        o32[f"c{l}.mid"] = o[l][2].detach()
+    o32["seg_logit"] = torch.cat([z.detach().reshape(-1) for per in net.seg_logits for z in per])
+    ol = [onet.detection_loss(o[l], gt_lv[l]) for l in range(4)] + [onet.seg_loss(o[4], masks, boxes, S, S)]
+    sum(ol).backward()
+    l32 = [float(v) for v in ol]
+    g32 = {n: osd[n].grad for n in names}
+    del net, o, ol
+    t32 = time.time() - t0
+    o64, l64, t64 = fs.oracle_forward(sd, x, boxes, gt_lv, masks, S, torch.float64)
+    print(f"oracle float32 forward + backward {t32:.0f} s, float64 forward {t64:.0f} s")
+
+    # ---- losses ---------------------------------------------------------------------------------------------------------------------
+    print("losses oracle64:", ["%.8f" % v for v in l64])
+    print("losses oracle32:", ["%.8f" % v for v in l32])
+    print("losses policy  :", ["%.8f" % v for v in lg])
+    assert max(abs(a - b) / abs(b) for a, b in zip(lg, l64)) <= 1e-6
+    assert max(abs(a - b) / abs(b) for a, b in zip(lg, l32)) <= 2e-6
+
+    # ---- maps: every element ----------------------------------------------------------------------------------------------------------
+    floor = pol64 = pol32 = 0.0
+    print("%-12s %9s %7s | o32 vs o64 | policy vs o32 (frac > 1) | policy vs o64 (frac > 1)" % ("map", "elements", "rms"))
+    for name in o64:
+        assert got[name].shape == o64[name].shape == o32[name].shape, name
+        a = fs.worst_ratio(name, o32[name], o64[name])
+        b = fs.worst_ratio(name, got[name], o32[name])
+        c = fs.worst_ratio(name, got[name], o64[name])
+        print("%-12s %9d %7.3g |   %6.3f   |   %6.3f (%.1e)     |   %6.3f (%.1e)" % (name, o64[name].numel(), a[2], a[0], b[0], b[1], c[0], c[1]))
+        floor, pol32, pol64 = max(floor, a[0]), max(pol32, b[0]), max(pol64, c[0])
+        assert b[1] <= 1e-3 and c[1] <= 1e-3, name
+    print(f"worst over all maps: oracle32 vs oracle64 {floor:.3f}; policy vs oracle64 {pol64:.3f} (ratio {pol64 / floor:.3f}); policy vs oracle32 {pol32:.3f}")
+    assert pol64 <= FLOOR_SLACK * floor, (pol64, floor)
+    assert pol32 <= min(ABS_CAP_VS_ORACLE32, pol64 + floor), (pol32, pol64, floor)
+
+    # ---- every parameter gradient against the float32 oracle's autograd -----------------------------------------------------------------
+    rows = []
+    for n, g in grads.items():
+        a, b = g.double().flatten(), g32[n].double().flatten()
+        rows.append((float(a @ b / (a.norm() * b.norm() + 1e-300)), n, float(a.norm() / (b.norm() + 1e-300))))
+    rows.sort()
+    print("parameter gradients (%d tensors, full): min cosine %.7f (%s), median %.8f; norm ratio in [%.5f, %.5f]" %
+          (len(rows), rows[0][0], rows[0][1], rows[len(rows) // 2][0], min(r for _, _, r in rows), max(r for _, _, r in rows)))
+    assert len(rows) == 217
+    assert rows[0][0] >= 0.9999 and all(abs(r - 1) <= 2e-3 for _, _, r in rows), rows[:4]

@@ -395,6 +395,21 @@ def test_gather_128x64_variant_on_small_problems():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_four_wave_blocked_7x7_halo_kernel_matches():
+    """conv_halo7_w4_kernel (csrc/conv_halo.hip: four waves of 64 couts x 128 pixels, accumulation restarted every 14 taps into a second
+    accumulator) serves the multi-chunk 3-product forward launches by default; KG_HALO7_W4=2 sends EVERY dense 7x7 rows-output launch of the
+    halo / plane conv tests through it (forward and flipped input gradient, both 16-bit formats, masks / residuals, partial tiles)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KG_HALO7_W4="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), os.path.join(root, "tests", "test_gpu_planes.py"),
+                        "-q", "-x", "-k", "test_conv_halo_forward_and_dgrad or test_conv_forward_dgrad_wgrad_planes"],
+                       capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 WGRAD_HALO_CASES = [(64, 64, 3, 2, 20, 28), (64, 192, 7, 1, 32, 32), (64, 5, 7, 1, 16, 24), (3, 64, 3, 1, 24, 24),
                     (256, 128, 3, 1, 16, 16), (128, 64, 7, 2, 18, 21), (1024, 512, 3, 1, 8, 8),
                     (64, 10, 7, 1, 20, 20), (128, 40, 7, 1, 17, 33), (64, 1, 3, 2, 19, 23)]

@@ -190,17 +190,3 @@ def test_paste_masks_vs_oracle(image_hw):
     dev_masks, _ = kpp.paste_masks(pred, S, S, iw, ih, 0.5, device_u8=True)
     assert dev_masks.dtype == torch.uint8 and np.array_equal(dev_masks.cpu().numpy().astype(np.float32), ref[0])
     assert kpp.paste_masks(None, S, S, iw, ih, 0.5) is None
-
-
-def test_first_hough_formulation_still_bit_exact():
-    """The count -> scan -> fill -> sum formulation of the Hough vote (KG_HOUGH_V1=1; the default is the one-pass scatter with inline
-    slots, csrc/postproc.hip) stays in the library for A/B runs: the golden stage tests in a process that selects it."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, KG_HOUGH_V1="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_postproc.py"), "-q", "-x", "-k", "stages_vs_golden"],
-                       capture_output=True, text=True, env=env, cwd=root)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "4 passed" in r.stdout, r.stdout[-500:]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of environment switches / library variants on the train step: each line = one bench run (ms/step, dominant-kernel fraction, its launch time)
-#   bash tools/ab_env.sh "KG_HALO7_DB=0" "KG_HALO7_DB=1" ...        (an argument is an env assignment list; repeated 3 times round-robin)
+#   bash tools/ab_env.sh "KG_HALO7_W4=0" "KG_HALO7_W4=2" ...        (an argument is an env assignment list; repeated 3 times round-robin)
 for i in 1 2 3; do
   for V in "$@"; do
     echo -n "$V  "

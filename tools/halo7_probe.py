@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Times the first-layer 7x7 head conv (kg_conv2d_halo, KS = 7) alone at the three shapes that carry it in the bench step, forward with hi + lo
 planes (3 products) and single-plane (the input-gradient arithmetic), on ReLU-like operands:
-    python tools/halo7_probe.py        (GPU box; KG_HALO7_DB=0 -> the single-buffered kernel; KG_LIB_F16_PATH selects another build)"""
+    python tools/halo7_probe.py        (GPU box; KG_HALO7_W4=0 -> the 8-wave kernel everywhere, 2 -> the 4-wave blocked-accumulation kernel everywhere; KG_LIB_F16_PATH selects another build)"""
 import os
 import sys
 import time

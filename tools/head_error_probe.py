@@ -41,6 +41,42 @@ def heads_cpu(sd, x, lvl, dtype):
     return out
 
 
+def hidden_cpu(sd, x, lvl, dtype):
+    """the three first layers (+ ReLU), channels concatenated in arch.HEADS order: [N, 3C, H, W]"""
+    return torch.cat([F.relu(F.conv2d(x.to(dtype), sd[f"{h}_head_c{lvl}.0.weight"].to(dtype), sd[f"{h}_head_c{lvl}.0.bias"].to(dtype), 1, 3)) for h, _ in arch.HEADS], 1)
+
+
+def second_cpu(sd, hid, lvl, dtype):
+    C = hid.shape[1] // 3
+    out = {}
+    for k, (h, _) in enumerate(arch.HEADS):
+        p = f"{h}_head_c{lvl}.2"
+        out[{"kp": "kp_logit", "short_offset": "short", "mid_offset": "mid"}[h]] = F.conv2d(hid[:, k * C:(k + 1) * C].to(dtype), sd[p + ".weight"].to(dtype), sd[p + ".bias"].to(dtype), 1, 3)
+    return out
+
+
+def layers_gpu(model, x, hid_in, lvl):
+    """(hidden of the fused first layer on x as fp32 NCHW, maps of the grouped second layer on the GIVEN hidden tensor hid_in)"""
+    eng = model._engine
+    N, C, H, W = x.shape
+    r = x.permute(0, 2, 3, 1).reshape(N * H * W, C).contiguous().to(DEV)
+    pt = ops.alloc_pt(N * H * W, C, eng.pd, DEV, dtype=eng.dt)
+    ops.f32_to_planes(r, pt, C)
+    eng.tape = None
+    eng.raw_kp_logits = True
+    fused = [f"{h}_head_c{lvl}.0" for h, _ in arch.HEADS]
+    hid, _, _ = eng.conv(Var(pt, C, relu=True, req=False), eng.spec(f"heads_c{lvl}.0", C, C, 7, 1, 3, fused=fused, P=eng.ph), N, H, W, True)
+    hf = torch.empty(N * H * W, 3 * C, dtype=torch.float32, device=DEV)
+    ops.planes_to_f32(hid.t, 3 * C, hf)
+    hr = hid_in.permute(0, 2, 3, 1).reshape(N * H * W, 3 * C).contiguous().to(DEV)
+    hp = ops.alloc_pt(N * H * W, 3 * C, eng.ph, DEV, dtype=eng.dt)
+    ops.f32_to_planes(hr, hp, 3 * C)
+    eng.head_slots = []
+    outs = eng.heads_second(Var(hp, 3 * C, relu=True, req=False), lvl, C, N, H, W)
+    torch.cuda.synchronize()
+    return hf.cpu().view(N, H, W, 3 * C).permute(0, 3, 1, 2), dict(zip(("kp_logit", "short", "mid"), [o.cpu() for o in outs]))
+
+
 def heads_gpu(model, x, lvl):
     eng = model._engine
     N, C, H, W = x.shape
@@ -90,6 +126,25 @@ def main():
                 d = (got[p][name].double() - r)
                 line += " | %.3e  %6.3f" % (float(d.pow(2).mean().sqrt()), float((d.abs() / b).max()))
             print(line)
+    print()
+    print("the two layers separately (relative rms error = rms(err) / rms(ref)): first layer = hidden tensor of the fused C -> 3C conv + ReLU on the SAME fp32 input;")
+    print("second layer = the three maps from the SAME fp32 hidden tensor (the float64 hidden rounded to fp32)")
+    print("%-22s | %-12s" % ("tensor", "torch-CPU f32") + "".join(f" | {p:>10}" for p in policies))
+    for lvl in range(4):
+        xin = net.head_in[lvl].float()
+        with torch.no_grad():
+            h64 = hidden_cpu(sd, xin, lvl, torch.float64)
+            h32 = hidden_cpu(sd, xin, lvl, torch.float32)
+            hin = h64.float()
+            m64 = second_cpu(sd, hin, lvl, torch.float64)
+            m32 = second_cpu(sd, hin, lvl, torch.float32)
+            got = {p: layers_gpu(models[p], xin, hin, lvl) for p in policies}
+
+        def rel(a, r):
+            return float((a.double() - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt())
+        print("%-22s | %.3e   " % (f"c{lvl} hidden (C={xin.shape[1]})", rel(h32, h64)) + "".join(" | %.3e" % rel(got[p][0], h64) for p in policies))
+        for name in ("kp_logit", "short", "mid"):
+            print("%-22s | %.3e   " % (f"c{lvl}.{name} (layer 2)", rel(m32[name], m64[name])) + "".join(" | %.3e" % rel(got[p][1][name], m64[name]) for p in policies))
 
 
 if __name__ == "__main__":
