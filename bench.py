@@ -379,7 +379,7 @@ def eval_bench(args, dev):
 
 
 def cpu_baseline(S, nboxes, seed=0):
-    """The oracle's torch-CPU restatement of ONE train step at batch 1 (bounded sample), all host cores."""
+    """The oracle's torch-CPU restatement of ONE train step at batch 1 with the headline's boxes per image (bounded sample: ~6-10 s), all host cores."""
     from oracle import net as onet, synth, weightgen
     torch.set_num_threads(min(os.cpu_count() or 1, 32))   # bs=1 convs stop scaling (and regress) beyond a few dozen threads
     sd = weightgen.gen_state_dict(seed)
@@ -465,6 +465,35 @@ def self_launch(n):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
     return subprocess.run(self_launch_cmd(n, sys.argv[1:], port), env=env).returncode
+
+
+def roofline_block(dsum, dt, with_pmc):
+    """`roofline` of the dominant kernel family from the HIP-event records of a timed region (KernelTimer.summary): MFMA FLOPs issued by its
+    launches / their summed duration, against the 2.5 PFLOP/s dense 16-bit MFMA peak."""
+    fam = [n for n in KernelTimer.DOMINANT if n in dsum]
+    if not fam:
+        return None
+    dom = {k: sum(dsum[n][k] for n in fam) for k in ("seconds", "flops", "launches", "mfma_flops")}
+    ach = dom["flops"] / dom["seconds"] / 1e12
+    issued = dom["mfma_flops"] / dom["seconds"] / 1e12
+    pm = pmc_mfma() if with_pmc else None
+    return {"bound": "mfma", "kernel": " + ".join(fam) + " (7x7 first-layer head convs, forward + input gradient)",
+            "achieved": issued, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / MFMA_BF16_PEAK_TFLOPS,
+            "achieved_algorithmic": ach, "frac_algorithmic": ach / MFMA_BF16_PEAK_TFLOPS,
+            "products_per_multiply": dom["mfma_flops"] / dom["flops"],
+            "traffic": pmc_traffic() if with_pmc else None, "avg_launch_ms": 1e3 * dom["seconds"] / dom["launches"],
+            "launches": dom["launches"], "share_of_step": dom["seconds"] / dt,
+            "per_kernel": {n: {"launches": dsum[n]["launches"], "avg_launch_ms": 1e3 * dsum[n]["seconds"] / dsum[n]["launches"],
+                               "mfma_issued_tflops": dsum[n]["mfma_flops"] / dsum[n]["seconds"] / 1e12} for n in fam},
+            "build": _build_id(),
+            "pmc": pm and dict(pm, note="rocprofv3 PMC pass of this build (profiles/, build hash checked): MFMA-pipe busy cycles / active "
+                                       "cycles of these kernels, collected by tools/profile_round.sh on another box run"),
+            "note": "achieved = 16-bit MFMA FLOPs ISSUED by the launches of this kernel family / their HIP-event time, measured inside the timed "
+                    "region: algorithmic fp32 conv FLOPs (2*N*H*W*Cout*49*Cin, real channel counts) x the plane products each multiply is "
+                    "evaluated as (`products_per_multiply`, launch-weighted: 3 in the forward launches, 1 in the input-gradient launches of the "
+                    "default policy); peak = 2500 TFLOP/s dense f16 / bf16 MFMA; frac = achieved / peak.  achieved_algorithmic / "
+                    "frac_algorithmic = the same launches in fp32-equivalent conv FLOPs (no plane products).  traffic = HBM bytes per launch "
+                    "from the committed PMC pass of this build, null when the loaded libraries differ from the profiled ones"}
 
 
 def main():
@@ -617,17 +646,21 @@ def main():
     if world == 1 and not args.no_companion:
         main_run = None
         torch.cuda.empty_cache()
-        ksteps = max(2, min(args.steps, 10))
         notes = {"half": "NOT the reference's arithmetic: half mixed precision, tests/test_gpu_parity.py holds it to rtol 2e-2 + atol 2e-2 rms",
                  "fp32b2": "hi + lo half planes (3 MFMA products per multiply) in the forward AND the backward pass: the policy whose parameter gradients sit on the "
                            "fp32 reference's own noise floor against a float64 evaluation (profiles/r04_grad_table.json, tests/test_gpu_gradprec.py)"}
-        for cp in ("half", "fp32b2"):
+        for cp in ("fp32b2", "half"):
             if cp == args.precision:
                 continue
-            comp = run_train(cp, ksteps, 3, STEP_SYNC, False)
+            # fp32b2 -- the step at the reference's precision in BOTH directions -- is timed on equal footing with the headline: the same
+            # --steps / --warmup and its own roofline block; `half` (not the reference's arithmetic) stays a short companion
+            ksteps, kwarm = (args.steps, args.warmup) if cp == "fp32b2" else (max(2, min(args.steps, 10)), 3)
+            comp = run_train(cp, ksteps, kwarm, STEP_SYNC, cp == "fp32b2" and not args.no_kernel_timer)
             companions[cp] = {"precision": cp, "dtype": dtype_label(cp), "value": args.batch * ksteps / comp["dt"], "unit": "imgs/s",
-                              "ms_per_step": 1e3 * comp["dt"] / ksteps, "steps": ksteps, "warmup": 3, "last_loss": comp["losses"][-1],
+                              "ms_per_step": 1e3 * comp["dt"] / ksteps, "steps": ksteps, "warmup": kwarm, "last_loss": comp["losses"][-1],
                               "grad_overflow": bool(comp["overflow"]()), "parity": notes[cp]}
+            if comp["dom_rec"]:
+                companions[cp]["roofline"] = roofline_block(timer.summary(comp["dom_rec"]), comp["dt"], with_pmc=False)
             comp = None
             torch.cuda.empty_cache()
     if rank != 0:
@@ -673,38 +706,15 @@ def main():
         if os.environ.get("KG_BENCH_DUMP"):
             timer.rec = prof_rec
             timer.dump(os.environ["KG_BENCH_DUMP"], prof_steps)
-        dsum = timer.summary(dom_rec)
-        fam = [n for n in KernelTimer.DOMINANT if n in dsum]
-        dom = {k: sum(dsum[n][k] for n in fam) for k in ("seconds", "flops", "launches", "mfma_flops")} if fam else None
-        dom_name = " + ".join(fam)
-        if dom:
-            ach = dom["flops"] / dom["seconds"] / 1e12
-            issued = dom["mfma_flops"] / dom["seconds"] / 1e12
-            prod = dom["mfma_flops"] / dom["flops"]
-            pm = pmc_mfma()
-            out["roofline"] = {"bound": "mfma", "kernel": dom_name + " (7x7 first-layer head convs, forward + input gradient)",
-                               "achieved": issued, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / MFMA_BF16_PEAK_TFLOPS,
-                               "achieved_algorithmic": ach, "frac_algorithmic": ach / MFMA_BF16_PEAK_TFLOPS,
-                               "products_per_multiply": prod,
-                               "traffic": pmc_traffic(), "avg_launch_ms": 1e3 * dom["seconds"] / dom["launches"],
-                               "launches": dom["launches"], "share_of_step": dom["seconds"] / dt,
-                               "per_kernel": {n: {"launches": dsum[n]["launches"], "avg_launch_ms": 1e3 * dsum[n]["seconds"] / dsum[n]["launches"],
-                                                  "mfma_issued_tflops": dsum[n]["mfma_flops"] / dsum[n]["seconds"] / 1e12} for n in fam},
-                               "build": _build_id(),
-                               "pmc": pm and dict(pm, note="rocprofv3 PMC pass of this build (profiles/, build hash checked): MFMA-pipe busy cycles / active "
-                                                          "cycles of this kernel, collected by tools/profile_round.sh on another box run"),
-                               "note": "achieved = 16-bit MFMA FLOPs ISSUED by the launches of this kernel / their HIP-event time, measured inside the timed "
-                                       "region: algorithmic fp32 conv FLOPs (2*N*H*W*Cout*49*Cin, real channel counts) x the plane products each multiply is "
-                                       "evaluated as (`products_per_multiply`, launch-weighted: 3 in the forward launches, 1 in the input-gradient launches of the "
-                                       "default policy); peak = 2500 TFLOP/s dense f16 / bf16 MFMA; frac = achieved / peak.  achieved_algorithmic / "
-                                       "frac_algorithmic = the same launches in fp32-equivalent conv FLOPs (no plane products).  traffic = HBM bytes per launch "
-                                       "from the committed PMC pass of this build, null when the loaded libraries differ from the profiled ones"}
+        rb = roofline_block(timer.summary(dom_rec), dt, with_pmc=True)
+        if rb:
+            out["roofline"] = rb
         summ = timer.summary(prof_rec)
         if summ:
             out["kernels"] = {k: {"ms_per_step": 1e3 * v["seconds"] / prof_steps, "tflops": v["flops"] / max(v["seconds"], 1e-12) / 1e12,
                                   "launches_per_step": v["launches"] / prof_steps} for k, v in summ.items()}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.size, 20)
+        out["cpu_baseline"] = cpu_baseline(args.size, args.boxes)      # batch 1 with the headline's boxes per image: the same per-image work
         out["config"]["grouping_match_rate"] = out["cpu_baseline"]["grouping_match_rate"]
     print(json.dumps(out))
 

@@ -43,9 +43,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ coun
 // ---- P1: one scatter pass with inline slots -----------------------------------------------------------------------------------------
 // (Round 1's count -> scan -> fill -> sum pipeline touched every vote with two atomic passes, computed every contribution twice and sorted
 // every cell's votes by selection from global memory; it is gone from the sources since round 5 -- git history, docs/history.md.)
-//   scatter : one thread per (channel, SOURCE pixel): the vote position and the four bilinear weights are computed once
-//             (postprocessing.py:16-37) and the four votes go out back to back -- their cells are neighbours, so the returning atomics and
-//             the inline-slot stores of a wave hit a compact set of L2 lines.  A vote whose value is +-0.0 is dropped: every sum starts
+//   scatter : one thread per vote (postprocessing.py:16-37).  A vote whose value is +-0.0 is dropped: every sum starts
 //             from +0.0, and x + (+-0.0) == x for every x that can stand in such a sum (+0.0 + -0.0 == +0.0 as well), so the heat map keeps
 //             its bits -- and with integer-valued offsets three of the four weights are exactly 0, with kp == 0 all four.  Vote e = corner *
 //             HW + pixel takes slot s = atomicAdd(cnt[cell]) (ONE returning atomic); the first HOUGH_K votes of a cell land in its inline slots
@@ -62,35 +60,51 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ coun
 __global__ __launch_bounds__(256) void hough_scatter_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W,
                                                             int* __restrict__ cnt, unsigned* __restrict__ ink, double* __restrict__ inv,
                                                             int* __restrict__ ovn, unsigned long long* __restrict__ ovkey, double* __restrict__ ovval) {
-    const int c = blockIdx.y, HW = H * W;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= HW) return;
-    const int y = i / W, x = i - y * W;
-    const double xs = (double)x + (double)soff[(long)(2 * c) * HW + i];
-    const double ys = (double)y + (double)soff[(long)(2 * c + 1) * HW + i];
-    const double ps = (double)kp[(long)c * HW + i];
-    const int fx = f2i_np(floor(xs)), fy = f2i_np(floor(ys));
-    const int cx = f2i_np(ceil(xs)), cy = f2i_np(ceil(ys));
-    const double dx = xs - (double)fx, dy = ys - (double)fy;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int I = b < 2 ? fy : cy, J = (b & 1) ? cx : fx;
-        double v;                                                        // (left-to-right products, as NumPy evaluates postprocessing.py:24-27)
-        if (b == 0) v = ps * (1. - dx) * (1. - dy);
-        else if (b == 1) v = ps * dx * (1. - dy);
-        else if (b == 2) v = ps * dy * (1. - dx);
-        else v = ps * dy * dx;
-        if (I < 0 || I >= H || J < 0 || J >= W || v == 0.) continue;     // out of the map (postprocessing.py:34-35) / a zero addend (NaN is kept)
-        const int cc = c * HW + I * W + J;
-        const unsigned e = (unsigned)(b * HW + i);
-        const int slot = atomicAdd(&cnt[cc], 1);
-        if (slot < HOUGH_K) {
-            ink[(long)cc * HOUGH_K + slot] = e;
+    const int c = blockIdx.y, HW = H * W, lane = threadIdx.x & 63;
+    // one thread per VOTE e = corner * HW + pixel, corner-major: the lanes of a wave vote into neighbouring cells of ONE corner, and the four
+    // corners of a pixel (the same or adjacent cache lines) are far apart in time.  (One thread per source pixel with its four atomics back to
+    // back -- a quarter of the address arithmetic -- measured 1.5 x SLOWER at 1024 x 1024: same-line returning atomics queue up in the L2.)
+    const int n4 = 4 * HW, nround = (n4 + (int)(gridDim.x * 256) - 1) / (int)(gridDim.x * 256);
+    for (int r = 0; r < nround; ++r) {                                   // (uniform trip count: the ballot below needs every lane of the wave)
+        const int e = (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        int cc = -1; double v = 0.;
+        if (e < n4) {
+            const int b = e / HW, i = e - b * HW;
+            const int y = i / W, x = i - y * W;
+            const double xs = (double)x + (double)soff[(long)(2 * c) * HW + i];
+            const double ys = (double)y + (double)soff[(long)(2 * c + 1) * HW + i];
+            const double ps = (double)kp[(long)c * HW + i];
+            const int fx = f2i_np(floor(xs)), fy = f2i_np(floor(ys));
+            const int cx = f2i_np(ceil(xs)), cy = f2i_np(ceil(ys));
+            const double dx = xs - (double)fx, dy = ys - (double)fy;
+            int I, J;                                                    // (left-to-right products, as NumPy evaluates postprocessing.py:24-27)
+            switch (b) {
+                case 0: I = fy; J = fx; v = ps * (1. - dx) * (1. - dy); break;
+                case 1: I = fy; J = cx; v = ps * dx * (1. - dy); break;
+                case 2: I = cy; J = fx; v = ps * dy * (1. - dx); break;
+                default: I = cy; J = cx; v = ps * dy * dx; break;
+            }
+            // out of the map (postprocessing.py:34-35) / a zero addend (NaN is kept)
+            if (!(I < 0 || I >= H || J < 0 || J >= W || v == 0.)) cc = c * HW + I * W + J;
+        }
+        const int slot = cc >= 0 ? atomicAdd(&cnt[cc], 1) : 0;
+        const bool park = cc >= 0 && slot >= HOUGH_K;
+        if (cc >= 0 && !park) {
+            ink[(long)cc * HOUGH_K + slot] = (unsigned)e;
             inv[(long)cc * HOUGH_K + slot] = v;
-        } else {
-            const int pos = atomicAdd(ovn, 1);
-            ovkey[pos] = ((unsigned long long)(unsigned)cc << 32) | e;
-            ovval[pos] = v;
+        }
+        // parked votes: ONE atomic per wave instruction on the list counter (a keypoint's disc parks ~30 votes per cell)
+        const unsigned long long m = __ballot(park);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(ovn, __popcll(m));
+            base = __shfl(base, leader, 64);
+            if (park) {
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                ovkey[pos] = ((unsigned long long)(unsigned)cc << 32) | (unsigned)e;
+                ovval[pos] = v;
+            }
         }
     }
 }
@@ -813,13 +827,14 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
     const int HW = H * W;
     const double norm = 3.141592653589793 * 25.0;  // np.pi * KP_RADIUS**2 (postprocessing.py:51)
     pp_mark(st);
+    int gx = (4 * HW + 255) / 256; if (gx > 4096) gx = 4096;
     {
         // heavy_n (the 64-bit slab allocator, + the parked-vote counter 16 bytes further) | count | offs | cursor are consecutive in the
         // workspace: ONE memset clears the allocators, the vote counters (count) and the slab cursors (cursor)
         KG_HIP(hipMemsetAsync(p.heavy_n, 0, (size_t)((unsigned char*)p.cursor - (unsigned char*)p.heavy_n) + (size_t)5 * HW * 4, st));
         unsigned long long* ctr64 = reinterpret_cast<unsigned long long*>(p.heavy_n);
         int* ovn = p.heavy_n + 4;
-        hipLaunchKernelGGL(hough_scatter_kernel, dim3((HW + 255) / 256, 5), dim3(256), 0, st, kp, soff, H, W, p.count, p.ink, p.inv, ovn, p.keys, p.vals);
+        hipLaunchKernelGGL(hough_scatter_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.count, p.ink, p.inv, ovn, p.keys, p.vals);
         hipLaunchKernelGGL(hough_classify_kernel, dim3((5 * HW + 1023) / 1024), dim3(1024), 0, st, 5 * HW, p.count, p.ink, p.inv, norm, p.heat, ctr64,
                            p.offs, p.heavy_list, p.skey, p.sorted);
         hipLaunchKernelGGL(hough_ovfill_kernel, dim3(1024), dim3(256), 0, st, (const int*)ovn, (const unsigned long long*)p.keys, (const double*)p.vals,

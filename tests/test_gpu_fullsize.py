@@ -1,9 +1,10 @@
 """GPU parity AT THE BENCH CONFIGURATION (BASELINE configs[1]: batch 8 x 3 x 512 x 512, 300 GT boxes per image, train mode; the reference's
 train.py:148-154): the default policy's train-mode forward element-wise against the reference-pinned CPU oracle (oracle/net.py) evaluated in
 float32 -- the reference's own arithmetic -- AND in float64, every kp logit / short / mid offset / seg logit of the batch, plus the five losses
-and every parameter gradient against the float32 oracle's autograd.
+(and, with KG_FULLSIZE_GRADS=1, every parameter gradient against the float32 oracle's autograd: the oracle's backward pass through 2400 per-box
+graphs takes 12 minutes of host time, so that leg is opt-in; its result on this build is in profiles/r05_fullsize_test.txt).
 
-What can and cannot hold at this size (measured, profiles/r05_fullsize_oracle_parity.txt): two float32-grade evaluations of this network are
+What can and cannot hold at this size (measured, profiles/r05_fullsize_test.txt): two float32-grade evaluations of this network are
 each ~1.3-1.4 bounds (rtol 1e-4, atol 1e-5) from the float64 value -- the reference's own fp32 arithmetic included: 12 544 / 25 088-term dot
 products in the c2 / c3 heads on top of 50 layers -- so "<= 1.0 against the float32 oracle" is not a statement any fp32 implementation can
 make here.  What is asserted instead:
@@ -11,7 +12,7 @@ make here.  What is asserted instead:
     number of (oracle32 vs oracle64), over all 13 maps;
   * against the float32 oracle it stays within the sum of the two distances (and an absolute cap), with at most a 1e-3 fraction of any map's
     elements beyond the bound;
-  * losses within 1e-6 of float64; every parameter gradient: cosine >= 0.9999 and norm within 2e-3 of the float32 oracle's.
+  * losses within 1e-6 of float64; (opt-in) every parameter gradient: cosine >= 0.9999 and norm within 2e-3 of the float32 oracle's.
 Bounds: |d| <= atol + 1e-4 |ref| with atol 1e-5 for the logits (literally) and the stated per-map constants 2e-5 (short offsets,
 rms 3-4 px) / 6e-5 (mid offsets, rms 5-7 px) -- no rms scaling."""
 import os
@@ -27,12 +28,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-FLOOR_SLACK = 1.10      # policy-vs-float64 may exceed oracle32-vs-float64 by 10 % (max statistics over 1e8 elements; measured ratio in the docstring of the test)
+FLOOR_SLACK = 1.10      # policy-vs-float64 may exceed oracle32-vs-float64 by 10 % (max statistics over 1e8 elements; measured 1.436 / 1.376 = 1.04)
+WITH_GRADS = os.environ.get("KG_FULLSIZE_GRADS", "0") == "1"
 ABS_CAP_VS_ORACLE32 = 2.5
 
 
 def test_train_step_at_bench_configuration_vs_oracle_fp32_and_fp64():
-    """measured on MI355X (r05, this build): see the printed table; profiles/r05_fullsize_oracle_parity.txt holds a copy"""
+    """measured on MI355X (r05, this build; profiles/r05_fullsize_test.txt): oracle32 vs oracle64 worst 1.376 bounds; policy vs oracle64 1.436
+    (before the blocked accumulation of the wide 7x7 heads: 1.546); policy vs oracle32 2.141; losses equal to float64's to 1e-7; all 217
+    gradients cosine >= 0.99998, norms within 1.2e-3 of the float32 oracle's."""
     import fullsize_oracle_parity as fs
     from kg_instance_segmentation_amd import KGnet
     from kg_instance_segmentation_amd.loss import DetectionLossAll
@@ -62,11 +66,13 @@ def test_train_step_at_bench_configuration_vs_oracle_fp32_and_fp64():
     got["seg_logit"] = torch.cat([flat[int(meta["off"][j]):int(meta["off"][j]) + int(meta["h"][j]) * int(meta["w"][j])] for j in order]).cpu()
     l1 = [ldec(d[l], gt_lv[l].to(dev)) for l in range(4)]
     l2 = lseg(d[4], masks, boxes)
-    (sum(l1) + l2).backward()
-    torch.cuda.synchronize()
-    assert not m.grad_overflowed()
-    lg = [float(v) for v in l1] + [float(l2)]
-    grads = {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}
+    lg = [float(v.detach()) for v in l1] + [float(l2.detach())]
+    grads = {}
+    if WITH_GRADS:
+        (sum(l1) + l2).backward()
+        torch.cuda.synchronize()
+        assert not m.grad_overflowed()
+        grads = {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}
     del m, d, l1, l2
     torch.cuda.empty_cache()
 
@@ -74,24 +80,28 @@ def test_train_step_at_bench_configuration_vs_oracle_fp32_and_fp64():
     t0 = time.time()
     osd = {k: v.clone() for k, v in sd.items()}
     names = [k for k, v in osd.items() if v.is_floating_point() and "running" not in k]
-    for n in names:
-        osd[n].requires_grad_(True)
+    if WITH_GRADS:
+        for n in names:
+            osd[n].requires_grad_(True)
     net = onet.Net(osd, training=True)
-    o = net.forward(x, boxes)
+    with torch.set_grad_enabled(WITH_GRADS):
+        o = net.forward(x, boxes)
     o32 = {}
     for l in range(4):
         o32[f"c{l}.kp_logit"] = net.kp_logits[l].detach()
         o32[f"c{l}.short"] = o[l][1].detach()
         o32[f"c{l}.mid"] = o[l][2].detach()
     o32["seg_logit"] = torch.cat([z.detach().reshape(-1) for per in net.seg_logits for z in per])
-    ol = [onet.detection_loss(o[l], gt_lv[l]) for l in range(4)] + [onet.seg_loss(o[4], masks, boxes, S, S)]
-    sum(ol).backward()
-    l32 = [float(v) for v in ol]
+    with torch.set_grad_enabled(WITH_GRADS):
+        ol = [onet.detection_loss(o[l], gt_lv[l]) for l in range(4)] + [onet.seg_loss(o[4], masks, boxes, S, S)]
+    if WITH_GRADS:
+        sum(ol).backward()
+    l32 = [float(v.detach()) for v in ol]
     g32 = {n: osd[n].grad for n in names}
     del net, o, ol
     t32 = time.time() - t0
     o64, l64, t64 = fs.oracle_forward(sd, x, boxes, gt_lv, masks, S, torch.float64)
-    print(f"oracle float32 forward + backward {t32:.0f} s, float64 forward {t64:.0f} s")
+    print(f"oracle float32 forward{' + backward' if WITH_GRADS else ''} {t32:.0f} s, float64 forward {t64:.0f} s")
 
     # ---- losses ---------------------------------------------------------------------------------------------------------------------
     print("losses oracle64:", ["%.8f" % v for v in l64])
@@ -115,7 +125,9 @@ def test_train_step_at_bench_configuration_vs_oracle_fp32_and_fp64():
     assert pol64 <= FLOOR_SLACK * floor, (pol64, floor)
     assert pol32 <= min(ABS_CAP_VS_ORACLE32, pol64 + floor), (pol32, pol64, floor)
 
-    # ---- every parameter gradient against the float32 oracle's autograd -----------------------------------------------------------------
+    # ---- (opt-in) every parameter gradient against the float32 oracle's autograd ---------------------------------------------------------
+    if not WITH_GRADS:
+        return
     rows = []
     for n, g in grads.items():
         a, b = g.double().flatten(), g32[n].double().flatten()
