@@ -94,7 +94,9 @@ class KernelTimer:
             tile = k.get("tile", 0) or (1 if cout <= 16 else 2 if cout <= 32 else 3 if cout <= 64 else 4)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             flushq(); s.record(); r = orig_conv(x, pw, cout, geom, *a, **k); e.record()
-            timer.rec.append((kname(x), 2.0 * M * cout * KH * KW * getattr(pw, "cin_real", pw.cin_pad), s, e, f"M={M} cout={cout} k={KH} cinp={pw.cin_pad} mode={k.get('mode', 0)} tile={tile}"))
+            yP = getattr(k.get("y"), "P", 1) if k.get("y") is not None else 0
+            timer.rec.append((kname(x), 2.0 * M * cout * KH * KW * getattr(pw, "cin_real", pw.cin_pad), s, e,
+                              f"M={M} cout={cout} k={KH} cinp={pw.cin_pad} mode={k.get('mode', 0)} tile={tile} stride={geom[7]} xP={getattr(pw, 'xP', 1)} yP={yP} products={getattr(pw, 'vp', 1)}"))
             return r
 
         def wgrad(x, dy, cin, cout, geom, grads, *a, **k):

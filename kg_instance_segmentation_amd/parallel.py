@@ -84,7 +84,7 @@ class FlatGradReducer:
         # the LAST bucket's all-reduce starts when the backward pass ends and is exposed in full: the final `tail_total_mb` of the
         # buffer (the 115 small backbone / c0_conv tensors, ~24 MB) go out in pieces of <= tail_mb, so what is left after the last
         # gradient kernel is one small piece (round 4's single 24 MB tail bucket was issued 0.04 ms before finish())
-        self.tail_cap, self.tail_total = tail_mb << 20, tail_total_mb << 20
+        self.tail_cap, self.tail_total = min(tail_mb << 20, self.cap), tail_total_mb << 20
         self.model = None
 
     def attach(self, model):

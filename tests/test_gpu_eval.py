@@ -74,7 +74,7 @@ def test_forward_dec_1024_vs_oracle(model, cal_sd):
             got = d[l][k].cpu().numpy()[..., ::7, ::5].astype(np.float64)
             ref = (net.kp_logits[l] if k == 0 else o[l][k]).numpy()[..., ::7, ::5].astype(np.float64)
             rms = float(np.sqrt(np.mean(ref ** 2)))
-            atol = 1e-5 * (1.0 if k == 0 else 2.0 if k == 1 else 6.0)      # logits literally; stated constants for the short / mid offset maps (pixels)
+            atol = 1e-5 * (1.0 if k == 0 else 3.0 if k == 1 else 6.0)      # logits literally; stated constants for the short / mid offset maps (pixels)
             ratio = float((np.abs(got - ref) / (atol + 1e-4 * np.abs(ref))).max())
             print(f"1024 c{l}.{nm}: rms {rms:.3g} worst |d|/bound {ratio:.3f}")
             worst = max(worst, ratio)

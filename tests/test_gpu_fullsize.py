@@ -13,7 +13,7 @@ make here.  What is asserted instead:
   * against the float32 oracle it stays within the sum of the two distances (and an absolute cap), with at most a 1e-3 fraction of any map's
     elements beyond the bound;
   * losses within 1e-6 of float64; (opt-in) every parameter gradient: cosine >= 0.9999 and norm within 2e-3 of the float32 oracle's.
-Bounds: |d| <= atol + 1e-4 |ref| with atol 1e-5 for the logits (literally) and the stated per-map constants 2e-5 (short offsets,
+Bounds: |d| <= atol + 1e-4 |ref| with atol 1e-5 for the logits (literally) and the stated per-map constants 3e-5 (short offsets,
 rms 3-4 px) / 6e-5 (mid offsets, rms 5-7 px) -- no rms scaling."""
 import os
 import sys

@@ -2,7 +2,7 @@
 """GPU box: TRAIN-mode forward of BASELINE's configuration (batch 8 x 512 x 512, 300 boxes per image; calibrated weights) element-wise
 against the reference-pinned CPU oracle (oracle/net.py) evaluated in float32 -- the reference's own arithmetic -- AND in float64:
 kp logits, short / mid offsets, seg logits, the five losses.  Three columns per map, all as worst |d| / bound with
-bound = atol + rtol |ref| (rtol 1e-4; atol 1e-5 literal for logits, 1e-5 * OFFSET_ATOL_SCALE[map] for the offset maps):
+bound = atol + rtol |ref| (rtol 1e-4; atol 1e-5 literal for logits, 1e-5 * OFFSET_ATOL_SCALE[map] = 3e-5 / 6e-5 for the short / mid offset maps):
     policy vs oracle32   -- the parity statement of SURVEY 8d at the bench configuration
     policy vs oracle64   -- distance from the true value
     oracle32 vs oracle64 -- what the reference's own fp32 arithmetic loses at this size (the floor)
@@ -19,7 +19,7 @@ from oracle import net as onet, synth, weightgen
 
 RTOL, ATOL = 1e-4, 1e-5
 # stated per-map constants of the offset maps' atol (pixels; the maps' rms on this fixture is 1-6 px): atol = 1e-5 * scale
-OFFSET_ATOL_SCALE = {"short": 2.0, "mid": 6.0}
+OFFSET_ATOL_SCALE = {"short": 3.0, "mid": 6.0}
 
 
 def bound_of(name, ref):
