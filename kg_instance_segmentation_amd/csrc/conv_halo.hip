@@ -867,20 +867,41 @@ __global__ __launch_bounds__(256) void conv_halo7_w4_kernel(const HaloArgs a) {
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         ldA(a0, I0{}, I0{}); ldB(b0, I0{}, I0{});
+        // One wave per SIMD: nobody else issues while this wave sits in its 12 fragment reads, so the reads of the NEXT k-step are dealt out
+        // between the MFMAs of the current one (one ds_read_b128 behind every second MFMA; the last eight MFMAs cover the latency of the
+        // last read) instead of standing in front of them -- with the reads in one block the MFMA pipe ran dry for ~60 cycles per k-step.
+        auto rd1 = [&](bf16x8 (&af)[4], bf16x8 (&bf)[8], auto tc, auto sc, auto kc) {
+            constexpr int TT = decltype(tc)::value, S = decltype(sc)::value, K = decltype(kc)::value;
+            if constexpr (K < 4) {
+                constexpr int SL = (TT % NSL) * WBUF_BYTES;
+                lds_rd128<SL + K * 512>(af[K], aaddr[S]);
+            } else {
+                constexpr int KY = TT / KS, KX = TT % KS, J = K - 4;
+                constexpr int OFF = (FLIP ? ((KS - 1 - KY) * HWD + (KS - 1 - KX)) * 128 : (KY * HWD + KX) * 128) + (J >> 2) * 2048 + (J & 3) * HWD * 128;
+                lds_rd128<OFF>(bf[J], baddr[KX][S]);
+            }
+        };
+        auto kstep = [&](bf16x8 (&af)[4], bf16x8 (&bf)[8], bf16x8 (&an)[4], bf16x8 (&bn)[8], auto tcn, auto scn, auto have_next) {
+            lwait(af, bf, I0{});
+            [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+                ((acc[(2 * Ks) >> 3][(2 * Ks) & 7] = KG_MFMA16(af[(2 * Ks) >> 3], bf[(2 * Ks) & 7], acc[(2 * Ks) >> 3][(2 * Ks) & 7]),
+                  acc[(2 * Ks + 1) >> 3][(2 * Ks + 1) & 7] = KG_MFMA16(af[(2 * Ks + 1) >> 3], bf[(2 * Ks + 1) & 7], acc[(2 * Ks + 1) >> 3][(2 * Ks + 1) & 7]),
+                  __builtin_amdgcn_sched_barrier(0),
+                  [&] { if constexpr (decltype(have_next)::value) rd1(an, bn, tcn, scn, std::integral_constant<int, Ks>{}); }(),
+                  __builtin_amdgcn_sched_barrier(0)), ...);
+            }(std::make_integer_sequence<int, 12>{});
+#pragma unroll
+            for (int q = 24; q < 32; ++q) acc[q >> 3][q & 7] = KG_MFMA16(af[q >> 3], bf[q & 7], acc[q >> 3][q & 7]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
         auto tap = [&](auto tc) {
             constexpr int TT = decltype(tc)::value;
             if constexpr (!(TT & 1)) {     // pair start: taps t + 4, t + 5 into the slots of taps t - 2, t - 1, which every wave has left
                 if constexpr (TT + 4 < T) wglds(((TT + 4) % NSL) * WBUF_BYTES);
                 if constexpr (TT + 5 < T) wglds(((TT + 5) % NSL) * WBUF_BYTES);
             }
-            ldA(a1, tc, I1{}); ldB(b1, tc, I1{});
-            lwait(a0, b0, std::integral_constant<int, 12>{});
-            mma(a0, b0);
-            if constexpr (TT + 1 < T) {
-                ldA(a0, std::integral_constant<int, TT + 1>{}, I0{}); ldB(b0, std::integral_constant<int, TT + 1>{}, I0{});
-                lwait(a1, b1, std::integral_constant<int, 12>{});
-            } else lwait(a1, b1, I0{});
-            mma(a1, b1);
+            kstep(a0, b0, a1, b1, tc, I1{}, std::true_type{});
+            kstep(a1, b1, a0, b0, std::integral_constant<int, (TT + 1 < T ? TT + 1 : TT)>{}, I0{}, std::bool_constant<(TT + 1 < T)>{});
             if constexpr ((TT & 1) && TT + 1 < T) {   // pair end: taps t + 1 .. t + 3 visible after the barrier; tap t + 4 may stay in flight
                 if constexpr (TT + 4 < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -949,12 +970,12 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
     // (not for the widest heads: 24 cout blocks of one tile stream 24 different 3 MB weight slices through the XCD's 4 MB L2: -2 %)
     a.xcd_map = use_xcd && !a.tiletab && grid.x % 8 == 0 && (grid.y > 1 || use_xcd > 1) && (long)a.Cout * a.K * 2 <= (24L << 20);
     if constexpr (KS == 7 && WC == 1 && WPX == 8 && GM == 0) {
-        // KG_HALO7_W4: 0 = never; 1 (default) = the 3-product forward launches with >= 2 channel chunks (C >= 128: where the blocked
-        // accumulation matters for the fp32 tolerance); 2 = every dense rows-output launch (forward and input gradient)
+        // KG_HALO7_W4: 0 = never; 1 (default) = the multi-product launches (hi + lo planes: 3 products; three bf16 planes: 6) with >= 2 channel
+        // chunks per plane (C >= 128: where the blocked accumulation matters for the fp32 tolerance); 2 = every dense rows-output launch
         static const int w4 = getenv("KG_HALO7_W4") ? atoi(getenv("KG_HALO7_W4")) : 1;
         static const int w4dir = getenv("KG_HALO7_W4_DIR") ? atoi(getenv("KG_HALO7_W4_DIR")) : 3;      // bisecting: bit 0 = forward launches, bit 1 = flipped (input gradient)
         const bool ok = !a.tiletab && a.y && !a.y_f32 && !a.stat_part && !a.oscale && a.ksplit <= 1 && ((w4dir >> (a.flip ? 1 : 0)) & 1);
-        if (ok && (w4 >= 2 || (w4 == 1 && a.walk3 && a.km.n >= 2))) {
+        if (ok && (w4 >= 2 || (w4 == 1 && a.cin_pad / 64 > a.km.n && a.km.n >= 2))) {
             static bool w4_attr = false;
             if (!w4_attr) {
                 KG_HIP(hipFuncSetAttribute((const void*)conv_halo7_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));

@@ -31,7 +31,32 @@ __device__ __forceinline__ void reads(f16x8 (&a)[TA], f16x8 (&b)[TB], unsigned l
     rd<0, TB>(b, lb);
 }
 
-template <int TA, int TB, int WAVES, bool LDS>
+// IL > 0: the reads of the next k-step are dealt out between the MFMAs of the current one, one ds_read_b128 behind every IL-th MFMA (the wait
+// at the head of a k-step is then lgkmcnt(0)); IL = 0: all reads in one block in front of the MFMAs (counted wait).
+template <int I, int TA, int TB, int IL>
+__device__ __forceinline__ void il_step(f32x4 (&acc)[TA][TB], f16x8 (&a)[TA], f16x8 (&b)[TB], f16x8 (&an)[TA], f16x8 (&bn)[TB], unsigned la, unsigned lb) {
+    if constexpr (I < TA * TB) {
+        acc[I / TB][I % TB] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[I / TB], b[I % TB], acc[I / TB][I % TB], 0, 0, 0);
+        if constexpr ((I + 1) % IL == 0 && (I + 1) / IL - 1 < TA + TB) {
+            constexpr int K = (I + 1) / IL - 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (K < TA) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(an[K]) : "v"(la), "n"(K * 1024));
+            else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bn[K - TA]) : "v"(lb), "n"((K - TA) * 1024));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        il_step<I + 1, TA, TB, IL>(acc, a, b, an, bn, la, lb);
+    }
+}
+template <int TA, int TB>
+__device__ __forceinline__ void tie_wait0(f16x8 (&a)[TA], f16x8 (&b)[TB]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < TA; ++i) asm volatile("" : "+v"(a[i]));
+#pragma unroll
+    for (int i = 0; i < TB; ++i) asm volatile("" : "+v"(b[i]));
+}
+
+template <int TA, int TB, int WAVES, bool LDS, int IL = 0>
 __global__ __launch_bounds__(WAVES * 64) void k(const uint4* __restrict__ g, float* out, int iters, int data) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,24 +99,33 @@ __global__ __launch_bounds__(WAVES * 64) void k(const uint4* __restrict__ g, flo
         if (LDS && !(it & 1))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + (it & 7) * (WAVES * 64)),
                                              (__attribute__((address_space(3))) void*)(smem + 65536 + (it & 7) * 8192 + __builtin_amdgcn_readfirstlane(wave) * 1024), 16, 0, 0);
+        if constexpr (LDS && IL > 0) {
+            tie_wait0<TA, TB>(a0, b0);
+            il_step<0, TA, TB, IL>(acc, a0, b0, a1, b1, offA + sh + 4096, offB + sh + 4096);
+            __builtin_amdgcn_sched_barrier(0);
+            tie_wait0<TA, TB>(a1, b1);
+            il_step<0, TA, TB, IL>(acc, a1, b1, a0, b0, offA + sh, offB + sh);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
         if (LDS) {
-            reads<TA, TB>(a1, b1, offA + sh + 4096, offB + sh + 4096);
-            Wait<TA + TB>::go();
+                reads<TA, TB>(a1, b1, offA + sh + 4096, offB + sh + 4096);
+                Wait<TA + TB>::go();
+            }
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int j = 0; j < TB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (LDS) {
+                reads<TA, TB>(a0, b0, offA + sh, offB + sh);
+                Wait<TA + TB>::go();
+            }
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int j = 0; j < TB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int i = 0; i < TA; ++i)
-#pragma unroll
-            for (int j = 0; j < TB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[i], b0[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (LDS) {
-            reads<TA, TB>(a0, b0, offA + sh, offB + sh);
-            Wait<TA + TB>::go();
-        }
-#pragma unroll
-        for (int i = 0; i < TA; ++i)
-#pragma unroll
-            for (int j = 0; j < TB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[i], b1[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
         if (LDS && ((it + 1) * 2 % PER_BARRIER == 0 || PER_BARRIER <= 2)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -107,21 +141,21 @@ __global__ __launch_bounds__(WAVES * 64) void k(const uint4* __restrict__ g, flo
     out[blockIdx.x * WAVES * 64 + tid] = s + (float)a0[0][0] + (float)b0[0][0];
 }
 
-template <int TA, int TB, int WAVES, bool LDS>
+template <int TA, int TB, int WAVES, bool LDS, int IL = 0>
 static void run(const uint4* g, float* out, int iters, int data) {
-    hipFuncSetAttribute((const void*)k<TA, TB, WAVES, LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
+    hipFuncSetAttribute((const void*)k<TA, TB, WAVES, LDS, IL>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
     hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
     // equal MFMA work per CU for every shape: iters k-step pairs of a 4 x 4 tile on 8 waves
     const int its = (int)((long)iters * 16 * 8 / (TA * TB * WAVES));
-    k<TA, TB, WAVES, LDS><<<256, WAVES * 64, 155 * 1024>>>(g, out, its, data);
+    k<TA, TB, WAVES, LDS, IL><<<256, WAVES * 64, 155 * 1024>>>(g, out, its, data);
     hipDeviceSynchronize();
     hipEventRecord(s);
-    k<TA, TB, WAVES, LDS><<<256, WAVES * 64, 155 * 1024>>>(g, out, its, data);
+    k<TA, TB, WAVES, LDS, IL><<<256, WAVES * 64, 155 * 1024>>>(g, out, its, data);
     hipEventRecord(e); hipEventSynchronize(e);
     float ms; hipEventElapsedTime(&ms, s, e);
     const double fl = 256.0 * WAVES * its * 2 * TA * TB * 16384.0;
-    printf("data %d  tile %3d x %3d  waves %d  %s: %8.3f ms  %7.1f TFLOP/s  (%d reads / %d MFMAs per k-step) %s\n", data, TA * 16, TB * 16, WAVES,
-           LDS ? "LDS-fed " : "registers", ms, fl / ms / 1e9, LDS ? TA + TB : 0, TA * TB, hipGetErrorString(hipGetLastError()));
+    printf("data %d  tile %3d x %3d  waves %d  %s%s: %8.3f ms  %7.1f TFLOP/s  (%d reads / %d MFMAs per k-step) %s\n", data, TA * 16, TB * 16, WAVES,
+           LDS ? "LDS-fed " : "registers", IL == 0 ? "            " : IL == 1 ? " read/MFMA   " : " read/2 MFMAs", ms, fl / ms / 1e9, LDS ? TA + TB : 0, TA * TB, hipGetErrorString(hipGetLastError()));
 }
 
 int main(int argc, char** argv) {
@@ -137,6 +171,12 @@ int main(int argc, char** argv) {
         run<8, 8, 4, false>(g, out, iters, data);
         run<8, 8, 4, true>(g, out, iters, data);
         run<4, 4, 4, true>(g, out, iters, data);
+        run<4, 4, 8, true, 1>(g, out, iters, data);
+        run<4, 4, 8, true, 2>(g, out, iters, data);
+        run<8, 4, 4, true, 1>(g, out, iters, data);
+        run<8, 4, 4, true, 2>(g, out, iters, data);
+        run<8, 8, 4, true, 2>(g, out, iters, data);
+        run<8, 8, 4, true, 3>(g, out, iters, data);
     }
     return 0;
 }
