@@ -46,6 +46,26 @@ __device__ __forceinline__ bool hough_contrib(const float* __restrict__ kp, cons
     return true;
 }
 
+// The four votes of source pixel i = (y, x) of channel c at once (the same expressions as hough_contrib, evaluated once): target (I, J), value
+// and validity per corner b (order tl, tr, bl, br = the reference's concatenation order, postprocessing.py:24-33).
+struct HVote4 { int I[4], J[4]; double v[4]; bool ok[4]; };
+__device__ __forceinline__ void hough_vote4(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W, int c, int i, int y, int x,
+                                            HVote4& o) {
+    const long HW = (long)H * W;
+    const double xs = (double)x + (double)soff[(long)(2 * c) * HW + i];
+    const double ys = (double)y + (double)soff[(long)(2 * c + 1) * HW + i];
+    const double ps = (double)kp[(long)c * HW + i];
+    const int fx = f2i_np(floor(xs)), fy = f2i_np(floor(ys));
+    const int cx = f2i_np(ceil(xs)), cy = f2i_np(ceil(ys));
+    const double dx = xs - (double)fx, dy = ys - (double)fy;
+    o.I[0] = fy; o.J[0] = fx; o.v[0] = ps * (1. - dx) * (1. - dy);
+    o.I[1] = fy; o.J[1] = cx; o.v[1] = ps * dx * (1. - dy);
+    o.I[2] = cy; o.J[2] = fx; o.v[2] = ps * dy * (1. - dx);
+    o.I[3] = cy; o.J[3] = cx; o.v[3] = ps * dy * dx;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) o.ok[b] = !(o.I[b] < 0 || o.I[b] >= H || o.J[b] < 0 || o.J[b] >= W || o.v[b] == 0.);
+}
+
 // exclusive scan of count[c][0..HW) -> offs; one block (1024 threads) per channel.
 __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ count, int* __restrict__ offs, int n, int* __restrict__ total = nullptr) {
     __shared__ int tot[1024];
@@ -86,7 +106,8 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ coun
 #define HOUGH_LCAP 512
 __global__ void hough_scatter_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W, int* __restrict__ cnt,
                                      unsigned* __restrict__ ink, double* __restrict__ inv, int* __restrict__ ovcell,
-                                     double* __restrict__ ovval) {
+                                     double* __restrict__ ovval, const int* __restrict__ hdr) {
+    if (!hdr[1]) return;                         // (the tile formulation produced the map)
     const int c = blockIdx.y, HW = H * W;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 4 * HW; e += gridDim.x * blockDim.x) {
         const int b = e / HW, i = e - b * HW;
@@ -117,7 +138,8 @@ __global__ __launch_bounds__(1024) void hough_classify_kernel(int ncells, const 
                                                               const double* __restrict__ inv, double norm, double* __restrict__ heat,
                                                               unsigned long long* __restrict__ ctr64, int* __restrict__ ovoff,
                                                               int* __restrict__ heavy_list, unsigned* __restrict__ skey,
-                                                              double* __restrict__ sval) {
+                                                              double* __restrict__ sval, const int* __restrict__ hdr) {
+    if (!hdr[1]) return;
     __shared__ int s_need[1024], s_hv[1024];
     __shared__ unsigned long long s_base;
     const int cc = blockIdx.x * 1024 + threadIdx.x;
@@ -179,7 +201,8 @@ __global__ __launch_bounds__(1024) void hough_classify_kernel(int ncells, const 
 }
 __global__ void hough_ovfill_kernel(long nvotes, int HW4, const int* __restrict__ ovcell, const double* __restrict__ ovval,
                                     const int* __restrict__ ovoff, int* __restrict__ ovcur, unsigned* __restrict__ skey,
-                                    double* __restrict__ sval) {
+                                    double* __restrict__ sval, const int* __restrict__ hdr) {
+    if (!hdr[1]) return;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvotes; i += (long)gridDim.x * blockDim.x) {
         const int cc = ovcell[i];
         if (cc < 0) continue;
@@ -191,7 +214,9 @@ __global__ void hough_ovfill_kernel(long nvotes, int HW4, const int* __restrict_
 __global__ __launch_bounds__(64) void hough_heavy2_kernel(const int* __restrict__ cnt, const int* __restrict__ ovoff,
                                                           const unsigned* __restrict__ skey, const double* __restrict__ sval,
                                                           double* __restrict__ srt, double norm, double* __restrict__ heat,
-                                                          const unsigned long long* __restrict__ ctr64, const int* __restrict__ heavy_list) {
+                                                          const unsigned long long* __restrict__ ctr64, const int* __restrict__ heavy_list,
+                                                          const int* __restrict__ hdr) {
+    if (!hdr[1]) return;
     __shared__ unsigned lk[HOUGH_LCAP];
     __shared__ double lv[HOUGH_LCAP];
     const int nh = (int)(unsigned)(*ctr64 >> 32);
@@ -231,6 +256,190 @@ __global__ __launch_bounds__(64) void hough_heavy2_kernel(const int* __restrict_
             __syncthreads();
         }
     }
+}
+
+// ---- P1, tile formulation (round 5): the same per-cell ordered sums with NO global atomics ---------------------------------------------
+// The scatter formulation above pays one returning global atomic per vote (21 M at 1024 x 1024: 1.3 ms) plus 480 MB of inline slots.  Votes are
+// local: a trained network's short offsets stay within the keypoint radius (5 px), so the votes of a 32 x 32-cell output tile come from the
+// 64 x 64 source pixels around it.  One workgroup per (tile, channel):
+//   pass A  every source pixel of the 64 x 64 region computes its four votes; the ones that land in the tile count up cnt[cell] (LDS atomic);
+//   scan    exclusive scan of the 1024 counters -> per-cell slabs in ONE compact LDS array (<= HT_CAP votes per tile);
+//   pass B  the votes again (kept in registers: 16 per thread), now stored at slab[off[cell] + cur[cell]++] as (key, value);
+//   sums    one thread per cell with <= 8 votes: the register sorting network + ordered sum of the scatter formulation; heavier cells: one wave
+//           per cell ranks the slab's keys and lane 0 adds the values in rank order (through an LDS scratch, HT_SCR ranks at a time).
+// A vote whose source lies OUTSIDE its target tile's region ("far": |offset| beyond 16 .. 48 px) is found by a pre-pass over the pixels
+// (hough_far_kernel: same integer test) and listed globally; every tile workgroup also scans that list.  More than HOUGH_FARCAP far votes (a
+// random-init network: offsets of hundreds of pixels) or more than HT_CAP votes in one tile raise hdr[1] and the scatter formulation runs
+// instead -- its kernels return at once while hdr[1] == 0.  Same keys, same order, same fp64 adds: the same bits.
+#define HT_T 32
+#define HT_R 16
+#define HT_S (HT_T + 2 * HT_R)
+#define HT_CAP 8192
+#define HT_SCR 320
+#define HOUGH_FARCAP 16384
+__device__ __forceinline__ bool hough_is_far(int y, int x, int I, int J) {
+    const int ry = y - ((I / HT_T) * HT_T - HT_R), rx = x - ((J / HT_T) * HT_T - HT_R);
+    return (unsigned)ry >= (unsigned)HT_S || (unsigned)rx >= (unsigned)HT_S;
+}
+__global__ __launch_bounds__(256) void hough_far_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W, int* __restrict__ hdr,
+                                                        int* __restrict__ farcell, unsigned* __restrict__ farkey, double* __restrict__ farval,
+                                                        int4* __restrict__ clr, long clr_n4) {
+    const int c = blockIdx.y, HW = H * W;
+    // (also: zero the vote counters / slab cursors of the scatter formulation, should the tile formulation give up -- 15 HW bytes, no launch of its own)
+    for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < clr_n4; i += (long)gridDim.x * gridDim.y * blockDim.x)
+        clr[i] = make_int4(0, 0, 0, 0);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        HVote4 o;
+        hough_vote4(kp, soff, H, W, c, i, y, x, o);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (o.ok[b] && hough_is_far(y, x, o.I[b], o.J[b])) {
+                const int pos = atomicAdd(&hdr[0], 1);
+                if (pos < HOUGH_FARCAP) { farcell[pos] = c * HW + o.I[b] * W + o.J[b]; farkey[pos] = (unsigned)(b * HW + i); farval[pos] = o.v[b]; }
+                else hdr[1] = 1;
+            }
+    }
+}
+__global__ __launch_bounds__(1024) void hough_tile_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W, double norm,
+                                                          double* __restrict__ heat, int* __restrict__ hdr, const int* __restrict__ farcell,
+                                                          const unsigned* __restrict__ farkey, const double* __restrict__ farval, int tiles_x) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    int* cnt = reinterpret_cast<int*>(sm);
+    int* off = cnt + 1024;
+    int* cur = off + 1024;                       // (after pass B: the list of heavy cells)
+    unsigned* keys = reinterpret_cast<unsigned*>(cur + 1024);
+    double* vals = reinterpret_cast<double*>(keys + HT_CAP);
+    double* scr = vals + HT_CAP;                 // [16 waves][HT_SCR]
+    __shared__ int s_nh, s_wtot[16];
+    if (hdr[1]) return;                          // (uniform: the scatter formulation takes over)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.y, HW = H * W;
+    const int tI = blockIdx.x / tiles_x, tJ = blockIdx.x - tI * tiles_x;
+    const int y0 = tI * HT_T - HT_R, x0 = tJ * HT_T - HT_R;
+    const int nfar = hdr[0] < HOUGH_FARCAP ? hdr[0] : HOUGH_FARCAP;
+    cnt[tid] = 0; cur[tid] = 0;
+    if (tid == 0) s_nh = 0;
+    __syncthreads();
+    // pass A: the thread's four source pixels (all twelve loads in flight at once), their 16 votes kept in registers for pass B
+    constexpr int NPX = HT_S * HT_S / 1024;
+    float pk[NPX], px[NPX], py[NPX];
+    int pi[NPX];
+#pragma unroll
+    for (int q = 0; q < NPX; ++q) {
+        const int idx = tid + q * 1024;
+        const int y = y0 + (idx >> 6), x = x0 + (idx & 63);
+        const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        pi[q] = in ? y * W + x : -1;
+        const int i = in ? y * W + x : 0;
+        pk[q] = kp[(long)c * HW + i]; px[q] = soff[(long)(2 * c) * HW + i]; py[q] = soff[(long)(2 * c + 1) * HW + i];
+    }
+    short lc[4 * NPX]; unsigned kk[4 * NPX]; double vv[4 * NPX];
+#pragma unroll
+    for (int q = 0; q < NPX; ++q) {
+        const int i = pi[q];
+        const int y = i / W, x = i - y * W;
+        // (the expressions of hough_vote4 / hough_contrib on the loaded values)
+        const double xs = (double)x + (double)px[q], ys = (double)y + (double)py[q], ps = (double)pk[q];
+        const int fx = f2i_np(floor(xs)), fy = f2i_np(floor(ys));
+        const int cx = f2i_np(ceil(xs)), cy = f2i_np(ceil(ys));
+        const double dx = xs - (double)fx, dy = ys - (double)fy;
+        const int I[4] = {fy, fy, cy, cy}, J[4] = {fx, cx, fx, cx};
+        const double v[4] = {ps * (1. - dx) * (1. - dy), ps * dx * (1. - dy), ps * dy * (1. - dx), ps * dy * dx};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const bool ok = i >= 0 && !(I[b] < 0 || I[b] >= H || J[b] < 0 || J[b] >= W || v[b] == 0.) && I[b] / HT_T == tI && J[b] / HT_T == tJ;
+            lc[4 * q + b] = ok ? (short)(((I[b] - tI * HT_T) << 5) | (J[b] - tJ * HT_T)) : (short)-1;
+            kk[4 * q + b] = (unsigned)(b * HW + i); vv[4 * q + b] = v[b];
+            if (ok) atomicAdd(&cnt[lc[4 * q + b]], 1);
+        }
+    }
+    auto visit_far = [&](auto&& f) {
+        for (int q = tid; q < nfar; q += 1024) {
+            const int cc = farcell[q] - c * HW;
+            if (cc < 0 || cc >= HW) continue;
+            const int I = cc / W, J = cc - I * W;
+            if (I / HT_T == tI && J / HT_T == tJ) f(((I - tI * HT_T) << 5) | (J - tJ * HT_T), farkey[q], farval[q]);
+        }
+    };
+    visit_far([&](int l, unsigned, double) { atomicAdd(&cnt[l], 1); });
+    __syncthreads();
+    // exclusive scan of cnt -> off (1024 entries, one per thread): wave scans by cross-lane moves, the 16 wave totals through LDS
+    const int n = cnt[tid];
+    int incl = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_wtot[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int t = s_wtot[w]; if (w < wave) wbase += t; total += t; }
+    const int base = wbase + incl - n;
+    off[tid] = base;
+    if (total > HT_CAP) {                        // (uniform) too many votes for the LDS slabs: the scatter formulation recomputes the whole map
+        if (tid == 0) hdr[1] = 1;
+        return;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4 * NPX; ++q)
+        if (lc[q] >= 0) { const int p = off[lc[q]] + atomicAdd(&cur[lc[q]], 1); keys[p] = kk[q]; vals[p] = vv[q]; }
+    visit_far([&](int l, unsigned k, double v) { const int p = off[l] + atomicAdd(&cur[l], 1); keys[p] = k; vals[p] = v; });
+    __syncthreads();
+    {
+        const int I = tI * HT_T + (tid >> 5), J = tJ * HT_T + (tid & 31);
+        const bool inside = I < H && J < W;
+        if (inside && n <= HOUGH_K) {
+            unsigned k[HOUGH_K]; double v[HOUGH_K];
+#pragma unroll
+            for (int e = 0; e < HOUGH_K; ++e) { k[e] = e < n ? keys[base + e] : 0xffffffffu; v[e] = e < n ? vals[base + e] : 0.; }
+            hough_cswap(k[0], v[0], k[1], v[1]); hough_cswap(k[2], v[2], k[3], v[3]); hough_cswap(k[4], v[4], k[5], v[5]); hough_cswap(k[6], v[6], k[7], v[7]);
+            hough_cswap(k[0], v[0], k[2], v[2]); hough_cswap(k[1], v[1], k[3], v[3]); hough_cswap(k[4], v[4], k[6], v[6]); hough_cswap(k[5], v[5], k[7], v[7]);
+            hough_cswap(k[1], v[1], k[2], v[2]); hough_cswap(k[5], v[5], k[6], v[6]);
+            hough_cswap(k[0], v[0], k[4], v[4]); hough_cswap(k[1], v[1], k[5], v[5]); hough_cswap(k[2], v[2], k[6], v[6]); hough_cswap(k[3], v[3], k[7], v[7]);
+            hough_cswap(k[2], v[2], k[4], v[4]); hough_cswap(k[3], v[3], k[5], v[5]);
+            hough_cswap(k[1], v[1], k[2], v[2]); hough_cswap(k[3], v[3], k[4], v[4]); hough_cswap(k[5], v[5], k[6], v[6]);
+            double s = 0.;
+#pragma unroll
+            for (int e = 0; e < HOUGH_K; ++e)
+                if (e < n) s += v[e];
+            heat[(long)c * HW + (long)I * W + J] = s / norm;
+        } else if (inside) {
+            cur[atomicAdd(&s_nh, 1)] = tid;      // (cur is free after pass B: the heavy cells of the tile, in any order)
+        }
+    }
+    __syncthreads();
+    const int nh = s_nh;
+    double* my = scr + wave * HT_SCR;
+    for (int h = wave; h < nh; h += 16) {
+        const int t = cur[h], m = cnt[t], b0 = off[t];
+        double s = 0.;
+        for (int r0 = 0; r0 < m; r0 += HT_SCR) {         // ranks r0 .. r0 + HT_SCR - 1 of the cell's votes, then the next window
+            for (int e = lane; e < m; e += 64) {
+                const unsigned ke = keys[b0 + e];
+                int rank = 0;
+                for (int j = 0; j < m; ++j) rank += keys[b0 + j] < ke;
+                if (rank >= r0 && rank < r0 + HT_SCR) my[rank - r0] = vals[b0 + e];
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                const int w = m - r0 < HT_SCR ? m - r0 : HT_SCR;
+                for (int q = 0; q < w; ++q) s += my[q];
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) heat[(long)c * HW + (long)(tI * HT_T + (t >> 5)) * W + (tJ * HT_T + (t & 31))] = s / norm;
+    }
+}
+// start of the scatter formulation when the tile formulation gave up (hdr[1] != 0): clears the slab allocator, the vote counters and the cursors
+__global__ void hough_clear_kernel(const int* __restrict__ hdr, int4* __restrict__ a, long n4) {
+    if (!hdr[1]) return;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) a[i] = make_int4(0, 0, 0, 0);
 }
 
 // ---- P2 ---------------------------------------------------------------------------------------
@@ -824,19 +1033,41 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
     const int HW = H * W;
     const double norm = 3.141592653589793 * 25.0;  // np.pi * KP_RADIUS**2 (postprocessing.py:51)
     pp_mark(st);
-    int gx = (4 * HW + 255) / 256; if (gx > 4096) gx = 4096;
+    int gx = (4 * HW + 255) / 256; if (gx > 2048) gx = 2048;
     {
-        // heavy_n (the 64-bit slab allocator) | count | offs | cursor are consecutive in the workspace: ONE memset clears the allocator, the
-        // vote counters (count) and the slab cursors (cursor)
-        KG_HIP(hipMemsetAsync(p.heavy_n, 0, (size_t)((unsigned char*)p.cursor - (unsigned char*)p.heavy_n) + (size_t)5 * HW * 4, st));
+        // header (p.heavy_n, 256 bytes): [0..1] the 64-bit slab allocator of the scatter formulation, [8] = far-vote count, [9] = "tile formulation
+        // gave up" flag (hdr = &heavy_n[8]).  KG_HOUGH_TILE=0: scatter formulation only.
+        static const int use_tile = getenv("KG_HOUGH_TILE") ? atoi(getenv("KG_HOUGH_TILE")) : 1;
+        int* hdr = p.heavy_n + 8;
+        const long clr = (long)(((unsigned char*)p.cursor - (unsigned char*)p.count) + (size_t)5 * HW * 4) / 16;
+        KG_HIP(hipMemsetAsync(p.heavy_n, 0, 256, st));
+        if (use_tile) {
+            // far list in the scatter formulation's (then unused) arrays: cells in `sorted`, keys in `keys`, values in `vals`
+            int* farcell = reinterpret_cast<int*>(p.sorted);
+            int gf = (HW + 255) / 256; if (gf > 2048) gf = 2048;
+            hipLaunchKernelGGL(hough_far_kernel, dim3(gf, 5), dim3(256), 0, st, kp, soff, H, W, hdr, farcell, p.keys, p.vals, reinterpret_cast<int4*>(p.count), clr);
+            constexpr int tile_lds = 3 * 1024 * 4 + HT_CAP * 4 + HT_CAP * 8 + 16 * HT_SCR * 8;
+            static bool tile_attr = false;
+            if (!tile_attr) {
+                KG_HIP(hipFuncSetAttribute((const void*)hough_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tile_lds));
+                tile_attr = true;
+            }
+            const int tiles_x = (W + HT_T - 1) / HT_T, tiles_y = (H + HT_T - 1) / HT_T;
+            hipLaunchKernelGGL(hough_tile_kernel, dim3(tiles_x * tiles_y, 5), dim3(1024), tile_lds, st, kp, soff, H, W, norm, p.heat, hdr, farcell, p.keys,
+                               p.vals, tiles_x);
+        } else {
+            KG_HIP(hipMemsetD32Async((hipDeviceptr_t)(hdr + 1), 1, 1, st));
+            hipLaunchKernelGGL(hough_clear_kernel, dim3(1024), dim3(256), 0, st, hdr, reinterpret_cast<int4*>(p.count), clr);
+        }
+        // scatter formulation, every kernel a no-op while hdr[1] == 0 (its counters count | offs | cursor were cleared by the far pass)
         unsigned long long* ctr64 = reinterpret_cast<unsigned long long*>(p.heavy_n);
-        hipLaunchKernelGGL(hough_scatter_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.count, p.ink, p.inv, (int*)p.keys, p.vals);
+        hipLaunchKernelGGL(hough_scatter_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.count, p.ink, p.inv, (int*)p.keys, p.vals, hdr);
         hipLaunchKernelGGL(hough_classify_kernel, dim3((5 * HW + 1023) / 1024), dim3(1024), 0, st, 5 * HW, p.count, p.ink, p.inv, norm, p.heat, ctr64,
-                           p.offs, p.heavy_list, p.skey, p.sorted);
-        int go = (int)(((long)20 * HW + 255) / 256); if (go > 8192) go = 8192;
+                           p.offs, p.heavy_list, p.skey, p.sorted, hdr);
+        int go = (int)(((long)20 * HW + 255) / 256); if (go > 4096) go = 4096;
         hipLaunchKernelGGL(hough_ovfill_kernel, dim3(go), dim3(256), 0, st, (long)20 * HW, 4 * HW, (const int*)p.keys, p.vals, p.offs, p.cursor, p.skey,
-                           p.sorted);
-        hipLaunchKernelGGL(hough_heavy2_kernel, dim3(4096), dim3(64), 0, st, p.count, p.offs, p.skey, p.sorted, p.srt, norm, p.heat, ctr64, p.heavy_list);
+                           p.sorted, hdr);
+        hipLaunchKernelGGL(hough_heavy2_kernel, dim3(4096), dim3(64), 0, st, p.count, p.offs, p.skey, p.sorted, p.srt, norm, p.heat, ctr64, p.heavy_list, hdr);
     }
     int gg = (5 * HW + 255) / 256; if (gg > 8192) gg = 8192;
     pp_mark(st);

@@ -190,3 +190,53 @@ def test_paste_masks_vs_oracle(image_hw):
     dev_masks, _ = kpp.paste_masks(pred, S, S, iw, ih, 0.5, device_u8=True)
     assert dev_masks.dtype == torch.uint8 and np.array_equal(dev_masks.cpu().numpy().astype(np.float32), ref[0])
     assert kpp.paste_masks(None, S, S, iw, ih, 0.5) is None
+
+
+def _heat(kp, short):
+    mid = np.zeros((1, 40) + kp.shape[2:], np.float32)
+    return run_stages(kp, short, mid)["heat"]
+
+
+@pytest.mark.parametrize("case", ["far_votes", "heavy_cell_beyond_scratch", "tile_overflow", "far_list_overflow"])
+def test_hough_tile_formulation_edge_cases(case):
+    """The tile formulation of the Hough vote (csrc/postproc.hip: one workgroup per 32 x 32-cell tile, votes gathered from the 64 x 64 source
+    pixels around it, LDS slabs) against the oracle, bit for bit, where it leaves its common path: votes from OUTSIDE a tile's source region
+    (the global far list), a cell with more votes than the rank-sort scratch holds (window loop), a tile with more votes than its LDS slabs
+    hold and more far votes than the list holds (both: the scatter formulation takes over)."""
+    rng = np.random.default_rng(31)
+    H, W = 160, 192
+    kp = np.clip(rng.random((1, 5, H, W)), 0.05, 1).astype(np.float32)
+    short = rng.normal(0, 0.6, (1, 10, H, W)).astype(np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    if case == "far_votes":
+        idx = rng.choice(H * W, 300, replace=False)
+        for c in range(10):
+            short[0, c].flat[idx] += rng.choice([-1, 1], 300) * rng.uniform(17, 120, 300)      # beyond the 16 .. 48 px reach of a tile's region
+    elif case == "heavy_cell_beyond_scratch":
+        # a 22 x 22 block of every channel votes into ONE cell with integer offsets (three of the four bilinear weights are 0): 484 votes > HT_SCR
+        short[0, 0::2, 40:62, 70:92] = (81 - xx[40:62, 70:92]).astype(np.float32)
+        short[0, 1::2, 40:62, 70:92] = (51 - yy[40:62, 70:92]).astype(np.float32)
+        short[0, :, 100:104, 100:104] = 0.5          # and cells fed by four half-weight votes from 16 pixels
+    elif case == "tile_overflow":
+        # a 48 x 48 block votes (fractional offsets: all four corners live) into the 4 x 4 cells around (80, 100): > HT_CAP votes in one tile
+        short[0, 0::2, 56:104, 76:124] = (100.3 - xx[56:104, 76:124]).astype(np.float32) + rng.uniform(0, 3, (48, 48)).astype(np.float32)
+        short[0, 1::2, 56:104, 76:124] = (80.3 - yy[56:104, 76:124]).astype(np.float32) + rng.uniform(0, 3, (48, 48)).astype(np.float32)
+    else:
+        short = (rng.normal(0, 60, (1, 10, H, W))).astype(np.float32)                          # an untrained network: nearly every vote is far
+    got = _heat(kp, short)
+    ref = op.hough(kp, short)
+    assert diff_report(case, got, ref)
+
+
+def test_scatter_formulation_of_the_hough_vote_still_bit_exact():
+    """KG_HOUGH_TILE=0 runs the scatter formulation alone (the path the tile formulation falls back to): the golden stage tests, the full-size
+    oracle comparison and the random maps in a process that selects it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KG_HOUGH_TILE="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_postproc.py"), "-q", "-x", "-k",
+                        "stages_vs_golden or full_size_vs_oracle or random_maps"], capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "9 passed" in r.stdout, r.stdout[-500:]
