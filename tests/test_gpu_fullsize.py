@@ -5,7 +5,7 @@ float32 -- the reference's own arithmetic -- AND in float64, every kp logit / sh
 graphs takes 12 minutes of host time, so that leg is opt-in; its result on this build is in profiles/r05_fullsize_test.txt).
 
 What can and cannot hold at this size (measured, profiles/r05_fullsize_test.txt): two float32-grade evaluations of this network are
-each ~1.3-1.4 bounds (rtol 1e-4, atol 1e-5) from the float64 value -- the reference's own fp32 arithmetic included: 12 544 / 25 088-term dot
+each ~1.1-1.2 bounds (rtol 1e-4, atol 1e-5) from the float64 value -- the reference's own fp32 arithmetic included: 12 544 / 25 088-term dot
 products in the c2 / c3 heads on top of 50 layers -- so "<= 1.0 against the float32 oracle" is not a statement any fp32 implementation can
 make here.  What is asserted instead:
   * the policy is AS CLOSE TO FLOAT64 AS THE REFERENCE'S ARITHMETIC IS: worst |d| / bound of (policy vs oracle64) <= FLOOR_SLACK x the same
@@ -28,15 +28,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-FLOOR_SLACK = 1.10      # policy-vs-float64 may exceed oracle32-vs-float64 by 10 % (max statistics over 1e8 elements; measured 1.436 / 1.376 = 1.04)
+FLOOR_SLACK = 1.10      # policy-vs-float64 may exceed oracle32-vs-float64 by 10 % (max statistics over 1e8 elements; measured 1.160 / 1.125 = 1.03)
 WITH_GRADS = os.environ.get("KG_FULLSIZE_GRADS", "0") == "1"
 ABS_CAP_VS_ORACLE32 = 2.5
 
 
 def test_train_step_at_bench_configuration_vs_oracle_fp32_and_fp64():
-    """measured on MI355X (r05, this build; profiles/r05_fullsize_test.txt): oracle32 vs oracle64 worst 1.376 bounds; policy vs oracle64 1.436
-    (before the blocked accumulation of the wide 7x7 heads: 1.546); policy vs oracle32 2.141; losses equal to float64's to 1e-7; all 217
-    gradients cosine >= 0.99998, norms within 1.2e-3 of the float32 oracle's."""
+    """measured on MI355X (r05, this build; profiles/r05_fullsize_test.txt): oracle32 vs oracle64 worst 1.125 bounds; policy vs oracle64 1.160
+    (ratio 1.03); policy vs oracle32 1.581; at most 1.2e-4 of a map's elements beyond the bound; losses equal to float64's to 1e-7; with
+    KG_FULLSIZE_GRADS=1 all 217 gradients cosine >= 0.99998, norms within 1.2e-3 of the float32 oracle's."""
     import fullsize_oracle_parity as fs
     from kg_instance_segmentation_amd import KGnet
     from kg_instance_segmentation_amd.loss import DetectionLossAll

@@ -22,10 +22,10 @@ for line in open(os.path.join(root, f"{tag}_bench_launches.txt")):
         continue
     k, cinp, mode = int(kv["k"]), int(kv["cinp"]), int(kv["mode"])
     xP, yP, prod, stride = int(kv.get("xP", 1)), int(kv.get("yP", 1)), int(kv.get("products", 1)), int(kv.get("stride", 1))
-    cin = cinp // max(prod, 1) if prod > 1 else cinp            # cinp counts the virtual channels of the packed weights
+    cin = cinp                                                   # (cin_pad of one plane; the packed weights hold `products` copies)
     per = ms / cnt
     m_in = M * stride * stride if mode in (0, 2) else M // (stride * stride) if stride > 1 else M
-    bytes_ = m_in * cin * xP * 2 + M * cout * max(yP, 1) * 2 + cout * k * k * cinp * 2
+    bytes_ = m_in * cin * xP * 2 + M * cout * max(yP, 1) * 2 + cout * k * k * cinp * prod * 2
     gbs = bytes_ / (per * 1e-3) / 1e9
     issued = tf * prod
     wgs = -(-M // (128 if name.endswith(", 1>") else 256)) * -(-cout // (64 if name.endswith(", 1>") else 128))
