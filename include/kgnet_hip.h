@@ -6,7 +6,11 @@
  * kg_instance_segmentation_amd/ bind the entry points below with ctypes; every entry point cites the
  * reference code it replaces.  Conventions:
  *   - extern "C", plain pointers and sizes, no torch types.  All pointers are DEVICE pointers unless
- *     stated otherwise; the library never allocates or retains device memory.
+ *     stated otherwise; the library never retains a caller's pointer past the call (the recorded weight-gradient reductions between
+ *     kg_wgrad_reduce_defer(1) and the flush excepted) and allocates no device memory of its own EXCEPT two per-device scratch buffers,
+ *     created on first use and kept for the life of the process: the split-K partial tiles of under-filled conv launches (64 MB) and
+ *     the partial maps of split kg_conv2d_halo_heads2 launches (grown to 3 x parts x N x 55 x H x W floats, <= 384 MB).  A launch that
+ *     uses one is followed by its finishing launch on the same stream, so conv calls of ONE device must come from one stream at a time.
  *   - every call enqueues on the caller's `stream` (a hipStream_t) and does not synchronise.
  *   - return value: 0 = ok, otherwise kg_last_error() (thread-local) describes the failure.
  *   - activations ("rows"): bf16, pixel-major [row][ld] (NHWC), channel counts multiples of 8.

@@ -178,6 +178,7 @@ class ResNet(nn.Module):
         if len(layers) < 3 or any(int(b) < 1 for b in layers[:3]):
             raise ValueError("layers must give the block counts of layer1..layer3")
         self.layers_tab = arch.layers_table(layers)          # KGnet.py:135-137 builds layers[0..2] only
+        self._slot_cache = {}            # get_tensor: key -> (the node's _parameters dict, its _buffers dict, leaf name)
         self._param_keys = []
         for key, shape, kind in arch.state_spec(layers):
             parts = key.split(".")
@@ -287,12 +288,18 @@ class ResNet(nn.Module):
 
     # ---- helpers ----------------------------------------------------------------------------------
     def get_tensor(self, key):
-        parts = key.split(".")
-        node = self
-        for p in parts[:-1]:
-            node = node._modules[p]
-        t = node._parameters.get(parts[-1])
-        return t if t is not None else node._buffers[parts[-1]]
+        """Parameter / buffer by its dotted reference key.  The containers of a key (the `_parameters` / `_buffers` dicts of its node) are resolved
+        once -- the module tree of this network never changes -- and read on every call, so a replaced Parameter is seen; ~700 look-ups per
+        train step go through here, and the 217 of the next step's first lines sit between the loss read-back and the step's first kernel."""
+        slot = self._slot_cache.get(key)
+        if slot is None:
+            parts = key.split(".")
+            node = self
+            for p in parts[:-1]:
+                node = node._modules[p]
+            slot = self._slot_cache[key] = (node._parameters, node._buffers, parts[-1])
+        t = slot[0].get(slot[2])
+        return t if t is not None else slot[1][slot[2]]
 
     def _check_input(self, x):
         if not x.is_cuda:

@@ -20,9 +20,12 @@ def main():
     for r in csv.DictReader(open(src)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.sub(r"\(.*", "", r["Kernel_Name"])))
     rows.sort()
-    # skip everything before the first adam_step_kernel (model setup / first warm-up step)
-    first = next((i for i, r in enumerate(rows) if "adam_step" in r[2]), 0)
-    rows = rows[first + 1:]
+    # steady-state steps only: from the SECOND adam_step_kernel (model set-up, the first warm-up step and its one-off allocations are out) to the last
+    marks = [i for i, r in enumerate(rows) if "adam_step" in r[2]]
+    if len(marks) >= 3:
+        rows = rows[marks[1] + 1:marks[-1] + 1]
+    else:
+        rows = rows[(marks[0] if marks else 0) + 1:]
     busy = 0
     end = rows[0][0]
     idle_by = defaultdict(lambda: [0, 0.0])
