@@ -396,8 +396,8 @@ def test_gather_128x64_variant_on_small_problems():
 
 
 def test_four_wave_blocked_7x7_halo_kernel_matches():
-    """conv_halo7_w4_kernel (csrc/conv_halo.hip: four waves of 64 couts x 128 pixels, accumulation restarted every 14 taps into a second
-    accumulator) serves the multi-chunk 3-product forward launches by default; KG_HALO7_W4=2 sends EVERY dense 7x7 rows-output launch of the
+    """conv_halo7_w4_kernel (csrc/conv_halo.hip: four waves of 64 couts x 128 pixels, accumulation restarted at every 64-channel chunk into a second
+    accumulator) serves the multi-product launches with >= 2 chunks per plane by default; KG_HALO7_W4=2 sends EVERY dense 7x7 rows-output launch of the
     halo / plane conv tests through it (forward and flipped input gradient, both 16-bit formats, masks / residuals, partial tiles)."""
     import os
     import subprocess

@@ -491,3 +491,30 @@ def test_weight_stationary_3x3_c64_ragged(dt):
         assert _lib.last_kernel(ops.fmt_of(xp)) == "conv3_ws_kernel"
         check(f"conv3_ws ragged yP={yP}", from_pt(y), ref, TOL[2] if yP == 2 else TOL[1])
     DT[0] = BF16
+
+
+def test_wide_7x7_accumulation_is_blocked():
+    """A 7x7 conv over 512 channels adds 784 MFMA results per output and plane product; in ONE fp32 accumulator the rounding error of that chain
+    is 1.0e-6 relative (tools/micro/mfma_accum.hip), torch-CPU's fp32 convolution -- the reference's arithmetic -- stays at 3.7e-7.  The default
+    route of hi + lo half operands (conv_halo7_w4_kernel: the chain cut at every 64-channel chunk) must be at the reference's level: relative rms
+    error against float64 <= 4.5e-7 (measured 2.3e-7 .. 3.7e-7; the 8-wave kernel alone: 9.9e-7, profiles/r05_head_error_probe.txt)."""
+    DT[0] = torch.float16
+    cin, cout, k, N, H, W = 512, 128, 7, 1, 32, 32
+    g = torch.Generator().manual_seed(5)
+    x = F.relu(torch.randn(N, cin, H, W, generator=g))
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 3)
+    c32 = F.conv2d(x, w, None, 1, 3)
+    xp = to_pt(rows_f32(x).to(DEV), 2)
+    pw = PackedWeight(cout, k * k, cin, DEV, xP=2, wP=2)
+    pw.pack(w.to(DEV))
+    y = alloc_pt(N * H * W, cout, 2, DEV)
+    route = ops.conv_auto(xp, pw, cout, (N * H * W, H, W, H, W, k, k, 1, 3), N, y=y, tiny=False)
+    torch.cuda.synchronize()
+    got = nchw(from_pt(y), N, H, W)
+
+    def rel(a):
+        return float((a.double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f"route {route}: relative rms error vs float64: HIP {rel(got):.3e}, torch-CPU float32 {rel(c32):.3e}")
+    assert route == "halo"
+    assert rel(got) <= 4.5e-7, (rel(got), rel(c32))
