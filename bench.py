@@ -67,7 +67,9 @@ class KernelTimer:
     # the 7x7 LDS-halo kernel family (forward + input gradient of the first-layer head convs), rocprofv3's names: the 8-wave kernel and
     # (round 5) its 4-wave sibling with the blocked accumulation, which serves the multi-chunk 3-product forward launches -- the same
     # workgroup tile, LDS image and load protocol; the roofline entry is taken over the launches of both
-    DOMINANT = ("conv_halo_kernel<7, 1, 8, 0>", "conv_halo7_w4_kernel<false>", "conv_halo7_w4_kernel<true>")
+    DOMINANT = ("conv_halo_kernel<7, 1, 8, 0>", "conv_halo7_w4_kernel<false, 1>", "conv_halo7_w4_kernel<true, 1>", "conv_halo7_w4_kernel<false, 2>",
+                "conv_halo7_w4_kernel<true, 2>", "conv_halo7_w4_kernel<false, 2> + conv_halo_kernel<7, 1, 8, 0>",
+                "conv_halo7_w4_kernel<true, 2> + conv_halo_kernel<7, 1, 8, 0>")
 
     def __init__(self):
         self.rec = []

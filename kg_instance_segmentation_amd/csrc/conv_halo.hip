@@ -56,6 +56,7 @@ struct HaloArgs {
     // the chunk sequence and stores its raw fp32 accumulators (kpart: [cout block][tile][z][wave][16 values][64 lanes]); conv_halo_finish_kernel
     // adds the parts in z order -- the order of the unsplit walk -- and runs the epilogue (+ statistics)
     int ksplit; float* kpart;
+    int nb2;          // launch_halo<7, 1, 8, 0>: 1 = this launch covers whole 128-cout blocks on conv_halo7_w4_kernel<*, 2>, -1 = never split off such a launch
 };
 
 // Planed input with the three products of the half-plane policies.  The packed weights keep the plane-major virtual-channel layout of
@@ -733,10 +734,14 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_finish_kernel(const H
 // Every tap offset is an instruction immediate (the 49 taps are a compile-time sequence, FLIP is a template parameter): no VALU in the loop
 // besides the pointer bumps of the ring loads.  Dense launches with bf16 / half row outputs only (no fp32 export, no statistics, no chunk
 // split, no ragged tiles): the first-layer head convs (KGnet.py:161-209 `.0`) and their input gradients.
-template <bool FLIP>
+// NB = 2 (round 5): TWO cout blocks per workgroup -- wave tile 128 couts x 128 pixels, 8 weight + 8 pixel fragments feed 64 MFMAs per k-step (16
+// ds_read_b128 per 64 MFMAs: the 128 x 128 skeleton of tools/micro/mfma_tile.hip, +11 % over the 64 x 64 tile under the power cap), the halo of a
+// chunk staged once per 128 couts.  256 accumulator registers leave no room for `tot`: single-product launches and single-chunk inputs only (the
+// chain is then no longer than in the 8-wave kernel).  16 KB ring slots: three of them (one tap per barrier, tap t + 2 loaded while tap t runs).
+template <bool FLIP, int NB>
 __global__ __launch_bounds__(256) void conv_halo7_w4_kernel(const HaloArgs a) {
-    constexpr int KS = 7, PAD = 3, TW = 32, HWD = TW + KS - 1, HPIX = (16 + KS - 1) * HWD, T = KS * KS, NT = 256, NSL = 6, WPT = 2;
-    constexpr int HALO_BYTES = HPIX * 128, WBUF_BYTES = 64 * 128;
+    constexpr int KS = 7, PAD = 3, TW = 32, HWD = TW + KS - 1, HPIX = (16 + KS - 1) * HWD, T = KS * KS, NT = 256, NSL = 6 / NB, WPT = 2 * NB;
+    constexpr int HALO_BYTES = HPIX * 128, WBUF_BYTES = NB * 64 * 128, NA = 4 * NB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo = smem;
     unsigned char* wbuf = smem + HALO_BYTES;
@@ -754,13 +759,19 @@ __global__ __launch_bounds__(256) void conv_halo7_w4_kernel(const HaloArgs a) {
     const int ty = bt % a.tiles_y; const int n = bt / a.tiles_y;
     const int oy0 = ty * 16, ox0 = tx * TW, Hd = a.H, Wd = a.W;
     const long rowbase = (long)n * a.H * a.W;
-    const int c0 = biy * 64;
+    const int c0 = biy * (64 * NB);
 
-    f32x4 acc[4][8], tot[4][8];
+    f32x4 acc[NA][8], tot[NB == 1 ? 4 : 1][NB == 1 ? 8 : 1];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (NB == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     const unsigned lds0 = lds_addr(smem);
     // weight fragments: row r = (lm >> 2) * 16 + i * 4 + (lm & 3) of the slot (the lane ends with 16 consecutive couts); the swizzle key of the
@@ -819,7 +830,7 @@ __global__ __launch_bounds__(256) void conv_halo7_w4_kernel(const HaloArgs a) {
             const int e = tid + i * NT, r = e >> 3, cs = e & 7;
             wsrc[i] = a.w + (long)(c0 + r) * a.K + cc * 64 + (cs ^ (2 * ((r >> 4) & 3) + ((r >> 1) & 1))) * 8;
         }
-        auto wglds = [&](int slot_bytes) {
+        auto wglds = [&](int slot_bytes) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < WPT; ++i) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc[i],
@@ -827,23 +838,32 @@ __global__ __launch_bounds__(256) void conv_halo7_w4_kernel(const HaloArgs a) {
                 wsrc[i] += a.cin_pad;
             }
         };
-        wglds(0); wglds(WBUF_BYTES); wglds(2 * WBUF_BYTES); wglds(3 * WBUF_BYTES);
-        if (ci > 0) {       // the previous chunk's block joins the total while this chunk's loads are in flight
+        if constexpr (NB == 1) {
+            wglds(0); wglds(WBUF_BYTES); wglds(2 * WBUF_BYTES); wglds(3 * WBUF_BYTES);
+            if (ci > 0) {       // the previous chunk's block joins the total while this chunk's loads are in flight
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { tot[i][j] += acc[i][j]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    for (int j = 0; j < 8; ++j) { tot[i][j] += acc[i][j]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");            // halo + taps 0..2 have landed; tap 3 may still be in flight
+        } else {
+            wglds(0); wglds(WBUF_BYTES);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // halo + taps 0, 1 have landed (the fragments of tap 1's first k-step are read during tap 0)
         }
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");            // halo + taps 0..2 have landed; tap 3 may still be in flight
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 
-        bf16x8 a0[4], b0[8], a1[4], b1[8];
-        auto ldA = [&](bf16x8 (&af)[4], auto tc, auto sc) {
+        bf16x8 a0[NA], b0[8], a1[NA], b1[8];
+        auto ldA = [&](bf16x8 (&af)[NA], auto tc, auto sc) __attribute__((always_inline)) {
             constexpr int SL = (decltype(tc)::value % NSL) * WBUF_BYTES, S = decltype(sc)::value;
             lds_rd128<SL>(af[0], aaddr[S]); lds_rd128<SL + 512>(af[1], aaddr[S]); lds_rd128<SL + 1024>(af[2], aaddr[S]); lds_rd128<SL + 1536>(af[3], aaddr[S]);
+            if constexpr (NB == 2) {
+                lds_rd128<SL + 8192>(af[4], aaddr[S]); lds_rd128<SL + 8192 + 512>(af[5], aaddr[S]); lds_rd128<SL + 8192 + 1024>(af[6], aaddr[S]);
+                lds_rd128<SL + 8192 + 1536>(af[7], aaddr[S]);
+            }
         };
-        auto ldB = [&](bf16x8 (&bf)[8], auto tc, auto sc) {
+        auto ldB = [&](bf16x8 (&bf)[8], auto tc, auto sc) __attribute__((always_inline)) {
             constexpr int TT = decltype(tc)::value, S = decltype(sc)::value, KY = TT / KS, KX = TT % KS;
             constexpr int OFF = FLIP ? ((KS - 1 - KY) * HWD + (KS - 1 - KX)) * 128 : (KY * HWD + KX) * 128;
             const unsigned ad = baddr[KX][S];
@@ -851,94 +871,112 @@ __global__ __launch_bounds__(256) void conv_halo7_w4_kernel(const HaloArgs a) {
             lds_rd128<OFF + 2048>(bf[4], ad); lds_rd128<OFF + 2048 + HWD * 128>(bf[5], ad); lds_rd128<OFF + 2048 + 2 * HWD * 128>(bf[6], ad);
             lds_rd128<OFF + 2048 + 3 * HWD * 128>(bf[7], ad);
         };
-        auto lwait = [&](bf16x8 (&af)[4], bf16x8 (&bf)[8], auto nc) {       // at most N later reads outstanding (LDS reads return in order)
-            asm volatile("s_waitcnt lgkmcnt(%12)"
-                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]),
-                           "+v"(bf[6]), "+v"(bf[7])
-                         : "n"(decltype(nc)::value));
-        };
-        auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bf)[8]) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = KG_MFMA16(af[i], bf[j], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
+        auto lwait0 = [&](bf16x8 (&af)[NA], bf16x8 (&bf)[8]) __attribute__((always_inline)) {       // every fragment read issued so far has landed; tied to the registers it guards
+            if constexpr (NB == 1)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]),
+                               "+v"(bf[6]), "+v"(bf[7]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]), "+v"(bf[0]), "+v"(bf[1]),
+                               "+v"(bf[2]), "+v"(bf[3]), "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7]));
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         ldA(a0, I0{}, I0{}); ldB(b0, I0{}, I0{});
-        // One wave per SIMD: nobody else issues while this wave sits in its 12 fragment reads, so the reads of the NEXT k-step are dealt out
-        // between the MFMAs of the current one (one ds_read_b128 behind every second MFMA; the last eight MFMAs cover the latency of the
-        // last read) instead of standing in front of them -- with the reads in one block the MFMA pipe ran dry for ~60 cycles per k-step.
-        auto rd1 = [&](bf16x8 (&af)[4], bf16x8 (&bf)[8], auto tc, auto sc, auto kc) {
+        // One wave per SIMD: nobody else issues while this wave sits in its fragment reads, so the reads of the NEXT k-step are dealt out
+        // between the MFMAs of the current one (NB = 1: one ds_read_b128 behind every second of 32 MFMAs; NB = 2: behind every third of 64; the
+        // last MFMAs cover the latency of the last read) instead of standing in front of them -- with the reads in one block the MFMA pipe ran
+        // dry for ~60 cycles per k-step.
+        auto rd1 = [&](bf16x8 (&af)[NA], bf16x8 (&bf)[8], auto tc, auto sc, auto kc) __attribute__((always_inline)) {
             constexpr int TT = decltype(tc)::value, S = decltype(sc)::value, K = decltype(kc)::value;
-            if constexpr (K < 4) {
+            if constexpr (K < NA) {
                 constexpr int SL = (TT % NSL) * WBUF_BYTES;
-                lds_rd128<SL + K * 512>(af[K], aaddr[S]);
+                lds_rd128<SL + (K >> 2) * 8192 + (K & 3) * 512>(af[K], aaddr[S]);
             } else {
-                constexpr int KY = TT / KS, KX = TT % KS, J = K - 4;
+                constexpr int KY = TT / KS, KX = TT % KS, J = K - NA;
                 constexpr int OFF = (FLIP ? ((KS - 1 - KY) * HWD + (KS - 1 - KX)) * 128 : (KY * HWD + KX) * 128) + (J >> 2) * 2048 + (J & 3) * HWD * 128;
                 lds_rd128<OFF>(bf[J], baddr[KX][S]);
             }
         };
-        auto kstep = [&](bf16x8 (&af)[4], bf16x8 (&bf)[8], bf16x8 (&an)[4], bf16x8 (&bn)[8], auto tcn, auto scn, auto have_next) {
-            lwait(af, bf, I0{});
-            [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
-                ((acc[(2 * Ks) >> 3][(2 * Ks) & 7] = KG_MFMA16(af[(2 * Ks) >> 3], bf[(2 * Ks) & 7], acc[(2 * Ks) >> 3][(2 * Ks) & 7]),
-                  acc[(2 * Ks + 1) >> 3][(2 * Ks + 1) & 7] = KG_MFMA16(af[(2 * Ks + 1) >> 3], bf[(2 * Ks + 1) & 7], acc[(2 * Ks + 1) >> 3][(2 * Ks + 1) & 7]),
-                  __builtin_amdgcn_sched_barrier(0),
-                  [&] { if constexpr (decltype(have_next)::value) rd1(an, bn, tcn, scn, std::integral_constant<int, Ks>{}); }(),
-                  __builtin_amdgcn_sched_barrier(0)), ...);
-            }(std::make_integer_sequence<int, 12>{});
+        auto kstep = [&](bf16x8 (&af)[NA], bf16x8 (&bf)[8], bf16x8 (&an)[NA], bf16x8 (&bn)[8], auto tcn, auto scn, auto have_next) __attribute__((always_inline)) {
+            lwait0(af, bf);
+            constexpr int NRD = NA + 8, PER = NB == 1 ? 2 : 3, NM = NA * 8;      // reads of the next k-step, MFMAs between two of them, MFMAs of a k-step
+            [&]<int... Ks>(std::integer_sequence<int, Ks...>) __attribute__((always_inline)) {
+                (([&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 24; q < 32; ++q) acc[q >> 3][q & 7] = KG_MFMA16(af[q >> 3], bf[q & 7], acc[q >> 3][q & 7]);
+                      for (int q = PER * Ks; q < PER * Ks + PER; ++q) acc[q >> 3][q & 7] = KG_MFMA16(af[q >> 3], bf[q & 7], acc[q >> 3][q & 7]);
+                  }(),
+                  __builtin_amdgcn_sched_barrier(0),
+                  [&]() __attribute__((always_inline)) { if constexpr (decltype(have_next)::value) rd1(an, bn, tcn, scn, std::integral_constant<int, Ks>{}); }(),
+                  __builtin_amdgcn_sched_barrier(0)), ...);
+            }(std::make_integer_sequence<int, NRD>{});
+#pragma unroll
+            for (int q = PER * NRD; q < NM; ++q) acc[q >> 3][q & 7] = KG_MFMA16(af[q >> 3], bf[q & 7], acc[q >> 3][q & 7]);
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto tap = [&](auto tc) {
+        auto tap = [&](auto tc) __attribute__((always_inline)) {
             constexpr int TT = decltype(tc)::value;
-            if constexpr (!(TT & 1)) {     // pair start: taps t + 4, t + 5 into the slots of taps t - 2, t - 1, which every wave has left
-                if constexpr (TT + 4 < T) wglds(((TT + 4) % NSL) * WBUF_BYTES);
-                if constexpr (TT + 5 < T) wglds(((TT + 5) % NSL) * WBUF_BYTES);
+            if constexpr (NB == 1) {
+                if constexpr (!(TT & 1)) {     // pair start: taps t + 4, t + 5 into the slots of taps t - 2, t - 1, which every wave has left
+                    if constexpr (TT + 4 < T) wglds(((TT + 4) % NSL) * WBUF_BYTES);
+                    if constexpr (TT + 5 < T) wglds(((TT + 5) % NSL) * WBUF_BYTES);
+                }
+            } else {                           // tap start: tap t + 2 into the slot of tap t - 1, which every wave left at the last barrier
+                if constexpr (TT + 2 < T) wglds(((TT + 2) % NSL) * WBUF_BYTES);
             }
             kstep(a0, b0, a1, b1, tc, I1{}, std::true_type{});
             kstep(a1, b1, a0, b0, std::integral_constant<int, (TT + 1 < T ? TT + 1 : TT)>{}, I0{}, std::bool_constant<(TT + 1 < T)>{});
-            if constexpr ((TT & 1) && TT + 1 < T) {   // pair end: taps t + 1 .. t + 3 visible after the barrier; tap t + 4 may stay in flight
-                if constexpr (TT + 4 < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (NB == 1) {
+                if constexpr ((TT & 1) && TT + 1 < T) {   // pair end: taps t + 1 .. t + 3 visible after the barrier; tap t + 4 may stay in flight
+                    if constexpr (TT + 4 < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            } else if constexpr (TT + 1 < T) {            // tap end: taps t + 1 AND t + 2 visible after the barrier -- tap t + 2's first fragments are read during tap
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // t + 1, before the next barrier; its loads had one tap (128 MFMAs per wave) to land
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
         };
-        [&]<int... Ns>(std::integer_sequence<int, Ns...>) { (tap(std::integral_constant<int, Ns>{}), ...); }(std::make_integer_sequence<int, T>{});
+        [&]<int... Ns>(std::integer_sequence<int, Ns...>) __attribute__((always_inline)) { (tap(std::integral_constant<int, Ns>{}), ...); }(std::make_integer_sequence<int, T>{});
     }
 
+    if constexpr (NB == 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) tot[i][j] += acc[i][j];
-    // ---- epilogue: lane owns pixels (oy0 + 4 * wave + j, ox0 + 16 * h + lm) and couts cb .. cb + 15 ----------------------
-    const int cb = c0 + g * 16;
-    if (cb >= a.Cout) return;
-    float bv[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
-    const EpiArgs ep{a.y, a.res, a.mask, a.ldy, a.ldres, a.ldmask, a.Cout, a.relu, a.yP, a.yps, a.rP, a.rps};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int ox = ox0 + h * 16 + lm;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int oy = oy0 + wave * 4 + j;
-            if (oy >= Hd || ox >= Wd) continue;
-            const long m = rowbase + (long)oy * Wd + ox;
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(tot[i][h * 4 + j][r]) + bv[i * 4 + r];
-            kg_conv_epilogue<16>(ep, m, cb, v);
-        }
+            for (int j = 0; j < 8; ++j) acc[i][j] += tot[i][j];
     }
+    // ---- epilogue: lane owns pixels (oy0 + 4 * wave + j, ox0 + 16 * h + lm) and couts cb .. cb + 15 of each of its NB cout blocks -------
+    const EpiArgs ep{a.y, a.res, a.mask, a.ldy, a.ldres, a.ldmask, a.Cout, a.relu, a.yP, a.yps, a.rP, a.rps};
+    auto epi = [&](auto nbc) __attribute__((always_inline)) {
+        constexpr int nb = decltype(nbc)::value;
+        const int cb = c0 + nb * 64 + g * 16;
+        if (cb >= a.Cout) return;
+        float bv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bv[e] = (a.bias && cb + e < a.Cout) ? a.bias[cb + e] : 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ox = ox0 + h * 16 + lm;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int oy = oy0 + wave * 4 + j;
+                if (oy >= Hd || ox >= Wd) continue;
+                const long m = rowbase + (long)oy * Wd + ox;
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(acc[nb * 4 + i][h * 4 + j][r]) + bv[i * 4 + r];
+                kg_conv_epilogue<16>(ep, m, cb, v);
+            }
+        }
+    };
+    epi(std::integral_constant<int, 0>{});
+    if constexpr (NB == 2) epi(std::integral_constant<int, 1>{});
 }
 
 template <int KS, int WC, int WPX, int GM = 0>
@@ -974,18 +1012,51 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
         // chunks per plane (C >= 128: where the blocked accumulation matters for the fp32 tolerance); 2 = every dense rows-output launch
         static const int w4 = getenv("KG_HALO7_W4") ? atoi(getenv("KG_HALO7_W4")) : 1;
         static const int w4dir = getenv("KG_HALO7_W4_DIR") ? atoi(getenv("KG_HALO7_W4_DIR")) : 3;      // bisecting: bit 0 = forward launches, bit 1 = flipped (input gradient)
+        // KG_HALO7_NB2 (default 1): launches that need no blocked accumulation (a single product, or one channel chunk per plane) and have >= 128
+        // couts run their whole 128-cout blocks on the 128 x 128 wave tiles of conv_halo7_w4_kernel<*, 2>; a remainder of 64 couts (the fused
+        // 64 -> 192 first layers of the c0 / c1 heads) follows as its own launch on the kernel it had before
+        static const int nb2 = getenv("KG_HALO7_NB2") ? atoi(getenv("KG_HALO7_NB2")) : 1;
         const bool ok = !a.tiletab && a.y && !a.y_f32 && !a.stat_part && !a.oscale && a.ksplit <= 1 && ((w4dir >> (a.flip ? 1 : 0)) & 1);
-        if (ok && (w4 >= 2 || (w4 == 1 && a.cin_pad / 64 > a.km.n && a.km.n >= 2))) {
-            static bool w4_attr = false;
-            if (!w4_attr) {
-                KG_HIP(hipFuncSetAttribute((const void*)conv_halo7_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                KG_HIP(hipFuncSetAttribute((const void*)conv_halo7_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                w4_attr = true;
-            }
-            if (a.flip) hipLaunchKernelGGL(conv_halo7_w4_kernel<true>, grid, dim3(256), smem, st, a);
-            else hipLaunchKernelGGL(conv_halo7_w4_kernel<false>, grid, dim3(256), smem, st, a);
+        const bool multi = a.cin_pad / 64 > a.km.n;
+        static bool w4_attr = false;
+        if (!w4_attr) {
+            KG_HIP(hipFuncSetAttribute((const void*)conv_halo7_w4_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            KG_HIP(hipFuncSetAttribute((const void*)conv_halo7_w4_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            KG_HIP(hipFuncSetAttribute((const void*)conv_halo7_w4_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            KG_HIP(hipFuncSetAttribute((const void*)conv_halo7_w4_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            w4_attr = true;
+        }
+        if (ok && nb2 && a.nb2 == 0 && a.Cout >= 128 && (!multi || a.km.n == 1) && w4 < 2) {
+            const int c128 = a.Cout / 128 * 128;
+            HaloArgs a1 = a;
+            a1.Cout = c128; a1.nb2 = 1;
+            const int rc = launch_halo<KS, WC, WPX, GM>(a1, st);
+            if (rc != KG_OK || c128 == a.Cout) return rc;
+            HaloArgs a2 = a;                     // the remaining couts: the same conv on the weight rows / output columns from c128 on
+            a2.nb2 = -1; a2.Cout = a.Cout - c128;
+            a2.w = a.w + (long)c128 * a.K; a2.y = a.y + c128;
+            if (a.bias) a2.bias = a.bias + c128;
+            if (a.res) a2.res = a.res + c128;
+            if (a.mask) a2.mask = a.mask + c128;
+            const int rc2 = launch_halo<KS, WC, WPX, GM>(a2, st);
+            // (one call, two launches: the measurement name says so)
+            kg_note_kernel(a.flip ? "conv_halo7_w4_kernel<true, 2> + conv_halo_kernel<7, 1, 8, 0>" : "conv_halo7_w4_kernel<false, 2> + conv_halo_kernel<7, 1, 8, 0>");
+            return rc2;
+        }
+        if (ok && a.nb2 == 1) {
+            dim3 g2(grid.x, a.Cout / 128);
+            a.xcd_map = use_xcd && g2.x % 8 == 0 && (g2.y > 1 || use_xcd > 1) && (long)a.Cout * a.K * 2 <= (24L << 20);
+            if (a.flip) hipLaunchKernelGGL((conv_halo7_w4_kernel<true, 2>), g2, dim3(256), smem, st, a);
+            else hipLaunchKernelGGL((conv_halo7_w4_kernel<false, 2>), g2, dim3(256), smem, st, a);
             KG_CHECK_LAUNCH("conv_halo7_w4");
-            kg_note_kernel(a.flip ? "conv_halo7_w4_kernel<true>" : "conv_halo7_w4_kernel<false>");
+            kg_note_kernel(a.flip ? "conv_halo7_w4_kernel<true, 2>" : "conv_halo7_w4_kernel<false, 2>");
+            return KG_OK;
+        }
+        if (ok && (w4 >= 2 || (w4 == 1 && multi && a.km.n >= 2))) {
+            if (a.flip) hipLaunchKernelGGL((conv_halo7_w4_kernel<true, 1>), grid, dim3(256), smem, st, a);
+            else hipLaunchKernelGGL((conv_halo7_w4_kernel<false, 1>), grid, dim3(256), smem, st, a);
+            KG_CHECK_LAUNCH("conv_halo7_w4");
+            kg_note_kernel(a.flip ? "conv_halo7_w4_kernel<true, 1>" : "conv_halo7_w4_kernel<false, 1>");
             return KG_OK;
         }
     }

@@ -104,6 +104,7 @@ PLANE_CONV_CASES = [
     (256, 128, 3, 1, 1, 1, 12, 20, True, True),      # conv_halo<3>
     (64, 192, 7, 1, 3, 1, 16, 24, True, True),       # conv_halo<7>
     (128, 64, 7, 1, 3, 2, 20, 36, True, True),       # conv_halo<7>, two channel chunks per plane (the shared-halo walk over several chunks)
+    (256, 256, 7, 1, 3, 1, 20, 36, True, True),      # wide 7x7: planed -> conv_halo7_w4<*, 1> (blocked accumulation); single plane -> the 128-cout blocks of conv_halo7_w4<*, 2>
     (128, 64, 1, 1, 0, 2, 16, 16, True, True),       # 1x1 -> conv_gather (64 couts)
     (128, 64, 1, 1, 0, 2, 192, 176, True, True),     # 1x1, 64 couts, 528 tiles of 128 pixels -> conv_gather's 128 x 64 variant
     (64, 256, 1, 1, 0, 2, 16, 16, False, False),     # 1x1 -> conv_gather

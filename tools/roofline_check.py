@@ -11,7 +11,8 @@ alg = issued = ms_ev = 0.0
 n = 0
 for line in open(os.path.join(root, f"{tag}_bench_launches.txt")):
     m = re.match(r"\s*([\d.]+) ms/step\s+([\d.]+) TF\s+x\s*([\d.]+)\s+(\S.*?)\s{2,}(.*)", line)
-    if not m or m.group(4).replace(" ", "") not in ("conv_halo<7,1>", "conv_halo_kernel<7,1,8,0>", "conv_halo7_w4_kernel<false>", "conv_halo7_w4_kernel<true>"):
+    nm = m.group(4).replace(" ", "") if m else ""
+    if not m or not (nm in ("conv_halo<7,1>", "conv_halo_kernel<7,1,8,0>") or nm.startswith("conv_halo7_w4_kernel<")):      # (incl. "w4<*,2>+conv_halo_kernel<7,1,8,0>": one call, two launches)
         continue
     ms, tf, cnt, desc = float(m.group(1)), float(m.group(2)), float(m.group(3)), m.group(5)
     prod = int(re.search(r"products=(\d+)", desc).group(1)) if "products=" in desc else 1
@@ -19,7 +20,8 @@ for line in open(os.path.join(root, f"{tag}_bench_launches.txt")):
     alg += fl; issued += fl * prod; ms_ev += ms; n += cnt
 prof_ms = calls = 0.0      # (the family: the 8-wave kernel + its 4-wave sibling with the blocked accumulation, round 5)
 for r in csv.DictReader(open(os.path.join(root, f"{tag}_bench_kernel_stats.csv"))):
-    if r["Name"].replace(" ", "") in ("voidconv_halo_kernel<7,1,8,0>(HaloArgs)", "voidconv_halo7_w4_kernel<false>(HaloArgs)", "voidconv_halo7_w4_kernel<true>(HaloArgs)"):
+    nm = r["Name"].replace(" ", "")
+    if nm == "voidconv_halo_kernel<7,1,8,0>(HaloArgs)" or nm.startswith("voidconv_halo7_w4_kernel<"):
         prof_ms += float(r["MsPerStep"]); calls += float(r["CallsPerStep"])
 print(f"conv_halo<7,1,8,0> + conv_halo7_w4: {n:.0f} launches/step (profiler: {calls:.0f}), algorithmic {alg / 1e12:.2f} TFLOP/step, MFMA-issued {issued / 1e12:.2f} TFLOP/step "
       f"(x{issued / alg:.3f} products per multiply)")
