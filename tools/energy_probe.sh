@@ -1,12 +1,16 @@
 #!/bin/bash
-# Energy per launch of the first-layer 7x7 head conv, 8-wave kernel against the 4-wave kernel with the blocked accumulation (KG_HALO7_W4=0 / 2):
+# Energy per launch of the first-layer 7x7 head conv: the 8-wave kernel alone, the 4-wave kernel with the blocked accumulation for every launch, and the
+# default routing (blocked 4-wave kernel for the wide 3-product launches, 128 x 128 wave tiles where no blocked accumulation is needed):
 # tools/halo7_probe.py runs its six bench launches KG_PROBE_REPS times back to back per shape while rocm-smi samples the socket power; the
 # accumulated-energy counter is read before and after when the box exposes it.     bash tools/energy_probe.sh > profiles/r05_energy_probe.txt
 export KG_PROBE_REPS=${KG_PROBE_REPS:-400}
-for V in 0 2; do
+for V in 0 2 1; do
+  case $V in 0) ENVV="KG_HALO7_W4=0 KG_HALO7_NB2=0"; LBL='8-wave kernel only: 64 couts x 64 px per wave, 8 ds_read_b128 per 16 MFMAs';;
+             2) ENVV="KG_HALO7_W4=2 KG_HALO7_NB2=0"; LBL='4-wave kernel for every launch: 64 couts x 128 px per wave, 12 ds_read_b128 per 32 MFMAs, blocked accumulation';;
+             1) ENVV="KG_HALO7_W4=1 KG_HALO7_NB2=1"; LBL='default routing: 8-wave | 4-wave blocked (wide 3-product) | 4-wave 128 couts x 128 px, 16 reads per 64 MFMAs (single product, 64 -> 192 forward)';; esac
   E0=$(rocm-smi --showenergycounter 2>/dev/null | grep -i "Accumulated Energy" | grep -oE "[0-9.]+" | tail -1)
   T0=$(date +%s.%N)
-  KG_HALO7_W4=$V python tools/halo7_probe.py > /tmp/probe_$V.out 2>&1 &
+  env $ENVV python tools/halo7_probe.py > /tmp/probe_$V.out 2>&1 &
   PID=$!
   : > /tmp/pw_$V.txt
   while kill -0 $PID 2>/dev/null; do
@@ -17,7 +21,7 @@ for V in 0 2; do
   wait $PID
   T1=$(date +%s.%N)
   E1=$(rocm-smi --showenergycounter 2>/dev/null | grep -i "Accumulated Energy" | grep -oE "[0-9.]+" | tail -1)
-  echo "== KG_HALO7_W4=$V ($( [ $V = 0 ] && echo '8 waves x 64 couts x 64 px, 8 ds_read_b128 per 16 MFMAs' || echo '4 waves x 64 couts x 128 px, 12 ds_read_b128 per 32 MFMAs, blocked accumulation'))"
+  echo "== $ENVV ($LBL)"
   grep -v amdgpu.ids /tmp/probe_$V.out
   python3 - "$V" "$E0" "$E1" "$T0" "$T1" <<'PY'
 import re, sys
