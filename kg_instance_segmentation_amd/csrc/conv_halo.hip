@@ -56,7 +56,7 @@ struct HaloArgs {
     // the chunk sequence and stores its raw fp32 accumulators (kpart: [cout block][tile][z][wave][16 values][64 lanes]); conv_halo_finish_kernel
     // adds the parts in z order -- the order of the unsplit walk -- and runs the epilogue (+ statistics)
     int ksplit; float* kpart;
-    int nb2;          // launch_halo<7, 1, 8, 0>: 1 = this launch covers whole 128-cout blocks on conv_halo7_w4_kernel<*, 2>, -1 = never split off such a launch
+    int nb2;          // launch_halo<7 | 3, 1, 8, 0>: 1 = this launch covers whole 128-cout blocks on conv_halo7_w4_kernel<*, 2>, -1 = never split off such a launch
 };
 
 // Planed input with the three products of the half-plane policies.  The packed weights keep the plane-major virtual-channel layout of
@@ -738,9 +738,12 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_finish_kernel(const H
 // ds_read_b128 per 64 MFMAs: the 128 x 128 skeleton of tools/micro/mfma_tile.hip, +11 % over the 64 x 64 tile under the power cap), the halo of a
 // chunk staged once per 128 couts.  256 accumulator registers leave no room for `tot`: single-product launches and single-chunk inputs only (the
 // chain is then no longer than in the 8-wave kernel).  16 KB ring slots: three of them (one tap per barrier, tap t + 2 loaded while tap t runs).
-template <bool FLIP, int NB>
-__global__ __launch_bounds__(256) void conv_halo7_w4_kernel(const HaloArgs a) {
-    constexpr int KS = 7, PAD = 3, TW = 32, HWD = TW + KS - 1, HPIX = (16 + KS - 1) * HWD, T = KS * KS, NT = 256, NSL = 6 / NB, WPT = 2 * NB;
+// KS = 3 (conv_halo3_w4_kernel, NB = 2 only): the same body for the dense 3x3 convs with >= 128 couts -- the decoder's up convs (512 -> 256 on 128^2,
+// 1024 -> 512 on 64^2) and their input gradients are K = 4.6 k .. 9.2 k GEMMs per product that the 8-wave 3x3 kernel runs at 0.45 of peak: it stages a
+// 78 KB halo per 18 k-steps of a 64-cout tile; here the same halo feeds 128 couts.
+template <bool FLIP, int NB, int KS>
+__device__ __forceinline__ void conv_halo_w4_body(const HaloArgs& a) {
+    constexpr int PAD = KS / 2, TW = 32, HWD = TW + KS - 1, HPIX = (16 + KS - 1) * HWD, T = KS * KS, NT = 256, NSL = 6 / NB, WPT = 2 * NB;
     constexpr int HALO_BYTES = HPIX * 128, WBUF_BYTES = NB * 64 * 128, NA = 4 * NB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* halo = smem;
@@ -979,6 +982,11 @@ __global__ __launch_bounds__(256) void conv_halo7_w4_kernel(const HaloArgs a) {
     if constexpr (NB == 2) epi(std::integral_constant<int, 1>{});
 }
 
+template <bool FLIP, int NB>
+__global__ __launch_bounds__(256) void conv_halo7_w4_kernel(const HaloArgs a) { conv_halo_w4_body<FLIP, NB, 7>(a); }
+template <bool FLIP>
+__global__ __launch_bounds__(256) void conv_halo3_w4_kernel(const HaloArgs a) { conv_halo_w4_body<FLIP, 2, 3>(a); }
+
 template <int KS, int WC, int WPX, int GM = 0>
 static int launch_halo(HaloArgs a, hipStream_t st) {
     constexpr int TW = 4 * WPX, HWD = TW + KS - 1, TC = WC * 64;
@@ -1007,6 +1015,44 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
     static const int use_xcd = getenv("KG_HALO_XCD") ? atoi(getenv("KG_HALO_XCD")) : 1;
     // (not for the widest heads: 24 cout blocks of one tile stream 24 different 3 MB weight slices through the XCD's 4 MB L2: -2 %)
     a.xcd_map = use_xcd && !a.tiletab && grid.x % 8 == 0 && (grid.y > 1 || use_xcd > 1) && (long)a.Cout * a.K * 2 <= (24L << 20);
+    if constexpr (KS == 3 && WC == 1 && WPX == 8 && GM == 0) {
+        // KG_HALO3_NB2 (default 1): dense 3x3 launches with >= 128 couts and at least 192 workgroups of 128 couts (the decoder's up convs and their
+        // input gradients) run their 128-cout blocks on conv_halo3_w4_kernel (4 waves, wave tile 128 couts x 128 px: conv_halo_w4_body<*, 2, 3>)
+        static const int nb2_3 = getenv("KG_HALO3_NB2") ? atoi(getenv("KG_HALO3_NB2")) : 1;
+        constexpr int smem_w4 = (16 + KS - 1) * HWD * 128 + 3 * 128 * 128;
+        const bool ok3 = !a.tiletab && a.y && !a.y_f32 && !a.stat_part && !a.oscale && a.ksplit <= 1;
+        if (ok3 && nb2_3 && a.nb2 == 0 && a.Cout >= 128 && (nb2_3 >= 2 || (long)grid.x * (a.Cout / 128) >= 192)) {      // (2: every such launch -- the tests)
+            const int c128 = a.Cout / 128 * 128;
+            HaloArgs a1 = a;
+            a1.Cout = c128; a1.nb2 = 1;
+            const int rc = launch_halo<KS, WC, WPX, GM>(a1, st);
+            if (rc != KG_OK || c128 == a.Cout) return rc;
+            HaloArgs a2 = a;
+            a2.nb2 = -1; a2.Cout = a.Cout - c128;
+            a2.w = a.w + (long)c128 * a.K; a2.y = a.y + c128;
+            if (a.bias) a2.bias = a.bias + c128;
+            if (a.res) a2.res = a.res + c128;
+            if (a.mask) a2.mask = a.mask + c128;
+            const int rc2 = launch_halo<KS, WC, WPX, GM>(a2, st);
+            kg_note_kernel(a.flip ? "conv_halo3_w4_kernel<true> + conv_halo_kernel<3, 1, 8, 0>" : "conv_halo3_w4_kernel<false> + conv_halo_kernel<3, 1, 8, 0>");
+            return rc2;
+        }
+        if (ok3 && a.nb2 == 1) {
+            static bool w43_attr = false;
+            if (!w43_attr) {
+                KG_HIP(hipFuncSetAttribute((const void*)conv_halo3_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_w4));
+                KG_HIP(hipFuncSetAttribute((const void*)conv_halo3_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_w4));
+                w43_attr = true;
+            }
+            dim3 g2(grid.x, a.Cout / 128);
+            a.xcd_map = use_xcd && g2.x % 8 == 0 && (g2.y > 1 || use_xcd > 1) && (long)a.Cout * a.K * 2 <= (24L << 20);
+            if (a.flip) hipLaunchKernelGGL((conv_halo3_w4_kernel<true>), g2, dim3(256), smem_w4, st, a);
+            else hipLaunchKernelGGL((conv_halo3_w4_kernel<false>), g2, dim3(256), smem_w4, st, a);
+            KG_CHECK_LAUNCH("conv_halo3_w4");
+            kg_note_kernel(a.flip ? "conv_halo3_w4_kernel<true>" : "conv_halo3_w4_kernel<false>");
+            return KG_OK;
+        }
+    }
     if constexpr (KS == 7 && WC == 1 && WPX == 8 && GM == 0) {
         // KG_HALO7_W4: 0 = never; 1 (default) = the multi-product launches (hi + lo planes: 3 products; three bf16 planes: 6) with >= 2 channel
         // chunks per plane (C >= 128: where the blocked accumulation matters for the fp32 tolerance); 2 = every dense rows-output launch

@@ -410,6 +410,23 @@ def test_four_wave_blocked_7x7_halo_kernel_matches():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_four_wave_3x3_halo_kernel_matches():
+    """conv_halo3_w4_kernel (the 4-wave body with 128-cout x 128-pixel wave tiles, csrc/conv_halo.hip) serves the dense 3x3 convs with >= 128 couts
+    and >= 192 workgroups (the decoder's up convs at the bench size); KG_HALO3_NB2=2 sends EVERY dense 3x3 launch with >= 128 couts of the halo /
+    plane conv tests and of the sub-graph tests through it (forward and flipped input gradient, both formats, masks / residuals, partial tiles,
+    a 64-cout remainder)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KG_HALO3_NB2="2", KG_HALO_SPLIT="0")      # (no K split: under-filled test launches would take it first)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), os.path.join(root, "tests", "test_gpu_planes.py"),
+                        os.path.join(root, "tests", "test_gpu_blocks.py"), "-q", "-x", "-k",
+                        "test_conv_halo_forward_and_dgrad or test_conv_forward_dgrad_wgrad_planes or test_stem_and_decoder_level or test_bottleneck_block"],
+                       capture_output=True, text=True, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 WGRAD_HALO_CASES = [(64, 64, 3, 2, 20, 28), (64, 192, 7, 1, 32, 32), (64, 5, 7, 1, 16, 24), (3, 64, 3, 1, 24, 24),
                     (256, 128, 3, 1, 16, 16), (128, 64, 7, 2, 18, 21), (1024, 512, 3, 1, 8, 8),
                     (64, 10, 7, 1, 20, 20), (128, 40, 7, 1, 17, 33), (64, 1, 3, 2, 19, 23)]

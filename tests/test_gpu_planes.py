@@ -102,6 +102,7 @@ PLANE_CONV_CASES = [
     # cin, cout, k, stride, pad, N, H, W, relu, bias     (route)
     (64, 64, 3, 1, 1, 2, 20, 28, True, True),        # conv_halo<3>, 64 channels (conv3_c64 is bf16-only)
     (256, 128, 3, 1, 1, 1, 12, 20, True, True),      # conv_halo<3>
+    (128, 192, 3, 1, 1, 1, 20, 36, True, True),      # conv_halo<3>; under KG_HALO3_NB2=2: conv_halo3_w4 for couts 0..127 + a 64-cout remainder
     (64, 192, 7, 1, 3, 1, 16, 24, True, True),       # conv_halo<7>
     (128, 64, 7, 1, 3, 2, 20, 36, True, True),       # conv_halo<7>, two channel chunks per plane (the shared-halo walk over several chunks)
     (256, 256, 7, 1, 3, 1, 20, 36, True, True),      # wide 7x7: planed -> conv_halo7_w4<*, 1> (blocked accumulation); single plane -> the 128-cout blocks of conv_halo7_w4<*, 2>
