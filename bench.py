@@ -490,14 +490,17 @@ def roofline_block(dsum, dt, with_pmc):
             "per_kernel": {n: {"launches": dsum[n]["launches"], "avg_launch_ms": 1e3 * dsum[n]["seconds"] / dsum[n]["launches"],
                                "mfma_issued_tflops": dsum[n]["mfma_flops"] / dsum[n]["seconds"] / 1e12} for n in fam},
             "build": _build_id(),
-            "pmc": pm and dict(pm, note="rocprofv3 PMC pass of this build (profiles/, build hash checked): MFMA-pipe busy cycles / active "
-                                       "cycles of these kernels, collected by tools/profile_round.sh on another box run"),
-            "note": "achieved = 16-bit MFMA FLOPs ISSUED by the launches of this kernel family / their HIP-event time, measured inside the timed "
-                    "region: algorithmic fp32 conv FLOPs (2*N*H*W*Cout*49*Cin, real channel counts) x the plane products each multiply is "
-                    "evaluated as (`products_per_multiply`, launch-weighted: 3 in the forward launches, 1 in the input-gradient launches of the "
-                    "default policy); peak = 2500 TFLOP/s dense f16 / bf16 MFMA; frac = achieved / peak.  achieved_algorithmic / "
-                    "frac_algorithmic = the same launches in fp32-equivalent conv FLOPs (no plane products).  traffic = HBM bytes per launch "
-                    "from the committed PMC pass of this build, null when the loaded libraries differ from the profiled ones"}
+            "pmc": pm}
+
+
+ROOFLINE_NOTE = ("achieved = 16-bit MFMA FLOPs ISSUED by the launches of this kernel family / their HIP-event time, measured inside the timed "
+                 "region: algorithmic fp32 conv FLOPs (2*N*H*W*Cout*49*Cin, real channel counts) x the plane products each multiply is "
+                 "evaluated as (`products_per_multiply`, launch-weighted: 3 in the forward launches, 1 in the input-gradient launches of the "
+                 "default policy); peak = 2500 TFLOP/s dense f16 / bf16 MFMA; frac = achieved / peak.  achieved_algorithmic / "
+                 "frac_algorithmic = the same launches in fp32-equivalent conv FLOPs (no plane products).  traffic = HBM bytes per launch "
+                 "from the committed PMC pass of this build, null when the loaded libraries differ from the profiled ones.  pmc = rocprofv3 PMC "
+                 "pass of this build (profiles/, build hash checked): MFMA-pipe busy cycles / active cycles of these kernels, collected by "
+                 "tools/profile_round.sh on another box run")
 
 
 def main():
@@ -519,6 +522,9 @@ def main():
                     "no per-kernel pass, no CPU baseline): the command rocprofv3 wraps, so that steps + warmup launches are traced")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--details", default=os.environ.get("KG_BENCH_DETAILS", ""),
+                    help="file for the long-form record (per-kernel table, per-step times, companions with their roofline blocks, notes); default "
+                         "gpurun_out/bench_details.json when that directory exists, else stderr.  The stdout JSON line stays under 3 KB")
     args = ap.parse_args()
     if args.profile_run:
         args.no_companion = args.no_cpu_baseline = args.no_kernel_timer = True
@@ -693,19 +699,25 @@ def main():
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None,
            "dtype": out_dtype, "data": "synthetic",
-           "config": {"workload": f"KGnet train step (forward_dec+forward_seg, 4x DetectionLossAll + SEG_loss, backward, Adam), "
-                                  f"batch {args.batch}/GPU, 3x{args.size}x{args.size}, {args.boxes} GT boxes/img, full HIP path",
-                      "precision_policy": args.precision, "planes": list(pol), "precision": PDESC.get(args.precision, args.precision),
+           "config": {"workload": f"KGnet train step fwd(dec+seg)+4xDetectionLossAll+SEG_loss+bwd+Adam, batch {args.batch}/GPU 3x{args.size}x{args.size}, "
+                                  f"{args.boxes} boxes/img, full HIP path",
+                      "precision_policy": args.precision, "planes": list(pol),
                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "last_loss": last,
                       "loss_readback": "every step (train.py:156)" if STEP_SYNC else "after the timed region",
                       "other_readback_policy_imgs_per_s": imgs / other_dt,
                       "gc_enabled_imgs_per_s": (imgs / gc_on_dt) if gc_on_dt else None,
-                      "grad_overflow": overflowed,      # sticky device flag of the half-precision backward (KGnet.grad_overflowed): must be false
-                      "step_ms": [round(1e3 * (b - a), 2) for a, b in zip([t0] + marks[:-1], marks)]}}
-    if "half" in companions:
-        out["half_companion"] = companions["half"]
-    if "fp32b2" in companions:
-        out["fp32b2_companion"] = companions["fp32b2"]       # the all-22-bit policy (forward and backward), timed the same way
+                      "grad_overflow": overflowed}}     # sticky device flag of the half-precision backward (KGnet.grad_overflowed): must be false
+    # long-form record (side file, not the stdout line -- the driver keeps `config` scalars and cuts long strings / nested tables)
+    details = {"precision": PDESC.get(args.precision, args.precision), "roofline_note": ROOFLINE_NOTE,
+               "step_ms": [round(1e3 * (b - a), 2) for a, b in zip([t0] + marks[:-1], marks)]}
+    for cp, comp in companions.items():
+        details[cp + "_companion"] = comp
+        # the companions as SCALARS of `config`: fp32b2 = the step at the reference's precision in both directions (train.py:153 is fp32 autograd)
+        out["config"][cp + "_imgs_per_s"] = comp["value"]
+        out["config"][cp + "_ms_per_step"] = comp["ms_per_step"]
+        if comp.get("roofline"):
+            out["config"][cp + "_roofline_frac"] = comp["roofline"]["frac"]
+        out["config"][cp + "_grad_overflow"] = comp["grad_overflow"]
     if not args.no_kernel_timer:
         if os.environ.get("KG_BENCH_DUMP"):
             timer.rec = prof_rec
@@ -715,12 +727,23 @@ def main():
             out["roofline"] = rb
         summ = timer.summary(prof_rec)
         if summ:
-            out["kernels"] = {k: {"ms_per_step": 1e3 * v["seconds"] / prof_steps, "tflops": v["flops"] / max(v["seconds"], 1e-12) / 1e12,
+            details["kernels"] = {k: {"ms_per_step": 1e3 * v["seconds"] / prof_steps, "tflops": v["flops"] / max(v["seconds"], 1e-12) / 1e12,
                                   "launches_per_step": v["launches"] / prof_steps} for k, v in summ.items()}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.boxes)      # batch 1 with the headline's boxes per image: the same per-image work
         out["config"]["grouping_match_rate"] = out["cpu_baseline"]["grouping_match_rate"]
-    print(json.dumps(out))
+    line = json.dumps(out)
+    details["line"] = out
+    import tempfile
+    path = args.details or ("gpurun_out/bench_details.json" if os.path.isdir("gpurun_out") else os.path.join(tempfile.gettempdir(), "kg_bench_details.json"))
+    try:
+        with open(path, "w") as f:
+            json.dump(details, f, indent=1)
+        out["config"]["details_file"] = path
+        line = json.dumps(out)
+    except OSError as e:
+        print(f"bench details not written ({e})", file=sys.stderr)
+    print(line)
 
 
 if __name__ == "__main__":

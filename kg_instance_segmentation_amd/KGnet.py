@@ -266,17 +266,33 @@ class ResNet(nn.Module):
     def load_state_dict(self, state_dict, strict=True, **kw):
         """As nn.Module.load_state_dict (KGnet.py:384-385, test.py:60-61 load any checkpoint).  A checkpoint whose conv weights leave the
         half policies' range (|w| >= 16) switches the model to the policy's bf16-plane sibling (same tolerance class, 8-bit exponent; "fp32" ->
-        "fp32bf") with a warning instead of failing; KG_HALF_RANGE=raise restores the hard error."""
+        "fp32bf") with a warning instead of failing (recorded in `model.precision_switch` = (from, to, key, max |w|)); KG_HALF_RANGE=raise
+        restores the hard error.  Non-finite weights always raise; so does a needed switch once a FlatGradReducer is attached."""
         r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.precision_switch = None
         bad = self.half_range_violations()
         if bad:
+            nonfinite = [(k, m) for k, m in bad if not m < float("inf")]
+            if nonfinite:      # a NaN / inf weight is a broken checkpoint in ANY policy: never a reason to change the arithmetic
+                raise ValueError(f"KGnet.load_state_dict: {nonfinite[0][0]} holds non-finite values ({len(nonfinite)} tensor(s))")
             if os.environ.get("KG_HALF_RANGE", "fallback") == "raise":
                 self.check_half_range()
+            if self._engine.grad_store is not None:
+                # FlatGradReducer.attach sized its flat views / scale bookkeeping for the current policy, and under data parallelism every
+                # rank would take this decision on its own: refuse instead of switching underneath it
+                raise ValueError(f"KGnet.load_state_dict: {bad[0][0]} (max |w| = {bad[0][1]:g}) is outside the range of precision="
+                                 f"{self.precision!r} and a gradient reducer is attached; load the checkpoint (or call set_precision("
+                                 f"{self.BF16_SIBLING[self.precision]!r})) BEFORE FlatGradReducer.attach")
             sib = self.BF16_SIBLING[self.precision]
             warnings.warn(f"KGnet: {len(bad)} conv weight tensor(s) (e.g. {bad[0][0]}, max |w| = {bad[0][1]:g}) are outside the range of precision="
                           f"{self.precision!r} (packed weights x 2^12 in IEEE half: |w| < {self.HALF_WEIGHT_LIMIT:g}); switching this model to "
                           f"precision={sib!r} (bf16 planes)", RuntimeWarning, stacklevel=2)
+            self.precision_switch = (self.precision, sib, bad[0][0], bad[0][1])      # visible to the caller: model.precision_switch, r.kg_precision_switch
             self.set_precision(sib)
+        try:
+            r.kg_precision_switch = self.precision_switch
+        except AttributeError:         # (a namedtuple result without __dict__: the model attribute carries it)
+            pass
         return r
 
     def invalidate_caches(self):

@@ -339,11 +339,10 @@ extern "C" int kg_conv1x1(const void* x, const void* w, const float* bias, void*
         const int nb = (use_nb && kc == 1 && Cout > 64) ? (Cout > 128 ? 4 : 2) : 1;   // cout blocks per workgroup (K = 64: X is the big operand)
         // weights + X tile (16 / 32 KB) aliased with the 32 KB fp32 output tile; nb > 1: separate X and output tiles
         const int smem_s = nb == 1 ? kc * 8192 + 32768 : nb * 8192 + 16384 + 32768;
-        static bool attr_done_s = false;
-        if (!attr_done_s) {
+        static KgPerDevice attr_done_s;
+        if (attr_done_s.first()) {
             KG_HIP(hipFuncSetAttribute((const void*)conv1x1_stream_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 8192 + 49152));
             KG_HIP(hipFuncSetAttribute((const void*)conv1x1_stream_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8192 + 49152));
-            attr_done_s = true;
         }
         const long nt = (M + 127) / 128;
         const int nyb = kg_cdiv(Cout, 64 * nb);

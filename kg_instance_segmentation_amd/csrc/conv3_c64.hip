@@ -212,10 +212,9 @@ extern "C" int kg_conv3x3_c64(const void* x, const void* w, const float* bias, v
     a.tiletab = (const int4*)tiletab16; a.ntiles = ntiles; a.N = N; a.H = H; a.W = W; a.tiles_x = kg_cdiv(W, 16); a.tiles_y = kg_cdiv(H, 16);
     a.ldx = ldx; a.Cout = Cout; a.ldy = ldy; a.ldres = ldres; a.ldmask = ldmask; a.K = K; a.flip = flip; a.relu = relu;
     constexpr int smem = 9 * 8192 + 2 * 18 * 18 * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static KgPerDevice attr_done;
+    if (attr_done.first()) {
         KG_HIP(hipFuncSetAttribute((const void*)conv3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_done = true;
     }
     const int total = tiletab16 ? ntiles : N * a.tiles_x * a.tiles_y;
     const int ny = kg_cdiv(Cout, 64);                // 64-cout blocks: each (persistent) workgroup keeps one block's weights

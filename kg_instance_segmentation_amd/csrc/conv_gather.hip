@@ -277,13 +277,12 @@ __global__ __launch_bounds__(256 * TCW) void conv_gather_kernel(const ConvArgs a
 
 int kg_launch_conv_gather(ConvArgs a, int cin_pad, hipStream_t st, bool stats_ok) {
     constexpr int smem = 3 * (256 * 128 + 128 * 128);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static KgPerDevice attr_done;
+    if (attr_done.first()) {
         KG_HIP(hipFuncSetAttribute((const void*)conv_gather_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         KG_HIP(hipFuncSetAttribute((const void*)conv_gather_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         KG_HIP(hipFuncSetAttribute((const void*)conv_gather_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem / 2));
         KG_HIP(hipFuncSetAttribute((const void*)conv_gather_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem / 2));
-        attr_done = true;
     }
     // hi + lo planes on both operands (3 virtual planes: x_hi w_lo, x_lo w_hi, x_hi w_hi): paired stages of 32 channels (KG_GATHER_P2=0: the
     // virtual-plane walk)

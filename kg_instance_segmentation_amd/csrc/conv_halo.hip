@@ -992,10 +992,9 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
     constexpr int TW = 4 * WPX, HWD = TW + KS - 1, TC = WC * 64;
     constexpr int smem = (16 + KS - 1) * HWD * 128 + ((KS == 7 && WC <= 2) ? 6 : 3) * TC * 128;
     a.tiles_x = kg_cdiv(a.W, TW);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static KgPerDevice attr_done;
+    if (attr_done.first()) {
         KG_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<KS, WC, WPX, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_done = true;
     }
     dim3 grid(a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y, GM == 1 ? (a.head_split ? 3 : 1) : kg_cdiv(a.Cout, TC), (GM == 1 && a.prod_split) ? 3 * a.prod_split : 1);
     if (a.stat_part) a.stat_part = (GM == 0 && !a.tiletab) ? kg_conv_stats_claim(grid.x, a.Cout) : nullptr;   // (armed by the caller: BatchNorm statistics)
@@ -1038,11 +1037,10 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
             return rc2;
         }
         if (ok3 && a.nb2 == 1) {
-            static bool w43_attr = false;
-            if (!w43_attr) {
+            static KgPerDevice w43_attr;
+            if (w43_attr.first()) {
                 KG_HIP(hipFuncSetAttribute((const void*)conv_halo3_w4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_w4));
                 KG_HIP(hipFuncSetAttribute((const void*)conv_halo3_w4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_w4));
-                w43_attr = true;
             }
             dim3 g2(grid.x, a.Cout / 128);
             a.xcd_map = use_xcd && g2.x % 8 == 0 && (g2.y > 1 || use_xcd > 1) && (long)a.Cout * a.K * 2 <= (24L << 20);
@@ -1064,13 +1062,12 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
         static const int nb2 = getenv("KG_HALO7_NB2") ? atoi(getenv("KG_HALO7_NB2")) : 1;
         const bool ok = !a.tiletab && a.y && !a.y_f32 && !a.stat_part && !a.oscale && a.ksplit <= 1 && ((w4dir >> (a.flip ? 1 : 0)) & 1);
         const bool multi = a.cin_pad / 64 > a.km.n;
-        static bool w4_attr = false;
-        if (!w4_attr) {
+        static KgPerDevice w4_attr;
+        if (w4_attr.first()) {
             KG_HIP(hipFuncSetAttribute((const void*)conv_halo7_w4_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             KG_HIP(hipFuncSetAttribute((const void*)conv_halo7_w4_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             KG_HIP(hipFuncSetAttribute((const void*)conv_halo7_w4_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             KG_HIP(hipFuncSetAttribute((const void*)conv_halo7_w4_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            w4_attr = true;
         }
         if (ok && nb2 && a.nb2 == 0 && a.Cout >= 128 && (!multi || a.km.n == 1) && w4 < 2) {
             const int c128 = a.Cout / 128 * 128;
@@ -1216,17 +1213,25 @@ extern "C" int kg_conv2d_halo_heads2(const void* x, const void* w, const float* 
     //    KG_HEADS2_KPART chunks (default 2) -- blocked accumulation, see HaloArgs.prod_split.
     static const int split_mode = getenv("KG_HEADS2_SPLIT") ? atoi(getenv("KG_HEADS2_SPLIT")) : 1;   // 0 never, 1 small maps + wide heads, 2 whenever it fits
     static const int kpart = getenv("KG_HEADS2_KPART") ? atoi(getenv("KG_HEADS2_KPART")) : 2;        // chunks per part of a wide head (0: no blocked accumulation)
-    const long per_z = (long)N * 55 * H * W;
     const int nchunk = C / 64;
     const int parts = (kpart > 0 && nchunk >= 4) ? kg_cdiv(nchunk, kpart) : 1;
     const bool want = split_mode && vplanes == 3 && (parts > 1 || (a.head_split && (split_mode == 2 || tiles * 3 < 128)));
-    if (want && 3L * parts * per_z <= (96L << 20)) {
-        static float* part[16] = {nullptr};
-        static long part_floats[16] = {0};
+    if (want) {
+        // The partial maps live in a per-device scratch of at most 96 M floats.  A batch whose partials would not fit is processed in image
+        // groups (same kernels, same order of additions per element: the result does not depend on the grouping); only a SINGLE image
+        // beyond the cap gives up parts (then the split) -- recorded in the launch's kernel note ("…/unsplit"), never silently.
+        constexpr long CAP = 96L << 20;
+        static float* part[32] = {nullptr};
+        static long part_floats[32] = {0};
         int dev = 0;
         KG_HIP(hipGetDevice(&dev));
-        if (dev >= 0 && dev < 16) {
-            const long need = 3L * parts * per_z;
+        const long per_img = 55L * H * W;
+        int use_parts = parts;
+        while (use_parts > 1 && 3L * use_parts * per_img > CAP) use_parts = (use_parts + 1) / 2;
+        if (dev >= 0 && dev < 32 && 3L * use_parts * per_img <= CAP && (use_parts > 1 || parts == 1 || a.head_split)) {
+            long group = CAP / (3L * use_parts * per_img);
+            if (group > N) group = N;
+            const long need = 3L * use_parts * per_img * group;
             if (part_floats[dev] < need) {
                 if (part[dev]) KG_HIP(hipFree(part[dev]));
                 part[dev] = nullptr; part_floats[dev] = 0;
@@ -1235,15 +1240,29 @@ extern "C" int kg_conv2d_halo_heads2(const void* x, const void* w, const float* 
                 part_floats[dev] = sz;
             }
             a.head_split = 1;
-            a.prod_split = parts; a.part = part[dev];
-            const int rc = launch_halo<7, 1, 8, 1>(a, (hipStream_t)stream);
-            if (rc != KG_OK) return rc;
-            int blocks = (int)((per_z + 255) / 256); if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(heads2_finish_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)part[dev], per_z, 3 * parts, N, (long)H * W, kp, sh, md,
-                               a.kp_raw);
-            KG_CHECK_LAUNCH("heads2_finish");
+            a.prod_split = use_parts; a.part = part[dev];
+            for (long n0 = 0; n0 < N; n0 += group) {
+                const int ng = (int)(N - n0 < group ? N - n0 : group);
+                HaloArgs g = a;
+                g.N = ng;
+                g.x = a.x + n0 * H * W * (long)ldx;
+                float* kp_g = kp + n0 * 5 * (long)H * W;
+                float* sh_g = sh + n0 * 10 * (long)H * W;
+                float* md_g = md + n0 * 40 * (long)H * W;
+                g.y_f32 = kp_g; g.f32_b = sh_g; g.f32_c = md_g;
+                const int rc = launch_halo<7, 1, 8, 1>(g, (hipStream_t)stream);
+                if (rc != KG_OK) return rc;
+                const long pz = per_img * ng;
+                int blocks = (int)((pz + 255) / 256); if (blocks > 4096) blocks = 4096;
+                hipLaunchKernelGGL(heads2_finish_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)part[dev], pz, 3 * use_parts, ng, (long)H * W,
+                                   kp_g, sh_g, md_g, a.kp_raw);
+                KG_CHECK_LAUNCH("heads2_finish");
+            }
             return KG_OK;
         }
+        const int rc = launch_halo<7, 1, 8, 1>(a, (hipStream_t)stream);
+        if (parts > 1) kg_note_kernel("conv_halo_kernel<7, 1, 8, 1>/unsplit: blocked accumulation dropped (one image's partial maps exceed the scratch cap)");
+        return rc;
     }
     return launch_halo<7, 1, 8, 1>(a, (hipStream_t)stream);
 }

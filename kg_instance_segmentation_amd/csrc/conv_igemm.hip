@@ -210,11 +210,10 @@ template <int WC, int WP, int CF, int KS>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
     constexpr int TC = WC * CF * 16, TP = WP * 64, NT = WC * WP * 64;
     constexpr int smem = 2 * (KS * TC * 64 + KS * TP * 64) + 256;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static KgPerDevice attr_done;
+    if (attr_done.first()) {
         KG_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<WC, WP, CF, KS>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_done = true;
     }
     dim3 grid(kg_cdiv(a.M, TP), kg_cdiv(a.Cout, TC));
     hipLaunchKernelGGL((conv_igemm_kernel<WC, WP, CF, KS>), grid, dim3(NT), smem, st, a);

@@ -247,10 +247,9 @@ int kg_launch_conv_small(const ConvArgs& a, hipStream_t st) {
         return KG_OK;
     }
     const int smem = a.ntaps * 8 * 64 * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static KgPerDevice attr_done;
+    if (attr_done.first()) {
         KG_HIP(hipFuncSetAttribute((const void*)conv_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 49 * 8 * 64 * 4));
-        attr_done = true;
     }
     const long groups = (a.M + 127) / 128;
     const int per_cu = smem <= 32768 ? 4 : 1;

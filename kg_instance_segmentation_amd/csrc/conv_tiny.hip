@@ -210,10 +210,9 @@ int kg_launch_splitk_finish(const ConvArgs& a, int Z, const float* part, int npt
 int kg_launch_conv_tiny(const ConvArgs& a, int cin_virt, hipStream_t st) {
     constexpr int smem = 4 * 4 * 16 * 64 * 4;
     constexpr int MAX_SLOTS = KG_SPLITK_MAX_SLOTS;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static KgPerDevice attr_done;
+    if (attr_done.first()) {
         KG_HIP(hipFuncSetAttribute((const void*)conv_tiny_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_done = true;
     }
     const int tiles = kg_cdiv(a.M, 64) * kg_cdiv(a.Cout, 64);
     const int nunits = a.ntaps * (cin_virt / 64);

@@ -517,8 +517,8 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
     if (use_ring && g_wgrad_use_tr && cin_lim >= 128 && cout_lim >= 64) {   // (ops.wgrad_splits sizes nsplit for these tiles under the same condition)
         const int nh = cout_lim >= 256 ? 2 : 1;
         const int smem = 3 * (nh + 1) * 64 * 256 + 3 * 512;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static KgPerDevice attr_done;
+        if (attr_done.first()) {
             constexpr int smem2 = 3 * 3 * 64 * 256 + 3 * 512, smem1 = 3 * 2 * 64 * 256 + 3 * 512;
             KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
             KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
@@ -526,7 +526,6 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
             KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1));
             KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1));
             KG_HIP(hipFuncSetAttribute((const void*)conv_wgrad_ring_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1));
-            attr_done = true;
         }
         dim3 gridr(((cin_lim + 127) / 128) * ((cout_lim + 128 * nh - 1) / (128 * nh)), KH * KW, nsplit);
         const int md = a.mode >= 2 ? 2 : (a.direct ? 0 : 1);

@@ -52,6 +52,19 @@ void kg_set_error(const char* fmt, ...);
 void kg_note_kernel(const char* name);
 #define KG_KNAME(buf, fmt, ...) static char buf[96] = ""; if (!buf[0]) snprintf(buf, sizeof(buf), fmt, __VA_ARGS__)
 
+// One-time per-DEVICE set-up of a launcher (hipFuncSetAttribute for > 64 KB of dynamic LDS): function attributes belong to the device's
+// code object, so a process that drives several devices must set them on each (a plain `static bool` assumed one device per process).
+struct KgPerDevice {
+    bool done[32] = {};
+    bool first() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) return true;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+
 #define KG_CHECK_ARG(cond, ...)                 \
     do {                                        \
         if (!(cond)) {                          \

@@ -298,10 +298,9 @@ extern "C" int kg_grad_pack(const float* g, const float* prob, void* out, int N,
     int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
     if (cpad <= 64) {
         const int smem = cpad * 257 * 4;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static KgPerDevice attr_done;
+        if (attr_done.first()) {
             KG_HIP(hipFuncSetAttribute((const void*)grad_pack_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 257 * 4));
-            attr_done = true;
         }
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(grad_pack_tr_kernel, dim3(blocks), dim3(256), smem, (hipStream_t)stream, g, prob, (bf16_t*)out, total, C, (long)H * W, ld, cpad,

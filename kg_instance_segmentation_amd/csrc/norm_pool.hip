@@ -650,12 +650,19 @@ extern "C" int kg_rows_rescale(void* g, int ld, long M, int C, int target_log2, 
     KG_CHECK_ARG(g && cum_in && cum_out && r_out && scratch && C % 8 == 0 && ld % 8 == 0, "kg_rows_rescale: bad args");
     if (M == 0) return KG_OK;
     const long total = M * (C / 8);
-    int blocks = (int)((total + 4095) / 4096); if (blocks > 256) blocks = 256;     // 1024 threads x 4 chunks in flight each; one workgroup per CU
+    // 1024 threads x 4 chunks in flight each; at most one workgroup per CU, and for the tensors that fit the L2 / Infinity Cache they were just
+    // written to (<= 4 M chunks = 64 MB per plane) a quarter of that: the launch is then bound by the 2 serialised same-address atomics
+    // per workgroup (~13 ns each), not by the read
+    int blocks = (int)((total + 4095) / 4096);
+    const int cap = total <= (4L << 20) ? 64 : 256;
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(rows_absmax_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, RowsR{(const bf16_t*)g, ld, pp.a_planes, pp.a_pstride}, M, C / 8,
                        target_log2, cum_in, cum_out, r_out, (unsigned*)scratch);
     KG_CHECK_LAUNCH("rows_absmax");
-    int b2 = (int)((total * pp.a_planes + 255) / 256); if (b2 > 2048) b2 = 2048;      // (grid-stride; the usual factor is 1 and the kernel returns at once: dispatching 16 384 empty workgroups cost 11 us)
-    hipLaunchKernelGGL(rows_scale_kernel, dim3(b2), dim3(256), 0, (hipStream_t)stream, (bf16_t*)g, ld, pp.a_planes, pp.a_pstride, M, C / 8, (const float*)r_out,
+    // (grid-stride; a factor of 1 returns at once: dispatching 2048 empty 256-thread workgroups still cost 12 us per boundary, 24 boundaries per
+    // step -- 512 workgroups of 1024 threads keep every CU's wave slots full when there IS work and cost a quarter of that when there is none)
+    int b2 = (int)((total * pp.a_planes + 1023) / 1024); if (b2 > 512) b2 = 512;
+    hipLaunchKernelGGL(rows_scale_kernel, dim3(b2), dim3(1024), 0, (hipStream_t)stream, (bf16_t*)g, ld, pp.a_planes, pp.a_pstride, M, C / 8, (const float*)r_out,
                        (const float*)nullptr);
     KG_CHECK_LAUNCH("rows_scale");
     return KG_OK;

@@ -103,11 +103,15 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int* __restrict__ coun
 //   heavy   : one wave per heavy cell: rank sort by key in LDS (n <= HOUGH_LCAP; through global scratch beyond), lane 0 adds in order.
 // Every sum is still formed in increasing key order from +0.0 with separate fp64 adds (-ffp-contract=off): bit-identical heat maps.
 #define HOUGH_K 8
+// hdr[1]: raised by hough_far_kernel (far list overflow) -- complete before hough_tile_kernel starts, so that kernel's entry test is
+// workgroup-uniform; hdr[2]: raised by a tile workgroup whose votes exceed its LDS slabs -- never read by the tile kernel itself (a sibling
+// workgroup's late write would otherwise let the waves of one workgroup diverge around its barriers).
+__device__ __forceinline__ bool hough_gave_up(const int* hdr) { return (hdr[1] | hdr[2]) != 0; }
 #define HOUGH_LCAP 512
 __global__ void hough_scatter_kernel(const float* __restrict__ kp, const float* __restrict__ soff, int H, int W, int* __restrict__ cnt,
                                      unsigned* __restrict__ ink, double* __restrict__ inv, int* __restrict__ ovcell,
                                      double* __restrict__ ovval, const int* __restrict__ hdr) {
-    if (!hdr[1]) return;                         // (the tile formulation produced the map)
+    if (!hough_gave_up(hdr)) return;             // (the tile formulation produced the map)
     const int c = blockIdx.y, HW = H * W;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 4 * HW; e += gridDim.x * blockDim.x) {
         const int b = e / HW, i = e - b * HW;
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(1024) void hough_classify_kernel(int ncells, const 
                                                               unsigned long long* __restrict__ ctr64, int* __restrict__ ovoff,
                                                               int* __restrict__ heavy_list, unsigned* __restrict__ skey,
                                                               double* __restrict__ sval, const int* __restrict__ hdr) {
-    if (!hdr[1]) return;
+    if (!hough_gave_up(hdr)) return;
     __shared__ int s_need[1024], s_hv[1024];
     __shared__ unsigned long long s_base;
     const int cc = blockIdx.x * 1024 + threadIdx.x;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(1024) void hough_classify_kernel(int ncells, const 
 __global__ void hough_ovfill_kernel(long nvotes, int HW4, const int* __restrict__ ovcell, const double* __restrict__ ovval,
                                     const int* __restrict__ ovoff, int* __restrict__ ovcur, unsigned* __restrict__ skey,
                                     double* __restrict__ sval, const int* __restrict__ hdr) {
-    if (!hdr[1]) return;
+    if (!hough_gave_up(hdr)) return;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvotes; i += (long)gridDim.x * blockDim.x) {
         const int cc = ovcell[i];
         if (cc < 0) continue;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(64) void hough_heavy2_kernel(const int* __restrict_
                                                           double* __restrict__ srt, double norm, double* __restrict__ heat,
                                                           const unsigned long long* __restrict__ ctr64, const int* __restrict__ heavy_list,
                                                           const int* __restrict__ hdr) {
-    if (!hdr[1]) return;
+    if (!hough_gave_up(hdr)) return;
     __shared__ unsigned lk[HOUGH_LCAP];
     __shared__ double lv[HOUGH_LCAP];
     const int nh = (int)(unsigned)(*ctr64 >> 32);
@@ -269,8 +273,8 @@ __global__ __launch_bounds__(64) void hough_heavy2_kernel(const int* __restrict_
 //           per cell ranks the slab's keys and lane 0 adds the values in rank order (through an LDS scratch, HT_SCR ranks at a time).
 // A vote whose source lies OUTSIDE its target tile's region ("far": |offset| beyond 16 .. 48 px) is found by a pre-pass over the pixels
 // (hough_far_kernel: same integer test) and listed globally; every tile workgroup also scans that list.  More than HOUGH_FARCAP far votes (a
-// random-init network: offsets of hundreds of pixels) or more than HT_CAP votes in one tile raise hdr[1] and the scatter formulation runs
-// instead -- its kernels return at once while hdr[1] == 0.  Same keys, same order, same fp64 adds: the same bits.
+// random-init network: offsets of hundreds of pixels) or more than HT_CAP votes in one tile raise hdr[1] / hdr[2] and the scatter formulation runs
+// instead -- its kernels return at once while both are 0.  Same keys, same order, same fp64 adds: the same bits.
 #define HT_T 32
 #define HT_R 16
 #define HT_S (HT_T + 2 * HT_R)
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(1024) void hough_tile_kernel(const float* __restric
     double* vals = reinterpret_cast<double*>(keys + HT_CAP);
     double* scr = vals + HT_CAP;                 // [16 waves][HT_SCR]
     __shared__ int s_nh, s_wtot[16];
-    if (hdr[1]) return;                          // (uniform: the scatter formulation takes over)
+    if (hdr[1]) return;                          // (uniform: only hough_far_kernel, a finished launch, writes hdr[1]; the scatter formulation takes over)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.y, HW = H * W;
     const int tI = blockIdx.x / tiles_x, tJ = blockIdx.x - tI * tiles_x;
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(1024) void hough_tile_kernel(const float* __restric
     const int base = wbase + incl - n;
     off[tid] = base;
     if (total > HT_CAP) {                        // (uniform) too many votes for the LDS slabs: the scatter formulation recomputes the whole map
-        if (tid == 0) hdr[1] = 1;
+        if (tid == 0) hdr[2] = 1;               // (hdr[2], not hdr[1]: see hough_gave_up)
         return;
     }
     __syncthreads();
@@ -436,9 +440,9 @@ __global__ __launch_bounds__(1024) void hough_tile_kernel(const float* __restric
         if (lane == 0) heat[(long)c * HW + (long)(tI * HT_T + (t >> 5)) * W + (tJ * HT_T + (t & 31))] = s / norm;
     }
 }
-// start of the scatter formulation when the tile formulation gave up (hdr[1] != 0): clears the slab allocator, the vote counters and the cursors
+// start of the scatter formulation when the tile formulation gave up (hdr[1] | hdr[2] != 0): clears the slab allocator, the vote counters and the cursors
 __global__ void hough_clear_kernel(const int* __restrict__ hdr, int4* __restrict__ a, long n4) {
-    if (!hdr[1]) return;
+    if (!hough_gave_up(hdr)) return;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) a[i] = make_int4(0, 0, 0, 0);
 }
 
@@ -1035,11 +1039,11 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
     pp_mark(st);
     int gx = (4 * HW + 255) / 256; if (gx > 2048) gx = 2048;
     {
-        // header (p.heavy_n, 256 bytes): [0..1] the 64-bit slab allocator of the scatter formulation, [8] = far-vote count, [9] = "tile formulation
-        // gave up" flag (hdr = &heavy_n[8]).  KG_HOUGH_TILE=0: scatter formulation only.
+        // header (p.heavy_n, 256 bytes): [0..1] the 64-bit slab allocator of the scatter formulation, [8] = far-vote count, [9] / [10] = "tile formulation
+        // gave up" flags (far-list overflow / tile overflow; hdr = &heavy_n[8]).  KG_HOUGH_TILE=0: scatter formulation only.
         static const int use_tile = getenv("KG_HOUGH_TILE") ? atoi(getenv("KG_HOUGH_TILE")) : 1;
         int* hdr = p.heavy_n + 8;
-        const long clr = (long)(((unsigned char*)p.cursor - (unsigned char*)p.count) + (size_t)5 * HW * 4) / 16;
+        const long clr = (long)(((unsigned char*)p.cursor - (unsigned char*)p.count) + (size_t)5 * HW * 4 + 15) / 16;      // (rounded UP: the al256 padding behind `cursor` takes the 1-3 extra ints)
         KG_HIP(hipMemsetAsync(p.heavy_n, 0, 256, st));
         if (use_tile) {
             // far list in the scatter formulation's (then unused) arrays: cells in `sorted`, keys in `keys`, values in `vals`
@@ -1047,10 +1051,9 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
             int gf = (HW + 255) / 256; if (gf > 2048) gf = 2048;
             hipLaunchKernelGGL(hough_far_kernel, dim3(gf, 5), dim3(256), 0, st, kp, soff, H, W, hdr, farcell, p.keys, p.vals, reinterpret_cast<int4*>(p.count), clr);
             constexpr int tile_lds = 3 * 1024 * 4 + HT_CAP * 4 + HT_CAP * 8 + 16 * HT_SCR * 8;
-            static bool tile_attr = false;
-            if (!tile_attr) {
+            static KgPerDevice tile_attr;
+            if (tile_attr.first()) {
                 KG_HIP(hipFuncSetAttribute((const void*)hough_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, tile_lds));
-                tile_attr = true;
             }
             const int tiles_x = (W + HT_T - 1) / HT_T, tiles_y = (H + HT_T - 1) / HT_T;
             hipLaunchKernelGGL(hough_tile_kernel, dim3(tiles_x * tiles_y, 5), dim3(1024), tile_lds, st, kp, soff, H, W, norm, p.heat, hdr, farcell, p.keys,
@@ -1059,7 +1062,7 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
             KG_HIP(hipMemsetD32Async((hipDeviceptr_t)(hdr + 1), 1, 1, st));
             hipLaunchKernelGGL(hough_clear_kernel, dim3(1024), dim3(256), 0, st, hdr, reinterpret_cast<int4*>(p.count), clr);
         }
-        // scatter formulation, every kernel a no-op while hdr[1] == 0 (its counters count | offs | cursor were cleared by the far pass)
+        // scatter formulation, every kernel a no-op while hdr[1] | hdr[2] == 0 (its counters count | offs | cursor were cleared by the far pass)
         unsigned long long* ctr64 = reinterpret_cast<unsigned long long*>(p.heavy_n);
         hipLaunchKernelGGL(hough_scatter_kernel, dim3(gx, 5), dim3(256), 0, st, kp, soff, H, W, p.count, p.ink, p.inv, (int*)p.keys, p.vals, hdr);
         hipLaunchKernelGGL(hough_classify_kernel, dim3((5 * HW + 1023) / 1024), dim3(1024), 0, st, 5 * HW, p.count, p.ink, p.inv, norm, p.heat, ctr64,
@@ -1082,10 +1085,9 @@ extern "C" int kg_postproc_scale(const float* kp, const float* soff, const float
     hipLaunchKernelGGL(kp_rank_kernel, dim3(512), dim3(256), 0, st, p.npk, peak_cap, p.ids, p.xs, p.ys, p.conf, p.sid, p.sx, p.sy,
                        p.sconf);
     pp_mark(st);
-    static bool group_attr = false;
-    if (!group_attr) {
+    static KgPerDevice group_attr;
+    if (group_attr.first()) {
         KG_HIP(hipFuncSetAttribute((const void*)group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(GroupLds)));
-        group_attr = true;
     }
     hipLaunchKernelGGL(group_kernel, dim3(1), dim3(256), sizeof(GroupLds), st, p.npk, peak_cap, p.sid, p.sx, p.sy, p.sconf, mid, H, W, p.alive,
                        skel_cap, p.skxy, skel, nskel);
@@ -1123,10 +1125,9 @@ extern "C" int kg_nms(const double* boxes, const int* nbox, int box_cap, double 
     unsigned char* dead = q;
     hipStream_t st = (hipStream_t)stream;
     constexpr int nms_lds = NMS_NL * (5 * 8 + 1);
-    static bool nms_attr = false;
-    if (!nms_attr) {
+    static KgPerDevice nms_attr;
+    if (nms_attr.first()) {
         KG_HIP(hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, nms_lds));
-        nms_attr = true;
     }
     hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(1024), nms_lds, st, nbox, box_cap, boxes, thresh, order, dead, keep, nkeep);
     hipLaunchKernelGGL(gather_rows5_kernel, dim3(64), dim3(256), 0, st, boxes, keep, nkeep, out);

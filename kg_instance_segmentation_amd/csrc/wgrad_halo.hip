@@ -301,10 +301,9 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
 template <int KS, int CIF, int NCF = 4, bool BIAS = false>
 static int launch_wg(const WgHaloArgs& a, hipStream_t st) {
     constexpr int smem = 2 * WgGeom<KS, CIF>::BUF;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static KgPerDevice attr_done;
+    if (attr_done.first()) {
         KG_HIP(hipFuncSetAttribute((const void*)wgrad_halo_kernel<KS, CIF, NCF, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_done = true;
     }
     const int n_ci = (a.cin_lim + 16 * CIF - 1) / (16 * CIF), n_co = (a.cout_lim + 63) / 64;
     hipLaunchKernelGGL((wgrad_halo_kernel<KS, CIF, NCF, BIAS>), dim3(n_ci * n_co, a.nsplit), dim3(512), smem, st, a);

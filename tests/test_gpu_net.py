@@ -496,12 +496,18 @@ def test_half_range_violation_is_loud(state_dict0):
     with pytest.warns(RuntimeWarning, match="fp32bf"):
         m2.load_state_dict(m.state_dict())
     assert m2.precision == "fp32bf"
+    assert m2.precision_switch[:3] == ("fp32", "fp32bf", "c3_cat_refine.0.weight")      # the switch is recorded where a training script can see it
     m2 = m2.to(DEV).eval()
     with torch.no_grad():
         assert all(torch.isfinite(t).all() for d in m2.forward_dec(x.to(DEV))[:4] for t in d)      # bf16 planes carry such a weight
     m3 = KGnet.resnet50(pretrained=False, precision="fp32bf")
     m3.load_state_dict(m.state_dict())
-    assert m3.precision == "fp32bf"
+    assert m3.precision == "fp32bf" and m3.precision_switch is None
+    # a non-finite weight is a broken checkpoint, not a range question: it raises in every case
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["c3_cat_refine.0.weight"][0, 0, 0, 0] = float("nan")
+    with pytest.raises(ValueError, match="non-finite"):
+        KGnet.resnet50(pretrained=False).load_state_dict(sd)
 
 
 def test_resnet101_random_init_gradients_stay_in_half_range():
