@@ -566,12 +566,8 @@ def main():
         model = KGnet.resnet50(pretrained=False, precision=precision).to(dev).train()
         parallel.broadcast_parameters(model)
         # train.py:71 (torch.optim.Adam is caller code; `fused=True` selects PyTorch's single-kernel multi-tensor implementation)
-        if os.environ.get("KG_ADAM", "hip") == "hip":     # the build's one-launch Adam (kg_adam_step), same update rule
-            from kg_instance_segmentation_amd.optim import Adam
-            opt = Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4,
-                       prepack=model if os.environ.get("KG_PREPACK", "1") == "1" else None)     # (packs the next forward's weights behind the update kernel)
-        else:
-            opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4, fused=os.environ.get("KG_ADAM_FUSED", "1") == "1")
+        from kg_instance_segmentation_amd.optim import Adam      # the build's one-launch Adam (kg_adam_step), torch.optim.Adam's update rule
+        opt = Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-4, prepack=model)     # (prepack: packs the next forward's weights behind the update kernel)
         reducer = parallel.FlatGradReducer().attach(model) if world > 1 else None
 
         def step(sync):

@@ -335,7 +335,7 @@ extern "C" int kg_conv1x1(const void* x, const void* w, const float* bias, void*
     if (K <= 128 && Cout % 8 == 0 && ldy % 8 == 0 && al16(y) && al16(x) && (!res || (ldres % 8 == 0 && al16(res))) &&
         (!mask || (ldmask % 8 == 0 && al16(mask)))) {
         const int kc = K / 64;
-        static const int use_nb = getenv("KG_C1_NB") ? atoi(getenv("KG_C1_NB")) : 1;
+        constexpr int use_nb = 1;
         const int nb = (use_nb && kc == 1 && Cout > 64) ? (Cout > 128 ? 4 : 2) : 1;   // cout blocks per workgroup (K = 64: X is the big operand)
         // weights + X tile (16 / 32 KB) aliased with the 32 KB fp32 output tile; nb > 1: separate X and output tiles
         const int smem_s = nb == 1 ? kc * 8192 + 32768 : nb * 8192 + 16384 + 32768;

@@ -286,7 +286,7 @@ int kg_launch_conv_gather(ConvArgs a, int cin_pad, hipStream_t st, bool stats_ok
     }
     // hi + lo planes on both operands (3 virtual planes: x_hi w_lo, x_lo w_hi, x_hi w_hi): paired stages of 32 channels (KG_GATHER_P2=0: the
     // virtual-plane walk)
-    static const int use_p2 = getenv("KG_GATHER_P2") ? atoi(getenv("KG_GATHER_P2")) : 1;
+    constexpr int use_p2 = 1;
     const bool p2 = use_p2 && a.km.total == 3 * a.km.n && a.km.xtab == (0u | (1u << 2) | (0u << 4));
     const int cin_real = p2 ? cin_pad / 3 : cin_pad;
     // at most 64 couts and enough pixels to fill the chip with 128-pixel tiles: the 4-wave 128 x 64 variant, two workgroups per CU

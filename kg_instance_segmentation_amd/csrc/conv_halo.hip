@@ -69,7 +69,7 @@ struct HaloArgs {
 static void halo_set_walk(HaloArgs& a, int xP, int wP) {
     int xi[6], wj[6];
     const int nv = kg_plane_pairs(xP, wP, xi, wj);
-    static const int on = getenv("KG_HALO_SHARE") ? atoi(getenv("KG_HALO_SHARE")) : 1;
+    constexpr int on = 1;
     a.walk3 = on && nv == 3 && xi[0] == 0 && xi[1] == 1 && xi[2] == 0;
 }
 
@@ -1011,7 +1011,7 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
             if (part) { a.ksplit = Z; a.kpart = part; grid.z = Z; }
         }
     }
-    static const int use_xcd = getenv("KG_HALO_XCD") ? atoi(getenv("KG_HALO_XCD")) : 1;
+    constexpr int use_xcd = 1;
     // (not for the widest heads: 24 cout blocks of one tile stream 24 different 3 MB weight slices through the XCD's 4 MB L2: -2 %)
     a.xcd_map = use_xcd && !a.tiletab && grid.x % 8 == 0 && (grid.y > 1 || use_xcd > 1) && (long)a.Cout * a.K * 2 <= (24L << 20);
     if constexpr (KS == 3 && WC == 1 && WPX == 8 && GM == 0) {
@@ -1055,7 +1055,7 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
         // KG_HALO7_W4: 0 = never; 1 (default) = the multi-product launches (hi + lo planes: 3 products; three bf16 planes: 6) with >= 2 channel
         // chunks per plane (C >= 128: where the blocked accumulation matters for the fp32 tolerance); 2 = every dense rows-output launch
         static const int w4 = getenv("KG_HALO7_W4") ? atoi(getenv("KG_HALO7_W4")) : 1;
-        static const int w4dir = getenv("KG_HALO7_W4_DIR") ? atoi(getenv("KG_HALO7_W4_DIR")) : 3;      // bisecting: bit 0 = forward launches, bit 1 = flipped (input gradient)
+        constexpr int w4dir = 3;      // bisecting: bit 0 = forward launches, bit 1 = flipped (input gradient)
         // KG_HALO7_NB2 (default 1): launches that need no blocked accumulation (a single product, or one channel chunk per plane) and have >= 128
         // couts run their whole 128-cout blocks on the 128 x 128 wave tiles of conv_halo7_w4_kernel<*, 2>; a remainder of 64 couts (the fused
         // 64 -> 192 first layers of the c0 / c1 heads) follows as its own launch on the kernel it had before
@@ -1211,7 +1211,7 @@ extern "C" int kg_conv2d_halo_heads2(const void* x, const void* w, const float* 
     //  * small maps (single-image inference: a 64 x 64 map is 8 tiles x 3 heads = 24 workgroups walking 24 chunks each): one part per product;
     //  * wide heads (C >= 256: 4 / 8 chunks per product, 392 / 784 MFMA additions into one accumulator in the hi * hi product): parts of
     //    KG_HEADS2_KPART chunks (default 2) -- blocked accumulation, see HaloArgs.prod_split.
-    static const int split_mode = getenv("KG_HEADS2_SPLIT") ? atoi(getenv("KG_HEADS2_SPLIT")) : 1;   // 0 never, 1 small maps + wide heads, 2 whenever it fits
+    constexpr int split_mode = 1;   // 0 never, 1 small maps + wide heads, 2 whenever it fits
     static const int kpart = getenv("KG_HEADS2_KPART") ? atoi(getenv("KG_HEADS2_KPART")) : 2;        // chunks per part of a wide head (0: no blocked accumulation)
     const int nchunk = C / 64;
     const int parts = (kpart > 0 && nchunk >= 4) ? kg_cdiv(nchunk, kpart) : 1;

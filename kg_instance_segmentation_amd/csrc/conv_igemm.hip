@@ -268,13 +268,13 @@ extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, 
         a.km = kg_make_kmap(cin_pad, 64, pp.a_planes, pp.a_pstride, pp.w_planes);
         return kg_launch_conv_tiny(a, cin_virt, st);
     }
-    static const int use_gather2 = getenv("KG_GATHER2") ? atoi(getenv("KG_GATHER2")) : 2;   // 2: also 64-cout 3x3 convs (half the cout tile idle, still 2x the 64 x 256 tile)
+    constexpr int use_gather2 = 2;   // 2: also 64-cout 3x3 convs (half the cout tile idle, still 2x the 64 x 256 tile)
     if (use_gather2 && tile == 0 && cin_pad % 64 == 0 && y && !y_f32 && (Cout > 64 || (use_gather2 >= 2 && Cout == 64 && (KH * KW > 1 || vplanes > 1))) && dil == 1) {
         a.km = kg_make_kmap(cin_pad, 64, pp.a_planes, pp.a_pstride, pp.w_planes);
         // deep-prefetch LDS-ring variant (conv_gather.hip); it may carry the BatchNorm statistics epilogue when armed
         return kg_launch_conv_gather(a, cin_virt, st, !relu && !res && !mask && (mode == 0 || mode == 2));
     }
-    static const int use_small = getenv("KG_CONV_SMALL") ? atoi(getenv("KG_CONV_SMALL")) : 6;   // (6: the stride-2 7x7 stem too)
+    constexpr int use_small = 6;   // (6: the stride-2 7x7 stem too)
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (use_small && tile == 0 && cin_pad == 8 && (vplanes == 1 || K >= 32 * vplanes * ((KH * KW + 3) / 4)) && KH * KW <= use_small * 9 && y && !y_f32 && Cout % 8 == 0 && ldy % 8 == 0 && al16(y) &&
         (!res || (ldres % 8 == 0 && al16(res))) && (!mask || (ldmask % 8 == 0 && al16(mask))) && dil == 1)

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void conv_small_mfma_kernel(const ConvArgs a) 
 
 // cin_pad == 8, Cout % 8 == 0, bf16 row output with 16-byte aligned rows (checked by the caller, kg_conv2d_igemm)
 int kg_launch_conv_small(const ConvArgs& a, hipStream_t st) {
-    static const int use_mfma = getenv("KG_CONV_SMALL_MFMA") ? atoi(getenv("KG_CONV_SMALL_MFMA")) : 1;
+    constexpr int use_mfma = 1;
     const bool planed = a.km.total > 1 || a.yP > 1 || a.rP > 1;
     if (planed && !(a.K >= 32 * a.km.total * ((a.ntaps + 3) / 4))) { kg_set_error("conv_small: packed rows too short for the plane layout"); return KG_ERR_ARG; }
     if (a.oscale && !(a.K >= 32 * a.km.total * ((a.ntaps + 3) / 4))) { kg_set_error("conv_small: an output scale needs the MFMA variant's packed layout"); return KG_ERR_ARG; }

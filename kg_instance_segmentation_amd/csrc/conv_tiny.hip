@@ -216,8 +216,8 @@ int kg_launch_conv_tiny(const ConvArgs& a, int cin_virt, hipStream_t st) {
     }
     const int tiles = kg_cdiv(a.M, 64) * kg_cdiv(a.Cout, 64);
     const int nunits = a.ntaps * (cin_virt / 64);
-    static const int target = getenv("KG_CONV_TINY_TARGET") ? atoi(getenv("KG_CONV_TINY_TARGET")) : 256;   // workgroups a launch should reach
-    static const int min_units = getenv("KG_CONV_TINY_UNITS") ? atoi(getenv("KG_CONV_TINY_UNITS")) : 2;    // units per wave below which a split does not pay
+    constexpr int target = 256;   // workgroups a launch should reach
+    constexpr int min_units = 2;    // units per wave below which a split does not pay
     int Z = kg_cdiv(target, tiles);
     if (Z > nunits / (4 * min_units)) Z = nunits / (4 * min_units);
     if (Z > 16) Z = 16;

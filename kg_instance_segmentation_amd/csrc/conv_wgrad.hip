@@ -512,8 +512,8 @@ extern "C" int kg_conv2d_wgrad(const void* x, const void* dy, float* dwp, const 
     const int total_chunks = a.wp.n * a.chunks_per_plane;
     a.chunks_per_split = (total_chunks + nsplit - 1) / nsplit;
     a.split_stride = split_stride;
-    static const int use128 = getenv("KG_WGRAD128") ? atoi(getenv("KG_WGRAD128")) : 1;
-    static const int use_ring = getenv("KG_WGRAD_RING") ? atoi(getenv("KG_WGRAD_RING")) : 1;
+    constexpr int use128 = 1;
+    constexpr int use_ring = 1;
     if (use_ring && g_wgrad_use_tr && cin_lim >= 128 && cout_lim >= 64) {   // (ops.wgrad_splits sizes nsplit for these tiles under the same condition)
         const int nh = cout_lim >= 256 ? 2 : 1;
         const int smem = 3 * (nh + 1) * 64 * 256 + 3 * 512;

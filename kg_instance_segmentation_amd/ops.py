@@ -240,6 +240,7 @@ class PackQueue:
         self.fmt = fmt
         self.jobs, self.keep = [], []
         self.sig, self.table = None, None
+        self.pending = None      # a built and uploaded batch whose launch is held back (flush_packs(hold=True))
 
     @property
     def defer(self):
@@ -257,7 +258,7 @@ class PackQueue:
                           pw.K, pw.cin_pad, row0, c0, 1 if transposed else 0, gx, gx * gy, pw.xP, pw.wP, tap_stride))
         self.keep.append((w, pw, rowmap))
 
-    def flush(self):
+    def flush(self, hold=False):
         if not self.jobs:
             return
         import numpy as np
@@ -273,20 +274,46 @@ class PackQueue:
         if sig != self.sig or self.table is None or self.table.device != dev:
             self.table = h2d(arr.view(np.uint8).reshape(-1), dev)
             self.sig = sig
-        _lib.call("kg_pack_weight_batch", ptr(self.table), len(self.jobs), blk, stream_ptr(), fmt=self.fmt)
+        launch = (self.table, len(self.jobs), blk, dev, self.keep)       # (keep: the tensors stay alive until the launch is enqueued)
         self.jobs, self.keep = [], []
+        if hold:
+            self.pending = launch
+        else:
+            self._launch(launch)
+
+    def _launch(self, launch):
+        table, n, blk, dev, _ = launch
+        with torch.cuda.device(dev):
+            _lib.call("kg_pack_weight_batch", ptr(table), n, blk, stream_ptr(), fmt=self.fmt)
+
+    def launch_pending(self):
+        launch, self.pending = self.pending, None
+        if launch is not None:
+            self._launch(launch)
 
 
 PACKQ = PackQueue(0)
 PACKQ16 = PackQueue(1)
 
 
-def flush_packs():
-    """packs every weight queued since the last conv launch (one kg_pack_weight_batch launch per 16-bit format)"""
+def flush_packs(hold=False):
+    """packs every weight queued since the last conv launch (one kg_pack_weight_batch launch per 16-bit format).
+    hold (Engine.prepack, called by the optimizer right after its update kernel): build and upload the job tables now but keep the LAUNCH
+    back until launch_held_packs() -- the first thing the next step does (optim.Adam.zero_grad, forward_dec, forward_seg, any flush).  The
+    per-step loss read-back (train.py:156) then waits for the update kernel only, and the 0.6 ms pack kernel runs while the host is busy with
+    zero_grad and the forward's entry, where the GPU used to idle."""
+    launch_held_packs()
     if PACKQ.jobs:
-        PACKQ.flush()
+        PACKQ.flush(hold)
     if PACKQ16.jobs:
-        PACKQ16.flush()
+        PACKQ16.flush(hold)
+
+
+def launch_held_packs():
+    if PACKQ.pending is not None:
+        PACKQ.launch_pending()
+    if PACKQ16.pending is not None:
+        PACKQ16.launch_pending()
 
 
 class PackedWeight:
@@ -374,15 +401,15 @@ def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=
 
 
 USE_HALO = True
-WGRAD128 = __import__("os").environ.get("KG_WGRAD128", "1") == "1"
-USE_C3 = __import__("os").environ.get("KG_CONV3_C64", "1") == "1"
-IM2COL_WGRAD = __import__("os").environ.get("KG_IM2COL_WGRAD", "1") == "1"
+WGRAD128 = True           # (module constants: tests and probes may flip them; the environment switches of rounds 1-5 are gone, docs/history.md)
+USE_C3 = True
+IM2COL_WGRAD = True
 
 
-HALO_WC = int(__import__("os").environ.get("KG_HALO_WC", "0"))   # tuning override (0 = library default)
+HALO_WC = 0               # tuning override of the halo kernels' cout blocks per workgroup (0 = library default)
 
 
-USE_WS = __import__("os").environ.get("KG_CONV3_WS", "1") == "1"     # A/B switch of the weight-stationary 64 -> 64 kernel (conv3_ws.hip)
+USE_WS = True             # the weight-stationary 64 -> 64 kernel (conv3_ws.hip)
 
 
 def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, flip=False, wc=0,
@@ -424,7 +451,7 @@ def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None,
 
 
 USE_1X1 = True
-GATHER_1X1 = __import__("os").environ.get("KG_GATHER_1X1", "1") == "1"
+GATHER_1X1 = True
 
 
 def conv1x1(x, pw, cout, y, bias=None, res=None, mask=None, relu=False):
@@ -446,8 +473,8 @@ def can_1x1(x, pw, KH, stride, pad, y, y_f32, res=None):
             and 64 <= pw.cin_pad <= 1024 and x.shape[1] >= pw.cin_pad and y.shape[0] == x.shape[0])
 
 
-CONV_TINY_WGS = int(__import__("os").environ.get("KG_CONV_TINY_WGS", "96"))     # 0 = never
-CONV_TINY_TILES = int(__import__("os").environ.get("KG_CONV_TINY_TILES", "384"))
+CONV_TINY_WGS = 96        # regular workgroups below which a launch goes to the split-K kernel (0 = never)
+CONV_TINY_TILES = 384
 
 
 def conv_auto(x, pw, cout, geom, N, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, transposed=False, tile=0, oscale=None,
@@ -478,8 +505,8 @@ def conv_auto(x, pw, cout, geom, N, y=None, y_f32=None, bias=None, res=None, mas
     return "igemm"
 
 
-WGRAD_RING = os.environ.get("KG_WGRAD_RING", "1") != "0"
-WGRAD_RING_WGS = int(os.environ.get("KG_WGRAD_RING_WGS", "256"))      # workgroups of a ring launch (one 96 / 144 KB workgroup per CU)
+WGRAD_RING = True
+WGRAD_RING_WGS = 256      # workgroups of a ring launch (one 96 / 144 KB workgroup per CU)
 
 
 WGRAD_TR = [True]      # mirror of the library's kg_set_wgrad_tr switch (set_wgrad_tr below keeps the two in step)
@@ -494,7 +521,7 @@ def set_wgrad_tr(on):
 
 def wgrad_splits(M, cin_lim, cout_lim, taps, nelem):
     """pixel splits of kg_conv2d_wgrad, sized for the tile the library will pick: the conditions below are kg_conv2d_wgrad's own
-    (conv_wgrad.hip: ring iff KG_WGRAD_RING && transpose reads && cin >= 128 && cout >= 64; 128 x 128 iff KG_WGRAD128 && transpose reads
+    (conv_wgrad.hip: ring iff transpose reads && cin >= 128 && cout >= 64; 128 x 128 iff transpose reads
     && cin, cout >= 128)"""
     chunks = math.ceil(M / 64)
     if WGRAD_RING and WGRAD_TR[0] and cin_lim >= 128 and cout_lim >= 64:
@@ -655,7 +682,7 @@ def bn_stats_train(x, C, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5):
     return st[0], st[1], st[2], st[3]
 
 
-CONV_BN_STATS = __import__("os").environ.get("KG_CONV_BN_STATS", "1") == "1"   # BatchNorm statistics in the producing conv's epilogue
+CONV_BN_STATS = True      # BatchNorm statistics in the producing conv's epilogue
 
 
 _STATS_ARMED = [False]

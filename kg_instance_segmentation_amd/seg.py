@@ -78,7 +78,7 @@ class LazyList(list):
         self._fill(); super().append(v); self._n = super().__len__()
 
 
-SEG_C1 = os.environ.get("KG_SEG_C1", "1") == "1"       # A/B switch: seg_head.2 on the dot-product kernel (kg_seg_conv3_c1)
+SEG_C1 = True       # seg_head.2 on the dot-product kernel (kg_seg_conv3_c1); False: the generic ragged conv (kept for probes)
 
 
 class SegPredictions(list):
@@ -133,6 +133,7 @@ class SegBranch:
         self.packed = {}
         self.train_steps, self.stamp = 0, ("e", 0, 0)     # see Engine.prepare: training forwards always repack
         self.prepack_stamp = None                         # Engine.prepack / forward_dec: the stamp the weights of this step were packed ahead under
+        self.fast_stamp = None                            # ... and that stamp again when the model's fingerprint has not moved since (Engine.fingerprint)
 
     @property
     def P_(self):
@@ -166,9 +167,12 @@ class SegBranch:
 
     def packw(self, key, need_T):
         """key -> (PackedWeight fwd, PackedWeight dgrad, bias) repacked when the parameter version changes."""
+        e = self.packed.get(key)
+        if self.fast_stamp is not None and e is not None and e["ver"][:3] == self.fast_stamp and (not need_T or e["T_ok"]):
+            e["need_T"] = bool(need_T) or e.get("need_T", False)      # prepacked under this stamp, fingerprint unchanged (Engine.prepare)
+            return e["pw"], e["pwT"], self.P(key + ".bias").detach()
         w = self.P(key + ".weight")
         ver = self.stamp + (w._version, w.data_ptr())
-        e = self.packed.get(key)
         cout, cin, k, _ = w.shape
         if e is None or e["ver"] != ver or e["pw"].buf.device != w.device:
             pw = e["pw"] if e is not None and e["pw"].buf.device == w.device else PackedWeight(cout, k * k, ops.round_up(cin, 8), w.device, xP=self.P_, wP=self.P_, dtype=self.dt)
@@ -388,13 +392,16 @@ class SegBranch:
         dev = feats[0].device
         if plan.nb[0] == 0:
             return torch.zeros(0, dtype=torch.float32, device=dev), None
+        ops.launch_held_packs()
         if record:
             self.train_steps += 1
         self.stamp = ("t" if record else "e", self.train_steps, ops.PARAM_EPOCH[0])
         if record and self.prepack_stamp is not None:
             self.stamp = self.prepack_stamp
         self.prepack_stamp = None
-        self.prepare_all(record)
+        if not (record and self.fast_stamp is not None and self.stamp == self.fast_stamp):
+            self.fast_stamp = None
+            self.prepare_all(record)
         fr = [f if isinstance(f, PT) else self.feat_rows(f) for f in feats]
         CH = arch.FEAT_CH
         pre = [None] * 5

@@ -11,21 +11,25 @@ import torch
 from . import net as onet
 
 
-def oracle_grads(sd, x, gt_boxes, gt_masks, gt_lv, H, W, dtype=torch.float64):
+def oracle_grads(sd, x, gt_boxes, gt_masks, gt_lv, H, W, dtype=torch.float64, head_hidden=None):
     """One train step (forward incl. seg branch, 4 detection losses + seg loss, backward: train.py:148-153) of the oracle in `dtype`.
-    Returns (loss, {parameter name: gradient tensor (dtype) or None})."""
+    Returns (loss, {parameter name: gradient tensor (dtype) or None}).  head_hidden (optional dict): receives the ReLU pattern of the first
+    7x7 layer of every head, {(level, head): bool [N, C, H, W]} (which hidden units pass their gradient)."""
     sd = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     names = [k for k, v in sd.items() if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))]
     for n in names:
         sd[n].requires_grad_(True)
     net = onet.Net(sd, training=True)
+    net.keep_head_hidden = head_hidden is not None
     o0, o1, o2, o3, opred = net.forward(x.to(dtype), gt_boxes)
+    if head_hidden is not None:
+        head_hidden.update(net.head_hidden)
     loss = sum(onet.detection_loss(p, t.to(dtype)) for p, t in zip((o0, o1, o2, o3), gt_lv))
     l2 = onet.seg_loss(opred, gt_masks, gt_boxes, H, W)
     if l2 is not None:
         loss = loss + l2
     loss.backward()
-    return float(loss), {n: sd[n].grad for n in names}
+    return float(loss.detach()), {n: sd[n].grad for n in names}
 
 
 def rel_l2(got, ref64):
@@ -72,3 +76,25 @@ def by_group(errs):
         if v:
             out[gname] = {"median": float(np.median(v)), "p25": float(np.quantile(v, 0.25)), "max": float(np.max(v)), "n": len(v)}
     return out
+
+
+HEAD_NAMES = ("kp", "short_offset", "mid_offset")
+
+
+def flipped_units(pattern, ref_pattern):
+    """{first-layer head parameter prefix "<head>_head_c<l>.0": bool [C]} -- output channels with AT LEAST ONE pixel whose ReLU state differs
+    between two forward passes (pattern / ref_pattern: {(level, head): bool [N, C, H, W]}).  The gradient row of such a channel contains
+    (or lacks) a whole pixel's contribution: its error against the reference is the size of that contribution, not rounding."""
+    out = {}
+    for (lvl, head), a in pattern.items():
+        b = ref_pattern[(lvl, head)]
+        out[f"{head}_head_c{lvl}.0"] = (a != b).flatten(2).any(2).any(0)
+    return out
+
+
+def masked_rel_l2(got, ref64, keep):
+    """relative L2 error over the leading-dimension rows `keep` (bool [C]) of a first-layer weight / bias gradient"""
+    a = got.detach().double().cpu()[keep].flatten()
+    b = ref64.detach().double().cpu()[keep].flatten()
+    nb = float(b.norm())
+    return float((a - b).norm()) / nb if nb > 0 else 0.0

@@ -25,6 +25,8 @@ class Net:
         self.training = training
         self.layers = [(n, p, int(b), st) for (n, p, _, st), b in zip(LAYERS, layers[:3])]   # KGnet.py:135-137
         self.kp_logits, self.seg_logits = {}, []      # pre-sigmoid values of the last forward (parity tests compare logits)
+        self.keep_head_hidden = False                 # test hook: keep the ReLU pattern (hidden > 0) of the first 7x7 layer of every head
+        self.head_hidden = {}                         # ... as {(level, head): bool [N, C, H, W]}
 
     # -- primitives ---------------------------------------------------------
     @staticmethod
@@ -77,7 +79,10 @@ class Net:
             out = []
             for head in ("kp", "short_offset", "mid_offset"):
                 p = f"{head}_head_c{lvl}"
-                y = self.conv(self.conv(h, p + ".0", 1, 3, True), p + ".2", 1, 3)
+                hid = self.conv(h, p + ".0", 1, 3, True)
+                if self.keep_head_hidden:
+                    self.head_hidden[(lvl, head)] = hid.detach() > 0
+                y = self.conv(hid, p + ".2", 1, 3)
                 if head == "kp":
                     self.kp_logits[lvl] = y
                 out.append(torch.sigmoid(y) if head == "kp" else y)

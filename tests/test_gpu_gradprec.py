@@ -29,8 +29,9 @@ N, S, NB, SEED = 2, 128, 8, 11
 HEADS = ("heads .2 (7x7 second layers)", "heads .0 (7x7 first layers)")
 
 
-def _gpu_grads(sd, policy, batch):
-    from kg_instance_segmentation_amd import KGnet
+def _gpu_grads(sd, policy, batch, pattern=None, size=S):
+    """pattern (optional dict): receives the ReLU pattern of the first 7x7 layer of every head, {(level, head): bool [N, C, H, W]}"""
+    from kg_instance_segmentation_amd import KGnet, arch, ops
     from kg_instance_segmentation_amd.loss import DetectionLossAll
     from kg_instance_segmentation_amd.seg_loss import SEG_loss
     x, gt_boxes, gt_masks, gt_lv = batch
@@ -38,8 +39,19 @@ def _gpu_grads(sd, policy, batch):
     m.load_state_dict(sd)
     m = m.to(DEV).train()
     m.zero_grad()
-    ldec, lseg = DetectionLossAll(kp_radius=5), SEG_loss(height=S, width=S)
+    m._engine.keep_head_hidden = pattern is not None
+    ldec, lseg = DetectionLossAll(kp_radius=5), SEG_loss(height=size, width=size)
     d0, d1, d2, d3, pred = m(x.to(DEV), gt_boxes)
+    if pattern is not None:
+        for lvl, hid in m._engine.head_hidden.items():
+            C = arch.HEAD_CH[lvl]
+            Hh, Wh = d0[0].shape[2] >> lvl, d0[0].shape[3] >> lvl
+            f = torch.empty(hid.shape[0], 3 * C, dtype=torch.float32, device=DEV)
+            ops.planes_to_f32(hid, 3 * C, f)
+            pos = (f > 0).view(x.shape[0], Hh, Wh, 3 * C).permute(0, 3, 1, 2).cpu()
+            for k, (head, _) in enumerate(arch.HEADS):
+                pattern[(lvl, head)] = pos[:, k * C:(k + 1) * C]
+        m._engine.head_hidden = {}
     loss = sum(ldec(p, t.to(DEV)) for p, t in zip((d0, d1, d2, d3), gt_lv)) + lseg(pred, gt_masks, gt_boxes)
     loss.backward()
     torch.cuda.synchronize()
@@ -52,17 +64,33 @@ def table():
     torch.set_num_threads(min(torch.get_num_threads(), 32))
     sd = weightgen.gen_state_dict(0, variant="cal")
     batch = synth.train_batch(N, S, S, SEED, n_boxes=NB)
-    l64, g64 = gradref.oracle_grads(sd, *batch, S, S, torch.float64)
-    l32, g32 = gradref.oracle_grads(sd, *batch, S, S, torch.float32)
+    pat64, pat32, patgpu = {}, {}, {}
+    l64, g64 = gradref.oracle_grads(sd, *batch, S, S, torch.float64, head_hidden=pat64)
+    l32, g32 = gradref.oracle_grads(sd, *batch, S, S, torch.float32, head_hidden=pat32)
     out = {"oracle_fp32": gradref.column(g32, g64, 1e-12), "loss64": l64}
     grads = {}
     for p in ("fp32", "fp32b2"):
-        lp, grads[p] = _gpu_grads(sd, p, batch)
+        lp, grads[p] = _gpu_grads(sd, p, batch, pattern=patgpu if p == "fp32b2" else None)
         out[p] = gradref.column(grads[p], g64, 1e-12)
         out[p]["loss_rel"] = abs(lp - l64) / abs(l64)
         out[p]["groups"] = gradref.by_group(out[p]["per_tensor"])
     out["oracle_fp32"]["groups"] = gradref.by_group(out["oracle_fp32"]["per_tensor"])
     out["fp32_vs_fp32b2"] = gradref.column(grads["fp32"], grads["fp32b2"], 1e-12)
+    # First-layer head gradients with the ReLU flips taken out: output channels of which at least one pixel changed its ReLU state against
+    # the float64 oracle are excluded from BOTH norms (gradref.flipped_units) -- what is left is rounding
+    out["flips"] = {"fp32b2": gradref.flipped_units(patgpu, pat64), "oracle_fp32": gradref.flipped_units(pat32, pat64)}
+    out["masked"] = {}
+    for col, g in (("fp32b2", grads["fp32b2"]), ("oracle_fp32", g32)):
+        errs = {}
+        for prefix, fl in out["flips"][col].items():
+            for suffix in (".weight", ".bias"):
+                n = prefix + suffix
+                if g.get(n) is not None and bool((~fl).any()):
+                    errs[n] = gradref.masked_rel_l2(g[n], g64[n], ~fl)
+        out["masked"][col] = errs
+        nfl = {k: int(v.sum()) for k, v in out["flips"][col].items()}
+        print(f"[{col}] first-layer head channels with a ReLU flip against float64: {sum(nfl.values())} in {sum(1 for v in nfl.values() if v)} of {len(nfl)} layers; "
+              f"masked error median {np.median(list(errs.values())):.2e} max {max(errs.values()):.2e}")
     for c in ("oracle_fp32", "fp32", "fp32b2", "fp32_vs_fp32b2"):
         r = out[c]
         print(f"[{c}] median {r['median']:.2e} p90 {r['p90']:.2e} max {r['max']:.2e} worst {r['worst'][0]}", {k: f"{v['median']:.1e}" for k, v in r.get("groups", {}).items()})
@@ -93,13 +121,21 @@ def test_single_plane_backward_adds_mixed_precision_grade_error(table):
 def test_two_plane_backward_sits_on_the_fp32_floor_in_heads_and_decoder(table):
     """`fp32b2`: hi + lo half planes in the backward pass -- heads at the float32 oracle's own error (measured 2.9e-7 / 5.9e-7 against
     3.6e-7 / 6.0e-7), decoder within 2e-4 (measured 5e-5 against 1.4e-5), overall within 4 x the float32 oracle (measured 2.3 / 2.0 / 1.7).
-    The first-layer tensors of the c2 / c3 heads are asserted through their LOWER QUARTILE and a cap: a hidden unit whose pre-activation is
-    within rounding of zero passes or blocks its whole gradient (ReLU), and one such flip against float64 costs a tensor 4e-5 .. 6e-4 -- the
-    float32 oracle shows the same (max 2.0e-4); which tensors are hit depends on the last bit of the forward pass (round 5: 11 or 12 of the 24
-    first-layer tensors, depending on the kernel that computes the hidden tensor)."""
+    The second layers are asserted through their plain median.  The FIRST layers through the median over the hidden units whose ReLU state
+    equals the float64 oracle's at every pixel: a hidden unit whose pre-activation is within rounding of zero passes or blocks a whole pixel's
+    gradient, and one such flip against float64 costs a tensor 4e-5 .. 6e-4 -- the float32 oracle shows the same; which tensors are hit depends
+    on the last bit of the forward pass.  With exactly those channels excluded (gradref.flipped_units; the same rule for the float32 oracle's
+    column) every first-layer tensor is back on the floor -- which is the proof that the raised medians of round 5 were flips, not arithmetic;
+    the unmasked values keep a cap."""
     o, p = table["oracle_fp32"], table["fp32b2"]
-    for h in HEADS:
-        assert p["groups"][h]["p25"] <= max(3.0 * o["groups"][h]["p25"], 2e-6), (h, p["groups"][h], o["groups"][h])
+    h2, h0 = HEADS
+    assert p["groups"][h2]["median"] <= max(3.0 * o["groups"][h2]["median"], 2e-6), (p["groups"][h2], o["groups"][h2])
+    mo, mp = table["masked"]["oracle_fp32"], table["masked"]["fp32b2"]
+    assert len(mp) >= 20, len(mp)                                      # (24 first-layer tensors + their biases; a tensor with every channel flipped is skipped)
+    med_o, med_p = float(np.median(list(mo.values()))), float(np.median(list(mp.values())))
+    assert med_p <= max(3.0 * med_o, 2e-6), (med_p, med_o)              # the median, restored (round 4's assertion) on the unflipped units
+    assert max(mp.values()) <= max(10.0 * max(mo.values()), 2e-5), (max(mp.values()), max(mo.values()))
+    for h in HEADS:                                                    # unmasked: caps only (a flip is a legitimate fp32-grade difference)
         assert p["groups"][h]["median"] <= 1e-4 and p["groups"][h]["max"] <= 2e-3, (h, p["groups"][h])
     assert p["groups"]["decoder + c0_conv"]["median"] <= 2e-4
     for k in ("median", "p90", "max"):

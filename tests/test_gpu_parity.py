@@ -7,7 +7,7 @@ logits of +-500 (saturated sigmoids) and is chaotic in train mode, see test_gpu_
 Stated tolerances |got - ref| <= atol + rtol * |ref|  (rms = root mean square of the reference map), per policy (engine.PRECISIONS):
   "fp32" (DEFAULT: hi + lo IEEE-half planes, 3 MFMA products) and "fp32bf" (hi + mid + lo bf16 planes, 6 products):
             rtol 1e-4, atol 1e-5 -- SURVEY 8d's fp32 tolerance, literally, for the kp / seg logits; atol 3e-5 / 6e-5 for the short / mid
-            offset maps (pixels; stated constants), 1e-5 * max(1, rms) for the feature maps -- in eval AND train mode (measured worst |d| / bound on MI355X: 0.44 / 0.87 for "fp32",
+            offset maps (pixels; stated constants), 1e-5 for the feature maps -- in eval AND train mode (measured worst |d| / bound on MI355X: 0.44 / 0.87 for "fp32",
             0.45 / 0.78 for "fp32bf"); every parameter gradient: cosine >= 0.9999, norm within 2e-3 (measured 0.999987 / 6e-4);
   "half"    (single IEEE-half planes, 11 significant bits): SURVEY 8d's reduced-precision clause, rtol 2e-2, with atol 2e-2 * rms
             (measured max |d| = 1.6e-2 rms in train mode, 5e-3 rms in eval mode);
@@ -42,6 +42,7 @@ LOSS_TOL = {"fp32": 2e-5, "fp32bf": 2e-5, "half": 2e-3, "halfmix": 1e-3, "trunk2
 STAT_TOL = {"fp32": (1e-4, 1e-6), "fp32bf": (1e-4, 1e-6), "half": (2e-3, 1e-4), "halfmix": (1e-3, 1e-5), "trunk2": (1e-3, 1e-5), "mixed": (1e-3, 1e-5), "bf16": (3e-2, 3e-3)}
 POLICIES = ["fp32", "fp32bf", "half", "halfmix", "trunk2", "mixed", "bf16"]
 OFFSET_ATOL_SCALE = {"short": 3.0, "mid": 6.0}      # atol of the offset maps = 1e-5 x these (tools/fullsize_oracle_parity.py uses the same constants)
+FEAT_ATOL_SCALE = 1.0                                # feature maps c0 .. c4 (rms 0.04 .. 0.3 on the calibrated fixture): atol 1e-5, literally
 
 
 def sha(a):
@@ -60,9 +61,9 @@ def assert_close(name, got, ref, tol, worst):
     rms = float(np.sqrt(np.mean(ref ** 2)))
     # SURVEY 8d states atol 1e-5 for heatmap / seg LOGITS: taken literally for them.  The offset maps are in pixels (rms 3-4 px short, 5-7 px mid on
     # this fixture): stated per-map constants 3e-5 / 6e-5 (round 5; rounds 2-4 scaled with the map's rms).  The feature maps have no unit scale
-    # of their own: atol 1e-5 * max(1, rms).
+    # of their own: the stated constant 1e-5 (round 6; rounds 2-5 wrote 1e-5 * max(1, rms), which was 1e-5 on every fixture anyway).
     literal = "kp_logit" in name or "seg_logit" in name
-    scale = 1.0 if literal else OFFSET_ATOL_SCALE["short"] if name.endswith("short") else OFFSET_ATOL_SCALE["mid"] if name.endswith("mid") else max(1.0, rms)
+    scale = 1.0 if literal else OFFSET_ATOL_SCALE["short"] if name.endswith("short") else OFFSET_ATOL_SCALE["mid"] if name.endswith("mid") else FEAT_ATOL_SCALE
     bound = atol * scale + arms * rms + rtol * np.abs(ref)
     ratio = np.abs(got - ref) / bound
     k = int(np.argmax(ratio))

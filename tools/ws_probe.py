@@ -36,7 +36,6 @@ def timed(fn, reps=20):
 t = timed(lambda: ops.conv_halo(x, pw, 64, N, H, H, 3, y=y, bias=b, relu=True))
 fl = 2.0 * M * 64 * 9 * 64 * 3
 print(f"dense 8x512^2: {t:.3f} ms = {fl / t / 1e9:.0f} TFLOP/s issued, {(M * 64 * 2 * 2 * 2) / t / 1e6:.0f} GB/s in+out")
-os.environ["KG_CONV3_WS"] = "0"
 ops.USE_WS = False
 t0 = timed(lambda: ops.conv_halo(x, pw, 64, N, H, H, 3, y=y, bias=b, relu=True))
 print(f"conv_halo<3> on the same problem: {t0:.3f} ms")
