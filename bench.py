@@ -408,7 +408,7 @@ def cpu_baseline(S, nboxes, seed=0):
         loss = loss + l2
     loss.backward()
     opt.step()
-    float(loss)
+    float(loss.detach())
     dt = time.time() - t0
     out = {"value": 1.0 / dt, "unit": "imgs/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": f"1 train step, batch 1, 3x{S}x{S}, {nboxes} GT boxes, torch-CPU oracle (oracle/net.py), {dt:.1f} s"}

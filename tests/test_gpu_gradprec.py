@@ -56,7 +56,7 @@ def _gpu_grads(sd, policy, batch, pattern=None, size=S):
     loss.backward()
     torch.cuda.synchronize()
     assert not m.grad_overflowed()
-    return float(loss), {n: (p.grad.detach().double().cpu() if p.grad is not None else None) for n, p in m.named_parameters()}
+    return float(loss.detach()), {n: (p.grad.detach().double().cpu() if p.grad is not None else None) for n, p in m.named_parameters()}
 
 
 @pytest.fixture(scope="module")

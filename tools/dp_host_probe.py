@@ -58,7 +58,7 @@ def worker(rank, world, port, steps, out):
             red.finish()                              # (waits for the collectives: device time, not counted as enqueue)
         opt.step()
         t2 = time.perf_counter()
-        float(loss)
+        float(loss.detach())
         if it >= 2:
             host.append((1e3 * (t1 - t0), 1e3 * (t2 - t0), 1e3 * (c1 - c0)))
     out[rank] = host

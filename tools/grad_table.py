@@ -49,7 +49,7 @@ def gpu_grads(sd, policy, batch, H, W):
     loss.backward()
     torch.cuda.synchronize()
     assert not m.grad_overflowed()
-    return float(loss), {n: (p.grad.detach().double().cpu() if p.grad is not None else None) for n, p in m.named_parameters()}
+    return float(loss.detach()), {n: (p.grad.detach().double().cpu() if p.grad is not None else None) for n, p in m.named_parameters()}
 
 
 def main():
