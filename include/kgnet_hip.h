@@ -189,7 +189,9 @@ int kg_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int N, int IH,
                     const kg_planes_t* planes, void* stream);
                     /* mask != NULL: dx is zeroed where mask <= 0 (ReLU backward of the upsampled tensor, KGnet.py:110) */
 int kg_add_rows(const void* a, int lda, const void* b, int ldb, const void* mask, int ldm, void* y, int ldy, long M,
-                int C, const kg_planes_t* planes, void* stream);
+                int C, const float* scale, const float* scale2, const kg_planes_t* planes, void* stream);
+                /* y = (a + b) [* *scale [* *scale2]] [where mask > 0]; scale / scale2: optional device scalars (powers of two: a gradient written
+                   under an earlier running scale of the half-precision backward is converted inside the join that reads it, cf. kg_rows_scale) */
 int kg_sigmoid_inplace(float* x, long n, void* stream);                              /* torch.sigmoid, KGnet.py:300,345 */
 int kg_grad_pack(const float* g_nchw, const float* prob, void* out_rows, int N, int C, int H, int W, int ld, int cpad,
                  const kg_planes_t* planes, void* stream);   /* planes: y = out_rows */

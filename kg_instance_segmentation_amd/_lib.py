@@ -59,7 +59,7 @@ _SIGS = {
     "kg_maxpool3s2_bwd": [P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P],
     "kg_bilinear_fwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_long, P, P],
     "kg_bilinear_bwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_long, P, c_int, P, P],
-    "kg_add_rows": [P, c_int, P, c_int, P, c_int, P, c_int, c_long, c_int, P, P],
+    "kg_add_rows": [P, c_int, P, c_int, P, c_int, P, c_int, c_long, c_int, P, P, P, P],
     "kg_detection_loss_fwd": [P, P, P, P, c_int, c_int, c_int, c_float, P, P, c_int, P, P],
     "kg_detection_loss_bwd": [P, P, P, P, c_int, c_int, c_int, c_float, P, P, P, P, P, P],
     "kg_seg_loss": [P, P, P, P, c_int, P, P, P, P, P],

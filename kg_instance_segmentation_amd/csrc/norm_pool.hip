@@ -511,8 +511,10 @@ extern "C" int kg_bilinear_bwd(const void* dy, int lddy, void* dx, int lddx, int
 // ---------------------------------------------------------------------------------------------
 // out[row][c] = a[row][c] + b[row][c] (+ optional ReLU mask by m > 0); used for gradient joins.
 __global__ void add_rows_kernel(const RowsR a, const RowsR b,
-                                const bf16_t* __restrict__ m, int ldm, const RowsW y, long M, int C8) {
+                                const bf16_t* __restrict__ m, int ldm, const RowsW y, long M, int C8, const float* __restrict__ sc,
+                                const float* __restrict__ sc2) {
     long total = M * C8;
+    const float s = sc ? *sc * (sc2 ? *sc2 : 1.f) : 1.f;      // (a power of two: the conversion of both operands into the running gradient scale)
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r; int c; kg_divmod(i, C8, &r, &c); c *= 8;
         float v[8];
@@ -522,6 +524,10 @@ __global__ void add_rows_kernel(const RowsR a, const RowsR b,
             rd8(b, r, c, bs);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += bs[e];
+        }
+        if (s != 1.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= s;
         }
         if (m) {
             uint4 mv = *reinterpret_cast<const uint4*>(m + r * ldm + c);
@@ -533,15 +539,17 @@ __global__ void add_rows_kernel(const RowsR a, const RowsR b,
     }
 }
 // planes: a = a, b = b, y = y (mask: plane 0)
+// scale / scale2 (optional device scalars): y = (a + b) * *scale (* *scale2) -- the half-precision backward's conversion of a gradient
+// written under an earlier running scale (kg_rows_scale), folded into the join that reads it anyway
 extern "C" int kg_add_rows(const void* a, int lda, const void* b, int ldb, const void* mask, int ldm, void* y, int ldy,
-                           long M, int C, const kg_planes_t* planes, void* stream) {
+                           long M, int C, const float* scale, const float* scale2, const kg_planes_t* planes, void* stream) {
     KG_PLANES(planes);
     KG_CHECK_ARG(a && y && C % 8 == 0 && lda % 8 == 0 && ldy % 8 == 0 && (!b || ldb % 8 == 0) && (!mask || ldm % 8 == 0), "kg_add_rows: bad args");
     if (M == 0) return KG_OK;
     long total = M * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(add_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, RowsR{(const bf16_t*)a, lda, pp.a_planes, pp.a_pstride},
-                       RowsR{(const bf16_t*)b, ldb, pp.b_planes, pp.b_pstride}, (const bf16_t*)mask, ldm, RowsW{(bf16_t*)y, ldy, pp.y_planes, pp.y_pstride}, M, C / 8);
+                       RowsR{(const bf16_t*)b, ldb, pp.b_planes, pp.b_pstride}, (const bf16_t*)mask, ldm, RowsW{(bf16_t*)y, ldy, pp.y_planes, pp.y_pstride}, M, C / 8, scale, scale2);
     KG_CHECK_LAUNCH("add_rows");
     return KG_OK;
 }
@@ -650,12 +658,9 @@ extern "C" int kg_rows_rescale(void* g, int ld, long M, int C, int target_log2, 
     KG_CHECK_ARG(g && cum_in && cum_out && r_out && scratch && C % 8 == 0 && ld % 8 == 0, "kg_rows_rescale: bad args");
     if (M == 0) return KG_OK;
     const long total = M * (C / 8);
-    // 1024 threads x 4 chunks in flight each; at most one workgroup per CU, and for the tensors that fit the L2 / Infinity Cache they were just
-    // written to (<= 4 M chunks = 64 MB per plane) a quarter of that: the launch is then bound by the 2 serialised same-address atomics
-    // per workgroup (~13 ns each), not by the read
-    int blocks = (int)((total + 4095) / 4096);
-    const int cap = total <= (4L << 20) ? 64 : 256;
-    if (blocks > cap) blocks = cap;
+    // 1024 threads x 4 chunks in flight each; one workgroup per CU.  (Round 6 tried 64 workgroups for tensors that fit the L2 / Infinity Cache --
+    // fewer serialised atomics -- and measured 14.9 -> 23.8 us per launch: the read, not the atomics, is the bound.)
+    int blocks = (int)((total + 4095) / 4096); if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(rows_absmax_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, RowsR{(const bf16_t*)g, ld, pp.a_planes, pp.a_pstride}, M, C / 8,
                        target_log2, cum_in, cum_out, r_out, (unsigned*)scratch);
     KG_CHECK_LAUNCH("rows_absmax");

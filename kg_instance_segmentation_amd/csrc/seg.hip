@@ -4,6 +4,7 @@
 // pixel list [rows][C] (box-major, raster inside a box); convolutions on it run through
 // kg_conv2d_igemm's ragged modes with the row descriptors built below.
 #include "kg_common.h"
+#include <type_traits>
 
 // boxtab[b] = {n, y1, x1, h, w, row0, H, W}; one block per box.
 __global__ void seg_build_rows_kernel(const int* __restrict__ boxtab, int2* __restrict__ rowdesc,
@@ -228,8 +229,8 @@ extern "C" int kg_crop_grad_reduce(const void* ga, int lda, const void* gb, int 
 // reference's per-crop conv), and the 8 partial sums meet through three wave shuffles in a fixed order.  Arithmetic: the plane sum of x
 // (the exact stored value) times the fp32 master weight, fp32 FMA chain in (tap, channel) order -- not the 3-product MFMA evaluation,
 // but the same values to fp32 rounding.
-template <int C>
-__global__ __launch_bounds__(256) void seg_conv3_c1_kernel(const bf16_t* __restrict__ x, int ldx, int P, int ps, const float* __restrict__ w,
+template <int C, int PP>
+__global__ __launch_bounds__(256) void seg_conv3_c1_kernel(const bf16_t* __restrict__ x, int ldx, int ps, const float* __restrict__ w,
                                                            const float* __restrict__ bias, const int2* __restrict__ rowdesc, long M,
                                                            float* __restrict__ y) {
     static_assert(C == 64, "one 128-byte row per pixel");
@@ -247,15 +248,30 @@ __global__ __launch_bounds__(256) void seg_conv3_c1_kernel(const bf16_t* __restr
         if (live) {
             const int2 d = rowdesc[m];
             const int py = d.x >> 16, px = d.x & 0xffff, h = d.y >> 16, wd = d.y & 0xffff;
+            // all 9 x P loads of the pixel are issued unconditionally (a tap outside the box reads the centre row instead and is dropped by the
+            // select below): with the bounds test as a branch around the load the compiler kept one tap in flight at a time and the kernel sat
+            // at 0.9 TB/s, 82 % of its wave cycles parked on memory (profiles/r06_pmc_wait.json).  Same taps, same order, same fmaf chain.
+            uint4 q[9][PP];
+            bool in[9];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int dy = t / 3 - 1, dx = t % 3 - 1;
-                if ((unsigned)(py + dy) >= (unsigned)h || (unsigned)(px + dx) >= (unsigned)wd) continue;
-                const bf16_t* xp = x + (m + (long)dy * wd + dx) * ldx + chunk * 8;
-                float v[8];
-                kg_load_planes8(xp, P, ps, v);
+                in[t] = (unsigned)(py + dy) < (unsigned)h && (unsigned)(px + dx) < (unsigned)wd;
+                const bf16_t* xp = x + (m + (in[t] ? (long)dy * wd + dx : 0)) * ldx + chunk * 8;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc = fmaf(v[e], wr[t][e], acc);
+                for (int p = 0; p < PP; ++p) q[t][p] = *reinterpret_cast<const uint4*>(xp + (long)p * ps);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float v[8];                               // plane sum, lowest plane first (kg_load_planes8): the exact stored value
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = bf2f(reinterpret_cast<const bf16_t*>(&q[t][PP - 1])[e]);
+#pragma unroll
+                for (int p = PP - 2; p >= 0; --p)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bf2f(reinterpret_cast<const bf16_t*>(&q[t][p])[e]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = in[t] ? fmaf(v[e], wr[t][e], acc) : acc;
             }
         }
         acc += __shfl_xor(acc, 1, 64);
@@ -273,8 +289,13 @@ extern "C" int kg_seg_conv3_c1(const void* x, int ldx, int C, const float* w, co
     if (M == 0) return KG_OK;
     long blocks = (M + 31) / 32;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(seg_conv3_c1_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, pp.a_planes,
-                       pp.a_pstride, w, bias, (const int2*)rowdesc, M, y);
+    auto go = [&](auto pp_c) {
+        hipLaunchKernelGGL((seg_conv3_c1_kernel<64, decltype(pp_c)::value>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                           pp.a_pstride, w, bias, (const int2*)rowdesc, M, y);
+    };
+    if (pp.a_planes == 1) go(std::integral_constant<int, 1>{});
+    else if (pp.a_planes == 2) go(std::integral_constant<int, 2>{});
+    else go(std::integral_constant<int, 3>{});
     KG_CHECK_LAUNCH("seg_conv3_c1");
     return KG_OK;
 }

@@ -101,18 +101,30 @@ class Var:
             return p.grad.cols(self.c0, self.c0 + self.C)
         return ops.alloc_pt(self.rows, self.C, self.gP, self.t.device, dtype=self.t.t.dtype)
 
-    def to_current_scale(self):
-        """half build: a gradient written under an earlier (larger) running scale is converted before it is combined or consumed"""
+    def stale_scale(self):
+        """half build: (scale_now, 1 / scale_then) device scalars when this Var's gradient tensors were written under an earlier (larger) running
+        scale than the pass is in now, else None; marks them converted -- the caller applies the factor (<= 1: never out of range)"""
         eng = Var.ENG
         if eng is not None and eng.gscale is not None and self.gsc is not None and self.gsc is not eng.gscale:
+            f = (eng.gscale[0:1], self.gsc[1:2])
+            self.gsc = eng.gscale
+            return f
+        return None
+
+    def to_current_scale(self):
+        """half build: a gradient written under an earlier (larger) running scale is converted before it is combined or consumed"""
+        f = self.stale_scale()
+        if f is not None:
             ts = [(t, self.C) for t in (self.grad, self.pending) if t is not None]
             if ts:
-                ops.rows_scale_multi(ts, eng.gscale[0:1], self.gsc[1:2])      # * scale_now / scale_then <= 1: never out of range
-            self.gsc = eng.gscale
+                ops.rows_scale_multi(ts, f[0], f[1])      # * scale_now / scale_then <= 1: never out of range
 
     def add_grad(self, g, masked):
+        f = None
         if Var.ENG is not None:
-            if self.grad is not None or self.pending is not None:
+            if self.grad is not None and self.pending is not None and self.parent is None:
+                f = self.stale_scale()       # third contribution: the join below reads both tensors anyway and converts them on the way
+            elif self.grad is not None or self.pending is not None:
                 self.to_current_scale()
             self.gsc = Var.ENG.gscale
         if self.parent is not None:      # written in place into the parent's buffer
@@ -123,7 +135,7 @@ class Var:
         elif self.pending is None:
             self.pending, self.pmasked = g, masked
         else:
-            ops.add_rows(self.grad, self.pending, self.grad, self.C)
+            ops.add_rows(self.grad, self.pending, self.grad, self.C, scale=f)
             self.masked = self.masked and self.pmasked
             self.pending, self.pmasked = g, masked
 
@@ -131,13 +143,14 @@ class Var:
         g = self.grad
         if g is None:
             return None
-        self.to_current_scale()
         need_mask = self.relu and not (self.masked and self.pmasked)
-        if self.pending is not None:       # sum of the two contributions and the ReLU mask in ONE pass
-            ops.add_rows(g, self.pending, g, self.C, mask=self.t.hi() if need_mask else None)
+        if self.pending is not None:       # sum of the two contributions, their conversion into the running scale and the ReLU mask in ONE pass
+            ops.add_rows(g, self.pending, g, self.C, mask=self.t.hi() if need_mask else None, scale=self.stale_scale())
             self.pending, self.pmasked = None, True
         elif need_mask:
-            ops.add_rows(g, None, g, self.C, mask=self.t.hi())
+            ops.add_rows(g, None, g, self.C, mask=self.t.hi(), scale=self.stale_scale())
+        else:
+            self.to_current_scale()
         if need_mask:
             self.masked = True
         return g

@@ -758,10 +758,12 @@ def bilinear_bwd(dy, dx, N, IH, IW, OH, OW, C, boxdesc=None, row2box=None, mask=
               c_long(rows), ptr(base(mask)), ld(mask) if mask is not None else 0, pl(a=dy, y=dx), stream_ptr(), fmt=fmt_of(dy))
 
 
-def add_rows(a, b, y, C, mask=None):
-    """y = (a + b) [masked by mask > 0]; b may be None."""
+def add_rows(a, b, y, C, mask=None, scale=None):
+    """y = (a + b) [* scale[0] * scale[1]] [masked by mask > 0]; b may be None.  scale: pair of device scalars (the second may be None)."""
+    r, r2 = scale if scale is not None else (None, None)
     _lib.call("kg_add_rows", ptr(_rows(a)), ld(a), ptr(base(b)), ld(b) if b is not None else 0, ptr(base(mask)),
-              ld(mask) if mask is not None else 0, ptr(_rows(y)), ld(y), c_long(base(a).shape[0]), C, pl(a=a, b=b, y=y), stream_ptr(), fmt=fmt_of(a))
+              ld(mask) if mask is not None else 0, ptr(_rows(y)), ld(y), c_long(base(a).shape[0]), C, ptr(r), ptr(r2), pl(a=a, b=b, y=y), stream_ptr(),
+              fmt=fmt_of(a))
 
 
 def planes_to_f32(x, C, out):

@@ -8,7 +8,7 @@ R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
-python bench.py --steps 10 --warmup 3 > $O/${tag}_bench_n1.json 2> $O/${tag}_bench.err      # (re-taken at the end, once the PMC files of this build exist)
+python bench.py --steps 10 --warmup 3 --details $O/${tag}_bench_details.json > $O/${tag}_bench_n1.json 2> $O/${tag}_bench.err      # (re-taken at the end, once the PMC files of this build exist)
 KG_BENCH_DUMP=$O/${tag}_bench_launches.txt python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-companion > /dev/null 2>&1
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/${tag}_prof -o p -- python $R/bench.py --steps 10 --warmup 3 --profile-run > $O/${tag}_prof.log 2>&1
@@ -31,5 +31,5 @@ rm -rf $O/${tag}_shp
 # only when their build hash matches the loaded libraries
 cd $R
 cp $O/${tag}_pmc_hbm.json $O/${tag}_pmc_mfma_lds.json $R/profiles/
-python bench.py --steps 10 --warmup 3 > $O/${tag}_bench_n1.json 2> $O/${tag}_bench.err
+python bench.py --steps 20 --warmup 5 --details $O/${tag}_bench_details.json > $O/${tag}_bench_n1.json 2> $O/${tag}_bench.err
 cut -c1-400 $O/${tag}_bench_n1.json
