@@ -89,6 +89,18 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(const WgHaloArgs a) {
         const int L = blockIdx.y * gridDim.x + blockIdx.x;
         const int xcd = L & 7, slot = L >> 3;
         blk = slot % gridDim.x; split = (slot / gridDim.x) * 8 + xcd;
+    } else if (((gridDim.x * gridDim.y) & 7) == 0 && gridDim.x >= 16) {
+        // Fewer than 8 (or an odd number of) splits -- the wide heads: 192 .. 768 (co, ci) blocks x 4 splits.  Dealt round-robin, every XCD
+        // fetched every dY slice and every X slice of every tile (8 x 632 KB per tile at 256 -> 768).  Give each XCD a CONTIGUOUS range of the
+        // co-major work list instead: its workgroups then share 1 .. 2 dY slices (and the X slices of the tile, which every cout block needs
+        // anyway) -- half the L2 fills.  (co block, split, ci block), ci fastest: the workgroups that run together share a dY tile.
+        const int L = blockIdx.y * gridDim.x + blockIdx.x;
+        const int per = (gridDim.x * gridDim.y) >> 3;
+        const int j = (L & 7) * per + (L >> 3);
+        const int per_co = n_ci_tiles * gridDim.y;
+        const int cob = j / per_co, rem = j - cob * per_co;
+        split = rem / n_ci_tiles;
+        blk = cob * n_ci_tiles + (rem - split * n_ci_tiles);
     }
     const int ci0 = (blk % n_ci_tiles) * 16 * CIF, co0 = (blk / n_ci_tiles) * 64;
     const int G = lane >> 4, i16 = lane & 15;
