@@ -274,7 +274,9 @@ class PackQueue:
         if sig != self.sig or self.table is None or self.table.device != dev:
             self.table = h2d(arr.view(np.uint8).reshape(-1), dev)
             self.sig = sig
-        launch = (self.table, len(self.jobs), blk, dev, self.keep)       # (keep: the tensors stay alive until the launch is enqueued)
+        with torch.cuda.device(dev):
+            st = stream_ptr()            # the launch -- now or held back -- goes to the stream the parameters were written on (the optimizer's)
+        launch = (self.table, len(self.jobs), blk, dev, self.keep, st)       # (keep: the tensors stay alive until the launch is enqueued)
         self.jobs, self.keep = [], []
         if hold:
             self.pending = launch
@@ -282,9 +284,9 @@ class PackQueue:
             self._launch(launch)
 
     def _launch(self, launch):
-        table, n, blk, dev, _ = launch
+        table, n, blk, dev, _, st = launch
         with torch.cuda.device(dev):
-            _lib.call("kg_pack_weight_batch", ptr(table), n, blk, stream_ptr(), fmt=self.fmt)
+            _lib.call("kg_pack_weight_batch", ptr(table), n, blk, st, fmt=self.fmt)
 
     def launch_pending(self):
         launch, self.pending = self.pending, None
