@@ -178,7 +178,17 @@ int kg_bn_apply(const void* x, int ldx, const float* scale, const float* shift, 
                 int ldy, int M, int C, int relu, const kg_planes_t* planes, void* stream);
 int kg_bn_bwd(const void* x, int ldx, const void* dy, int lddy, const float* gamma, const float* mean,
               const float* invstd, float* dgamma, float* dbeta, int accumulate, void* dx, int lddx, int M, int C,
-              float* scratch, int scratch_floats, const kg_planes_t* planes, void* stream);
+              float* scratch, int scratch_floats, const float* parts, int nb_parts, const float* parts_scale,
+              const kg_planes_t* planes, void* stream);
+/* BACKWARD statistics from the input gradient that completes dy (train-mode BatchNorm under autograd, KGnet.py:82-93 + train.py:153):
+ * kg_conv_bstats_begin arms the calling host thread's next dense input-gradient launch (kg_conv2d_igemm mode 1 on the gather kernel, kg_conv2d_halo
+ * with flip = 1 and KS = 3; output channels a multiple of 64): besides storing the gradient rows g (after the residual add and the ReLU mask of
+ * its epilogue) that launch writes per-(pixel tile, channel) partials {sum g, sum g * xhat}, xhat = (x - mean[c]) * invstd[c] over the rows x of
+ * the BatchNorm's INPUT (same row index; x_planes planes, x_pstride elements apart).  kg_conv_stats_end returns the tile count (0: the launch took
+ * a kernel without this epilogue) and disarms.  kg_bn_bwd takes the partials as parts / nb_parts and skips its own column reduction over x and
+ * dy; parts_scale (optional device scalar): a power of two dy was multiplied by AFTER the partials were taken (kg_rows_rescale). */
+int kg_conv_bstats_begin(float* part, long cap_floats, const void* x, int ldx, int x_planes, int x_pstride, const float* mean,
+                         const float* invstd);
 int kg_maxpool3s2_fwd(const void* x, int ldx, void* y, int ldy, void* argmax_u8, int N, int H, int W, int C, const kg_planes_t* planes, void* stream);
 int kg_maxpool3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, const void* argmax_u8, int N, int H, int W, int C,
                       const kg_planes_t* planes, void* stream);   /* argmax_u8 (optional): [N*OH*OW][C] winning taps written by the forward */

@@ -51,10 +51,11 @@ _SIGS = {
     "kg_bn_stats_train": [P, c_int, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P, c_int, P, P],
     "kg_bn_scale_shift_eval": [c_int, P, P, P, P, c_float, P, P, P],
     "kg_conv_stats_begin": [P, c_long],
+    "kg_conv_bstats_begin": [P, c_long, P, c_int, c_int, c_int, P, P],
     "kg_conv_stats_end": [P],
     "kg_bn_finalize_train": [P, c_int, c_int, c_int, P, P, P, P, c_float, c_float, P, P, P, P, P],
     "kg_bn_apply": [P, c_int, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P, P],
-    "kg_bn_bwd": [P, c_int, P, c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_int, P, c_int, P, P],
+    "kg_bn_bwd": [P, c_int, P, c_int, P, P, P, P, P, c_int, P, c_int, c_int, c_int, P, c_int, P, c_int, P, P, P],
     "kg_maxpool3s2_fwd": [P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P],
     "kg_maxpool3s2_bwd": [P, c_int, P, c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, P],
     "kg_bilinear_fwd": [P, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_long, P, P],

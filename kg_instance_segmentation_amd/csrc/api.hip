@@ -48,11 +48,22 @@ extern "C" int kg_tr_probe(void* out, void* stream) {
 }
 
 // ---- BatchNorm statistics from the producing conv's epilogue (conv_args.h): arm -> conv launch -> read back the tile count.
-static thread_local KgConvStats g_conv_stats = {nullptr, 0, 0};
+static thread_local KgConvStats g_conv_stats = {nullptr, 0, 0, {nullptr, 0, 0, 0, nullptr, nullptr}};
 KgConvStats& kg_conv_stats() { return g_conv_stats; }
 extern "C" int kg_conv_stats_begin(float* part, long cap_floats) {
     KG_CHECK_ARG(part && cap_floats > 0, "kg_conv_stats_begin: bad buffer");
-    g_conv_stats = KgConvStats{part, cap_floats, 0};
+    g_conv_stats = KgConvStats{part, cap_floats, 0, {nullptr, 0, 0, 0, nullptr, nullptr}};
+    return KG_OK;
+}
+// Backward variant: arms the next INPUT-GRADIENT launch (dense transposed mode of kg_conv2d_igemm, flip = 1 of kg_conv2d_halo, output channels a
+// multiple of 64) to write partials [nb][C][2] = per-tile sums of (g, g * xhat) over the gradient rows it stores -- g after the residual add and
+// the ReLU mask of its epilogue, xhat = (x - mean[c]) * invstd[c] of the rows x (x_planes planes, x_pstride elements apart).  kg_bn_bwd takes them
+// in place of its own column reduction (parts / nb arguments).  kg_conv_stats_end reads the tile count back and disarms, as for the forward.
+extern "C" int kg_conv_bstats_begin(float* part, long cap_floats, const void* x, int ldx, int x_planes, int x_pstride, const float* mean,
+                                    const float* invstd) {
+    KG_CHECK_ARG(part && cap_floats > 0 && x && mean && invstd && ldx % 8 == 0 && x_planes >= 1 && x_planes <= 3 && x_pstride % 8 == 0,
+                 "kg_conv_bstats_begin: bad arguments");
+    g_conv_stats = KgConvStats{part, cap_floats, 0, {(const unsigned short*)x, ldx, x_planes, x_pstride, mean, invstd}};
     return KG_OK;
 }
 // *nb = pixel tiles whose partials [nb][Cout][2] the conv wrote (0: the launch took a kernel without the statistics epilogue, or
@@ -60,7 +71,7 @@ extern "C" int kg_conv_stats_begin(float* part, long cap_floats) {
 extern "C" int kg_conv_stats_end(int* nb) {
     KG_CHECK_ARG(nb, "kg_conv_stats_end: null pointer");
     *nb = g_conv_stats.nb;
-    g_conv_stats = KgConvStats{nullptr, 0, 0};
+    g_conv_stats = KgConvStats{nullptr, 0, 0, {nullptr, 0, 0, 0, nullptr, nullptr}};
     return KG_OK;
 }
 

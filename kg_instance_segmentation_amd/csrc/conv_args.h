@@ -14,6 +14,7 @@ struct ConvArgs {
     int yP, yps, rP, rps;      // planes / plane strides of the output rows and of the residual
     float* stat_part;          // != null: BatchNorm statistics of the output (kg_conv_stats_begin): partials [pixel tile][Cout][2]
     const float* oscale;       // != null: per-cout factor of the accumulator (kg_planes_t.oscale: folded inference BatchNorm)
+    KgBStat bs;                // bs.x != null (with stat_part): BACKWARD statistics -- sums of (g, g * xhat) over the stored rows (kg_common.h)
 };
 
 // ---- BatchNorm statistics in the conv epilogue ---------------------------------------------------------------------------------
@@ -60,7 +61,7 @@ struct EpiArgs {
     int ldy, ldres, ldmask, Cout, relu, yP, yps, rP, rps;
 };
 template <int NV>
-__device__ __forceinline__ void kg_conv_epilogue(const EpiArgs& e, long m, int cb, float (&v)[NV]) {
+__device__ __forceinline__ void kg_conv_epi_apply(const EpiArgs& e, long m, int cb, float (&v)[NV]) {
     const bool full = cb + NV <= e.Cout;
     const int nvalid = full ? NV : e.Cout - cb;
     if (e.res) {
@@ -99,6 +100,11 @@ __device__ __forceinline__ void kg_conv_epilogue(const EpiArgs& e, long m, int c
                 if (k < nvalid) v[k] = bf2f(mp[k]) > 0.f ? v[k] : 0.f;
         }
     }
+}
+template <int NV>
+__device__ __forceinline__ void kg_conv_epi_store(const EpiArgs& e, long m, int cb, float (&v)[NV]) {
+    const bool full = cb + NV <= e.Cout;
+    const int nvalid = full ? NV : e.Cout - cb;
     if (e.y) {
         bf16_t* yp = e.y + m * e.ldy + cb;
         if constexpr (NV % 8 == 0) {
@@ -106,6 +112,56 @@ __device__ __forceinline__ void kg_conv_epilogue(const EpiArgs& e, long m, int c
         }
         kg_store_planes_n<NV>(yp, e.yP, e.yps, v, nvalid);
     }
+}
+template <int NV>
+__device__ __forceinline__ void kg_conv_epilogue(const EpiArgs& e, long m, int cb, float (&v)[NV]) {
+    kg_conv_epi_apply<NV>(e, m, cb, v);
+    kg_conv_epi_store<NV>(e, m, cb, v);
+}
+// Backward statistics (KgBStat, kg_common.h) in the epilogue of one row: (residual, ReLU, mask) -> s += g, q += g * xhat on the FINAL fp32
+// gradient values, before their rounding to the stored planes (like the forward statistics: from the accumulators) -> plane store.
+// mean / invstd of the 8-channel chunk are re-read per row (L1 hits) instead of living in 2 NV registers next to the accumulators: preloaded,
+// they pushed conv_halo_kernel<3,1,8,0> from 234 registers to 256 + 56 spilled.  Cout % 64 == 0 (host-checked): whole 16-byte chunks.
+template <int NV>
+__device__ __forceinline__ void kg_conv_epilogue_bstat(const EpiArgs& e, const KgBStat& b, long m, int cb, float (&v)[NV], float (&s)[NV], float (&q)[NV]) {
+    static_assert(NV % 8 == 0, "whole 16-byte chunks of x");
+    kg_conv_epi_apply<NV>(e, m, cb, v);
+    const bf16_t* xp = reinterpret_cast<const bf16_t*>(b.x) + m * b.ldx + cb;
+#pragma unroll
+    for (int c = 0; c < NV / 8; ++c) {
+        float xs[8];
+        kg_load_planes8(xp + c * 8, b.P, b.ps, xs);
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(b.mean + cb + c * 8), m1 = *reinterpret_cast<const f32x4*>(b.mean + cb + c * 8 + 4);
+        const f32x4 i0 = *reinterpret_cast<const f32x4*>(b.invstd + cb + c * 8), i1 = *reinterpret_cast<const f32x4*>(b.invstd + cb + c * 8 + 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float g = v[c * 8 + k];
+            const float mu = k < 4 ? m0[k & 3] : m1[k & 3], is = k < 4 ? i0[k & 3] : i1[k & 3];
+            s[c * 8 + k] += g;
+            q[c * 8 + k] += g * ((xs[k] - mu) * is);
+        }
+    }
+    kg_conv_epi_store<NV>(e, m, cb, v);
+}
+// the same with xhat of the row already in registers (the one-row-per-lane finishing kernels load x, mean and invstd BEFORE they add up their
+// partial accumulators: the loads ride under that chain instead of following it)
+template <int NV>
+__device__ __forceinline__ void kg_bstat_xhat(const KgBStat& b, long m, int cb, float (&xh)[NV]) {
+    const bf16_t* xp = reinterpret_cast<const bf16_t*>(b.x) + m * b.ldx + cb;
+#pragma unroll
+    for (int c = 0; c < NV / 8; ++c) {
+        float xs[8];
+        kg_load_planes8(xp + c * 8, b.P, b.ps, xs);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xh[c * 8 + k] = (xs[k] - b.mean[cb + c * 8 + k]) * b.invstd[cb + c * 8 + k];
+    }
+}
+template <int NV>
+__device__ __forceinline__ void kg_conv_epilogue_bstat_pre(const EpiArgs& e, long m, int cb, float (&v)[NV], float (&s)[NV], float (&q)[NV], const float (&xh)[NV]) {
+    kg_conv_epi_apply<NV>(e, m, cb, v);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { s[k] += v[k]; q[k] += v[k] * xh[k]; }
+    kg_conv_epi_store<NV>(e, m, cb, v);
 }
 static inline void kg_fill_planes(ConvArgs& a, const kg_planes_t& pp, int cin_pad_plane, int unit) {
     a.km = kg_make_kmap(cin_pad_plane, unit, pp.a_planes, pp.a_pstride, pp.w_planes);

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256 * TCW) void conv_gather_kernel(const ConvArgs a
     float ss[NV], sq[NV];
 #pragma unroll
     for (int e = 0; e < NV; ++e) ss[e] = sq[e] = 0.f;
+    const bool bst = stats && a.bs.x != nullptr;               // (uniform) backward statistics: sums of (g, g * xhat) -- KgBStat
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const long m = (long)m0 + wp * 64 + j * 16 + lm;
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(256 * TCW) void conv_gather_kernel(const ConvArgs a
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(acc[i][j][r]) * sv[i * 4 + r] + bv[i * 4 + r];
+        if (bst) { kg_conv_epilogue_bstat<NV>(ep, a.bs, m, cb, v, ss, sq); continue; }
         if (stats) kg_stat_add(ss, sq, v);
         kg_conv_epilogue<NV>(ep, m, cb, v);
     }
@@ -295,6 +297,7 @@ int kg_launch_conv_gather(ConvArgs a, int cin_pad, hipStream_t st, bool stats_ok
     if (n64_tiles > 0 && a.Cout <= 64 && kg_cdiv(a.M, 128) >= n64_tiles) {
         dim3 grid1(kg_cdiv(a.M, 128), 1);
         if (stats_ok) a.stat_part = kg_conv_stats_claim((int)grid1.x, a.Cout);       // (BatchNorm statistics, when armed: per 128-pixel tile)
+        if (a.stat_part) a.bs = kg_conv_stats().bs;
         if (p2) hipLaunchKernelGGL((conv_gather_kernel<true, 1>), grid1, dim3(256), smem / 2, st, a, cin_real / 32, (float*)nullptr);
         else hipLaunchKernelGGL((conv_gather_kernel<false, 1>), grid1, dim3(256), smem / 2, st, a, cin_pad / 64, (float*)nullptr);
         KG_CHECK_LAUNCH("conv_gather");
@@ -319,6 +322,7 @@ int kg_launch_conv_gather(ConvArgs a, int cin_pad, hipStream_t st, bool stats_ok
         if (!part) Z = 1;
     }
     if (stats_ok) a.stat_part = kg_conv_stats_claim(Z > 1 ? npt64 : (int)grid.x, a.Cout);   // (BatchNorm statistics, when armed: per 64- or 256-pixel tile)
+    if (a.stat_part) a.bs = kg_conv_stats().bs;
     grid.z = Z;
     if (p2) hipLaunchKernelGGL((conv_gather_kernel<true, 2>), grid, dim3(512), smem, st, a, cin_real / 32, Z > 1 ? part : (float*)nullptr);
     else hipLaunchKernelGGL((conv_gather_kernel<false, 2>), grid, dim3(512), smem, st, a, cin_pad / 64, Z > 1 ? part : (float*)nullptr);

@@ -41,6 +41,7 @@ struct HaloArgs {
     // virtual 64-channel chunk to its (x plane, channel chunk); GM = 1: grp_chunks virtual chunks and grp_C real channels per head
     KMap km; int grp_C;
     float* stat_part; // != null (GM = 0, bf16 rows output): BatchNorm statistics of the output, partials [pixel tile][Cout][2] (conv_args.h)
+    KgBStat bs;       // bs.x != null (with stat_part, flip = 1): BACKWARD statistics -- sums of (g, g * xhat) over the stored gradient rows (kg_common.h)
     int kp_raw;       // GM = 1: 1 = export the kp logits without the sigmoid of KGnet.py:300 (parity tests, logit-space consumers)
     int yP, yps, rP, rps;
     // 3-product input (x_hi * w_lo | x_lo * w_hi | x_hi * w_hi, kg_plane_pairs): walk order of the virtual chunks, see halo_set_walk
@@ -79,7 +80,9 @@ static void halo_set_walk(HaloArgs& a, int xP, int wP) {
 // kp -> group 0, short -> group 1, mid -> groups 2, 3 and the rest of group 0; a 64-channel input chunk that belongs to
 // head h only runs the MFMA row groups of that head (1, 1 and 3 of 4), instead of three launches that each pad their
 // 5 / 10 / 40 couts to a 64-cout tile.  Small images (head_split): blockIdx.y = head, a workgroup walks the chunks of one head and writes only its maps.
-template <int KS, int WC, int WPX, int GM = 0>
+// BSK: the instantiation whose epilogue carries the BACKWARD BatchNorm statistics (KgBStat; 3 x 3, WC = 1 only) -- a kernel of its own so that the
+// regular one keeps its register allocation (234 registers, no spills; with the statistics code inside: 256 + 8 spilled)
+template <int KS, int WC, int WPX, int GM = 0, bool BSK = false>
 __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs a) {
     constexpr int PAD = KS / 2, TW = 4 * WPX, HWD = TW + KS - 1, HPIX = (16 + KS - 1) * HWD, TC = WC * 64, NT = WC * WPX * 64, T = KS * KS;
     constexpr int HALO_BYTES = HPIX * 128, WBUF_BYTES = TC * 128;
@@ -612,6 +615,10 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     }
     const EpiArgs ep{a.y, a.res, a.mask, a.ldy, a.ldres, a.ldmask, a.Cout, a.relu, a.yP, a.yps, a.rP, a.rps};
     const int ox = ox0 + (wp >> 2) * 16 + lm;
+    // backward statistics: sums of (g, g * xhat) -- KgBStat; 3 x 3 only (what follows a BatchNorm in KGnet.py:64-99; the 7 x 7 instantiations
+    // keep their epilogue -- and their register allocation -- as they were)
+    constexpr bool BST = BSK && GM == 0 && KS == 3;
+    const bool bst = BST && stats && a.bs.x != nullptr;        // (uniform)
     int vm[16];
     if constexpr (GM == 1) {
 #pragma unroll
@@ -627,6 +634,9 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(acc[i][j][r]) + bv[i * 4 + r];
+        if constexpr (BST) {
+            if (bst) { kg_conv_epilogue_bstat<16>(ep, a.bs, m, cb, v, ss, sq); continue; }
+        }
         if (stats) kg_stat_add(ss, sq, v);
         if constexpr (GM == 1) {   // fp32 NCHW export to the kp (sigmoid, KGnet.py:300) / short / mid maps
             const long hw = (long)a.H * a.W;
@@ -703,6 +713,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_finish_kernel(const H
     }
     const EpiArgs ep{a.y, a.res, a.mask, a.ldy, a.ldres, a.ldmask, a.Cout, a.relu, a.yP, a.yps, a.rP, a.rps};
     const int ox = ox0 + (wp >> 2) * 16 + lm;
+    const bool bst = stats && a.bs.x != nullptr;               // (uniform) backward statistics -- KgBStat
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int oy = oy0 + (wp & 3) * 4 + j;
@@ -713,6 +724,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_finish_kernel(const H
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[i * 4 + r] = KG_ACC(accv[(i * 4 + j) * 4 + r] * sv[i * 4 + r]) + bv[i * 4 + r];
+        if (bst) { kg_conv_epilogue_bstat<16>(ep, a.bs, m, cb, v, ss, sq); continue; }
         if (stats) kg_stat_add(ss, sq, v);
         kg_conv_epilogue<16>(ep, m, cb, v);
     }
@@ -998,6 +1010,7 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
     }
     dim3 grid(a.tiletab ? a.ntiles : a.N * a.tiles_x * a.tiles_y, GM == 1 ? (a.head_split ? 3 : 1) : kg_cdiv(a.Cout, TC), (GM == 1 && a.prod_split) ? 3 * a.prod_split : 1);
     if (a.stat_part) a.stat_part = (GM == 0 && !a.tiletab) ? kg_conv_stats_claim(grid.x, a.Cout) : nullptr;   // (armed by the caller: BatchNorm statistics)
+    if (a.stat_part) a.bs = kg_conv_stats().bs;
     // chunk split of under-filled 3x3 launches (KG_HALO_SPLIT: 0 = never; default: at most 128 workgroups, >= 2 chunks per part, <= 8 parts)
     static const int split_wgs = getenv("KG_HALO_SPLIT") ? atoi(getenv("KG_HALO_SPLIT")) : 128;
     if (GM == 0 && KS == 3 && split_wgs > 0 && a.y && !a.y_f32 && (int)(grid.x * grid.y) <= split_wgs) {
@@ -1103,10 +1116,22 @@ static int launch_halo(HaloArgs a, hipStream_t st) {
             return KG_OK;
         }
     }
-    hipLaunchKernelGGL((conv_halo_kernel<KS, WC, WPX, GM>), grid, dim3(WC * WPX * 64), smem, st, a);
+    bool bsk = false;
+    if constexpr (KS == 3 && WC == 1 && WPX == 8 && GM == 0) {
+        if (a.stat_part && a.bs.x) {
+            static KgPerDevice bs_attr;
+            if (bs_attr.first()) KG_HIP(hipFuncSetAttribute((const void*)conv_halo_kernel<3, 1, 8, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            hipLaunchKernelGGL((conv_halo_kernel<3, 1, 8, 0, true>), grid, dim3(512), smem, st, a);
+            kg_note_kernel("conv_halo_kernel<3, 1, 8, 0, true>");
+            bsk = true;
+        }
+    }
+    if (!bsk) {
+        hipLaunchKernelGGL((conv_halo_kernel<KS, WC, WPX, GM>), grid, dim3(WC * WPX * 64), smem, st, a);
+        KG_KNAME(kname, "conv_halo_kernel<%d, %d, %d, %d>", KS, WC, WPX, GM);
+        kg_note_kernel(kname);
+    }
     KG_CHECK_LAUNCH("conv_halo");
-    KG_KNAME(kname, "conv_halo_kernel<%d, %d, %d, %d>", KS, WC, WPX, GM);
-    kg_note_kernel(kname);
     if (a.ksplit > 1) {
         hipLaunchKernelGGL((conv_halo_finish_kernel<WC, WPX>), dim3(grid.x, grid.y), dim3(WC * WPX * 64), 0, st, a);
         KG_CHECK_LAUNCH("conv_halo_finish");
@@ -1143,8 +1168,13 @@ extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, v
     a.N = N; a.H = H; a.W = W; a.tiles_x = kg_cdiv(W, 16); a.tiles_y = kg_cdiv(H, 16);
     a.cin_pad = cin_pad * vplanes; a.ldx = ldx; a.Cout = Cout; a.ldy = ldy; a.ldres = ldres; a.ldmask = ldmask; a.K = K;
     a.flip = flip; a.relu = relu; a.f32_C = f32_C; a.tiletab = (const int4*)tiletab; a.ntiles = ntiles; a.f32_hw = total_rows;
-    if (y && !y_f32 && !res && !mask && !relu && !flip && kg_conv_stats().part && kg_conv_stats().nb == 0)
-        a.stat_part = kg_conv_stats().part;      // provisional: launch_halo claims it with the tile count of the variant it launches
+    {
+        const KgConvStats& cs = kg_conv_stats();
+        // forward statistics: a plain conv output; backward statistics (kg_conv_bstats_begin): the input gradient (flip), whole 64-channel blocks
+        const bool want = cs.bs.x ? (flip && KS == 3 && wc <= 1 && !tiletab && Cout % 64 == 0) : (!res && !mask && !relu && !flip);
+        if (y && !y_f32 && want && cs.part && cs.nb == 0)
+            a.stat_part = cs.part;      // provisional: launch_halo claims it with the tile count of the variant it launches
+    }
     const int k1skip = wc >> 8; wc &= 255;   // bit 8: the weights are zero for channels 32..63 of every chunk -> k-step 1 is skipped
     if (wc == 0) wc = 1;   // measured on MI355X: the 16x32-pixel x 64-cout tile (8 waves) beats the 16x16 x 128/192-cout tiles at every KGnet shape
     hipStream_t st = (hipStream_t)stream;

@@ -272,7 +272,9 @@ extern "C" int kg_conv2d_igemm(const void* x, const void* w, const float* bias, 
     if (use_gather2 && tile == 0 && cin_pad % 64 == 0 && y && !y_f32 && (Cout > 64 || (use_gather2 >= 2 && Cout == 64 && (KH * KW > 1 || vplanes > 1))) && dil == 1) {
         a.km = kg_make_kmap(cin_pad, 64, pp.a_planes, pp.a_pstride, pp.w_planes);
         // deep-prefetch LDS-ring variant (conv_gather.hip); it may carry the BatchNorm statistics epilogue when armed
-        return kg_launch_conv_gather(a, cin_virt, st, !relu && !res && !mask && (mode == 0 || mode == 2));
+        // (forward statistics: a plain conv output; backward statistics -- kg_conv_bstats_begin --: the dense input gradient, whole 64-channel blocks)
+        const bool bwd_stats = kg_conv_stats().bs.x != nullptr;
+        return kg_launch_conv_gather(a, cin_virt, st, bwd_stats ? (mode == 1 && Cout % 64 == 0) : (!relu && !res && !mask && (mode == 0 || mode == 2)));
     }
     constexpr int use_small = 6;   // (6: the stride-2 7x7 stem too)
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };

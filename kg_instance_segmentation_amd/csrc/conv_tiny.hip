@@ -163,14 +163,19 @@ __global__ __launch_bounds__(256) void conv_tiny_finish_kernel(const ConvArgs a,
     const long m = (long)blockIdx.x * 64 + wave * 16 + lm;
     const long tile = (long)blockIdx.y * gridDim.x + blockIdx.x;
     const float* base = sk_part + (tile * Z * 4 + wave) * 1024;
+    const bool stats = a.stat_part != nullptr;                 // (uniform)
+    const bool live = cb < a.Cout && m < a.M;
+    const bool bst = stats && a.bs.x != nullptr;               // (uniform) backward statistics: sums of (g, g * xhat) -- KgBStat
+    float xh[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) xh[e] = 0.f;
+    if (bst && live) kg_bstat_xhat<16>(a.bs, m, cb, xh);       // (issued before the partial sums: they ride under that chain)
     float sum[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) sum[e] = base[e * 64 + lane];
     for (int z = 1; z < Z; ++z)
 #pragma unroll
         for (int e = 0; e < 16; ++e) sum[e] += base[(long)z * 4096 + e * 64 + lane];
-    const bool stats = a.stat_part != nullptr;                 // (uniform)
-    const bool live = cb < a.Cout && m < a.M;
     if (!live && !stats) return;
     float v[16];
 #pragma unroll
@@ -182,9 +187,13 @@ __global__ __launch_bounds__(256) void conv_tiny_finish_kernel(const ConvArgs a,
     float ss[16], sq[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) ss[e] = sq[e] = 0.f;
-    if (stats && live) kg_stat_add(ss, sq, v);
     const EpiArgs ep = kg_epi(a);
-    if (live) kg_conv_epilogue<16>(ep, m, cb, v);
+    if (bst) {
+        if (live) kg_conv_epilogue_bstat_pre<16>(ep, m, cb, v, ss, sq, xh);
+    } else {
+        if (stats && live) kg_stat_add(ss, sq, v);
+        if (live) kg_conv_epilogue<16>(ep, m, cb, v);
+    }
     if (stats) kg_stat_commit<4, 64>(ss, sq, red, wave, g * 16, lm, a.stat_part + (long)blockIdx.x * a.Cout * 2, blockIdx.y * 64, a.Cout);
 }
 

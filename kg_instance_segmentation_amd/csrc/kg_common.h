@@ -148,7 +148,12 @@ __device__ __forceinline__ void kg_divmod(long i, int d, long* q, int* r) {
 
 // Side channel of kg_conv_stats_begin / kg_conv_stats_end (api.hip): the NEXT conv launch of this host thread that supports it
 // writes the BatchNorm statistics partials of its output (conv_args.h) into `part` and records its pixel-tile count.
-struct KgConvStats { float* part; long cap_floats; int nb; };
+// BACKWARD statistics (kg_conv_bstats_begin): the armed launch is the input gradient that COMPLETES the gradient g of a train-mode BatchNorm's
+// output; besides storing g its epilogue sums, per channel, g and g * xhat with xhat = (x - mean) * invstd of the BatchNorm's input x
+// (KgBStat: the rows of x, same row index as the gradient rows) -- the two sums of the BatchNorm backward (KGnet.py:82-93 under autograd),
+// which the separate column reduction re-read g and x for (43 launches, 0.9 ms per step).
+struct KgBStat { const unsigned short* x; int ldx, P, ps; const float* mean; const float* invstd; };
+struct KgConvStats { float* part; long cap_floats; int nb; KgBStat bs; };
 KgConvStats& kg_conv_stats();
 static inline float* kg_conv_stats_claim(int tiles, int Cout) {   // launcher side: returns the partial buffer when armed and large enough
     KgConvStats& st = kg_conv_stats();

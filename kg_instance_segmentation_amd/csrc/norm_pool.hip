@@ -135,15 +135,18 @@ __global__ void bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, 
 }
 // backward finalize: dgamma, dbeta and the per-channel coefficients of
 //   dx = a*dy + b*xhat + c0   with a = gamma*invstd, b = -a*dgamma/M, c0 = -a*dbeta/M
+// rs (optional device scalar): the partials were taken by the producing input gradient's epilogue (KgBStat) BEFORE the gradient tensor was
+// re-normalised by *rs (a power of two, kg_rows_rescale): the sums are multiplied alike
 __global__ void bn_finalize_bwd_kernel(const float* __restrict__ part, int nb, int C, long M,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                       float* __restrict__ coef) {
+                                       float* __restrict__ coef, const float* __restrict__ rs) {
     const int c = blockIdx.x;
     double s = 0., sx = 0.;
     for (int b = threadIdx.x; b < nb; b += 64) { s += part[((long)b * C + c) * 2]; sx += part[((long)b * C + c) * 2 + 1]; }
     s = wave_sum_d(s); sx = wave_sum_d(sx);
     if (threadIdx.x != 0) return;
+    if (rs) { s *= (double)*rs; sx *= (double)*rs; }
     float db = (float)s, dg = (float)sx;
     dgamma[c] = accumulate ? dgamma[c] + dg : dg;
     dbeta[c] = accumulate ? dbeta[c] + db : db;
@@ -257,20 +260,31 @@ __global__ void bn_bwd_apply_kernel(const RowsR x, const RowsR dy,
     }
 }
 // planes: a = x, b = dy, y = dx
+// parts / nb_parts / parts_scale (optional): partials [nb_parts][C][2] of (sum dy, sum dy * xhat) that the input gradient which produced dy
+// wrote in its epilogue (kg_conv_bstats_begin) -- the column reduction over x and dy is skipped; parts_scale: device scalar dy was multiplied
+// by after the partials were taken (kg_rows_rescale), or NULL
 extern "C" int kg_bn_bwd(const void* x, int ldx, const void* dy, int lddy, const float* gamma, const float* mean,
                          const float* invstd, float* dgamma, float* dbeta, int accumulate, void* dx, int lddx, int M,
-                         int C, float* scratch, int scratch_floats, const kg_planes_t* planes, void* stream) {
+                         int C, float* scratch, int scratch_floats, const float* parts, int nb_parts, const float* parts_scale,
+                         const kg_planes_t* planes, void* stream) {
     KG_PLANES(planes);
     const RowsR xr{(const bf16_t*)x, ldx, pp.a_planes, pp.a_pstride}, dyr{(const bf16_t*)dy, lddy, pp.b_planes, pp.b_pstride};
     KG_CHECK_ARG(x && dy && gamma && mean && invstd && dgamma && dbeta && dx && scratch, "kg_bn_bwd: null pointer");
     KG_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "kg_bn_bwd: C/ld must be multiples of 8");
     int nb, rpb;
-    KG_CHECK_ARG(reduce_geometry(M, C, scratch_floats - 3 * C, &nb, &rpb), "kg_bn_bwd: scratch too small");
     hipStream_t st = (hipStream_t)stream;
-    float* coef = scratch; float* part = scratch + 3 * C;
-    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, xr, dyr, mean, invstd, part, M, C, rpb);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, st, part, nb, C, (long)M, gamma,
-                       invstd, dgamma, dbeta, accumulate, coef);
+    float* coef = scratch;
+    if (parts && nb_parts > 0) {
+        KG_CHECK_ARG(scratch_floats >= 3 * C, "kg_bn_bwd: scratch too small");
+        hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, st, parts, nb_parts, C, (long)M, gamma, invstd, dgamma, dbeta, accumulate, coef,
+                           parts_scale);
+    } else {
+        KG_CHECK_ARG(reduce_geometry(M, C, scratch_floats - 3 * C, &nb, &rpb), "kg_bn_bwd: scratch too small");
+        float* part = scratch + 3 * C;
+        hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nb, (C + 63) / 64), dim3(256), 0, st, xr, dyr, mean, invstd, part, M, C, rpb);
+        hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(C), dim3(64), 0, st, part, nb, C, (long)M, gamma,
+                           invstd, dgamma, dbeta, accumulate, coef, (const float*)nullptr);
+    }
     long total = (long)M * (C / 8);
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, xr, dyr,

@@ -52,6 +52,7 @@ PRECISIONS = {
 HALF_POLICIES = ("fp32", "fp32b2", "half", "halfmix")
 DEFAULT_PRECISION = "fp32"
 PRE = [0]        # prepack generation counter (Engine.prepack)
+BN_BWD_STATS = True     # BatchNorm-backward statistics in the epilogue of the input gradient that completes the BatchNorm output's gradient (Engine.conv)
 
 
 def default_precision():
@@ -70,7 +71,8 @@ def trunc(t, P):
 
 class Var:
     """Activation (split-bf16 rows, ops.PT) + its gradient slot."""
-    __slots__ = ("t", "C", "relu", "grad", "masked", "pending", "pmasked", "req", "parent", "c0", "gP", "bn_part", "boundary", "gsc")
+    __slots__ = ("t", "C", "relu", "grad", "masked", "pending", "pmasked", "req", "parent", "c0", "gP", "bn_part", "boundary", "gsc",
+                 "uses", "ngot", "bn_in", "bstat")
     ENG = None       # half build, during a backward pass: the engine whose running gradient scale this pass's tensors are written in
 
     def __init__(self, t, C, relu=False, req=True, parent=None, c0=0, gP=None):
@@ -81,6 +83,9 @@ class Var:
         self.pending, self.pmasked = None, True     # one more contribution whose addition is deferred to take_grad (fused with the mask)
         self.parent, self.c0 = parent, c0
         self.boundary = False      # half build: the backward pass re-normalises itself when this gradient is complete (Engine.renormalise)
+        self.uses, self.ngot = 0, 0    # consumers of this tensor in the recorded forward / gradient contributions received so far in the backward
+        self.bn_in = None          # output of a train-mode BatchNorm: (its input rows, mean, invstd) -- what the backward statistics need
+        self.bstat = None          # (partials, tiles): the input gradient that completed this gradient summed the BatchNorm-backward statistics
         self.gsc = None            # half build: the scale object (device {scale, 1 / scale}) this tensor's gradient was last written in
 
     @property
@@ -121,6 +126,7 @@ class Var:
 
     def add_grad(self, g, masked):
         f = None
+        self.ngot += 1
         if Var.ENG is not None:
             if self.grad is not None and self.pending is not None and self.parent is None:
                 f = self.stale_scale()       # third contribution: the join below reads both tensors anyway and converts them on the way
@@ -256,8 +262,9 @@ class Engine:
         x4 per level through the adjoint of the 2x bilinear upsampling when they are spatially coherent (tools/gradmax_probe.py); the
         call sites are the outputs of every bottleneck, c1, the decoder's level outputs and the seg branch's levels."""
         if self.gscale is None:
-            return
-        _, self.gscale = ops.rows_rescale(g, C, self.gscale)
+            return None
+        r, self.gscale = ops.rows_rescale(g, C, self.gscale)
+        return r
 
     def place_grad(self, key, g):
         """a small (bias / BatchNorm) gradient vector produced as a slice of a shared buffer: copied into its flat slot if there is one"""
@@ -373,6 +380,7 @@ class Engine:
         affine = (scale, shift) fp32 [cout] / res (Var): inference only (conv_bn) -- y = act(conv * scale + shift + res) in the conv's epilogue."""
         train = self.tape is not None
         assert not (train and (affine is not None or res is not None))
+        xv.uses += 1
         self.prepare(s, need_T=train and xv.req)
         OH = (H + 2 * s.pad - s.k) // s.stride + 1
         OW = (W + 2 * s.pad - s.k) // s.stride + 1
@@ -426,10 +434,22 @@ class Engine:
                         xv.to_current_scale()       # (half build: the dgrad epilogue adds onto it in the running scale)
                     dx = existing if existing is not None else xv.alloc_grad()
                     gin = (N * H * W, OH, OW, H, W, s.k, s.k, s.stride, s.pad)
-                    ops.conv_auto(g, s.pwT, s.cin, gin, N, y=dx, res=existing, mask=xv.t.hi() if xv.relu else None, transposed=True)
+                    # xv is the output of a train-mode BatchNorm and this input gradient COMPLETES its gradient (every other consumer has
+                    # delivered: they sit in `existing`, which the epilogue adds): the launch also sums the BatchNorm-backward statistics of
+                    # the rows it stores (ops.conv_bstats_begin) -- bn()'s backward then skips its column reduction over x and dy
+                    arm = (BN_BWD_STATS and xv.bn_in is not None and xv.parent is None and xv.pending is None and xv.ngot == xv.uses - 1
+                           and (existing is not None or xv.uses == 1) and s.cin % 64 == 0)
+                    part = ops.conv_bstats_begin(xv.bn_in[0], xv.bn_in[1], xv.bn_in[2], N * H * W, s.cin, N) if arm else None
+                    try:
+                        ops.conv_auto(g, s.pwT, s.cin, gin, N, y=dx, res=existing, mask=xv.t.hi() if xv.relu else None, transposed=True, tiny=not arm)
+                    finally:
+                        if arm:
+                            nb = ops.conv_stats_end(self.fmt)
+                            xv.bstat = (part, nb) if nb > 0 else None
                     if existing is None:
                         xv.add_grad(dx, masked=xv.relu)
                     else:
+                        xv.ngot += 1
                         xv.masked = xv.masked or xv.relu
             self.tape.append(bwd)
         return yv, OH, OW
@@ -481,20 +501,29 @@ class Engine:
             mean = invstd = None
         ops.bn_apply(xv.t, C, scale, shift, out, res=res.t if res is not None else None, relu=relu)
         yv = Var(out, C, relu=relu, gP=min(self.bpt, self.pg))
+        xv.uses += 1
+        if res is not None:
+            res.uses += 1
         if self.tape is not None:
             if mean is None:
                 raise NotImplementedError("backward through eval-mode BatchNorm is not supported; call model.train()")
+            yv.bn_in = (xv.t, mean, invstd)
 
             def bwd():
+                # statistics summed by the input gradient that completed yv's gradient (conv's backward): valid only if nothing touches the
+                # tensor between that launch and here -- no pending contribution, no ReLU mask left to apply, no scale conversion
+                bst, yv.bstat = yv.bstat, None
+                if bst is not None and (yv.pending is not None or (yv.relu and not (yv.masked and yv.pmasked))
+                                        or (self.gscale is not None and yv.gsc is not None and yv.gsc is not self.gscale)):
+                    bst = None
                 g = yv.take_grad()
                 if g is None:
                     return
-                if yv.boundary:
-                    self.renormalise(g, yv.C)
+                r = self.renormalise(g, yv.C) if yv.boundary else None      # (the partials were taken before this factor: bn_bwd multiplies the sums)
                 dg = self.new_grad(p + ".weight", gamma)
                 db = self.new_grad(p + ".bias", beta)
                 dx = ops.alloc_pt(xv.rows, C, xv.gP, dev, dtype=self.dt)
-                ops.bn_bwd(xv.t, g, C, gamma.detach(), mean, invstd, dg, db, dx)
+                ops.bn_bwd(xv.t, g, C, gamma.detach(), mean, invstd, dg, db, dx, parts=bst, parts_scale=r if bst is not None else None)
                 self.param_grads[p + ".weight"] = dg
                 self.param_grads[p + ".bias"] = db
                 xv.add_grad(dx, masked=True)
@@ -509,6 +538,7 @@ class Engine:
         out = ops.alloc_pt(N * OH * OW, C, xv.P, xv.t.device, dtype=self.dt)
         arg = torch.empty(N * OH * OW, C, dtype=torch.uint8, device=xv.t.device) if self.tape is not None else None
         ops.maxpool_fwd(xv.t, out, N, H, W, C, argmax=arg)
+        xv.uses += 1
         yv = Var(out, C, relu=False, gP=xv.gP)
         if self.tape is not None:
             def bwd():
@@ -525,6 +555,7 @@ class Engine:
         C = xv.C
         out = ops.alloc_pt(N * OH * OW, C, xv.P if P is None else P, xv.t.device, dtype=self.dt)
         ops.bilinear_fwd(xv.t, out, N, IH, IW, OH, OW, C)
+        xv.uses += 1
         yv = Var(out, C, relu=False, gP=min(out.P, self.pg))
         if self.tape is not None:
             def bwd():
@@ -540,6 +571,8 @@ class Engine:
     def concat(self, buf, parts):
         """buf = PT [rows, sum C]; parts = Vars whose .t are the column slices of buf (already written)."""
         cv = Var(buf, buf.shape[1], relu=all(p.relu for p in parts), gP=max(p.gP for p in parts))
+        for p in parts:
+            p.uses += 1
         if self.tape is not None:
             def bwd():
                 g = cv.take_grad()
@@ -668,6 +701,8 @@ class Engine:
         if self.stats_written:
             ops.PARAM_EPOCH[0] += 1      # the running statistics moved: folded eval-mode scale / shift copies are stale
         self.feats, self.dims, self.N, self.maps = feats, dims, N, maps
+        for fv in feats:
+            fv.uses += 1 << 20         # (c0 .. c4 may receive gradients from outside -- the seg branch, a caller's feat_grads: never "completed" by a conv)
         feats[1].boundary = True         # (c1; the bottleneck and decoder level outputs were marked where they were made)
         return maps, feats, dims
 

@@ -704,6 +704,21 @@ def conv_stats_begin(dev, fmt=0):
     return part
 
 
+def conv_bstats_begin(x, mean, invstd, M, C, N=1):
+    """Arms the next INPUT-GRADIENT conv launch of this thread to also write the BatchNorm-backward partials {sum g, sum g * xhat} of the
+    gradient rows it stores (kg_conv_bstats_begin): x = the BatchNorm's input rows (PT), mean / invstd its batch statistics.  Returns the
+    partials tensor (its own allocation: several armed gradients may be pending at once -- downsample branch -- unlike the forward's shared buffer)."""
+    xb = _rows(x)
+    P, ps = nplanes(x)
+    # tiles of the kernel that will claim the buffer: 64-pixel tiles of the gather kernel's K split (4 per 256-pixel workgroup, whatever M), 128- or
+    # 256-pixel tiles, or the halo kernel's 16 x 32 tiles per image
+    tiles = 4 * math.ceil(M / 256) + 4 * N + 8
+    part = torch.empty(tiles * C * 2, dtype=torch.float32, device=xb.device)
+    _lib.call("kg_conv_bstats_begin", ptr(part), c_long(part.numel()), ptr(xb), ld(x), P, ps, ptr(mean), ptr(invstd), fmt=fmt_of(x))
+    _STATS_ARMED[0] = True
+    return part
+
+
 def conv_stats_end(fmt=0):
     """Pixel tiles the armed conv wrote partials for (0: its kernel has no statistics epilogue); disarms."""
     import ctypes
@@ -732,10 +747,14 @@ def bn_apply(x, C, scale, shift, y, res=None, relu=False):
               base(x).shape[0], C, 1 if relu else 0, pl(a=x, b=res, y=y), stream_ptr(), fmt=fmt_of(x))
 
 
-def bn_bwd(x, dy, C, gamma, mean, invstd, dgamma, dbeta, dx, accumulate=False):
+def bn_bwd(x, dy, C, gamma, mean, invstd, dgamma, dbeta, dx, accumulate=False, parts=None, parts_scale=None):
+    """parts = (partials tensor, tile count) written by the input gradient that produced dy (conv_bstats_begin): no column reduction over x and dy;
+    parts_scale: device scalar dy was re-normalised by after the partials were taken (rows_rescale's r)"""
     sc = scratch_f32(2 * C * 512 + 3 * C, base(x).device, "bn")
+    pt, nbp = parts if parts is not None else (None, 0)
     _lib.call("kg_bn_bwd", ptr(_rows(x)), ld(x), ptr(_rows(dy)), ld(dy), ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
-              1 if accumulate else 0, ptr(_rows(dx)), ld(dx), base(x).shape[0], C, ptr(sc), sc.numel(), pl(a=x, b=dy, y=dx), stream_ptr(), fmt=fmt_of(x))
+              1 if accumulate else 0, ptr(_rows(dx)), ld(dx), base(x).shape[0], C, ptr(sc), sc.numel(), ptr(pt), nbp, ptr(parts_scale),
+              pl(a=x, b=dy, y=dx), stream_ptr(), fmt=fmt_of(x))
 
 
 def maxpool_fwd(x, y, N, H, W, C, argmax=None):

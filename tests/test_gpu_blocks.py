@@ -111,6 +111,72 @@ def test_bottleneck_block(model, state_dict0, block, inpl, planes, stride, H, W)
     eng.tape = None
 
 
+def test_two_bottlenecks_batchnorm_backward_statistics_from_the_dgrad_epilogue(model, state_dict0):
+    """Two consecutive bottlenecks (layer3.0 with its downsample branch -> layer3.1): the gradient of the first block's OUTPUT is completed by
+    the second block's conv1 input gradient, whose epilogue adds the identity path's gradient (residual operand), applies the ReLU mask AND -- round
+    6 -- sums the BatchNorm-backward statistics {sum g, sum g * xhat} of bn3 (engine.BN_BWD_STATS, kg_conv_bstats_begin); the gradients of the
+    single-consumer BatchNorm outputs (bn1 / bn2 of both blocks) are completed by conv2's 3 x 3 / strided and conv3's 1 x 1 input gradients.
+    Asserted: the statistics path is actually taken (>= 5 of the 7 BatchNorm layers), every output / gradient against the oracle's autograd
+    within the policy's bound, and the BatchNorm parameter gradients equal to the two-pass path's to fp32 rounding."""
+    from kg_instance_segmentation_amd import engine as kengine
+    N, H, W, inpl, planes = 2, 12, 16, 512, 256
+    g = torch.Generator().manual_seed(3)
+    x = F.relu(bfr(torch.randn(N, inpl, H, W, generator=g)))
+    eng = model._engine
+    thr = 1.0 - 2.0 * (1.0 - THR[eng.precision])        # (two blocks deep: twice the single-block allowance)
+    dy = bfr(torch.randn(N, planes * 4, H // 2, W // 2, generator=g))
+
+    def run():
+        eng.tape, eng.param_grads = [], {}
+        xv = Var(to_pt(x, eng.pt), inpl, relu=True, req=True)
+        y0, OH, OW = eng.bottleneck(xv, "layer3.0", N, H, W, inpl, planes, 2, True)
+        y1, _, _ = eng.bottleneck(y0, "layer3.1", N, OH, OW, planes * 4, planes, 1, False)
+        y1.grad, y1.masked = to_pt(dy, eng.pt), False
+        y1.ngot = 0
+        for fn in reversed(eng.tape):
+            fn()
+        gx = xv.take_grad()
+        torch.cuda.synchronize()
+        grads = {k: v.clone() for k, v in eng.param_grads.items()}
+        eng.tape = None
+        return y1, gx, grads, OH, OW
+    taken = []
+    orig = ops.bn_bwd
+
+    def spy(*a, parts=None, **k):
+        taken.append(parts is not None)
+        print("   bn_bwd C =", a[2], "rows =", ops.base(a[0]).shape[0], "statistics from the dgrad epilogue:", parts is not None)
+        return orig(*a, parts=parts, **k)
+    ops.bn_bwd = spy
+    try:
+        y1, gx, grads, OH, OW = run()
+        n_fused = sum(taken)
+        kengine.BN_BWD_STATS = False
+        taken.clear()
+        _, gx2, grads2, _, _ = run()
+        assert not any(taken)
+    finally:
+        ops.bn_bwd = orig
+        kengine.BN_BWD_STATS = True
+    print(f"BatchNorm layers whose backward statistics came from a dgrad epilogue: {n_fused} of 7")
+    assert n_fused >= 5, n_fused
+    sd = oracle_params(state_dict0, ["layer3.0.", "layer3.1."])
+    net = onet.Net(sd, training=True)
+    xd = x.clone().requires_grad_(True)
+    yo = net.bottleneck(net.bottleneck(F.relu(xd), "layer3.0", 2, True), "layer3.1", 1, False)
+    yo.backward(dy)
+    check("out", val(y1.t, N, OH, OW), yo, thr)
+    check("dx", val(gx, N, H, W), xd.grad, thr)
+    for k, gg in grads.items():
+        check(k, gg, sd[k].grad, thr)
+        if ".bn" in k or "downsample.1" in k:          # fused statistics against the two-pass column reduction: the same sums to fp32 rounding
+            rel = float((gg.double() - grads2[k].double()).norm() / (grads2[k].double().norm() + 1e-30))
+            # (the fused sums see the fp32 gradient values, the column reduction their stored 16-bit planes: one 8- / 11-bit plane in every policy
+            # but fp32bf, whose gradients travel in hi + lo bf16 planes)
+            assert rel <= (5e-4 if eng.precision == "fp32bf" else 1e-2), (k, rel)
+    check("dx fused vs two-pass", val(gx, N, H, W), val(gx2, N, H, W), 0.99999 if eng.precision == "fp32bf" else 0.999)
+
+
 def test_stem_and_decoder_level(model, state_dict0):
     """conv1+bn1+relu+maxpool, then one decoder level: upsample -> 3x3 conv into a concat slice -> 1x1 refine,
     with the skip tensor also feeding a second consumer (gradient accumulation + mask folding)."""
