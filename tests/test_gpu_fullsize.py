@@ -148,9 +148,11 @@ def test_train_step_at_bench_configuration_vs_oracle_fp32_and_fp64():
     assert rows[0][0] >= 0.9999 and all(abs(r - 1) <= 2e-3 for _, _, r in rows), rows[:4]
 
 
-def test_train_step_gradients_at_2x512_both_backward_policies():
-    """The gradient leg, by default: batch 2 x 512 x 512 with 300 boxes per image (the bench configuration's image size and box density at a
-    batch the CPU oracle's autograd finishes in minutes), EVERY parameter gradient of the default policy `fp32` (single-plane half backward)
+def test_train_step_gradients_at_512_both_backward_policies():
+    """The gradient leg, by default: batch KG_GRADLEG_BATCH (default 1) x 512 x 512 with 300 boxes per image (the bench configuration's image
+    size and box density at a batch the CPU oracle's autograd finishes in minutes: float32 + float64 autograd take 63 + 136 s per image on the
+    box's 32 host cores, and the driver's pytest step ends at 1200 s -- at batch 2, 126 + 273 s, the whole GPU suite measured ~980 s, too close;
+    the batch-2 result of this build is in profiles/r06_fullsize_test.txt), EVERY parameter gradient of the default policy `fp32` (single-plane half backward)
     AND of `fp32b2` (hi + lo planes in the backward pass: the reference's precision in both directions) against the reference-pinned oracle's
     autograd in float32 (cosine / norm per tensor) and in float64 (relative L2 per tensor, oracle/gradref.py):
       * both policies: all 217 tensors cosine >= 0.9999 and norm within 2e-3 of the float32 oracle's (train.py:153 is fp32 autograd);
@@ -162,7 +164,7 @@ def test_train_step_gradients_at_2x512_both_backward_policies():
     from kg_instance_segmentation_amd.seg_loss import SEG_loss
     from oracle import gradref, synth, weightgen
     import test_gpu_gradprec as gp
-    N, S, NB = 2, 512, 300
+    N, S, NB = int(os.environ.get("KG_GRADLEG_BATCH", "1")), 512, 300
     torch.set_num_threads(min(os.cpu_count() or 8, 64))
     sd = weightgen.gen_state_dict(0, variant="cal")
     batch = synth.train_batch(N, S, S, 41, n_boxes=NB, smin=14, smax=40)

@@ -21,7 +21,7 @@ for line in open(os.path.join(root, f"{tag}_bench_launches.txt")):
 prof_ms = calls = 0.0      # (the family: the 8-wave kernel + its 4-wave sibling with the blocked accumulation, round 5)
 for r in csv.DictReader(open(os.path.join(root, f"{tag}_bench_kernel_stats.csv"))):
     nm = r["Name"].replace(" ", "")
-    if nm == "voidconv_halo_kernel<7,1,8,0>(HaloArgs)" or nm.startswith("voidconv_halo7_w4_kernel<"):
+    if nm in ("voidconv_halo_kernel<7,1,8,0>(HaloArgs)", "voidconv_halo_kernel<7,1,8,0,false>(HaloArgs)") or nm.startswith("voidconv_halo7_w4_kernel<"):
         prof_ms += float(r["MsPerStep"]); calls += float(r["CallsPerStep"])
 print(f"conv_halo<7,1,8,0> + conv_halo7_w4: {n:.0f} launches/step (profiler: {calls:.0f}), algorithmic {alg / 1e12:.2f} TFLOP/step, MFMA-issued {issued / 1e12:.2f} TFLOP/step "
       f"(x{issued / alg:.3f} products per multiply)")
