@@ -205,6 +205,10 @@ int kg_add_rows(const void* a, int lda, const void* b, int ldb, const void* mask
 int kg_sigmoid_inplace(float* x, long n, void* stream);                              /* torch.sigmoid, KGnet.py:300,345 */
 int kg_grad_pack(const float* g_nchw, const float* prob, void* out_rows, int N, int C, int H, int W, int ld, int cpad,
                  const kg_planes_t* planes, void* stream);   /* planes: y = out_rows */
+int kg_grad_pack3(const float* g0_nchw, const float* g1_nchw, const float* g2_nchw, const float* prob0, void* out_rows, int N, int C0, int C1, int C2,
+                  int H, int W, int ld, int pad0, int pad1, int pad2, const kg_planes_t* planes, void* stream);
+                  /* the three map gradients of one pyramid level (kp | short | mid: the backward of KGnet.py:300-316) side by side in one pass: columns
+                     [0, pad0) <- g0 (* prob0 (1 - prob0) when given), then pad1 columns of g1, pad2 of g2 (pads % 8 == 0, sum <= 64); planes: y = out_rows */
 
 /* ---- losses: DetectionLossAll (loss.py:12-49) and the per-pair mask BCE of SEG_loss (seg_loss.py:86-94) ---- */
 int kg_detection_loss_fwd(const float* kp, const float* sh, const float* md, const float* gt, int N, int H, int W,
@@ -264,7 +268,11 @@ int kg_mask_inter_pairs(const void* a, const void* b, const int* pairs, int npai
 
 /* ---- per-box segmentation branch (KGnet.py:246-267, 321-350): ragged row bookkeeping ---- */
 int kg_seg_build_rows(const int* boxtab8, int nb, int* rowdesc, int* row2box, int* srcrow, void* stream);
+int kg_seg_build_rows_levels(int nlev, const int* const* boxtab8, const int* nb, int* const* rowdesc, int* const* row2box, int* const* srcrow,
+                             void* stream);   /* kg_seg_build_rows for all (<= 8) pyramid levels in one launch: HOST arrays of device pointers / box counts */
 int kg_rows_gather(const void* src, int ldsrc, const int* srcrow, void* dst, int lddst, long nrows, int C, void* stream);
+int kg_rows_gather_planes(const void* src, int ldsrc, int src_pstride, const int* srcrow, void* dst, int lddst, int dst_pstride, long nrows, int C,
+                          int P, void* stream);     /* kg_rows_gather for the P planes of split rows in one launch (plane p at column p * pstride) */
 /* seg_head.2 (KGnet.py:145-147: Conv2d(64, 1, 3, padding=1), used at KGnet.py:266): the one-output-channel 3x3 conv over the ragged pixel
  * list as a per-pixel dot product (zero padding at the box border, as each crop is convolved on its own).  x: rows [M][ldx], C = 64 channels
  * (planes: a); w: fp32 OIHW [1][64][3][3], the master parameter itself; bias: fp32 [1] or NULL; rowdesc: kg_seg_build_rows; y: fp32 [M] logits. */

@@ -66,6 +66,7 @@ _SIGS = {
     "kg_seg_loss": [P, P, P, P, c_int, P, P, P, P, P],
     "kg_sigmoid_inplace": [P, c_long, P],
     "kg_grad_pack": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
+    "kg_grad_pack3": [P, P, P, P, P] + [c_int] * 10 + [P, P],
     "kg_postproc_workspace_bytes": [c_int, c_int, c_int, c_int],
     "kg_postproc_scale": [P, P, P, c_int, c_int, c_double, P, c_long, c_int, c_int, P, P, P, P, P, P, P, P],
     "kg_postproc_timing_begin": [],
@@ -83,7 +84,9 @@ _SIGS = {
     "kg_mask_inter_pairs": [P, P, P, c_int, c_long, P, P],
     "kg_f64_probe": [P, P, P, c_int, P],
     "kg_seg_build_rows": [P, c_int, P, P, P, P],
+    "kg_seg_build_rows_levels": [c_int, P, P, P, P, P, P],
     "kg_rows_gather": [P, c_int, P, P, c_int, c_long, c_int, P],
+    "kg_rows_gather_planes": [P, c_int, c_int, P, P, c_int, c_int, c_long, c_int, c_int, P],
     "kg_seg_conv3_c1": [P, c_int, c_int, P, P, P, c_long, P, P, P],
     "kg_f32_to_bf16_rows": [P, P, c_int, c_long, c_int, P, c_int, P],
     "kg_rows_gather_f32": [P, c_int, P, P, c_int, c_long, c_int, P, P],

@@ -288,6 +288,90 @@ __global__ __launch_bounds__(256) void grad_pack_tr_kernel(const float* __restri
         __syncthreads();
     }
 }
+// Three maps of one pyramid level side by side in ONE pass (the kp | short | mid gradients of the fused second-layer input gradient,
+// engine.HEAD_OFF / HEAD_PAD): the same read / transpose / store scheme, the sources dealt to the channel rows off[s] .. off[s] + C[s] of the
+// tile, the padding rows zero; writes whole cpad-channel rows instead of three column slices (and is one launch instead of three).
+struct GradPack3 { const float* g[3]; const float* prob; int C[3]; int off[3]; int end[3]; };
+__global__ __launch_bounds__(256) void grad_pack3_tr_kernel(const GradPack3 a, bf16_t* __restrict__ out, long total, long HW, int ld, int cpad, int P, int ps,
+                                                            const float* __restrict__ scale) {
+    extern __shared__ float gp_tile[];                       // [cpad][257]
+    const float S = scale ? *scale : 1.f;
+    const int t = threadIdx.x, K = cpad >> 3;
+    for (long i0 = (long)blockIdx.x * 256; i0 < total; i0 += (long)gridDim.x * 256) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            for (int c = a.off[s] + a.C[s]; c < a.end[s]; ++c) gp_tile[c * 257 + t] = 0.f;      // padding rows of the source's column block
+            const float* __restrict__ g = a.g[s];
+            const float* __restrict__ prob = s == 0 ? a.prob : nullptr;
+            const int C = a.C[s], r0 = a.off[s];
+            if ((HW & 3) == 0) {
+                const int cs = t >> 6, pq = (t & 63) * 4;
+                const long i = i0 + pq;
+                if (i < total) {
+                    const long n = i / HW, p = i - n * HW;
+#pragma unroll 2
+                    for (int c = cs; c < C; c += 4) {
+                        const long o = (n * C + c) * HW + p;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(g + o);
+                        if (prob) {
+                            const f32x4 q = *reinterpret_cast<const f32x4*>(prob + o);
+                            v[0] *= q[0] * (1.f - q[0]); v[1] *= q[1] * (1.f - q[1]); v[2] *= q[2] * (1.f - q[2]); v[3] *= q[3] * (1.f - q[3]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gp_tile[(r0 + c) * 257 + pq + e] = v[e] * S;
+                    }
+                }
+            } else {
+                const long i = i0 + t;
+                if (i < total) {
+                    const long n = i / HW, p = i - n * HW;
+                    for (int c = 0; c < C; ++c) {
+                        const long o = (n * C + c) * HW + p;
+                        float v = g[o];
+                        if (prob) { const float q = prob[o]; v *= q * (1.f - q); }
+                        gp_tile[(r0 + c) * 257 + t] = v * S;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int q = t; q < 256 * K; q += 256) {
+            const int px = q / K, k8 = q - px * K;
+            if (i0 + px < total) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gp_tile[(k8 * 8 + e) * 257 + px];
+                kg_store_planes<8>(out + (i0 + px) * ld + k8 * 8, P, ps, v, true);
+            }
+        }
+        __syncthreads();
+    }
+}
+// planes: y = out.  g0 / g1 / g2: fp32 NCHW with C0 / C1 / C2 channels; out columns [0, pad0) <- g0 (times prob0 (1 - prob0) when prob0 is given),
+// [pad0, pad0 + pad1) <- g1, [pad0 + pad1, pad0 + pad1 + pad2) <- g2; pads are multiples of 8, their sum <= 64.
+extern "C" int kg_grad_pack3(const float* g0, const float* g1, const float* g2, const float* prob0, void* out, int N, int C0, int C1, int C2, int H, int W,
+                             int ld, int pad0, int pad1, int pad2, const kg_planes_t* planes, void* stream) {
+    const int cpad = pad0 + pad1 + pad2;
+    KG_CHECK_ARG(g0 && g1 && g2 && out && ld % 8 == 0 && pad0 % 8 == 0 && pad1 % 8 == 0 && pad2 % 8 == 0 && pad0 >= C0 && pad1 >= C1 && pad2 >= C2 &&
+                 cpad <= 64 && C0 > 0 && C1 > 0 && C2 > 0, "kg_grad_pack3: bad args");
+    const kg_planes_t pp = kg_planes_or_default(planes);
+    KG_CHECK_ARG(kg_planes_ok(pp), "kg_grad_pack3: bad kg_planes_t");
+    long total = (long)N * H * W;
+    if (total == 0) return KG_OK;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    static KgPerDevice attr_done;
+    if (attr_done.first()) {
+        KG_HIP(hipFuncSetAttribute((const void*)grad_pack3_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 257 * 4));
+    }
+    GradPack3 a;
+    a.g[0] = g0; a.g[1] = g1; a.g[2] = g2; a.prob = prob0;
+    a.C[0] = C0; a.C[1] = C1; a.C[2] = C2; a.off[0] = 0; a.off[1] = pad0; a.off[2] = pad0 + pad1;
+    a.end[0] = pad0; a.end[1] = pad0 + pad1; a.end[2] = cpad;
+    hipLaunchKernelGGL(grad_pack3_tr_kernel, dim3(blocks), dim3(256), cpad * 257 * 4, (hipStream_t)stream, a, (bf16_t*)out, total, (long)H * W, ld, cpad,
+                       pp.y_planes, pp.y_pstride, pp.scale);
+    KG_CHECK_LAUNCH("grad_pack3_tr");
+    return KG_OK;
+}
 // planes: y = out (split-bf16 planes of the packed gradient rows)
 extern "C" int kg_grad_pack(const float* g, const float* prob, void* out, int N, int C, int H, int W, int ld, int cpad,
                             const kg_planes_t* planes, void* stream) {

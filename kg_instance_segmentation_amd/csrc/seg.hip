@@ -26,6 +26,43 @@ extern "C" int kg_seg_build_rows(const int* boxtab, int nb, int* rowdesc, int* r
     return KG_OK;
 }
 
+// all pyramid levels of a batch in ONE launch (five launches of a few microseconds each otherwise): block -> (level, box) through the level starts
+struct SegLevels { const int* boxtab[8]; int2* rowdesc[8]; int* row2box[8]; int* srcrow[8]; int start[9]; int nlev; };
+__global__ void seg_build_rows_levels_kernel(const SegLevels a) {
+    int l = 0;
+    while (l + 1 < a.nlev && (int)blockIdx.x >= a.start[l + 1]) ++l;
+    const int b = blockIdx.x - a.start[l];
+    const int* t = a.boxtab[l] + b * 8;
+    const int n = t[0], y1 = t[1], x1 = t[2], h = t[3], w = t[4], row0 = t[5], H = t[6], W = t[7];
+    int2* rowdesc = a.rowdesc[l];
+    int* row2box = a.row2box[l];
+    int* srcrow = a.srcrow[l];
+    for (int r = threadIdx.x; r < h * w; r += blockDim.x) {
+        int y = r / w, x = r - y * w;
+        rowdesc[row0 + r] = make_int2((y << 16) | x, (h << 16) | w);
+        row2box[row0 + r] = b;
+        srcrow[row0 + r] = (n * H + y1 + y) * W + x1 + x;
+    }
+}
+// host arrays of nlev (<= 8) device pointers / box counts; a level with nb[l] == 0 is skipped
+extern "C" int kg_seg_build_rows_levels(int nlev, const int* const* boxtab, const int* nb, int* const* rowdesc, int* const* row2box, int* const* srcrow,
+                                        void* stream) {
+    KG_CHECK_ARG(nlev >= 1 && nlev <= 8 && boxtab && nb && rowdesc && row2box && srcrow, "kg_seg_build_rows_levels: bad args");
+    SegLevels a;
+    a.nlev = 0; a.start[0] = 0;
+    for (int l = 0; l < nlev; ++l) {
+        if (nb[l] <= 0) continue;
+        KG_CHECK_ARG(boxtab[l] && rowdesc[l] && row2box[l] && srcrow[l], "kg_seg_build_rows_levels: null pointer");
+        a.boxtab[a.nlev] = boxtab[l]; a.rowdesc[a.nlev] = (int2*)rowdesc[l]; a.row2box[a.nlev] = row2box[l]; a.srcrow[a.nlev] = srcrow[l];
+        a.start[a.nlev + 1] = a.start[a.nlev] + nb[l];
+        ++a.nlev;
+    }
+    if (a.nlev == 0) return KG_OK;
+    hipLaunchKernelGGL(seg_build_rows_levels_kernel, dim3(a.start[a.nlev]), dim3(256), 0, (hipStream_t)stream, a);
+    KG_CHECK_LAUNCH("seg_build_rows_levels");
+    return KG_OK;
+}
+
 // dst[r][0:C] = src[srcrow[r]][0:C]
 __global__ void rows_gather_kernel(const bf16_t* __restrict__ src, int ldsrc, const int* __restrict__ srcrow,
                                    bf16_t* __restrict__ dst, int lddst, long nrows, int C8) {
@@ -44,6 +81,30 @@ extern "C" int kg_rows_gather(const void* src, int ldsrc, const int* srcrow, voi
     hipLaunchKernelGGL(rows_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ldsrc, srcrow,
                        (bf16_t*)dst, lddst, nrows, C / 8);
     KG_CHECK_LAUNCH("rows_gather");
+    return KG_OK;
+}
+
+// the same for P planes in one launch: dst[r][p * dps + c] = src[srcrow[r]][p * sps + c] (split rows keep their planes at column offsets p * ps)
+__global__ void rows_gather_planes_kernel(const bf16_t* __restrict__ src, int ldsrc, int sps, const int* __restrict__ srcrow,
+                                          bf16_t* __restrict__ dst, int lddst, int dps, long nrows, int C8, int P) {
+    const int PC8 = P * C8;
+    long total = nrows * PC8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r; int c; kg_divmod(i, PC8, &r, &c);
+        const int p = c / C8; c = (c - p * C8) * 8;
+        *reinterpret_cast<uint4*>(dst + r * lddst + p * dps + c) = *reinterpret_cast<const uint4*>(src + (long)srcrow[r] * ldsrc + p * sps + c);
+    }
+}
+extern "C" int kg_rows_gather_planes(const void* src, int ldsrc, int src_pstride, const int* srcrow, void* dst, int lddst, int dst_pstride, long nrows, int C,
+                                     int P, void* stream) {
+    KG_CHECK_ARG(src && srcrow && dst && C % 8 == 0 && ldsrc % 8 == 0 && lddst % 8 == 0 && src_pstride % 8 == 0 && dst_pstride % 8 == 0 && P >= 1 && P <= 4,
+                 "kg_rows_gather_planes: bad args");
+    if (nrows == 0) return KG_OK;
+    long total = nrows * (C / 8) * P;
+    int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(rows_gather_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ldsrc, src_pstride, srcrow,
+                       (bf16_t*)dst, lddst, dst_pstride, nrows, C / 8, P);
+    KG_CHECK_LAUNCH("rows_gather_planes");
     return KG_OK;
 }
 

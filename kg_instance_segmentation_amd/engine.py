@@ -825,6 +825,11 @@ class Engine:
                 continue
             dev = self.maps[3 * lvl].device
             packed = ops.alloc_pt(N * Hh * Wh, 64, min(self.ph, self.pg), dev, dtype=self.dt)
+            if all(g is not None for g in gs) and self.HEAD_OFF == (0, 8, 24) and sum(self.HEAD_PAD) == 64:
+                # (the usual case: one pass writes whole 64-channel rows instead of three column slices)
+                ops.grad_pack3([g.contiguous().float() for g in gs], self.maps[3 * lvl], packed, N, [co for _, co in arch.HEADS], Hh, Wh, self.HEAD_PAD, scale=gsc)
+                slot["grad"] = packed
+                continue
             for k, g in enumerate(gs):
                 co = arch.HEADS[k][1]
                 view = packed.cols(self.HEAD_OFF[k], self.HEAD_OFF[k] + self.HEAD_PAD[k])

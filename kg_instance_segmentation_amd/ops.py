@@ -807,6 +807,12 @@ def grad_pack(g, prob, out, N, C, H, W, cpad, scale=None):
     _lib.call("kg_grad_pack", ptr(g), ptr(prob), ptr(_rows(out)), N, C, H, W, ld(out), cpad, pl(y=out, scale=scale), stream_ptr(), fmt=fmt_of(out))
 
 
+def grad_pack3(gs, prob0, out, N, Cs, H, W, pads, scale=None):
+    """the three fp32 NCHW map gradients of a level into the column blocks pads[0] | pads[1] | pads[2] of out (kg_grad_pack3: one launch)"""
+    _lib.call("kg_grad_pack3", ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(prob0), ptr(_rows(out)), N, Cs[0], Cs[1], Cs[2], H, W, ld(out),
+              pads[0], pads[1], pads[2], pl(y=out, scale=scale), stream_ptr(), fmt=fmt_of(out))
+
+
 # ---- gradient scale of the half-precision backward pass (csrc/gradscale.hip) ------------------------------------------------------
 # Magnitude target of the gradient scale: ops.grad_scale places the largest loss gradient of a step in [8, 16); the re-normalisation
 # points of the backward pass (engine.renormalise) bring a gradient tensor that has grown beyond it back there -- only ever DOWN: a

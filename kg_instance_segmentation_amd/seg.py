@@ -314,9 +314,12 @@ class SegBranch:
             rd = torch.empty(R, 2, dtype=torch.int32, device=dev)
             r2b = torch.empty(R, dtype=torch.int32, device=dev)
             sr = torch.empty(R, dtype=torch.int32, device=dev)
-            if p.nb[l]:
-                _lib.call("kg_seg_build_rows", ptr(p.tab_d[l]), p.nb[l], ptr(rd), ptr(r2b), ptr(sr), stream_ptr())
             p.rowdesc.append(rd); p.row2box.append(r2b); p.srcrow.append(sr)
+        if any(p.nb):          # the row tables of all five levels in one launch (kg_seg_build_rows_levels: host arrays of device pointers)
+            VP5, I5 = ctypes.c_void_p * 5, ctypes.c_int * 5
+            as_ptrs = lambda ts: VP5(*[t.data_ptr() for t in ts])
+            _lib.call("kg_seg_build_rows_levels", 5, as_ptrs(p.tab_d), I5(*[int(n) for n in p.nb]), as_ptrs(p.rowdesc), as_ptrs(p.row2box),
+                      as_ptrs(p.srcrow), stream_ptr())
         return p
 
     # ---- device work --------------------------------------------------------------------------------
@@ -338,6 +341,10 @@ class SegBranch:
             return
         sr = _lib.c_void_p(srcrow.data_ptr() + 4 * row_off)
         if isinstance(frows, PT):
+            if 1 < dst.P <= frows.P:      # every plane the branch carries exists in the source: ONE launch for all of them
+                _lib.call("kg_rows_gather_planes", ptr(frows.t), ops.ld(frows), frows.ps, sr, ptr(ops.base(dst)), ops.ld(dst), dst.ps, c_long(nrows), C, dst.P,
+                          stream_ptr(), fmt=ops.fmt_of(dst))
+                return
             for p_ in range(dst.P):
                 if p_ < frows.P:
                     _lib.call("kg_rows_gather", ops.ctypes_offset(frows.t, p_ * frows.ps), ops.ld(frows), sr,

@@ -675,3 +675,49 @@ def test_grad_pack_matches_torch(case, dt):
         assert float((got[:, :C] - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-7
         assert float(got[:, C:cpad].abs().max()) == 0.0 if cpad > C else True
         assert float((out.t[:, cpad:80].float() - 7.0).abs().max()) == 0.0           # columns past cpad untouched
+
+
+@pytest.mark.parametrize("dt", [BF16, torch.float16], ids=["bf16", "f16"])
+def test_rows_gather_planes_equals_per_plane_gathers(dt):
+    """kg_rows_gather_planes (the crop rows of a split feature map, both planes in one launch: seg.SegBranch.gather) against a torch gather of each
+    plane, into a whole-width destination and into a column slice of a wider (concat) buffer whose plane stride differs from the source's."""
+    from kg_instance_segmentation_amd import _lib
+    from kg_instance_segmentation_amd._lib import c_long, ptr, stream_ptr
+    g = torch.Generator().manual_seed(5)
+    R, C, n = 300, 64, 1111
+    src = ops.alloc_pt(R, C, 2, DEV, dtype=dt)
+    src.t.copy_(torch.randn(R, C, generator=g))
+    src.plane(1).copy_(torch.randn(R, C, generator=g))
+    idx = torch.randint(0, R, (n,), generator=g, dtype=torch.int32).to(DEV)
+    wide = ops.alloc_pt(n, C + 32, 2, DEV, zero=True, dtype=dt)
+    for dst in (ops.alloc_pt(n, C, 2, DEV, zero=True, dtype=dt), wide.cols(0, C)):
+        _lib.call("kg_rows_gather_planes", ptr(src.t), ops.ld(src), src.ps, ptr(idx), ptr(ops.base(dst)), ops.ld(dst), dst.ps, c_long(n), C, 2, stream_ptr(),
+                  fmt=ops.fmt_of(dst))
+        torch.cuda.synchronize()
+        for p in range(2):
+            assert torch.equal(dst.plane(p), src.plane(p)[idx.long()])
+    assert float(wide.t[:, C:].float().abs().max()) == 0.0 and float(wide.plane(1)[:, C:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", [BF16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", [(2, 33, 37), (1, 40, 40), (3, 16, 16), (8, 64, 64)])
+def test_grad_pack3_equals_three_grad_packs(case, dt):
+    """kg_grad_pack3 (the kp | short | mid map gradients of a level in one pass, engine.backward_dec) writes bit for bit what three kg_grad_pack
+    launches into the column blocks 0..8 | 8..24 | 24..64 write: odd pixel counts (scalar read path), multiples of 4 (16-byte reads), one and two planes."""
+    N, H, W = case
+    g = torch.Generator().manual_seed(H * 7 + W)
+    Cs, pads, offs = (5, 10, 40), (8, 16, 40), (0, 8, 24)
+    grads = [torch.randn(N, c, H, W, generator=g).to(DEV) for c in Cs]
+    prob = torch.rand(N, 5, H, W, generator=g).to(DEV)
+    scale = torch.tensor([8.0], device=DEV)
+    for P in (1, 2):
+        one = ops.alloc_pt(N * H * W, 64, P, DEV, dtype=dt)
+        three = ops.alloc_pt(N * H * W, 64, P, DEV, dtype=dt)
+        one.t.fill_(3.0)
+        three.t.fill_(5.0)
+        ops.grad_pack3(grads, prob, one, N, Cs, H, W, pads, scale=scale)
+        for k in range(3):
+            ops.grad_pack(grads[k], prob if k == 0 else None, three.cols(offs[k], offs[k] + pads[k]), N, Cs[k], H, W, pads[k], scale=scale)
+        torch.cuda.synchronize()
+        for p in range(P):
+            assert torch.equal(one.plane(p), three.plane(p)), (case, P, p)
