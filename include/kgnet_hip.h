@@ -80,6 +80,9 @@ int kg_conv2d_halo(const void* x, const void* w, const float* bias, void* y, flo
                    const void* mask, int N, int H, int W, int cin_pad, int ldx, int Cout, int ldy, int ldres, int ldmask,
                    int K, int KS, int flip, int relu, int f32_C, int wc, const int* tiletab, int ntiles, int total_rows,
                    const kg_planes_t* planes, void* stream);   /* planes: a = x, b = res, y = y.  tiletab != NULL: ragged boxes, one {row0,(h<<16)|w,(oy0<<16)|ox0,0} entry per workgroup */
+                   /* wc: couts per workgroup / 64 (0 = default) | 256: the packed weights are zero for channels 32..63 of every chunk | 512 / 1024: the NARROW
+                      input gradient (flip = 1, KS = 7, one single-plane 64-channel dY: only channels 0..7 / 8..23 carry data -- the kp / short second-layer
+                      heads, KGnet.py:161-209 `.2`): w packed by kg_pack_weight_narrow (7 / 14 virtual taps of 64 columns), 4 / 2 kernel columns per k-step */
 /* the three second-layer 7x7 head convolutions of one scale (KGnet.py:161-209 `.2` layers, sigmoid on kp :300) in one launch
  * over the fused hidden rows [N*H*W][>=3C]: w = packed [64 virtual couts][49][3C] (kg_pack_weight_rows), bias64 / vmap[64]
  * indexed by virtual cout (vmap: channel of kp 0-4 | short 5-14 | mid 15-54, or -1); fp32 NCHW outputs */
@@ -93,6 +96,12 @@ int kg_conv2d_halo_heads2(const void* x, const void* w, const float* bias64, con
 int kg_conv3x3_c64(const void* x, const void* w, const float* bias, void* y, const void* res, const void* mask, int N, int H, int W,
                    int ldx, int Cout, int ldy, int ldres, int ldmask, int K, int flip, int relu, const int* tiletab16, int ntiles,
                    void* stream);
+/* 7x7 stride-1 "same" input gradient (flip = 1; 0: forward) of a NARROW conv -- the kp / short second-layer head convs (KGnet.py:161-209 `.2`: C -> 5 / 10):
+ * the rows x [N*H*W][ldx] carry data in the chan_slot (8 or 16) channels from chan_lo on; w packed by kg_pack_weight_narrow (7 / 14 virtual taps of 64
+ * columns, resident in LDS), persistent workgroups over 16 x 16-pixel tiles with compact double-buffered halos; y rows of Cout channels, zeroed where
+ * mask <= 0 (ReLU backward of the hidden tensor; NULL: none).  Single 16-bit planes. */
+int kg_conv7_narrow(const void* x, const void* w, void* y, const void* mask, int N, int H, int W, int ldx, int chan_lo, int chan_slot, int Cout, int ldy,
+                    int ldmask, int K, int flip, void* stream);
 /* Weight-stationary variant for the full-resolution 64 -> 64 channel 3x3 convs of the fp32-tolerance forward pass (c0_conv.2 KGnet.py:139-142,
  * c1_up_conv :153, seg_head.0 :145-147, skip_combine.0.up :116-119): x in hi + lo planes (planes->a_planes == 2), w packed by kg_pack_weight
  * with x_planes = w_planes = 2 (K >= 9 * 192), y = ReLU?(conv + bias) in 1 or 2 planes.  Dense (N images of H x W) or ragged
@@ -114,8 +123,12 @@ int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int KH, int KW,
  * tap row when several plane groups share the matrix (0 = vplanes * cin_pad) */
 int kg_pack_weight_rows(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int cin_pad, const int* rowmap,
                         int c0, int x_planes, int w_planes, int tap_stride, void* stream);
+/* transposed (input-gradient) packing of a narrow conv (Cout <= tap_stride in {8, 16}) for kg_conv2d_halo's wc | 512 / 1024 variants:
+ * dst[(row0 + ci) * K + (ky * tap_pitch + kx) * tap_stride + c0 + co] = w[co][ci][ky][kx]; single plane; K >= KH * tap_pitch * tap_stride */
+int kg_pack_weight_narrow(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int row0, int c0, int tap_stride, int tap_pitch,
+                          void* stream);
 /* all (re)packs of a step in one launch: jobs = device array of 80-byte records {const float* w; void* dst; const int* rowmap;
- * int Cout, Cin, taps, K, cin_pad, row0, c0, transposed, gx, blk0, x_planes, w_planes, tap_stride, pad;} (gx = Cout, or
+ * int Cout, Cin, taps, K, cin_pad, row0, c0, transposed, gx, blk0, x_planes, w_planes, tap_stride, tap_pitch;} (gx = Cout, or
  * ceil(Cout/64) when transposed; blk0 = first workgroup of the job); total_blocks = sum of gx * gy over the jobs */
 int kg_pack_weight_batch(const void* jobs, int njobs, int total_blocks, void* stream);
 /* im2col for <= 8 input channels (weight gradient of the stem conv1, KGnet.py:131, as a 1x1 weight-gradient GEMM):

@@ -34,6 +34,8 @@ _SIGS = {
     "kg_pack_weight": [P, P] + [c_int] * 11 + [P],
     "kg_pack_weight_rows": [P, P] + [c_int] * 6 + [P, c_int, c_int, c_int, c_int, P],
     "kg_pack_weight_batch": [P, c_int, c_int, P],
+    "kg_pack_weight_narrow": [P, P] + [c_int] * 9 + [P],
+    "kg_conv7_narrow": [P, P, P, P] + [c_int] * 11 + [P],
     "kg_im2col_small": [P, P] + [c_int] * 12 + [P],
     "kg_conv2d_halo_heads2": [P, P, P, P, P, P, P] + [c_int] * 7 + [P, P],
     "kg_set_wgrad_tr": [c_int],

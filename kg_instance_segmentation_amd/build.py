@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libkgnet_hip.so")
 LIB_F16 = os.path.join(HERE, "libkgnet_hip_f16.so")      # the same sources with IEEE-half rows (-DKG_F16, csrc/kg_common.h)
 # sources with rows / packed-weight operands: built once per 16-bit format
 ROWS_SOURCES = ("api.hip", "conv_igemm.hip", "conv_gather.hip", "conv_small.hip", "conv_halo.hip", "conv3_c64.hip", "conv1x1.hip",
-                "conv_wgrad.hip", "wgrad_halo.hip", "norm_pool.hip", "loss.hip", "seg.hip", "conv_tiny.hip", "conv3_ws.hip")
+                "conv_wgrad.hip", "wgrad_halo.hip", "norm_pool.hip", "loss.hip", "seg.hip", "conv_tiny.hip", "conv3_ws.hip", "conv7_narrow.hip")
 SOURCES = {
     "api.hip": [],
     "conv_igemm.hip": [],
@@ -39,6 +39,7 @@ SOURCES = {
     "gradscale.hip": [],
     "conv_tiny.hip": [],
     "conv3_ws.hip": [],
+    "conv7_narrow.hip": [],
 }
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -84,7 +84,13 @@ static void halo_set_walk(HaloArgs& a, int xP, int wP) {
 // regular one keeps its register allocation (234 registers, no spills; with the statistics code inside: 256 + 8 spilled)
 template <int KS, int WC, int WPX, int GM = 0, bool BSK = false>
 __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs a) {
-    constexpr int PAD = KS / 2, TW = 4 * WPX, HWD = TW + KS - 1, HPIX = (16 + KS - 1) * HWD, TC = WC * 64, NT = WC * WPX * 64, T = KS * KS;
+    // GM = 3 / 4: the input gradient of a NARROW conv (8 / 16 channels of the 64-channel dY rows carry data: the kp / short second-layer heads).  One
+    // 32-wide MFMA k-step multiplies 4 / 2 kernel COLUMNS of a kernel row at once -- lane group g of the B fragment reads the 16-byte channel slot of
+    // the pixel shifted by its own column (conv_small.hip's four-taps-per-k-step idea on the LDS halo) -- so a kernel row is KSX = 1 / 2 "virtual taps"
+    // of 64 packed weight columns ((kx, channel), the 8th column zero) instead of 7 taps that are 7/8 or 3/4 zeros: 14 / 28 k-steps, not 49.
+    constexpr int KSX = GM == 3 ? 1 : (GM == 4 ? 2 : KS);
+    constexpr int PAD = KS / 2, TW = 4 * WPX, HWD = TW + KS - 1, HPIX = (16 + KS - 1) * HWD, TC = WC * 64, NT = WC * WPX * 64, T = KS * KSX;
+    static_assert(GM < 3 || KS == 7, "the narrow variants are written for 7 x 7 kernels");
     constexpr int HALO_BYTES = HPIX * 128, WBUF_BYTES = TC * 128;
     // 7x7, 64-cout workgroups: the weight slices go global -> LDS with LDS-direct loads through a 6-slot ring (no staging registers,
     // no ds_write), two taps per barrier; the barrier is a raw s_barrier behind a COUNTED s_waitcnt vmcnt(1), so the newest slice
@@ -146,6 +152,19 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
     int kb[KS][2];
 #pragma unroll
     for (int kx = 0; kx < KS; ++kx) {
+        if constexpr (GM >= 3) {      // virtual tap q = kx of a kernel row, k-step s: lane group g -> kernel column kcol, channel slot of dY (kp: 0; short: 1, 2)
+            if (kx < KSX) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    int kcol = GM == 3 ? 4 * s + g : 4 * kx + 2 * s + (g >> 1);
+                    if (kcol > KS - 1) kcol = KS - 1;      // (the 8th column: its packed weights are zero; read the 7th column's pixel again)
+                    const int slot = GM == 3 ? 0 : 1 + (g & 1);
+                    const int fx = a.flip ? KS - 1 - kcol : kcol;
+                    kb[kx][s] = (((wp & 3) * 4) * HWD + xb + fx) * 128 + ((slot ^ ((xb + fx) & 6)) * 16);
+                }
+            } else kb[kx][0] = kb[kx][1] = 0;
+            continue;
+        }
         const int fx = a.flip ? KS - 1 - kx : kx;
         const int key = (xb + fx) & 6;   // conflict-free for every tap shift under the ds_read_b128 lane groups {0-3,12-15,20-27} ...; ((x >> 1) & 7 was 2-way for 3 of 4 shifts)
 #pragma unroll
@@ -469,7 +488,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
         int sbr[NSL];
 #pragma unroll
         for (int q = 0; q < NSL; ++q) { abr[q][0] = ab[q][0]; abr[q][1] = ab[q][1]; sbr[q] = q * WBUF_BYTES; }
-        int tapb = a.flip ? ((KS - 1) * HWD + (KS - 1)) * 128 : 0;   // halo byte offset of tap (ky, kx = 0)
+        int tapb = a.flip ? ((KS - 1) * HWD + (GM >= 3 ? 0 : KS - 1)) * 128 : 0;   // halo byte offset of tap (ky, kx = 0); narrow: of kernel row ky (the columns are in kb)
         const int sx = a.flip ? -128 : 128, sy = a.flip ? -HWD * 128 : HWD * 128;
         auto ldA = [&](auto mk, bf16x8 (&af)[4], int base) {
             constexpr int MK = decltype(mk)::value;
@@ -510,7 +529,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
 #pragma unroll (ASMRD ? KS : 1)   // 7x7: fully unrolled -> tap parity, ring slots and tails are compile-time, no branch merges (the waitcnt pass then counts lgkmcnt precisely)
         for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
-            for (int kx = 0; kx < KS; ++kx, ++t) {
+            for (int kx = 0; kx < KSX; ++kx, ++t) {
                 constexpr int dummy = 0; (void)dummy;
                 const int cur = kx % NSL, nxt = (kx + 1) % NSL, st = (kx + 2) % NSL;
                 if constexpr (GLW) {   // pair start (even t): taps t+4, t+5 into the slots of taps t-2, t-1, which every wave has left
@@ -519,9 +538,9 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                         if (t + 5 < T) wglds(sbr[(kx + 5) % NSL]);
                     }
                 }
-                const int nkx = (kx + 1 == KS) ? 0 : kx + 1;
-                const int tb = tapb + kx * sx;
-                const int ntb = (kx + 1 == KS) ? tapb + sy : tapb + (kx + 1) * sx;
+                const int nkx = (kx + 1 == KSX) ? 0 : kx + 1;
+                const int tb = GM >= 3 ? tapb : tapb + kx * sx;
+                const int ntb = (kx + 1 == KSX) ? tapb + sy : (GM >= 3 ? tapb : tapb + (kx + 1) * sx);
                 if constexpr ((decltype(mk)::value & 16) == 0) {
                     ldA(mk, a1, abr[cur][1]); ldB(b1, tb, kb[kx][1]);
                     lwait(mk, a0, b0, true);
@@ -530,7 +549,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
                     lwait(mk, a1, b1, t + 1 < T);
                     mma(mk, a1, b1);
                 } else {   // only k-step 0 of the chunk is non-zero: taps alternate between the two fragment buffers
-                    if (kx + 1 == KS) {
+                    if (kx + 1 == KSX) {
                         lwait(mk, a0, b0, false);
                         mma(mk, a0, b0);
                         if (t + 1 < T) { ldA(mk, a0, abr[nxt][0]); ldB(b0, ntb, kb[nkx][0]); }
@@ -561,7 +580,7 @@ __global__ __launch_bounds__(WC * WPX * 64) void conv_halo_kernel(const HaloArgs
             }
             tapb += sy;
             {   // KS taps per row: the ring slot of (ky+1, 0) is KS % NSL further -> rotate the slot tables
-                constexpr int SH = KS % NSL;
+                constexpr int SH = KSX % NSL;
                 int sb2[NSL], ab2[NSL][2];
 #pragma unroll
                 for (int q = 0; q < NSL; ++q) { sb2[q] = sbr[(q + SH) % NSL]; ab2[q][0] = abr[(q + SH) % NSL][0]; ab2[q][1] = abr[(q + SH) % NSL][1]; }
@@ -1161,7 +1180,10 @@ extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, v
     KG_CHECK_ARG(x && w && (y || y_f32), "kg_conv2d_halo: null pointer");
     KG_CHECK_ARG(KS == 3 || KS == 7, "kg_conv2d_halo: kernel size must be 3 or 7");
     KG_CHECK_ARG(cin_pad % 64 == 0 && ldx % 8 == 0, "kg_conv2d_halo: cin_pad must be a multiple of 64 (got %d)", cin_pad);
-    KG_CHECK_ARG(K >= KS * KS * cin_pad * vplanes, "kg_conv2d_halo: K too small");
+    const int narrow = (wc >> 9) & 3;      // bits 9 / 10 of wc: the narrow input-gradient variants (GM = 3 / 4: 8 / 16 live channels, 7 / 14 virtual taps of 64 columns)
+    KG_CHECK_ARG(narrow == 0 || (narrow <= 2 && KS == 7 && cin_pad == 64 && vplanes == 1 && (wc & 255) <= 1 && !tiletab && y && !y_f32),
+                 "kg_conv2d_halo: the narrow variants take one 64-channel single-plane dense input and a rows output");
+    KG_CHECK_ARG(K >= (narrow ? 7 * narrow * 64 : KS * KS * cin_pad * vplanes), "kg_conv2d_halo: K too small");
     KG_CHECK_ARG((tiletab && ntiles > 0 && Cout > 0) || (N > 0 && H > 0 && W > 0 && Cout > 0), "kg_conv2d_halo: empty problem");
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.y_f32 = y_f32;
     a.res = (const bf16_t*)res; a.mask = (const bf16_t*)mask;
@@ -1175,12 +1197,15 @@ extern "C" int kg_conv2d_halo(const void* x, const void* w, const float* bias, v
         if (y && !y_f32 && want && cs.part && cs.nb == 0)
             a.stat_part = cs.part;      // provisional: launch_halo claims it with the tile count of the variant it launches
     }
-    const int k1skip = wc >> 8; wc &= 255;   // bit 8: the weights are zero for channels 32..63 of every chunk -> k-step 1 is skipped
+    const int k1skip = (wc >> 8) & 1; wc &= 255;   // bit 8: the weights are zero for channels 32..63 of every chunk -> k-step 1 is skipped
     if (wc == 0) wc = 1;   // measured on MI355X: the 16x32-pixel x 64-cout tile (8 waves) beats the 16x16 x 128/192-cout tiles at every KGnet shape
     hipStream_t st = (hipStream_t)stream;
     if (KS == 7) {
         switch (wc) {
-            case 1: return k1skip ? launch_halo<7, 1, 8, 2>(a, st) : launch_halo<7, 1, 8>(a, st);
+            case 1:
+                if (narrow == 1) return launch_halo<7, 1, 8, 3>(a, st);
+                if (narrow == 2) return launch_halo<7, 1, 8, 4>(a, st);
+                return k1skip ? launch_halo<7, 1, 8, 2>(a, st) : launch_halo<7, 1, 8>(a, st);
             case 2: return launch_halo<7, 2, 4>(a, st);
             case 3: return launch_halo<7, 3, 4>(a, st);
         }

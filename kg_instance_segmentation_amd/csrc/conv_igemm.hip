@@ -327,7 +327,7 @@ __device__ __forceinline__ void pack_store_planes(bf16_t* __restrict__ rowp, flo
 }
 __device__ __forceinline__ void pack_weight_block(float* tile, const float* __restrict__ w, bf16_t* __restrict__ dst, int Cout, int Cin,
                                                   int taps, int K, int cin_pad, int row0, int c0, int transposed,
-                                                  const int* __restrict__ rowmap, int bx, int by, const PackPlanes q) {
+                                                  const int* __restrict__ rowmap, int bx, int by, const PackPlanes q, int tap_pitch = 0) {
     if (!transposed) {
         const int co = bx, ci0 = by * 64;
         const int nci = Cin - ci0 < 64 ? Cin - ci0 : 64;
@@ -346,24 +346,28 @@ __device__ __forceinline__ void pack_weight_block(float* tile, const float* __re
             tile[co * 50 + tap] = w[((long)(co0 + co) * Cin + ci) * taps + tap];
         }
         __syncthreads();
+        // tap_pitch > 0 (the narrow input-gradient layout of conv_halo.hip, GM = 3 / 4): the columns of a kernel row are tap_pitch slots apart
+        // instead of KW -- tap (ky, kx) lands in slot ky * tap_pitch + kx (the slots kx >= KW stay zero)
+        const int kw = taps == 49 ? 7 : (taps == 9 ? 3 : taps);
         for (int e = threadIdx.x; e < taps * 64; e += 256) {
             const int tap = e >> 6, co = e & 63;
-            if (co < nco) pack_store_planes(dst + (long)(row0 + ci) * K + (long)tap * q.cin_virt + c0 + co0 + co, tile[co * 50 + tap], q, cin_pad);
+            const int tslot = tap_pitch > 0 ? (tap / kw) * tap_pitch + tap % kw : tap;
+            if (co < nco) pack_store_planes(dst + (long)(row0 + ci) * K + (long)tslot * q.cin_virt + c0 + co0 + co, tile[co * 50 + tap], q, cin_pad);
         }
     }
 }
 
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int Cout,
                                                           int Cin, int taps, int K, int cin_pad, int row0, int c0,
-                                                          int transposed, const int* __restrict__ rowmap, const PackPlanes q) {
+                                                          int transposed, const int* __restrict__ rowmap, const PackPlanes q, int tap_pitch) {
     __shared__ float tile[64 * 50];
-    pack_weight_block(tile, w, dst, Cout, Cin, taps, K, cin_pad, row0, c0, transposed, rowmap, blockIdx.x, blockIdx.y, q);
+    pack_weight_block(tile, w, dst, Cout, Cin, taps, K, cin_pad, row0, c0, transposed, rowmap, blockIdx.x, blockIdx.y, q, tap_pitch);
 }
 
 // All weight (re)packs of a training step in ONE launch: the 170+ per-tensor launches were launch-bound (5 us each).
 struct PackJob {   // 80 bytes, mirrored by ops.PackQueue
     const float* w; bf16_t* dst; const int* rowmap;
-    int Cout, Cin, taps, K, cin_pad, row0, c0, transposed, gx, blk0, xP, wP, tap_stride, pad_;   // tap_stride: 0 = vplanes * cin_pad
+    int Cout, Cin, taps, K, cin_pad, row0, c0, transposed, gx, blk0, xP, wP, tap_stride, tap_pitch;   // tap_stride: 0 = vplanes * cin_pad; tap_pitch: pack_weight_block
 };
 __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackJob* __restrict__ jobs, int njobs) {
     __shared__ float tile[64 * 50];
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const PackJob* _
             }
         q.cin_virt = j.tap_stride > 0 ? j.tap_stride : q.nv * j.cin_pad;
     }
-    pack_weight_block(tile, j.w, j.dst, j.Cout, j.Cin, j.taps, j.K, j.cin_pad, j.row0, j.c0, j.transposed, j.rowmap, b % j.gx, b / j.gx, q);
+    pack_weight_block(tile, j.w, j.dst, j.Cout, j.Cin, j.taps, j.K, j.cin_pad, j.row0, j.c0, j.transposed, j.rowmap, b % j.gx, b / j.gx, q, j.tap_pitch);
 }
 
 // x_planes / w_planes: split-bf16 layout of the packed matrix (1, 1 = plain bf16); cin_pad = channels of ONE plane, c0 = channel
@@ -400,8 +404,25 @@ extern "C" int kg_pack_weight(const float* w, void* dst, int Cout, int Cin, int 
     KG_CHECK_ARG(K >= KH * KW * q.cin_virt, "kg_pack_weight: K too small for the plane layout");
     dim3 grid = transposed ? dim3((Cout + 63) / 64, Cin) : dim3(Cout, (Cin + 63) / 64);
     hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, Cout,
-                       Cin, KH * KW, K, cin_pad, row0, c0, transposed, (const int*)nullptr, q);
+                       Cin, KH * KW, K, cin_pad, row0, c0, transposed, (const int*)nullptr, q, 0);
     KG_CHECK_LAUNCH("pack_weight");
+    return KG_OK;
+}
+
+// Transposed (input-gradient) packing of a NARROW conv for conv_halo.hip's GM = 3 / 4 variants (Cout <= tap_stride in {8, 16} channels, single plane):
+//   dst[(row0 + ci) * K + (ky * tap_pitch + kx) * tap_stride + c0 + co] = w[co][ci][ky][kx]
+// -- the (kernel column, channel) pairs of a kernel row side by side, tap_pitch = 8 columns per row (7 real + 1 zero): 64 / 128 packed columns per kernel row.
+extern "C" int kg_pack_weight_narrow(const float* w, void* dst, int Cout, int Cin, int KH, int KW, int K, int row0, int c0, int tap_stride, int tap_pitch,
+                                     void* stream) {
+    KG_CHECK_ARG(w && dst, "kg_pack_weight_narrow: null pointer");
+    KG_CHECK_ARG(KH == KW && (KH == 7 || KH == 3) && tap_pitch >= KW && tap_stride >= 8 && tap_stride % 8 == 0 && c0 + Cout <= tap_stride,
+                 "kg_pack_weight_narrow: bad layout");
+    KG_CHECK_ARG(K >= KH * tap_pitch * tap_stride, "kg_pack_weight_narrow: K too small");
+    PackPlanes q = make_pack_planes(1, 1, tap_stride);
+    q.cin_virt = tap_stride;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((Cout + 63) / 64, Cin), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, Cout,
+                       Cin, KH * KW, K, tap_stride, row0, c0, 1, (const int*)nullptr, q, tap_pitch);
+    KG_CHECK_LAUNCH("pack_weight_narrow");
     return KG_OK;
 }
 
@@ -416,7 +437,7 @@ extern "C" int kg_pack_weight_rows(const float* w, void* dst, int Cout, int Cin,
     PackPlanes q = make_pack_planes(x_planes, w_planes, cin_pad);
     if (tap_stride > 0) q.cin_virt = tap_stride;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(Cout, (Cin + 63) / 64), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst,
-                       Cout, Cin, KH * KW, K, cin_pad, 0, c0, 0, rowmap, q);
+                       Cout, Cin, KH * KW, K, cin_pad, 0, c0, 0, rowmap, q, 0);
     KG_CHECK_LAUNCH("pack_weight_rows");
     return KG_OK;
 }

@@ -52,6 +52,7 @@ PRECISIONS = {
 HALF_POLICIES = ("fp32", "fp32b2", "half", "halfmix")
 DEFAULT_PRECISION = "fp32"
 PRE = [0]        # prepack generation counter (Engine.prepack)
+NARROW_HEADS_DGRAD = int(os.environ.get("KG_NARROW_HEADS_DGRAD", "2"))      # (0: fused k1skip launch; 1: narrow halo variants; 2: persistent conv7_narrow) the kp / short second-layer input gradients on the narrow halo variants (Engine.prepare_heads2; tests flip it for the A/B)
 BN_BWD_STATS = True     # BatchNorm-backward statistics in the epilogue of the input gradient that completes the BatchNorm output's gradient (Engine.conv)
 
 
@@ -730,7 +731,7 @@ class Engine:
         if self.fast_stamp is not None and ent is not None and ent[0][:3] == self.fast_stamp and ent[1].buf.device == dev:
             entT = self.fusedT.get(f"heads_c{lvl}.2T") if train else None
             if not train or (entT is not None and entT[0][:3] == self.fast_stamp and entT[1].buf.device == dev):
-                return ent[1], ent[2], entT[1] if train else None       # (prepacked under this stamp, fingerprint unchanged: see prepare)
+                return ent[1], ent[2], (entT[1], entT[2]) if train else None       # (prepacked under this stamp, fingerprint unchanged: see prepare)
         ph = self.ph
         specs = [self.spec(f"{h}_head_c{lvl}.2", C, co, 7, 1, 3, P=ph) for h, co in arch.HEADS]
         ws = [self.P(s.names[0] + ".weight") for s in specs]
@@ -751,11 +752,23 @@ class Engine:
             ver = self.stamp + tuple(w._version for w in ws) + tuple(w.data_ptr() for w in ws)
             if ent is None or ent[0] != ver or ent[1].buf.device != dev:
                 gph = min(ph, self.pg)
-                pwT = ent[1] if ent is not None and ent[1].buf.device == dev else PackedWeight(3 * C, 49, 64, dev, xP=gph, wP=min(gph, self.pdw), dtype=self.dt)
+                reuse = ent is not None and ent[1].buf.device == dev
+                pwT = ent[1] if reuse else PackedWeight(3 * C, 49, 64, dev, xP=gph, wP=min(gph, self.pdw), dtype=self.dt)
+                # single-plane backward: the kp / short input gradients run on the narrow variants of the halo kernel (4 / 2 kernel columns per MFMA
+                # k-step instead of k-steps that are 3/4 or 1/2 zeros: ops.conv_halo(narrow=...)) from their own packed matrices; rows of pwT they do
+                # not use stay unpacked
+                narrow = NARROW_HEADS_DGRAD and gph == 1 and min(gph, self.pdw) == 1
+                pwN = None
+                if narrow:
+                    pwN = ent[2] if reuse and ent[2] is not None else (PackedWeight(C, 7, 64, dev, dtype=self.dt), PackedWeight(C, 14, 64, dev, dtype=self.dt))
+                    pwN[0].pack_narrow(ws[0].detach(), 8)
+                    pwN[1].pack_narrow(ws[1].detach(), 16)
                 for k, w in enumerate(ws):
+                    if narrow and k < 2:
+                        continue
                     pwT.pack(w.detach(), row0=k * C, c0=self.HEAD_OFF[k], transposed=True)
-                self.fusedT[key] = (ver, pwT)
-            pwT = self.fusedT[key][1]
+                self.fusedT[key] = (ver, pwT, pwN)
+            pwT = (self.fusedT[key][1], self.fusedT[key][2])
         return pwF, bias64, pwT
 
     def heads_second(self, hid, lvl, C, N, H, W):
@@ -767,7 +780,8 @@ class Engine:
         dev = hid.t.device
         train = self.tape is not None
         specs = [self.spec(f"{h}_head_c{lvl}.2", C, co, 7, 1, 3, P=self.ph) for h, co in arch.HEADS]
-        pwF, bias64, pwT = self.prepare_heads2(lvl, C, dev, train)
+        pwF, bias64, pwTN = self.prepare_heads2(lvl, C, dev, train)
+        pwT, pwN = pwTN if pwTN is not None else (None, None)
         outs = [torch.empty(N, co, H, W, dtype=torch.float32, device=dev) for _, co in arch.HEADS]
         ops.conv_halo_heads2(hid.t, pwF, bias64, self.heads2_tables(dev)["vmap"], outs[0], outs[1], outs[2], N, H, W, C,
                              kp_sigmoid=not self.raw_kp_logits)
@@ -794,7 +808,14 @@ class Engine:
                     self.param_grads[s.names[0] + ".bias"] = db
                 dh = ops.alloc_pt(hid.rows, 3 * C, hid.gP, dev, dtype=self.dt)
                 # kp / short cout blocks only see dY channels 0..23 (k-step 1 of the chunk skipped); mid sees 24..63
-                ops.conv_halo(g, pwT, 2 * C, N, H, W, 7, y=dh.cols(0, 2 * C), mask=hid.t.hi()[:, :2 * C], flip=True, k1skip=True, algo_cin=7.5)
+                if pwN is not None and g.P == 1 and NARROW_HEADS_DGRAD >= 2 and dh.P == 1:
+                    ops.conv7_narrow(g, pwN[0], C, N, H, W, dh.cols(0, C), mask=hid.t.hi()[:, :C], chan_lo=0, chan_slot=8, algo_cin=5)
+                    ops.conv7_narrow(g, pwN[1], C, N, H, W, dh.cols(C, 2 * C), mask=hid.t.hi()[:, C:2 * C], chan_lo=8, chan_slot=16, algo_cin=10)
+                elif pwN is not None and g.P == 1:
+                    ops.conv_halo(g, pwN[0], C, N, H, W, 7, y=dh.cols(0, C), mask=hid.t.hi()[:, :C], flip=True, narrow=8, algo_cin=5)
+                    ops.conv_halo(g, pwN[1], C, N, H, W, 7, y=dh.cols(C, 2 * C), mask=hid.t.hi()[:, C:2 * C], flip=True, narrow=16, algo_cin=10)
+                else:
+                    ops.conv_halo(g, pwT, 2 * C, N, H, W, 7, y=dh.cols(0, 2 * C), mask=hid.t.hi()[:, :2 * C], flip=True, k1skip=True, algo_cin=7.5)
                 ops.conv_halo(g, pwT.rows_from(2 * C), C, N, H, W, 7, y=dh.cols(2 * C, 3 * C), mask=hid.t.hi()[:, 2 * C:], flip=True, algo_cin=40)
                 hid.add_grad(dh, masked=True)
             self.tape.append(bwd)

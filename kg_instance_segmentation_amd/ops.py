@@ -250,12 +250,12 @@ class PackQueue:
     def defer(self, v):
         PackQueue.DEFER[0] = v
 
-    def add(self, w, pw, row0, c0, transposed, rowmap, tap_stride=0):
+    def add(self, w, pw, row0, c0, transposed, rowmap, tap_stride=0, tap_pitch=0, cin_pad=None):
         Cout, Cin, KH, KW = w.shape
         gx = (Cout + 63) // 64 if transposed else Cout
         gy = Cin if transposed else (Cin + 63) // 64
         self.jobs.append((w.data_ptr(), pw.buf.data_ptr(), rowmap.data_ptr() if rowmap is not None else 0, Cout, Cin, KH * KW,
-                          pw.K, pw.cin_pad, row0, c0, 1 if transposed else 0, gx, gx * gy, pw.xP, pw.wP, tap_stride))
+                          pw.K, pw.cin_pad if cin_pad is None else cin_pad, row0, c0, 1 if transposed else 0, gx, gx * gy, pw.xP, pw.wP, tap_stride, tap_pitch))
         self.keep.append((w, pw, rowmap))
 
     def flush(self, hold=False):
@@ -263,11 +263,11 @@ class PackQueue:
             return
         import numpy as np
         dt = np.dtype([("w", "<u8"), ("dst", "<u8"), ("rowmap", "<u8")] + [(n, "<i4") for n in
-                      ("Cout", "Cin", "taps", "K", "cin_pad", "row0", "c0", "transposed", "gx", "blk0", "xP", "wP", "tap_stride", "pad_")])
+                      ("Cout", "Cin", "taps", "K", "cin_pad", "row0", "c0", "transposed", "gx", "blk0", "xP", "wP", "tap_stride", "tap_pitch")])
         arr = np.zeros(len(self.jobs), dt)
         blk = 0
         for i, j in enumerate(self.jobs):
-            arr[i] = j[:12] + (blk,) + j[13:16] + (0,)
+            arr[i] = j[:12] + (blk,) + j[13:17]
             blk += j[12]
         dev = self.keep[0][0].device
         sig = arr.tobytes()
@@ -344,6 +344,17 @@ class PackedWeight:
                   1 if transposed else 0, self.xP, self.wP, stream_ptr(), fmt=fmt_of(self))
 
 
+    def pack_narrow(self, w, chan_slot, row0=0):
+        """transposed (input-gradient) packing of a narrow conv for conv_halo(..., narrow=chan_slot): chan_slot = 8 / 16 channels per kernel column,
+        8 column slots per kernel row (kg_pack_weight_narrow); self = PackedWeight(Cin, 7 * chan_slot // 8, 64, ...)"""
+        Cout, Cin, KH, KW = w.shape
+        assert w.dtype == torch.float32 and w.is_contiguous() and KH == KW == 7 and Cout <= chan_slot and self.xP == self.wP == 1
+        assert self.cin_pad == 64 and self.K >= 7 * 8 * chan_slot
+        if PACKQ.defer:
+            (PACKQ16 if fmt_of(self) else PACKQ).add(w, self, row0, 0, True, None, tap_stride=chan_slot, tap_pitch=8, cin_pad=chan_slot)
+            return
+        _lib.call("kg_pack_weight_narrow", ptr(w), ptr(self.buf), Cout, Cin, KH, KW, self.K, row0, 0, chan_slot, 8, stream_ptr(), fmt=fmt_of(self))
+
     def rows_from(self, r0):
         """View of the packed matrix starting at row r0 (a cout-block-aligned slice of a fused weight)."""
         v = PackedWeight.__new__(PackedWeight)
@@ -402,6 +413,17 @@ def conv_igemm(x, pw, cout, geom, y=None, y_f32=None, bias=None, res=None, mask=
               mode, 1 if relu else 0, f32_C, tile, pl(a=x, b=res, y=y, w=pw.wP, oscale=oscale), stream_ptr(), fmt=fmt_of(x))
 
 
+def conv7_narrow(x, pw, cout, N, H, W, y, mask=None, chan_lo=0, chan_slot=8, flip=True, algo_cin=None):
+    """kg_conv7_narrow: the input gradient (flip) of a 7x7 "same" conv whose single-plane dY rows x carry data in the chan_slot (8 / 16) channels from chan_lo
+    on (pw from PackedWeight.pack_narrow): persistent workgroups, the packed weights resident in LDS, compact halos (conv7_narrow.hip).
+    algo_cin: live input channels (FLOP accounting of bench.py's timer; unused here)."""
+    flush_packs()
+    assert nplanes(x)[0] == 1 and nplanes(y)[0] == 1 and pw.xP == pw.wP == 1 and chan_slot in (8, 16)
+    xb, yb, mb = _rows(x), base(y), base(mask)
+    _lib.call("kg_conv7_narrow", ptr(xb), ptr(pw.buf), ptr(yb), ptr(mb), N, H, W, ld(xb), chan_lo, chan_slot, cout, ld(yb),
+              ld(mb) if mb is not None else 0, pw.K, 1 if flip else 0, stream_ptr(), fmt=fmt_of(xb))
+
+
 USE_HALO = True
 WGRAD128 = True           # (module constants: tests and probes may flip them; the environment switches of rounds 1-5 are gone, docs/history.md)
 USE_C3 = True
@@ -415,10 +437,12 @@ USE_WS = True             # the weight-stationary 64 -> 64 kernel (conv3_ws.hip)
 
 
 def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None, mask=None, relu=False, flip=False, wc=0,
-              tiletab=None, total_rows=0, k1skip=False, algo_cin=None, tiletab16=None, oscale=None, tiletab8=None):
+              tiletab=None, total_rows=0, k1skip=False, algo_cin=None, tiletab16=None, oscale=None, tiletab8=None, narrow=0):
     """Stride-1 "same" KSxKS conv (or its input gradient when flip) with the input halo resident in LDS.
     tiletab (int32 [ntiles,4] device tensor): ragged boxes instead of N images of HxW.
     k1skip (7x7 only): the packed weights are zero for channels 32..63 of every 64-channel chunk.
+    narrow = 8 / 16 (7x7 input gradient of a conv whose dY rows carry data in channels 0..7 / 8..23 only; pw from PackedWeight.pack_narrow): 4 / 2 kernel
+    columns per MFMA k-step (conv_halo.hip GM = 3 / 4).
     algo_cin: number of input channels that carry data (FLOP accounting of bench.py's timer; unused here)."""
     flush_packs()
     assert nplanes(x)[0] == pw.xP, (nplanes(x), pw.xP)
@@ -443,6 +467,9 @@ def conv_halo(x, pw, cout, N, H, W, KS, y=None, y_f32=None, bias=None, res=None,
     if k1skip:
         assert KS == 7 and wc in (0, 1)
         wc = 1 | 256
+    if narrow:
+        assert KS == 7 and wc in (0, 1) and flip and narrow in (8, 16) and planes is None and tiletab is None and y is not None and y_f32 is None
+        wc = 1 | (512 if narrow == 8 else 1024)
     f32_C = 0
     if y_f32 is not None:
         f32_C = y_f32.shape[1] if y_f32.dim() == 4 else 1

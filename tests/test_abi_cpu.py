@@ -293,8 +293,8 @@ def test_half_build_loads_and_exports_the_rows_entry_points(lib):
     build.build()
     half = _lib.load(1)
     assert half.kg_rows_format() == 1 and lib.kg_rows_format() == 0
-    rows_entries = ["kg_conv2d_igemm", "kg_conv2d_halo", "kg_conv2d_halo_heads2", "kg_conv3x3_c64", "kg_conv1x1", "kg_pack_weight",
-                    "kg_pack_weight_rows", "kg_pack_weight_batch", "kg_im2col_small", "kg_conv2d_wgrad", "kg_conv2d_wgrad_halo", "kg_bias_grad",
+    rows_entries = ["kg_conv2d_igemm", "kg_conv2d_halo", "kg_conv7_narrow", "kg_conv2d_halo_heads2", "kg_conv3x3_c64", "kg_conv1x1", "kg_pack_weight",
+                    "kg_pack_weight_rows", "kg_pack_weight_batch", "kg_pack_weight_narrow", "kg_im2col_small", "kg_conv2d_wgrad", "kg_conv2d_wgrad_halo", "kg_bias_grad",
                     "kg_img_pack", "kg_bn_stats_train", "kg_bn_apply", "kg_bn_bwd", "kg_maxpool3s2_fwd", "kg_maxpool3s2_bwd", "kg_bilinear_fwd",
                     "kg_bilinear_bwd", "kg_add_rows", "kg_grad_pack", "kg_grad_pack3", "kg_rows_gather", "kg_rows_gather_planes", "kg_rows_gather_f32", "kg_planes_to_f32", "kg_f32_to_planes",
                     "kg_crop_grad_reduce", "kg_rows_rescale", "kg_rows_scale", "kg_conv_stats_begin", "kg_conv_stats_end", "kg_last_error", "kg_last_kernel"]

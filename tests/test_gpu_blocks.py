@@ -215,8 +215,14 @@ def test_stem_and_decoder_level(model, state_dict0):
     eng.tape = None
 
 
-def test_heads_level(model, state_dict0):
-    """fused first 7x7 convs + three second convs + sigmoid, gradients from fp32 NCHW map grads."""
+@pytest.mark.parametrize("narrow_route", [2, 1, 0])
+def test_heads_level(model, state_dict0, narrow_route, monkeypatch):
+    """fused first 7x7 convs + three second convs + sigmoid, gradients from fp32 NCHW map grads.  narrow_route: how the kp / short second-layer input
+    gradients run when the backward pass is single-plane (engine.NARROW_HEADS_DGRAD / KG_NARROW_HEADS_DGRAD): 2 = persistent conv7_narrow (default), 1 = the
+    narrow variants of the halo kernel, 0 = the fused launch with skipped k-steps."""
+    from kg_instance_segmentation_amd import engine as engine_mod
+    monkeypatch.setattr(engine_mod, "NARROW_HEADS_DGRAD", narrow_route)
+    model._engine.fusedT.pop("heads_c0.2T", None)      # (the packed input-gradient matrices depend on the route)
     N, H, W, C = 1, 16, 24, 64
     g = torch.Generator().manual_seed(3)
     x = F.relu(bfr(torch.randn(N, C, H, W, generator=g)))

@@ -678,6 +678,47 @@ def test_grad_pack_matches_torch(case, dt):
 
 
 @pytest.mark.parametrize("dt", [BF16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", [(1, 16, 32, 64), (2, 37, 45, 64), (1, 48, 80, 256), (3, 20, 33, 128)])
+@pytest.mark.parametrize("narrow", [8, 16])
+@pytest.mark.parametrize("route", ["halo", "persistent"])
+def test_narrow_halo_input_gradient(route, narrow, case, dt):
+    """route "persistent": ops.conv7_narrow (conv7_narrow.hip: weights resident in LDS, compact halos, persistent workgroups); route "halo":
+    conv_halo(narrow = 8 / 16): the input gradient of the kp (5 -> 8 channels) / short (10 -> 16) second-layer head convs (KGnet.py:161-209 `.2`) with 4 / 2
+    kernel columns per MFMA k-step (conv_halo.hip GM = 3 / 4, weights from PackedWeight.pack_narrow) against torch's conv_transpose2d of the same 16-bit
+    operands in float64, ReLU mask applied: maps that are no multiple of the 16 x 32 tile, several images, 1 / 2 / 4 cout blocks; the channels of the packed
+    dY rows that belong to the OTHER heads hold large junk the kernel must not see."""
+    N, H, W, C = case
+    co, c_lo = (5, 0) if narrow == 8 else (10, 8)
+    g = torch.Generator().manual_seed(narrow * 1000 + H * W + C)
+    w = (torch.randn(co, C, 7, 7, generator=g) * 0.05).to(DEV)
+    dy = torch.randn(N, co, H, W, generator=g)
+    hidden = torch.randn(N, C, H, W, generator=g)            # the forward value whose sign is the ReLU mask
+    rows = torch.randn(N * H * W, 64, generator=g) * 100.0      # junk in every channel ...
+    rows[:, c_lo:c_lo + narrow] = 0.0
+    rows[:, c_lo:c_lo + co] = dy.permute(0, 2, 3, 1).reshape(N * H * W, co)     # ... but this head's
+    gy = ops.alloc_pt(N * H * W, 64, 1, DEV, dtype=dt)
+    gy.t.copy_(rows)
+    mask = ops.alloc_pt(N * H * W, C, 1, DEV, dtype=dt)
+    mask.t.copy_(hidden.permute(0, 2, 3, 1).reshape(N * H * W, C))
+    pw = PackedWeight(C, 7 * narrow // 8, 64, DEV, dtype=dt)
+    pw.pack_narrow(w, narrow)
+    out = ops.alloc_pt(N * H * W, C + 64, 1, DEV, dtype=dt)      # (a column slice of a wider buffer, as engine.heads_second writes it)
+    out.t.fill_(9.0)
+    if route == "halo":
+        ops.conv_halo(gy, pw, C, N, H, W, 7, y=out.cols(32, 32 + C), mask=mask.t, flip=True, narrow=narrow)
+    else:
+        ops.conv7_narrow(gy, pw, C, N, H, W, out.cols(32, 32 + C), mask=mask.t, chan_lo=c_lo, chan_slot=narrow)
+    torch.cuda.synchronize()
+    dyq = gy.t[:, c_lo:c_lo + co].double().cpu().reshape(N, H, W, co).permute(0, 3, 1, 2)
+    wq = w.to(dt).double().cpu()
+    ref = F.conv_transpose2d(dyq, wq, padding=3) * (mask.t.double().cpu().reshape(N, H, W, C).permute(0, 3, 1, 2) > 0)
+    got = out.t[:, 32:32 + C].double().cpu().reshape(N, H, W, C).permute(0, 3, 1, 2)
+    tol = (2.0 ** -8 if dt == BF16 else 2.0 ** -11) * float(ref.abs().max()) + 1e-6
+    assert float((got - ref).abs().max()) <= tol, (float((got - ref).abs().max()), tol)
+    assert float((out.t[:, :32].float() - 9.0).abs().max()) == 0.0 and float((out.t[:, 32 + C:].float() - 9.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", [BF16, torch.float16], ids=["bf16", "f16"])
 def test_rows_gather_planes_equals_per_plane_gathers(dt):
     """kg_rows_gather_planes (the crop rows of a split feature map, both planes in one launch: seg.SegBranch.gather) against a torch gather of each
     plane, into a whole-width destination and into a column slice of a wider (concat) buffer whose plane stride differs from the source's."""

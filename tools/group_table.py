@@ -5,7 +5,7 @@ import sys
 
 GROUPS = [
     ("7x7 heads: conv_halo<7,1,8,0> + conv_halo7_w4 forward + input gradient (the dominant kernel family)", lambda n: "conv_halo_kernel<7, 1, 8, 0" in n or "conv_halo7_w4_kernel" in n),
-    ("7x7 heads: grouped second layers <7,1,8,1> (+ heads2_finish) + their fused input gradient <7,1,8,2>", lambda n: "conv_halo_kernel<7, 1, 8, 1" in n or "conv_halo_kernel<7, 1, 8, 2" in n or "heads2_finish" in n),
+    ("7x7 heads: grouped second layers <7,1,8,1> (+ heads2_finish) + the kp / short input gradients (conv7_narrow; <7,1,8,2..4>)", lambda n: "conv_halo_kernel<7, 1, 8, 1" in n or "conv_halo_kernel<7, 1, 8, 2" in n or "conv_halo_kernel<7, 1, 8, 3" in n or "conv_halo_kernel<7, 1, 8, 4" in n or "conv7_narrow" in n or "heads2_finish" in n),
     ("7x7 heads: weight gradients wgrad_halo<7,...>", lambda n: "wgrad_halo_kernel<7" in n),
     ("3x3: conv_halo<3> + conv_halo3_w4 + conv3_ws + conv3_c64 + wgrad_halo<3>", lambda n: "conv_halo_kernel<3" in n or "conv_halo3_w4" in n or "conv3_c64" in n or "conv3_ws" in n or "wgrad_halo_kernel<3" in n),
     ("conv_gather", lambda n: "conv_gather" in n),
