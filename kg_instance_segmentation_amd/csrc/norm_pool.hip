@@ -406,6 +406,11 @@ __device__ __forceinline__ void bil_src(int dst, float scale, int in, int* i0, i
     if (a > in - 1) a = in - 1;
     *i0 = a; *i1 = a + (a < in - 1 ? 1 : 0); *l1 = s - (float)a;
 }
+// the weighted sum of the four neighbours as ONE fixed sequence of roundings (left to the compiler, the contraction of the four products into FMAs
+// comes out differently in different kernels: the exact-2x kernel below would differ from the generic one in the last bit)
+__device__ __forceinline__ float bil_mix(float w00, float w01, float w10, float w11, float a, float b, float d, float e) {
+    return __builtin_fmaf(w11, e, __builtin_fmaf(w10, d, __builtin_fmaf(w01, b, w00 * a)));
+}
 // Dense mode: images [N][IH][IW] -> [N][OH][OW].
 // Ragged mode (desc != null): one box per "image"; desc[b] = {in_row0, ih, iw, out_row0, oh, ow} and
 // rows are box-local raster order (used by the per-box seg branch, KGnet.py:258-267).
@@ -434,8 +439,58 @@ __global__ void bilinear_fwd_kernel(const RowsR x, const RowsW y, int IH,
         rd8(x, in0 + (long)y1 * iw + x0, c, pd); rd8(x, in0 + (long)y1 * iw + x1, c, pe);
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = w00 * pa[e] + w01 * pb[e] + w10 * pd[e] + w11 * pe[e];
+        for (int e = 0; e < 8; ++e) v[e] = bil_mix(w00, w01, w10, w11, pa[e], pb[e], pd[e], pe[e]);
         wr8(y, p, c, v);
+    }
+}
+// Dense exact-2x upsampling (every decoder level, KGnet.py:288-298): the generic kernel issues 4 loads per plane for every 16-byte output chunk and
+// the texture path, not HBM, bounds it (tools/bilinear_probe.py with the loads / the stores switched off: 247 us as it is, 88 us without the loads,
+// 123 us without the stores at 8 x 256^2 -> 512^2 x 64 channels).  Here a thread owns one 8-channel chunk of one INPUT column and walks down a strip
+// of input rows with the 3 x 3 neighbourhood in registers: 3 loads per plane bring what 2 x 2 outputs need (0.75 - 0.94 loads per output chunk
+// instead of 4).  The same bil_src indices and the same weighted sum as the generic kernel, term for term: bit-identical output.
+constexpr int BIL2_ROWS = 8;     // input rows per thread (measured: 4 the same, 16 and a 128-register budget slower -- tools/bilinear_probe.py)
+__global__ __launch_bounds__(256) void bilinear2x_fwd_kernel(const RowsR x, const RowsW y, int N, int IH, int IW, int C8) {
+    const long per_img = (long)IW * C8;
+    const int strips = (IH + BIL2_ROWS - 1) / BIL2_ROWS;
+    const long total = (long)N * strips * per_img;
+    const int OH = 2 * IH, OW = 2 * IW;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        long q; int c; kg_divmod(t, C8, &q, &c); c *= 8;
+        int j; long q2; kg_divmod(q, IW, &q2, &j);
+        int strip; long n; kg_divmod(q2, strips, &n, &strip);
+        const int i0 = strip * BIL2_ROWS, i1 = i0 + BIL2_ROWS < IH ? i0 + BIL2_ROWS : IH;
+        const long in0 = n * IH * IW, out0 = n * OH * OW;
+        const int jl = j > 0 ? j - 1 : 0, jr = j < IW - 1 ? j + 1 : IW - 1;
+        // bil_src for scale 0.5: output 2k reads inputs (k - 1, k) with l = 0.75 -- (0, 1) with l = 0 for k = 0, where the second input has weight 0 and
+        // input 0 may stand in for it --, output 2k + 1 reads (k, min(k + 1, in - 1)) with l = 0.25: all indices static, the edge cases are weights
+        const float lx0 = j == 0 ? 0.f : 0.75f;
+        float prev[3][8], cur[3][8], next[3][8];               // [column: jl, j, jr]
+        {
+            const long bp = in0 + (long)(i0 > 0 ? i0 - 1 : 0) * IW, bc = in0 + (long)i0 * IW;
+            rd8(x, bp + jl, c, prev[0]); rd8(x, bp + j, c, prev[1]); rd8(x, bp + jr, c, prev[2]);
+            rd8(x, bc + jl, c, cur[0]); rd8(x, bc + j, c, cur[1]); rd8(x, bc + jr, c, cur[2]);
+        }
+        auto mix = [&](const float (&pa)[8], const float (&pb)[8], const float (&pd)[8], const float (&pe)[8], float ly, float lx, long orow) {
+            const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = bil_mix(w00, w01, w10, w11, pa[e], pb[e], pd[e], pe[e]);
+            wr8(y, orow, c, v);
+        };
+        for (int i = i0; i < i1; ++i) {
+            const long bn = in0 + (long)(i < IH - 1 ? i + 1 : IH - 1) * IW;
+            rd8(x, bn + jl, c, next[0]); rd8(x, bn + j, c, next[1]); rd8(x, bn + jr, c, next[2]);
+            const float ly0 = i == 0 ? 0.f : 0.75f;
+            const long o0 = out0 + (long)(2 * i) * OW + 2 * j, o1 = o0 + OW;
+            mix(prev[0], prev[1], cur[0], cur[1], ly0, lx0, o0);
+            mix(prev[1], prev[2], cur[1], cur[2], ly0, 0.25f, o0 + 1);
+            mix(cur[0], cur[1], next[0], next[1], 0.25f, lx0, o1);
+            mix(cur[1], cur[2], next[1], next[2], 0.25f, 0.25f, o1 + 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { prev[k][e] = cur[k][e]; cur[k][e] = next[k][e]; }
+        }
     }
 }
 // gather-form backward: each input pixel scans the output pixels that can reference it.
@@ -500,6 +555,15 @@ extern "C" int kg_bilinear_fwd(const void* x, int ldx, void* y, int ldy, int N, 
     long rows = boxdesc ? total_out_rows : (long)N * OH * OW;
     if (rows == 0) return KG_OK;
     long total = rows * (C / 8);
+    static const int fast2x = getenv("KG_BILINEAR_2X") ? atoi(getenv("KG_BILINEAR_2X")) : 1;
+    if (fast2x && !boxdesc && OH == 2 * IH && OW == 2 * IW && IH >= 2 && IW >= 2) {
+        const long threads = (long)N * ((IH + BIL2_ROWS - 1) / BIL2_ROWS) * IW * (C / 8);
+        int blocks2 = (int)((threads + 255) / 256); if (blocks2 > 65536) blocks2 = 65536;
+        hipLaunchKernelGGL(bilinear2x_fwd_kernel, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, RowsR{(const bf16_t*)x, ldx, pp.a_planes, pp.a_pstride},
+                           RowsW{(bf16_t*)y, ldy, pp.y_planes, pp.y_pstride}, N, IH, IW, C / 8);
+        KG_CHECK_LAUNCH("bilinear2x_fwd");
+        return KG_OK;
+    }
     int blocks = (int)((total + 255) / 256); if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, RowsR{(const bf16_t*)x, ldx, pp.a_planes, pp.a_pstride},
                        RowsW{(bf16_t*)y, ldy, pp.y_planes, pp.y_pstride}, IH, IW, OH, OW, C / 8, rows, (const BilBox*)boxdesc, row2box);

@@ -678,6 +678,39 @@ def test_grad_pack_matches_torch(case, dt):
 
 
 @pytest.mark.parametrize("dt", [BF16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("P", [1, 2])
+@pytest.mark.parametrize("case", [(1, 2, 2, 8), (2, 5, 7, 64), (3, 19, 33, 24), (1, 32, 16, 256), (2, 9, 40, 64)])
+def test_exact_2x_bilinear_kernel_is_bit_identical_to_the_generic_one(case, P, dt):
+    """kg_bilinear_fwd's dense exact-2x path (bilinear2x_fwd_kernel: one thread per 8-channel chunk of an input column, the 3 x 3 neighbourhood in registers,
+    strips of 8 input rows) against the generic gather kernel, reached through the ragged descriptor form with the images given as boxes: the same indices and
+    the same weighted sum term for term -- every element bit for bit, maps smaller than / not a multiple of the strip, one and two planes; and against
+    F.interpolate (KGnet.py:288-297) within the storage rounding."""
+    N, IH, IW, C = case
+    OH, OW = 2 * IH, 2 * IW
+    g = torch.Generator().manual_seed(IH * 100 + IW)
+    xf = torch.randn(N, C, IH, IW, generator=g)
+    x = ops.alloc_pt(N * IH * IW, C, P, DEV, dtype=dt)
+    rows = xf.permute(0, 2, 3, 1).reshape(N * IH * IW, C).to(DEV)
+    x.t.copy_(rows)
+    if P == 2:
+        x.plane(1).copy_(rows - x.t.float())
+    fast = ops.alloc_pt(N * OH * OW, C, P, DEV, dtype=dt)
+    slow = ops.alloc_pt(N * OH * OW, C, P, DEV, dtype=dt)
+    ops.bilinear_fwd(x, fast, N, IH, IW, OH, OW, C)
+    desc = torch.tensor([[n * IH * IW, IH, IW, n * OH * OW, OH, OW] for n in range(N)], dtype=torch.int32, device=DEV)
+    r2b = torch.arange(N, dtype=torch.int32, device=DEV).repeat_interleave(OH * OW).contiguous()
+    ops.bilinear_fwd(x, slow, N, IH, IW, OH, OW, C, boxdesc=desc, row2box=r2b)
+    torch.cuda.synchronize()
+    for p in range(P):
+        assert torch.equal(fast.plane(p), slow.plane(p)), (case, P, p)
+    val = sum(x.plane(p).double() for p in range(P)).cpu().reshape(N, IH, IW, C).permute(0, 3, 1, 2)
+    ref = F.interpolate(val, (OH, OW), mode="bilinear", align_corners=False)
+    got = sum(fast.plane(p).double() for p in range(P)).cpu().reshape(N, OH, OW, C).permute(0, 3, 1, 2)
+    tol = {1: 2.0 ** -8 if dt == BF16 else 2.0 ** -11, 2: 2.0 ** -15 if dt == BF16 else 2.0 ** -20}[P]
+    assert float((got - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("dt", [BF16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("case", [(1, 16, 32, 64), (2, 37, 45, 64), (1, 48, 80, 256), (3, 20, 33, 128)])
 @pytest.mark.parametrize("narrow", [8, 16])
 @pytest.mark.parametrize("route", ["halo", "persistent"])
